@@ -1,0 +1,496 @@
+/*
+ * oracle/cv2_restate.c  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C) of the OpenCV primitives that PySceneDetect's
+ * process_frame() hot path calls.  OpenCV is a third-party, un-vendored,
+ * un-pinned dependency of the reference (pyproject.toml:43-57; the only pin
+ * in-tree is opencv-python-headless==5.0.0.93 in
+ * packaging/windows/requirements.txt:8) and is NOT installed in this image,
+ * so these functions restate OpenCV's *published* 8-bit algorithms
+ * (modules/imgproc/src/color_hsv.simd.hpp RGB2HSV_b, color_yuv.simd.hpp
+ * RGB2YCrCb_i, histogram.cpp calcHist_8u/compareHist, core convert_scale /
+ * norm, canny.cpp, morph, resize.cpp) and anchor on the reference call sites:
+ *
+ *   cv2.cvtColor(BGR2HSV) + split   scenedetect/detectors/content_detector.py:155
+ *   cv2.Canny / cv2.dilate          scenedetect/detectors/content_detector.py:238-239
+ *   cv2.cvtColor(BGR2YUV) + split   scenedetect/detectors/histogram_detector.py:156
+ *   cv2.calcHist                    scenedetect/detectors/histogram_detector.py:159
+ *   cv2.normalize                   scenedetect/detectors/histogram_detector.py:163
+ *   cv2.compareHist(CORREL)         scenedetect/detectors/histogram_detector.py:98
+ *   cv2.resize(INTER_LINEAR)        scenedetect/scene_manager.py:670-678
+ *
+ * PARITY UNPINNED at the cv2 boundary: no real cv2 build and none of the
+ * reference's video fixtures exist in this environment, so
+ * this restatement cannot be checked against OpenCV output here.  It is
+ * pinned only by construction (integer formulas) and by self-consistency
+ * tests (tests/test_oracle_*.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#define HSV_SHIFT 12
+
+static int g_sdiv[256];
+static int g_hdiv180[256];
+static int g_tables_ready = 0;
+
+/* cv::saturate_cast<int>(double) == cvRound == lrint (round-half-even). */
+static void init_tables(void)
+{
+    if (g_tables_ready) return;
+    g_sdiv[0] = g_hdiv180[0] = 0;
+    for (int i = 1; i < 256; i++) {
+        g_sdiv[i] = (int)lrint((255 << HSV_SHIFT) / (1. * i));
+        g_hdiv180[i] = (int)lrint((180 << HSV_SHIFT) / (6. * i));
+    }
+    g_tables_ready = 1;
+}
+
+/* Export the fixed-point tables (used by tests to check the device LUTs). */
+void orc_hsv_tables(int32_t* sdiv, int32_t* hdiv180)
+{
+    init_tables();
+    for (int i = 0; i < 256; i++) { sdiv[i] = g_sdiv[i]; hdiv180[i] = g_hdiv180[i]; }
+}
+
+static inline void bgr2hsv_px(int b, int g, int r, uint8_t* h_out, uint8_t* s_out, uint8_t* v_out)
+{
+    int v = b, vmin = b;
+    if (g > v) v = g;
+    if (r > v) v = r;
+    if (g < vmin) vmin = g;
+    if (r < vmin) vmin = r;
+    int diff = v - vmin;
+    int vr = (v == r) ? -1 : 0;
+    int vg = (v == g) ? -1 : 0;
+    int s = (diff * g_sdiv[v] + (1 << (HSV_SHIFT - 1))) >> HSV_SHIFT;
+    int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    /* arithmetic shift of a possibly negative value, as in OpenCV */
+    h = (h * g_hdiv180[diff] + (1 << (HSV_SHIFT - 1))) >> HSV_SHIFT;
+    if (h < 0) h += 180;
+    *h_out = (uint8_t)(h < 0 ? 0 : (h > 255 ? 255 : h));
+    *s_out = (uint8_t)s;
+    *v_out = (uint8_t)v;
+}
+
+/* cv2.cvtColor(src, COLOR_BGR2HSV): interleaved HSV, H in [0,180). */
+void orc_bgr2hsv(const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int h, int w)
+{
+    init_tables();
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * src_step;
+        uint8_t* d = dst + (size_t)y * dst_step;
+        for (int x = 0; x < w; x++, s += 3, d += 3)
+            bgr2hsv_px(s[0], s[1], s[2], d + 0, d + 1, d + 2);
+    }
+}
+
+/* Planar variant (what cv2.split gives content_detector.py:155). */
+void orc_bgr2hsv_planes(const uint8_t* src, size_t src_step, uint8_t* hp, uint8_t* sp, uint8_t* vp,
+                        int h, int w)
+{
+    init_tables();
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * src_step;
+        size_t o = (size_t)y * w;
+        for (int x = 0; x < w; x++, s += 3, o++)
+            bgr2hsv_px(s[0], s[1], s[2], hp + o, sp + o, vp + o);
+    }
+}
+
+/* BT.601 fixed-point constants of OpenCV's RGB2YCrCb_i (yuv_shift = 14). */
+#define YUV_SHIFT 14
+#define R2Y 4899
+#define G2Y 9617
+#define B2Y 1868
+#define R2VI 14369
+#define B2UI 8061
+#define DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+static inline uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+/* cv2.cvtColor(src, COLOR_BGR2YUV): interleaved Y,U,V. */
+void orc_bgr2yuv(const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int h, int w)
+{
+    const int delta = 128 * (1 << YUV_SHIFT);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * src_step;
+        uint8_t* d = dst + (size_t)y * dst_step;
+        for (int x = 0; x < w; x++, s += 3, d += 3) {
+            int b = s[0], g = s[1], r = s[2];
+            int Y = DESCALE(b * B2Y + g * G2Y + r * R2Y, YUV_SHIFT);
+            int V = DESCALE((r - Y) * R2VI + delta, YUV_SHIFT); /* "Cr" slot */
+            int U = DESCALE((b - Y) * B2UI + delta, YUV_SHIFT); /* "Cb" slot */
+            d[0] = sat_u8(Y);
+            d[1] = sat_u8(U);
+            d[2] = sat_u8(V);
+        }
+    }
+}
+
+void orc_bgr2y(const uint8_t* src, size_t src_step, uint8_t* yp, int h, int w)
+{
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * src_step;
+        uint8_t* d = yp + (size_t)y * w;
+        for (int x = 0; x < w; x++, s += 3)
+            d[x] = sat_u8(DESCALE(s[0] * B2Y + s[1] * G2Y + s[2] * R2Y, YUV_SHIFT));
+    }
+}
+
+/* cv2.calcHist([plane],[0],None,[bins],[lo,hi]) for an 8-bit plane, uniform
+ * ranges.  OpenCV builds a 256-entry LUT: idx = cvFloor(j*a + b) with
+ * a = bins/(hi-lo), b = -a*lo, clamped to [0,bins-1] inside [lo,hi), values
+ * outside the range are skipped.  Output: float32 counts. */
+void orc_calc_hist_u8(const uint8_t* plane, size_t step, int h, int w, int bins, double lo, double hi,
+                      float* hist)
+{
+    int lut[256];
+    double a = bins / (hi - lo), b = -a * lo;
+    for (int j = 0; j < 256; j++) {
+        int idx = (int)floor(j * a + b);
+        if (j >= lo && j < hi) {
+            if (idx < 0) idx = 0;
+            if (idx > bins - 1) idx = bins - 1;
+        } else
+            idx = -1;
+        lut[j] = idx;
+    }
+    uint64_t* cnt = (uint64_t*)calloc((size_t)bins, sizeof(uint64_t));
+    for (int y = 0; y < h; y++) {
+        const uint8_t* p = plane + (size_t)y * step;
+        for (int x = 0; x < w; x++) {
+            int idx = lut[p[x]];
+            if (idx >= 0) cnt[idx]++;
+        }
+    }
+    /* OpenCV accumulates in int and converts; counts < 2^24 are exact in f32,
+     * larger counts round once (same as (float)int). */
+    for (int i = 0; i < bins; i++) hist[i] += (float)cnt[i];
+    free(cnt);
+}
+
+/* cv2.normalize(hist, hist) defaults: NORM_L2, alpha=1, beta=0.
+ * norm accumulates squares in double; scale = alpha/norm (0 if norm<=eps);
+ * convertTo 32f->32f multiplies in float: dst = src*(float)scale. */
+void orc_normalize_l2_f32(float* v, int n)
+{
+    double ss = 0.0;
+    for (int i = 0; i < n; i++) ss += (double)v[i] * (double)v[i];
+    double nrm = sqrt(ss);
+    double scale = nrm > DBL_EPSILON ? 1.0 / nrm : 0.0;
+    float fs = (float)scale;
+    for (int i = 0; i < n; i++) v[i] = v[i] * fs;
+}
+
+/* cv2.compareHist(h1,h2,HISTCMP_CORREL) on float32 histograms.  All sums are
+ * double.  x86-64 OpenCV builds accumulate with 2-lane f64 vectors
+ * (CV_SIMD_64F, baseline SSE2): lane k sums elements j with j%2==k, lanes are
+ * added at the end, the tail (n%4) is added sequentially.  Products of two
+ * f32 values are exact in f64, so only this summation order matters. */
+double orc_compare_hist_correl(const float* h1, const float* h2, int n)
+{
+    double s1[2] = {0, 0}, s2[2] = {0, 0}, s11[2] = {0, 0}, s12[2] = {0, 0}, s22[2] = {0, 0};
+    int j = 0;
+    for (; j <= n - 4; j += 4) {
+        for (int k = 0; k < 4; k++) {
+            double a = h1[j + k], b = h2[j + k];
+            int l = k & 1;
+            s12[l] += a * b;
+            s11[l] += a * a;
+            s22[l] += b * b;
+            s1[l] += a;
+            s2[l] += b;
+        }
+    }
+    double S1 = s1[0] + s1[1], S2 = s2[0] + s2[1], S11 = s11[0] + s11[1], S12 = s12[0] + s12[1],
+           S22 = s22[0] + s22[1];
+    for (; j < n; j++) {
+        double a = h1[j], b = h2[j];
+        S12 += a * b;
+        S1 += a;
+        S11 += a * a;
+        S2 += b;
+        S22 += b * b;
+    }
+    double scale = 1. / n;
+    double num = S12 - S1 * S2 * scale;
+    double denom2 = (S11 - S1 * S1 * scale) * (S22 - S2 * S2 * scale);
+    return fabs(denom2) > DBL_EPSILON ? num / sqrt(denom2) : 1.;
+}
+
+/* ---------------------------------------------------------------------------
+ * cv2.Canny(img8u, low, high)  (apertureSize=3, L2gradient=False)
+ * Sobel 3x3 with BORDER_REPLICATE -> s16 dx,dy; mag = |dx|+|dy|; magnitudes
+ * outside the image are 0; non-maximum suppression with TG22 fixed point;
+ * hysteresis = 8-connected reachability from strong pixels.
+ * ------------------------------------------------------------------------- */
+#define CANNY_SHIFT 15
+#define TG22 13573 /* (int)(0.4142135623730950488016887242097*(1<<15) + 0.5) */
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+void orc_sobel3(const uint8_t* src, size_t step, int h, int w, int16_t* dx, int16_t* dy)
+{
+    for (int y = 0; y < h; y++) {
+        const uint8_t* r0 = src + (size_t)clampi(y - 1, 0, h - 1) * step;
+        const uint8_t* r1 = src + (size_t)y * step;
+        const uint8_t* r2 = src + (size_t)clampi(y + 1, 0, h - 1) * step;
+        for (int x = 0; x < w; x++) {
+            int xl = clampi(x - 1, 0, w - 1), xr = clampi(x + 1, 0, w - 1);
+            int gx = (r0[xr] - r0[xl]) + 2 * (r1[xr] - r1[xl]) + (r2[xr] - r2[xl]);
+            int gy = (r2[xl] - r0[xl]) + 2 * (r2[x] - r0[x]) + (r2[xr] - r0[xr]);
+            dx[(size_t)y * w + x] = (int16_t)gx;
+            dy[(size_t)y * w + x] = (int16_t)gy;
+        }
+    }
+}
+
+void orc_canny(const uint8_t* src, size_t step, int h, int w, double low_thresh, double high_thresh,
+               uint8_t* dst)
+{
+    if (low_thresh > high_thresh) { double t = low_thresh; low_thresh = high_thresh; high_thresh = t; }
+    if (low_thresh > 32767.0) low_thresh = 32767.0;
+    if (high_thresh > 32767.0) high_thresh = 32767.0;
+    int low = (int)floor(low_thresh), high = (int)floor(high_thresh);
+
+    size_t n = (size_t)h * w;
+    int16_t* dx = (int16_t*)malloc(n * sizeof(int16_t));
+    int16_t* dy = (int16_t*)malloc(n * sizeof(int16_t));
+    orc_sobel3(src, step, h, w, dx, dy);
+
+    /* magnitude with a zero border of 1 px */
+    int mw = w + 2;
+    int* mag = (int*)calloc((size_t)(h + 2) * mw, sizeof(int));
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            mag[(size_t)(y + 1) * mw + x + 1] = abs(dx[(size_t)y * w + x]) + abs(dy[(size_t)y * w + x]);
+
+    /* map: 1 = cannot be an edge, 0 = weak candidate, 2 = edge */
+    uint8_t* map = (uint8_t*)malloc((size_t)(h + 2) * mw);
+    memset(map, 1, (size_t)(h + 2) * mw);
+    size_t* stack = (size_t*)malloc(n * sizeof(size_t) + sizeof(size_t));
+    size_t sp = 0;
+
+    for (int y = 0; y < h; y++) {
+        const int* mp = mag + (size_t)y * mw + 1;       /* previous row */
+        const int* ma = mag + (size_t)(y + 1) * mw + 1; /* current row  */
+        const int* mn = mag + (size_t)(y + 2) * mw + 1; /* next row     */
+        uint8_t* pm = map + (size_t)(y + 1) * mw + 1;
+        for (int x = 0; x < w; x++) {
+            int m = ma[x];
+            if (m > low) {
+                int xs = dx[(size_t)y * w + x], ys = dy[(size_t)y * w + x];
+                int ax = abs(xs), ay = abs(ys) << CANNY_SHIFT;
+                int tg22x = ax * TG22;
+                int is_max = 0;
+                if (ay < tg22x) {
+                    is_max = (m > ma[x - 1] && m >= ma[x + 1]);
+                } else {
+                    int tg67x = tg22x + (ax << (CANNY_SHIFT + 1));
+                    if (ay > tg67x) {
+                        is_max = (m > mp[x] && m >= mn[x]);
+                    } else {
+                        int s = (xs ^ ys) < 0 ? -1 : 1;
+                        is_max = (m > mp[x - s] && m > mn[x + s]);
+                    }
+                }
+                if (is_max) {
+                    if (m > high) {
+                        pm[x] = 2;
+                        stack[sp++] = (size_t)(y + 1) * mw + x + 1;
+                    } else
+                        pm[x] = 0;
+                    continue;
+                }
+            }
+            pm[x] = 1;
+        }
+    }
+    /* hysteresis */
+    while (sp) {
+        size_t p = stack[--sp];
+        const long off[8] = {-mw - 1, -mw, -mw + 1, -1, 1, mw - 1, mw, mw + 1};
+        for (int k = 0; k < 8; k++) {
+            size_t q = (size_t)((long)p + off[k]);
+            if (map[q] == 0) { map[q] = 2; stack[sp++] = q; }
+        }
+    }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            dst[(size_t)y * w + x] = (uint8_t)(map[(size_t)(y + 1) * mw + x + 1] == 2 ? 255 : 0);
+    free(stack); free(map); free(mag); free(dx); free(dy);
+}
+
+/* cv2.dilate(src, ones(kh,kw)): rectangular window max, anchor at the centre
+ * (k/2), iterations=1, default border (BORDER_CONSTANT with the morphology
+ * default value = no contribution from outside the image). */
+void orc_dilate_rect(const uint8_t* src, size_t step, int h, int w, int kh, int kw, uint8_t* dst)
+{
+    int ay = kh / 2, ax = kw / 2;
+    uint8_t* tmp = (uint8_t*)malloc((size_t)h * w);
+    for (int y = 0; y < h; y++) { /* horizontal pass */
+        const uint8_t* s = src + (size_t)y * step;
+        for (int x = 0; x < w; x++) {
+            int x0 = x - ax, x1 = x - ax + kw - 1;
+            if (x0 < 0) x0 = 0;
+            if (x1 > w - 1) x1 = w - 1;
+            uint8_t m = 0;
+            for (int i = x0; i <= x1; i++) if (s[i] > m) m = s[i];
+            tmp[(size_t)y * w + x] = m;
+        }
+    }
+    for (int y = 0; y < h; y++) { /* vertical pass */
+        int y0 = y - ay, y1 = y - ay + kh - 1;
+        if (y0 < 0) y0 = 0;
+        if (y1 > h - 1) y1 = h - 1;
+        for (int x = 0; x < w; x++) {
+            uint8_t m = 0;
+            for (int i = y0; i <= y1; i++) {
+                uint8_t v = tmp[(size_t)i * w + x];
+                if (v > m) m = v;
+            }
+            dst[(size_t)y * w + x] = m;
+        }
+    }
+    free(tmp);
+}
+
+/* ---------------------------------------------------------------------------
+ * cv2.resize(src, (dw,dh), interpolation=INTER_LINEAR) for 8-bit, cn channels.
+ * Classic fixed-point path of resize.cpp: 11-bit coefficients
+ * (INTER_RESIZE_COEF_SCALE = 2048), horizontal pass into int rows, vertical
+ * pass  dst = (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
+ * An exact 2x2 decimation is routed to INTER_AREA by OpenCV
+ * (interpolation == INTER_LINEAR && is_area_fast && iscale == 2), which for
+ * 8u is the rounded box mean (sum + 2) >> 2.
+ * ------------------------------------------------------------------------- */
+static short sat_s16_round(float v)
+{
+    long r = lrintf(v);
+    if (r > 32767) r = 32767;
+    if (r < -32768) r = -32768;
+    return (short)r;
+}
+
+void orc_resize_linear_u8(const uint8_t* src, size_t sstep, int sh, int sw, int cn, uint8_t* dst,
+                          size_t dstep, int dh, int dw)
+{
+    double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
+    int is_area_fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
+    if (is_area_fast && iscale_x == 2 && iscale_y == 2) {
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++)
+                for (int c = 0; c < cn; c++) {
+                    const uint8_t* p = src + (size_t)(2 * y) * sstep + (size_t)(2 * x) * cn + c;
+                    dst[(size_t)y * dstep + (size_t)x * cn + c] =
+                        (uint8_t)((p[0] + p[cn] + p[sstep] + p[sstep + cn] + 2) >> 2);
+                }
+        return;
+    }
+    int* xofs = (int*)malloc(sizeof(int) * dw);
+    short* ialpha = (short*)malloc(sizeof(short) * dw * 2);
+    int* yofs = (int*)malloc(sizeof(int) * dh);
+    short* ibeta = (short*)malloc(sizeof(short) * dh * 2);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ialpha[dx * 2] = sat_s16_round((1.f - fx) * 2048);
+        ialpha[dx * 2 + 1] = sat_s16_round(fx * 2048);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        ibeta[dy * 2] = sat_s16_round((1.f - fy) * 2048);
+        ibeta[dy * 2 + 1] = sat_s16_round(fy * 2048);
+    }
+    int* row0 = (int*)malloc(sizeof(int) * dw * cn);
+    int* row1 = (int*)malloc(sizeof(int) * dw * cn);
+    for (int dy = 0; dy < dh; dy++) {
+        int sy0 = clampi(yofs[dy], 0, sh - 1), sy1 = clampi(yofs[dy] + 1, 0, sh - 1);
+        const uint8_t* S0 = src + (size_t)sy0 * sstep;
+        const uint8_t* S1 = src + (size_t)sy1 * sstep;
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = xofs[dx];
+            int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+            int a0 = ialpha[dx * 2], a1 = ialpha[dx * 2 + 1];
+            for (int c = 0; c < cn; c++) {
+                row0[dx * cn + c] = S0[sx * cn + c] * a0 + S0[sx1 * cn + c] * a1;
+                row1[dx * cn + c] = S1[sx * cn + c] * a0 + S1[sx1 * cn + c] * a1;
+            }
+        }
+        int b0 = ibeta[dy * 2], b1 = ibeta[dy * 2 + 1];
+        uint8_t* D = dst + (size_t)dy * dstep;
+        for (int x = 0; x < dw * cn; x++)
+            D[x] = (uint8_t)((((b0 * (row0[x] >> 4)) >> 16) + ((b1 * (row1[x] >> 4)) >> 16) + 2) >> 2);
+    }
+    free(row0); free(row1); free(xofs); free(ialpha); free(yofs); free(ibeta);
+}
+
+/* ---------------------------------------------------------------------------
+ * Per-frame integer score records: the CPU restatement of exactly what the
+ * device kernels emit (include/psd_engine.h psd_frame_scores), composed from
+ * the primitives above the way the reference detectors compose them:
+ *   sad_{h,s,v}: sum |cur - prev| of the HSV planes  (content_detector.py:29-36,166-169)
+ *   byte_sum   : sum of all BGR bytes                (threshold_detector.py:127)
+ *   hist[256]  : 256-bin histogram of Y              (histogram_detector.py:156-159)
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t sad_h, sad_s, sad_v, edge_xor, byte_sum;
+    uint32_t hist[256];
+} orc_frame_scores;
+
+void orc_score_batch(const uint8_t* frames, int n, int h, int w, size_t row_stride, size_t frame_stride,
+                     const uint8_t* prev, orc_frame_scores* out)
+{
+    init_tables();
+    size_t np = (size_t)h * w;
+    uint8_t* cur = (uint8_t*)malloc(np * 3);
+    uint8_t* last = (uint8_t*)malloc(np * 3);
+    int have_last = 0;
+    if (prev) {
+        orc_bgr2hsv_planes(prev, row_stride, last, last + np, last + 2 * np, h, w);
+        have_last = 1;
+    }
+    for (int t = 0; t < n; t++) {
+        const uint8_t* f = frames + (size_t)t * frame_stride;
+        orc_frame_scores* o = out + t;
+        memset(o, 0, sizeof(*o));
+        orc_bgr2hsv_planes(f, row_stride, cur, cur + np, cur + 2 * np, h, w);
+        if (have_last) {
+            uint64_t a = 0, b = 0, c = 0;
+            for (size_t i = 0; i < np; i++) {
+                a += (uint64_t)abs((int)cur[i] - (int)last[i]);
+                b += (uint64_t)abs((int)cur[np + i] - (int)last[np + i]);
+                c += (uint64_t)abs((int)cur[2 * np + i] - (int)last[2 * np + i]);
+            }
+            o->sad_h = a; o->sad_s = b; o->sad_v = c;
+        }
+        uint64_t bs = 0;
+        for (int y = 0; y < h; y++) {
+            const uint8_t* s = f + (size_t)y * row_stride;
+            for (int x = 0; x < w; x++, s += 3) {
+                bs += (uint64_t)s[0] + s[1] + s[2];
+                o->hist[sat_u8(DESCALE(s[0] * B2Y + s[1] * G2Y + s[2] * R2Y, YUV_SHIFT))]++;
+            }
+        }
+        o->byte_sum = bs;
+        uint8_t* tsw = cur; cur = last; last = tsw;
+        have_last = 1;
+    }
+    free(cur); free(last);
+}
