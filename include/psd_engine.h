@@ -1,0 +1,205 @@
+/*
+ * psd_engine.h -- C-ABI of the MI355X-native per-frame scoring engine for PySceneDetect.
+ *
+ * The reference (pure Python) has no FFI of its own: its hot path is the four
+ * process_frame() loops that call cv2/numpy.  Each entry point below replaces the pixel
+ * arithmetic of one or more reference call sites (paths relative to the reference tree):
+ *
+ *   psd_score_batch / psd_score_batch_device   (flags select the terms)
+ *     PSD_SCORE_HSV_SAD   cv2.cvtColor(BGR2HSV)+split and 3x _mean_pixel_distance
+ *                         scenedetect/detectors/content_detector.py:29-36,155,166-169
+ *     PSD_SCORE_LUMA_HIST cv2.cvtColor(BGR2YUV)+split and cv2.calcHist
+ *                         scenedetect/detectors/histogram_detector.py:156-159
+ *     PSD_SCORE_BYTE_SUM  numpy.mean(frame_img)
+ *                         scenedetect/detectors/threshold_detector.py:127
+ *     PSD_SCORE_EDGES     numpy.median + cv2.Canny + cv2.dilate + _mean_pixel_distance(edges)
+ *                         scenedetect/detectors/content_detector.py:170-174,213-239
+ *   psd_resize_linear_device                   cv2.resize(..., INTER_LINEAR)
+ *                         scenedetect/scene_manager.py:666-678
+ *   psd_epilogue_*                             the O(1)-per-frame decisions that follow the pixel work
+ *                         content_detector.py:177-180,192-211 + detector.py:106-224 (FlashFilter)
+ *                         adaptive_detector.py:100-143
+ *                         histogram_detector.py:98-116,163 (normalize + compareHist + decision)
+ *                         threshold_detector.py:100-191
+ *
+ * All device results are exact integers; every floating-point operation of the reference
+ * happens in the epilogues (or in the Python host mirror) in the reference's own order.
+ *
+ * Conventions: plain C, caller-owned buffers, no exceptions across the ABI.  Every function
+ * returning int returns PSD_OK (0) or a negative psd_status; psd_last_error() then holds a
+ * thread-local message.  A psd_engine is bound to one HIP device; calls on one engine must be
+ * serialised by the caller, distinct engines may be used from distinct threads.
+ */
+#ifndef PSD_ENGINE_H
+#define PSD_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSD_ABI_VERSION 1
+
+typedef enum psd_status {
+    PSD_OK = 0,
+    PSD_ERR_INVALID = -1,     /* bad argument (maps to ValueError) */
+    PSD_ERR_NO_DEVICE = -2,   /* no usable HIP device */
+    PSD_ERR_HIP = -3,         /* HIP runtime error; message in psd_last_error() */
+    PSD_ERR_UNSUPPORTED = -4, /* valid request the engine does not implement */
+    PSD_ERR_NOMEM = -5
+} psd_status;
+
+enum {
+    PSD_SCORE_HSV_SAD = 1u,
+    PSD_SCORE_LUMA_HIST = 2u,
+    PSD_SCORE_BYTE_SUM = 4u,
+    PSD_SCORE_EDGES = 8u,
+    PSD_SCORE_ALL = 15u
+};
+
+/* One record per frame.  sad_* / edge_xor are relative to the previous frame (the last frame
+ * of the previous call when `prev` is given); they are 0 for a frame with no predecessor
+ * (content_detector.py:161-164).  edge_xor = number of pixels whose dilated edge map differs
+ * (the reference's delta_edges is 255*edge_xor/(H*W)).  hist is always the full 256-bin
+ * histogram of Y; cv2.calcHist with `bins` uniform bins over [0,256) is bin[j*bins/256]. */
+typedef struct psd_frame_scores {
+    uint64_t sad_h, sad_s, sad_v;
+    uint64_t edge_xor;
+    uint64_t byte_sum;
+    uint32_t hist[256];
+} psd_frame_scores; /* 1064 bytes */
+
+typedef struct psd_engine psd_engine;
+
+int psd_abi_version(void);
+const char* psd_last_error(void);
+int psd_device_count(int* count);
+
+int psd_create(int device, psd_engine** out);
+void psd_destroy(psd_engine* e);
+
+/* Score `n` frames that are already resident in device memory (HBM).
+ *   d_frames     device pointer, frame t at d_frames + t*frame_stride, rows at row_stride,
+ *                pixels packed B,G,R uint8 (detector.py:56).
+ *   d_prev       device pointer to the frame preceding frame 0, or NULL.
+ *   edge_kernel  dilation size for PSD_SCORE_EDGES (odd >= 3), or 0 for the reference's
+ *                _estimated_kernel_size(width,height) (content_detector.py:39-46).
+ *   out          host array of n records (written when the call returns).
+ *   stream       hipStream_t to launch on, or NULL for the engine's own stream.
+ * Fast path: 16-byte aligned base pointers, frame_stride % 16 == 0, row_stride == 3*width.
+ * Anything else takes a slower generic path with identical results. */
+int psd_score_batch_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width,
+                           size_t row_stride, size_t frame_stride, const uint8_t* d_prev,
+                           uint32_t flags, int edge_kernel, psd_frame_scores* out, void* stream);
+
+/* Asynchronous form: enqueue the work and the device->pinned-host copy of the records on
+ * `stream` and return.  psd_score_collect() waits for it and copies the records to `out`.
+ * At most PSD_MAX_INFLIGHT submissions may be pending; they complete in submission order. */
+#define PSD_MAX_INFLIGHT 4
+int psd_score_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width,
+                            size_t row_stride, size_t frame_stride, const uint8_t* d_prev,
+                            uint32_t flags, int edge_kernel, void* stream);
+int psd_score_collect(psd_engine* e, psd_frame_scores* out, int n);
+
+/* Same for frames in host memory: the engine stages them through its own pinned/device
+ * buffers in bounded chunks (H2D overlapped with scoring) and carries the one-frame halo
+ * between chunks itself.  h_prev may be NULL. */
+int psd_score_batch(psd_engine* e, const uint8_t* h_frames, int n, int height, int width,
+                    size_t row_stride, size_t frame_stride, const uint8_t* h_prev, uint32_t flags,
+                    int edge_kernel, psd_frame_scores* out);
+
+/* Device time (ms, HIP events on the launch stream) spent in the scoring kernels of the most
+ * recently *collected* submission, and the number of kernel launches it took. */
+int psd_last_kernel_ms(psd_engine* e, float* ms, int* launches);
+
+/* Raw device buffer helpers so hosts without their own allocator (plain C, ctypes) can keep
+ * batches resident in HBM. */
+int psd_device_alloc(psd_engine* e, size_t bytes, void** d_ptr);
+int psd_device_free(psd_engine* e, void* d_ptr);
+int psd_memcpy_h2d(psd_engine* e, void* d_dst, const void* h_src, size_t bytes);
+int psd_memcpy_d2h(psd_engine* e, void* h_dst, const void* d_src, size_t bytes);
+
+/* The device's fixed-point HSV tables (for validation against the oracle). */
+int psd_hsv_tables(int32_t sdiv[256], int32_t hdiv180[256]);
+
+/* Debug/validation: dilated Canny edge map (0/255 per pixel, uint8[H*W], host) of one
+ * device-resident frame, exactly as PSD_SCORE_EDGES computes it. */
+int psd_edge_map_device(psd_engine* e, const uint8_t* d_frame, int height, int width,
+                        size_t row_stride, int edge_kernel, uint8_t* h_edges);
+
+/* cv2.resize(src,(dst_w,dst_h),INTER_LINEAR) for n device-resident BGR frames (packed rows). */
+int psd_resize_linear_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w,
+                             size_t src_frame_stride, uint8_t* d_dst, int dst_h, int dst_w,
+                             size_t dst_frame_stride, void* stream);
+
+/* ---- host epilogues (no device involved) -------------------------------------------------
+ * Frame positions are frame numbers first_frame .. first_frame+n-1 at a constant frame rate
+ * fps_num/fps_den.  min_scene_len is given either in frames (min_len_frames >= 0 and
+ * min_len_secs < 0) or in seconds (min_len_secs >= 0), like the reference's TimecodeLike.
+ * Cut frame numbers are written to cuts[0..*n_cuts) (capacity n+1). */
+
+typedef struct psd_content_params {
+    double threshold;        /* ContentDetector(threshold=27.0) */
+    double weights[4];       /* Components(delta_hue, delta_sat, delta_lum, delta_edges) */
+    int filter_mode;         /* 0 = MERGE, 1 = SUPPRESS (detector.py:109-115) */
+    int64_t min_len_frames;
+    double min_len_secs;
+} psd_content_params;
+
+/* content_val[t] and the four components (any output pointer may be NULL).
+ * first_has_prev: 0 if recs[0] is the first frame of the video (score 0.0). */
+int psd_epilogue_content_scores(const psd_frame_scores* recs, int n, int height, int width,
+                                const double weights[4], int first_has_prev, double* content_val,
+                                double* delta_hue, double* delta_sat, double* delta_lum,
+                                double* delta_edges);
+
+int psd_epilogue_content_cuts(const double* content_val, int n, int64_t first_frame, int64_t fps_num,
+                              int64_t fps_den, const psd_content_params* p, int64_t* cuts,
+                              int* n_cuts);
+
+typedef struct psd_adaptive_params {
+    double adaptive_threshold; /* 3.0 */
+    double min_content_val;    /* 15.0 */
+    int window_width;          /* 2 */
+    int64_t min_len_frames;
+    double min_len_secs;
+} psd_adaptive_params;
+
+int psd_epilogue_adaptive_cuts(const double* content_val, int n, int64_t first_frame, int64_t fps_num,
+                               int64_t fps_den, const psd_adaptive_params* p, double* adaptive_ratio,
+                               int64_t* cuts, int* n_cuts);
+
+typedef struct psd_hist_params {
+    double threshold; /* HistogramDetector(threshold=0.20): cut iff correl <= 1-threshold */
+    int bins;         /* 128 */
+    int64_t min_len_frames;
+    double min_len_secs;
+} psd_hist_params;
+
+/* hist_diff[t] (t>=1, or t>=0 when prev_rec != NULL) = compareHist(CORREL) of the L2-normalised
+ * `bins`-bin histograms of consecutive frames. */
+int psd_epilogue_hist_cuts(const psd_frame_scores* recs, int n, const psd_frame_scores* prev_rec,
+                           int64_t first_frame, int64_t fps_num, int64_t fps_den,
+                           const psd_hist_params* p, double* hist_diff, int64_t* cuts, int* n_cuts);
+
+typedef struct psd_threshold_params {
+    int threshold;       /* int(threshold), default 12 */
+    int method;          /* 0 = FLOOR, 1 = CEILING */
+    double fade_bias;    /* 0.0 */
+    int add_final_scene; /* 0 */
+    int64_t min_len_frames;
+    double min_len_secs;
+} psd_threshold_params;
+
+/* Runs process_frame over all n frames and then post_process(last frame). */
+int psd_epilogue_threshold_cuts(const psd_frame_scores* recs, int n, int height, int width,
+                                int64_t first_frame, int64_t fps_num, int64_t fps_den,
+                                const psd_threshold_params* p, double* average_rgb, int64_t* cuts,
+                                int* n_cuts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSD_ENGINE_H */

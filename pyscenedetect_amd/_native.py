@@ -1,0 +1,168 @@
+"""ctypes binding of the C-ABI in ``include/psd_engine.h`` (``libpsd_hip.so``).
+
+There is deliberately no CPU fallback: if the HIP library is missing, or no GPU is visible when
+an engine is created, this raises.  The reference has no FFI of its own; the functions bound here
+replace the cv2/numpy pixel arithmetic of the four ``process_frame()`` loops (see the header).
+"""
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsd_hip.so")
+
+PSD_OK = 0
+PSD_ERR_INVALID = -1
+PSD_ERR_NO_DEVICE = -2
+PSD_ERR_HIP = -3
+PSD_ERR_UNSUPPORTED = -4
+PSD_ERR_NOMEM = -5
+
+SCORE_HSV_SAD = 1
+SCORE_LUMA_HIST = 2
+SCORE_BYTE_SUM = 4
+SCORE_EDGES = 8
+SCORE_ALL = 15
+
+MAX_INFLIGHT = 4
+
+#: numpy view of ``psd_frame_scores`` (1064 bytes).
+RECORD_DTYPE = np.dtype(
+    [
+        ("sad_h", "<u8"),
+        ("sad_s", "<u8"),
+        ("sad_v", "<u8"),
+        ("edge_xor", "<u8"),
+        ("byte_sum", "<u8"),
+        ("hist", "<u4", (256,)),
+    ]
+)
+assert RECORD_DTYPE.itemsize == 1064
+
+
+class ContentParams(ctypes.Structure):
+    _fields_ = [
+        ("threshold", ctypes.c_double),
+        ("weights", ctypes.c_double * 4),
+        ("filter_mode", ctypes.c_int),
+        ("min_len_frames", ctypes.c_int64),
+        ("min_len_secs", ctypes.c_double),
+    ]
+
+
+class AdaptiveParams(ctypes.Structure):
+    _fields_ = [
+        ("adaptive_threshold", ctypes.c_double),
+        ("min_content_val", ctypes.c_double),
+        ("window_width", ctypes.c_int),
+        ("min_len_frames", ctypes.c_int64),
+        ("min_len_secs", ctypes.c_double),
+    ]
+
+
+class HistParams(ctypes.Structure):
+    _fields_ = [
+        ("threshold", ctypes.c_double),
+        ("bins", ctypes.c_int),
+        ("min_len_frames", ctypes.c_int64),
+        ("min_len_secs", ctypes.c_double),
+    ]
+
+
+class ThresholdParams(ctypes.Structure):
+    _fields_ = [
+        ("threshold", ctypes.c_int),
+        ("method", ctypes.c_int),
+        ("fade_bias", ctypes.c_double),
+        ("add_final_scene", ctypes.c_int),
+        ("min_len_frames", ctypes.c_int64),
+        ("min_len_secs", ctypes.c_double),
+    ]
+
+
+#: name -> (restype, argtypes); every symbol ``include/psd_engine.h`` declares.
+_vp, _sz, _i, _u32, _i64, _f = (
+    ctypes.c_void_p,
+    ctypes.c_size_t,
+    ctypes.c_int,
+    ctypes.c_uint32,
+    ctypes.c_int64,
+    ctypes.c_float,
+)
+_P = ctypes.POINTER
+SYMBOLS = {
+    "psd_abi_version": (_i, []),
+    "psd_last_error": (ctypes.c_char_p, []),
+    "psd_device_count": (_i, [_P(_i)]),
+    "psd_create": (_i, [_i, _P(_vp)]),
+    "psd_destroy": (None, [_vp]),
+    "psd_score_batch_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _u32, _i, _vp, _vp]),
+    "psd_score_submit_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _u32, _i, _vp]),
+    "psd_score_collect": (_i, [_vp, _vp, _i]),
+    "psd_score_batch": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _u32, _i, _vp]),
+    "psd_last_kernel_ms": (_i, [_vp, _P(_f), _P(_i)]),
+    "psd_device_alloc": (_i, [_vp, _sz, _P(_vp)]),
+    "psd_device_free": (_i, [_vp, _vp]),
+    "psd_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "psd_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "psd_hsv_tables": (_i, [_vp, _vp]),
+    "psd_edge_map_device": (_i, [_vp, _vp, _i, _i, _sz, _i, _vp]),
+    "psd_resize_linear_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _sz, _vp]),
+    "psd_epilogue_content_scores": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "psd_epilogue_content_cuts": (_i, [_vp, _i, _i64, _i64, _i64, _P(ContentParams), _vp, _P(_i)]),
+    "psd_epilogue_adaptive_cuts": (_i, [_vp, _i, _i64, _i64, _i64, _P(AdaptiveParams), _vp, _vp, _P(_i)]),
+    "psd_epilogue_hist_cuts": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _P(HistParams), _vp, _vp, _P(_i)]),
+    "psd_epilogue_threshold_cuts": (_i, [_vp, _i, _i, _i, _i64, _i64, _i64, _P(ThresholdParams), _vp, _vp, _P(_i)]),
+}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    """libpsd_hip.so is missing or unusable.  There is no CPU fallback."""
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C pyscenedetect_amd/csrc`).  pyscenedetect_amd has no CPU fallback."
+        )
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as ex:  # e.g. libamdhip64 missing
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {ex}") from ex
+    for name, (restype, argtypes) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as ex:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from ex
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.psd_abi_version() != 1:
+        raise NativeLibraryError(f"ABI version mismatch: library has {lib.psd_abi_version()}, binding wants 1")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load().psd_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Map a psd_status to the Python exception the reference would raise for the same fault."""
+    if rc == PSD_OK:
+        return
+    msg = last_error()
+    if rc == PSD_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == PSD_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == PSD_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(f"psd error {rc}: {msg}")

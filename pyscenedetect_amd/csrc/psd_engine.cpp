@@ -1,0 +1,447 @@
+// psd_engine.cpp -- C-ABI engine around the HIP scoring kernels (include/psd_engine.h).
+//
+// Owns: one HIP device, one stream, the fixed-point HSV tables in device memory, a small ring
+// of record slots (device buffer + pinned host mirror + timing events) so submissions can be
+// pipelined, and a pair of device staging buffers for callers that hand over host frames.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "psd_internal.h"
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+extern "C" void psd_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            psd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PSD_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+namespace psd {
+// psd_edge_kernels.hip
+int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
+                size_t frame_stride, const uint8_t* d_prev, int edge_kernel, psd_frame_scores* d_out,
+                hipStream_t stream);
+int edges_map(psd_engine* e, const uint8_t* d_frame, int height, int width, size_t row_stride,
+              int edge_kernel, uint8_t* h_edges);
+void edges_release(psd_engine* e);
+int resize_linear(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride,
+                  uint8_t* d_dst, int dst_h, int dst_w, size_t dst_frame_stride, hipStream_t stream);
+}  // namespace psd
+
+struct psd_slot {
+    psd_frame_scores* d_recs = nullptr;
+    psd_frame_scores* h_recs = nullptr;  // pinned
+    int cap = 0;
+    int n = 0;
+    bool pending = false;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
+    int launches = 0;
+};
+
+struct psd_engine {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    uint32_t* d_lut = nullptr;
+    psd_slot slots[PSD_MAX_INFLIGHT];
+    int head = 0;   // next slot to submit into
+    int tail = 0;   // next slot to collect
+    int pending = 0;
+    float last_ms = 0.f;
+    int last_launches = 0;
+    uint8_t* d_stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    void* edge_ws = nullptr;  // owned by psd_edge_kernels.hip
+    size_t edge_ws_bytes = 0;
+};
+
+static void fill_tables(int32_t* sdiv, int32_t* hdiv)
+{
+    // OpenCV RGB2HSV_b tables: saturate_cast<int>(double) rounds half to even (lrint).
+    sdiv[0] = hdiv[0] = 0;
+    for (int i = 1; i < 256; i++) {
+        sdiv[i] = (int32_t)lrint((255 << 12) / (1. * i));
+        hdiv[i] = (int32_t)lrint((180 << 12) / (6. * i));
+    }
+}
+
+static int ensure_slot(psd_engine* e, psd_slot& s, int n)
+{
+    if (s.cap >= n) return PSD_OK;
+    int cap = n < 64 ? 64 : n;
+    if (s.d_recs) HIP_TRY(hipFree(s.d_recs));
+    if (s.h_recs) HIP_TRY(hipHostFree(s.h_recs));
+    s.d_recs = nullptr; s.h_recs = nullptr; s.cap = 0;
+    HIP_TRY(hipMalloc((void**)&s.d_recs, (size_t)cap * sizeof(psd_frame_scores)));
+    HIP_TRY(hipHostMalloc((void**)&s.h_recs, (size_t)cap * sizeof(psd_frame_scores), hipHostMallocDefault));
+    s.cap = cap;
+    (void)e;
+    return PSD_OK;
+}
+
+extern "C" {
+
+int psd_abi_version(void) { return PSD_ABI_VERSION; }
+
+const char* psd_last_error(void) { return g_err; }
+
+int psd_device_count(int* count)
+{
+    if (!count) { psd_set_error("psd_device_count: null argument"); return PSD_ERR_INVALID; }
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess) {
+        *count = 0;
+        psd_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(err));
+        return PSD_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return PSD_OK;
+}
+
+int psd_hsv_tables(int32_t sdiv[256], int32_t hdiv180[256])
+{
+    if (!sdiv || !hdiv180) { psd_set_error("psd_hsv_tables: null argument"); return PSD_ERR_INVALID; }
+    fill_tables(sdiv, hdiv180);
+    return PSD_OK;
+}
+
+int psd_create(int device, psd_engine** out)
+{
+    if (!out) { psd_set_error("psd_create: null out"); return PSD_ERR_INVALID; }
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        psd_set_error("psd_create: no HIP device available");
+        return PSD_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        psd_set_error("psd_create: device %d out of range (have %d)", device, count);
+        return PSD_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(device));
+    psd_engine* e = new (std::nothrow) psd_engine();
+    if (!e) { psd_set_error("psd_create: out of memory"); return PSD_ERR_NOMEM; }
+    e->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) e->num_cus = prop.multiProcessorCount;
+    int rc = PSD_OK;
+    do {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { rc = PSD_ERR_HIP; break; }
+        if (hipMalloc((void**)&e->d_lut, 512 * sizeof(uint32_t)) != hipSuccess) { rc = PSD_ERR_HIP; break; }
+        int32_t tab[512];
+        fill_tables(tab, tab + 256);
+        if (hipMemcpy(e->d_lut, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) { rc = PSD_ERR_HIP; break; }
+        for (auto& s : e->slots) {
+            if (hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess ||
+                hipEventCreate(&s.ev_done) != hipSuccess) { rc = PSD_ERR_HIP; break; }
+        }
+    } while (0);
+    if (rc != PSD_OK) {
+        psd_set_error("psd_create: HIP resource creation failed: %s", hipGetErrorString(hipGetLastError()));
+        psd_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return PSD_OK;
+}
+
+void psd_destroy(psd_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    psd::edges_release(e);
+    for (auto& s : e->slots) {
+        if (s.d_recs) (void)hipFree(s.d_recs);
+        if (s.h_recs) (void)hipHostFree(s.h_recs);
+        if (s.ev_start) (void)hipEventDestroy(s.ev_start);
+        if (s.ev_stop) (void)hipEventDestroy(s.ev_stop);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+    }
+    for (auto& d : e->d_stage) if (d) (void)hipFree(d);
+    if (e->d_lut) (void)hipFree(e->d_lut);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+static int validate(const void* frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
+                    uint32_t flags, int edge_kernel)
+{
+    if (n < 0 || height <= 0 || width <= 0) {
+        psd_set_error("invalid batch shape n=%d height=%d width=%d", n, height, width);
+        return PSD_ERR_INVALID;
+    }
+    if (n > 0 && !frames) { psd_set_error("frames pointer is null"); return PSD_ERR_INVALID; }
+    if (row_stride < (size_t)width * 3) {
+        psd_set_error("row_stride %zu smaller than width*3 = %zu", row_stride, (size_t)width * 3);
+        return PSD_ERR_INVALID;
+    }
+    if (n > 1 && frame_stride < (size_t)(height - 1) * row_stride + (size_t)width * 3) {
+        psd_set_error("frame_stride %zu smaller than one frame", frame_stride);
+        return PSD_ERR_INVALID;
+    }
+    if ((flags & ~(uint32_t)PSD_SCORE_ALL) || flags == 0) {
+        psd_set_error("invalid flags 0x%x", flags);
+        return PSD_ERR_INVALID;
+    }
+    if ((flags & PSD_SCORE_EDGES) && edge_kernel != 0 && (edge_kernel < 3 || edge_kernel % 2 == 0)) {
+        psd_set_error("kernel_size must be odd integer >= 3");
+        return PSD_ERR_INVALID;
+    }
+    if ((long long)height * width > 0x7fffffffLL / 4) {
+        psd_set_error("frame too large");
+        return PSD_ERR_UNSUPPORTED;
+    }
+    return PSD_OK;
+}
+
+int psd_score_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width,
+                            size_t row_stride, size_t frame_stride, const uint8_t* d_prev,
+                            uint32_t flags, int edge_kernel, void* stream_)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    int rc = validate(d_frames, n, height, width, row_stride, frame_stride, flags, edge_kernel);
+    if (rc != PSD_OK) return rc;
+    if (e->pending >= PSD_MAX_INFLIGHT) {
+        psd_set_error("too many submissions in flight (max %d); call psd_score_collect", PSD_MAX_INFLIGHT);
+        return PSD_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : e->stream;
+    psd_slot& s = e->slots[e->head];
+    rc = ensure_slot(e, s, n);
+    if (rc != PSD_OK) return rc;
+    s.n = n;
+    s.launches = 0;
+    if (n > 0) {
+        HIP_TRY(hipMemsetAsync(s.d_recs, 0, (size_t)n * sizeof(psd_frame_scores), stream));
+        HIP_TRY(hipEventRecord(s.ev_start, stream));
+        const bool hsv = flags & PSD_SCORE_HSV_SAD;
+        const bool luma = flags & (PSD_SCORE_LUMA_HIST | PSD_SCORE_BYTE_SUM);
+        if (hsv || luma) {
+            psd::ScoreParams p{};
+            p.frames = d_frames;
+            p.prev = d_prev;
+            p.out = s.d_recs;
+            p.lut = e->d_lut;
+            p.frame_stride = frame_stride;
+            p.row_stride = row_stride;
+            p.npix = (long)height * width;
+            p.width = width;
+            p.n = n;
+            const bool fast = row_stride == (size_t)width * 3 && ((uintptr_t)d_frames % 16 == 0) &&
+                              (frame_stride % 16 == 0 || n == 1) && (!d_prev || (uintptr_t)d_prev % 16 == 0);
+            // ~8 workgroups per CU over the launch keeps the tail short (one 1024-thread WG per CU).
+            HIP_TRY(psd::launch_score_frames(p, hsv, luma, fast, e->num_cus * 8, stream, &s.launches));
+        }
+        if (flags & PSD_SCORE_EDGES) {
+            rc = psd::edges_score(e, d_frames, n, height, width, row_stride, frame_stride, d_prev, edge_kernel,
+                                  s.d_recs, stream);
+            if (rc != PSD_OK) return rc;
+        }
+        HIP_TRY(hipEventRecord(s.ev_stop, stream));
+        HIP_TRY(hipMemcpyAsync(s.h_recs, s.d_recs, (size_t)n * sizeof(psd_frame_scores), hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipEventRecord(s.ev_done, stream));
+    s.pending = true;
+    e->head = (e->head + 1) % PSD_MAX_INFLIGHT;
+    e->pending++;
+    return PSD_OK;
+}
+
+int psd_score_collect(psd_engine* e, psd_frame_scores* out, int n)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    if (e->pending <= 0) { psd_set_error("psd_score_collect: nothing submitted"); return PSD_ERR_INVALID; }
+    psd_slot& s = e->slots[e->tail];
+    if (n != s.n || (n > 0 && !out)) {
+        psd_set_error("psd_score_collect: expected n=%d records, caller asked for %d", s.n, n);
+        return PSD_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    hipError_t err = hipEventSynchronize(s.ev_done);
+    s.pending = false;
+    e->tail = (e->tail + 1) % PSD_MAX_INFLIGHT;
+    e->pending--;
+    if (err != hipSuccess) {
+        psd_set_error("scoring failed on device: %s", hipGetErrorString(err));
+        return PSD_ERR_HIP;
+    }
+    if (n > 0) {
+        memcpy(out, s.h_recs, (size_t)n * sizeof(psd_frame_scores));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.ev_start, s.ev_stop) == hipSuccess) e->last_ms = ms;
+        e->last_launches = s.launches;
+    } else {
+        e->last_ms = 0.f;
+        e->last_launches = 0;
+    }
+    return PSD_OK;
+}
+
+int psd_score_batch_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width,
+                           size_t row_stride, size_t frame_stride, const uint8_t* d_prev,
+                           uint32_t flags, int edge_kernel, psd_frame_scores* out, void* stream)
+{
+    if (e && e->pending != 0) {
+        psd_set_error("psd_score_batch_device: asynchronous submissions are still pending");
+        return PSD_ERR_INVALID;
+    }
+    int rc = psd_score_submit_device(e, d_frames, n, height, width, row_stride, frame_stride, d_prev, flags,
+                                     edge_kernel, stream);
+    if (rc != PSD_OK) return rc;
+    return psd_score_collect(e, out, n);
+}
+
+int psd_last_kernel_ms(psd_engine* e, float* ms, int* launches)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    if (ms) *ms = e->last_ms;
+    if (launches) *launches = e->last_launches;
+    return PSD_OK;
+}
+
+int psd_score_batch(psd_engine* e, const uint8_t* h_frames, int n, int height, int width,
+                    size_t row_stride, size_t frame_stride, const uint8_t* h_prev, uint32_t flags,
+                    int edge_kernel, psd_frame_scores* out)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    int rc = validate(h_frames, n, height, width, row_stride, frame_stride, flags, edge_kernel);
+    if (rc != PSD_OK) return rc;
+    if (e->pending != 0) { psd_set_error("psd_score_batch: asynchronous submissions are still pending"); return PSD_ERR_INVALID; }
+    if (n == 0) return PSD_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t packed_row = (size_t)width * 3;
+    const size_t dstride = ((size_t)height * packed_row + 15) & ~(size_t)15;  // 16-B aligned frames
+    // Bounded staging: chunks of at most ~256 MiB (and at least one frame) per buffer, plus the
+    // halo slot [0] that keeps the previous chunk's last frame.
+    size_t per_chunk = (size_t)(256u << 20) / dstride;
+    if (per_chunk < 1) per_chunk = 1;
+    if (per_chunk > (size_t)n) per_chunk = (size_t)n;
+    const size_t need = (per_chunk + 1) * dstride;
+    if (e->stage_bytes < need) {
+        for (auto& d : e->d_stage) { if (d) HIP_TRY(hipFree(d)); d = nullptr; }
+        e->stage_bytes = 0;
+        for (auto& d : e->d_stage) HIP_TRY(hipMalloc((void**)&d, need));
+        e->stage_bytes = need;
+    }
+    auto upload = [&](uint8_t* dst, const uint8_t* src, size_t count) -> int {
+        // frames [count] from host (row_stride/frame_stride) to packed device layout
+        if (row_stride == packed_row && frame_stride == dstride) {
+            HIP_TRY(hipMemcpyAsync(dst, src, count * dstride, hipMemcpyHostToDevice, e->stream));
+        } else {
+            for (size_t i = 0; i < count; i++)
+                HIP_TRY(hipMemcpy2DAsync(dst + i * dstride, packed_row, src + i * frame_stride, row_stride,
+                                         packed_row, (size_t)height, hipMemcpyHostToDevice, e->stream));
+        }
+        return PSD_OK;
+    };
+    int done = 0, chunk_idx = 0;
+    const uint8_t* d_prev = nullptr;
+    if (h_prev) {
+        rc = upload(e->d_stage[1], h_prev, 1);  // park the halo in the *other* buffer's slot 0
+        if (rc != PSD_OK) return rc;
+        d_prev = e->d_stage[1];
+    }
+    while (done < n) {
+        const int cnt = (int)((size_t)(n - done) < per_chunk ? (size_t)(n - done) : per_chunk);
+        uint8_t* buf = e->d_stage[chunk_idx & 1] + dstride;  // slot 0 is reserved for a halo copy
+        rc = upload(buf, h_frames + (size_t)done * frame_stride, (size_t)cnt);
+        if (rc != PSD_OK) return rc;
+        rc = psd_score_batch_device(e, buf, cnt, height, width, packed_row, dstride, d_prev, flags, edge_kernel,
+                                    out + done, nullptr);
+        if (rc != PSD_OK) return rc;
+        d_prev = buf + (size_t)(cnt - 1) * dstride;
+        done += cnt;
+        chunk_idx++;
+    }
+    return PSD_OK;
+}
+
+int psd_device_alloc(psd_engine* e, size_t bytes, void** d_ptr)
+{
+    if (!e || !d_ptr) { psd_set_error("psd_device_alloc: null argument"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(e->device));
+    *d_ptr = nullptr;
+    hipError_t err = hipMalloc(d_ptr, bytes ? bytes : 1);
+    if (err != hipSuccess) {
+        psd_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+        return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
+    }
+    return PSD_OK;
+}
+
+int psd_device_free(psd_engine* e, void* d_ptr)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(e->device));
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return PSD_OK;
+}
+
+int psd_memcpy_h2d(psd_engine* e, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!e || (bytes && (!d_dst || !h_src))) { psd_set_error("psd_memcpy_h2d: null argument"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return PSD_OK;
+}
+
+int psd_memcpy_d2h(psd_engine* e, void* h_dst, const void* d_src, size_t bytes)
+{
+    if (!e || (bytes && (!h_dst || !d_src))) { psd_set_error("psd_memcpy_d2h: null argument"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return PSD_OK;
+}
+
+int psd_edge_map_device(psd_engine* e, const uint8_t* d_frame, int height, int width, size_t row_stride,
+                        int edge_kernel, uint8_t* h_edges)
+{
+    if (!e || !d_frame || !h_edges) { psd_set_error("psd_edge_map_device: null argument"); return PSD_ERR_INVALID; }
+    int rc = validate(d_frame, 1, height, width, row_stride, 0, PSD_SCORE_EDGES, edge_kernel);
+    if (rc != PSD_OK) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    return psd::edges_map(e, d_frame, height, width, row_stride, edge_kernel, h_edges);
+}
+
+int psd_resize_linear_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w,
+                             size_t src_frame_stride, uint8_t* d_dst, int dst_h, int dst_w,
+                             size_t dst_frame_stride, void* stream)
+{
+    if (!e || n < 0 || (n > 0 && (!d_src || !d_dst)) || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) {
+        psd_set_error("psd_resize_linear_device: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    return psd::resize_linear(d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride,
+                              stream ? (hipStream_t)stream : e->stream);
+}
+
+}  // extern "C"
+
+// Accessors used by psd_edge_kernels.hip (keeps the struct private to this file).
+namespace psd {
+void** engine_edge_ws(psd_engine* e) { return &e->edge_ws; }
+size_t* engine_edge_ws_bytes(psd_engine* e) { return &e->edge_ws_bytes; }
+int engine_num_cus(psd_engine* e) { return e->num_cus; }
+hipStream_t engine_stream(psd_engine* e) { return e->stream; }
+}  // namespace psd

@@ -1,0 +1,305 @@
+// psd_epilogue.cpp -- host epilogues: the O(1)-per-frame decisions that follow the pixel work.
+//
+// These replay, over whole clips of per-frame integer records, the same sequential logic the
+// reference runs inside process_frame() (paths relative to the reference tree):
+//   content   content_detector.py:177-180,192-211 and FlashFilter detector.py:106-224
+//   adaptive  adaptive_detector.py:100-143
+//   histogram histogram_detector.py:59-120,122-165 (cv2.normalize + cv2.compareHist restated)
+//   threshold threshold_detector.py:100-191
+// All floating point is IEEE double (float where OpenCV uses float) in the reference's order, so
+// metrics are bit-identical to the Python host mirror in pyscenedetect_amd/detectors/.
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "psd_engine.h"
+
+extern "C" void psd_set_error(const char* fmt, ...);
+
+namespace {
+
+// `(a - b) >= min_scene_len` on frame-number timecodes (common.py:627-638,700-755):
+// an int length compares frames; a float/str length is seconds -> round(secs * fps) frames
+// (Python round = half-to-even, as nearbyint in the default rounding mode).
+struct MinLen {
+    int64_t frames;
+    explicit MinLen(int64_t min_len_frames, double min_len_secs, double fps)
+    {
+        if (min_len_secs >= 0.0) frames = (int64_t)std::nearbyint(min_len_secs * fps);
+        else frames = min_len_frames;
+    }
+    bool met(int64_t a, int64_t b) const
+    {
+        int64_t d = a - b;
+        if (d < 0) d = 0;
+        return d >= frames;
+    }
+};
+
+double fps_of(int64_t num, int64_t den) { return (double)num / (double)den; }
+
+bool check_fps(int64_t num, int64_t den)
+{
+    if (num <= 0 || den <= 0) {
+        psd_set_error("frame rate must be positive (got %lld/%lld)", (long long)num, (long long)den);
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int psd_epilogue_content_scores(const psd_frame_scores* recs, int n, int height, int width,
+                                const double weights[4], int first_has_prev, double* content_val,
+                                double* delta_hue, double* delta_sat, double* delta_lum,
+                                double* delta_edges)
+{
+    if (!recs || n < 0 || height <= 0 || width <= 0 || !weights) {
+        psd_set_error("psd_epilogue_content_scores: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    const double num_pixels = (double)((int64_t)height * (int64_t)width);
+    const double wsum = std::fabs(weights[0]) + std::fabs(weights[1]) + std::fabs(weights[2]) + std::fabs(weights[3]);
+    for (int t = 0; t < n; t++) {
+        double dh = 0, ds = 0, dl = 0, de = 0, score = 0;
+        if (t > 0 || first_has_prev) {
+            dh = (double)recs[t].sad_h / num_pixels;
+            ds = (double)recs[t].sad_s / num_pixels;
+            dl = (double)recs[t].sad_v / num_pixels;
+            de = (double)(255 * recs[t].edge_xor) / num_pixels;
+            // sum(component*weight ...) starts from int 0 and adds left to right.
+            score = (((0.0 + dh * weights[0]) + ds * weights[1]) + dl * weights[2]) + de * weights[3];
+            score /= wsum;
+        }
+        if (content_val) content_val[t] = score;
+        if (delta_hue) delta_hue[t] = dh;
+        if (delta_sat) delta_sat[t] = ds;
+        if (delta_lum) delta_lum[t] = dl;
+        if (delta_edges) delta_edges[t] = de;
+    }
+    return PSD_OK;
+}
+
+int psd_epilogue_content_cuts(const double* content_val, int n, int64_t first_frame, int64_t fps_num,
+                              int64_t fps_den, const psd_content_params* p, int64_t* cuts, int* n_cuts)
+{
+    if (!content_val || n < 0 || !p || !cuts || !n_cuts || !check_fps(fps_num, fps_den)) {
+        if (!p || !cuts || !n_cuts || !content_val) psd_set_error("psd_epilogue_content_cuts: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    const double fps = fps_of(fps_num, fps_den);
+    int nc = 0;
+    // FlashFilter state (detector.py:127-143)
+    const bool secs_given = p->min_len_secs >= 0.0;
+    const bool disabled = secs_given ? (p->min_len_secs <= 0.0) : (p->min_len_frames <= 0);
+    // An int length is converted to seconds on the first frame (detector.py:176-177,194-195).
+    const double filter_secs = secs_given ? p->min_len_secs : (double)p->min_len_frames / fps;
+    const MinLen len(0, filter_secs, fps);
+    bool have_last_above = false, merge_enabled = false, merge_triggered = false;
+    int64_t last_above = 0, merge_start = 0;
+
+    for (int t = 0; t < n; t++) {
+        const int64_t tc = first_frame + t;
+        const bool above = content_val[t] >= p->threshold;
+        if (disabled) {
+            if (above) cuts[nc++] = tc;
+            continue;
+        }
+        if (!have_last_above) { last_above = tc; have_last_above = true; }
+        if (p->filter_mode == 1) {  // SUPPRESS
+            const bool min_length_met = len.met(tc, last_above);
+            if (above && min_length_met) { last_above = tc; cuts[nc++] = tc; }
+            continue;
+        }
+        // MERGE
+        const bool min_length_met = len.met(tc, last_above);
+        if (above) last_above = tc;
+        if (merge_triggered) {
+            if (min_length_met && !above && len.met(last_above, merge_start)) {
+                merge_triggered = false;
+                cuts[nc++] = last_above;
+            }
+            continue;
+        }
+        if (!above) continue;
+        if (min_length_met) { merge_enabled = true; cuts[nc++] = tc; continue; }
+        if (merge_enabled) { merge_triggered = true; merge_start = tc; }
+    }
+    *n_cuts = nc;
+    return PSD_OK;
+}
+
+int psd_epilogue_adaptive_cuts(const double* content_val, int n, int64_t first_frame, int64_t fps_num,
+                               int64_t fps_den, const psd_adaptive_params* p, double* adaptive_ratio,
+                               int64_t* cuts, int* n_cuts)
+{
+    if (!content_val || n < 0 || !p || !cuts || !n_cuts || p->window_width < 1 || !check_fps(fps_num, fps_den)) {
+        psd_set_error("psd_epilogue_adaptive_cuts: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    const double fps = fps_of(fps_num, fps_den);
+    const MinLen len(p->min_len_frames, p->min_len_secs, fps);
+    const int w = p->window_width;
+    const int required = 1 + 2 * w;
+    int nc = 0;
+    if (adaptive_ratio)
+        for (int t = 0; t < n; t++) adaptive_ratio[t] = NAN;  // no metric for the first/last w frames
+    int64_t last_cut = first_frame;
+    for (int t = 0; t < n; t++) {
+        if (t + 1 < required) continue;
+        const int lo = t - required + 1;  // buffer = content_val[lo .. t]
+        const int target = lo + w;
+        const double target_score = content_val[target];
+        double sum = 0.0;  // Python sum(): int 0 then left to right
+        for (int i = lo; i <= t; i++)
+            if (i != target) sum = sum + content_val[i];
+        const double avg = sum / (2.0 * w);
+        const bool average_is_zero = std::fabs(avg) < 0.00001;
+        double ratio = 0.0;
+        if (!average_is_zero) ratio = std::fmin(target_score / avg, 255.0);
+        else if (target_score >= p->min_content_val) ratio = 255.0;
+        if (adaptive_ratio) adaptive_ratio[target] = ratio;
+        const bool threshold_met = ratio >= p->adaptive_threshold && target_score >= p->min_content_val;
+        const bool min_length_met = len.met(first_frame + t, last_cut);
+        if (threshold_met && min_length_met) {
+            last_cut = first_frame + target;
+            cuts[nc++] = first_frame + target;
+        }
+    }
+    *n_cuts = nc;
+    return PSD_OK;
+}
+
+// cv2.calcHist LUT + cv2.normalize(NORM_L2) of one record's luma histogram.
+static void normalized_hist(const psd_frame_scores& r, int bins, const int* lut, float* out)
+{
+    std::vector<uint64_t> cnt((size_t)bins, 0);
+    for (int j = 0; j < 256; j++) cnt[(size_t)lut[j]] += r.hist[j];
+    double ss = 0.0;
+    for (int i = 0; i < bins; i++) {
+        out[i] = (float)cnt[(size_t)i];  // exact below 2^24, a single rounding above (as OpenCV's int->f32)
+        ss += (double)out[i] * (double)out[i];
+    }
+    const double nrm = std::sqrt(ss);
+    const float scale = (float)(nrm > DBL_EPSILON ? 1.0 / nrm : 0.0);
+    for (int i = 0; i < bins; i++) out[i] = out[i] * scale;
+}
+
+// cv2.compareHist(HISTCMP_CORREL): double sums in the lane order of OpenCV's 2-lane f64 SIMD
+// (x86-64 baseline): even and odd elements accumulate separately over the multiple-of-4 body.
+static double correl(const float* h1, const float* h2, int n)
+{
+    double s1[2] = {0, 0}, s2[2] = {0, 0}, s11[2] = {0, 0}, s12[2] = {0, 0}, s22[2] = {0, 0};
+    int j = 0;
+    for (; j <= n - 4; j += 4)
+        for (int k = 0; k < 4; k++) {
+            const double a = h1[j + k], b = h2[j + k];
+            const int l = k & 1;
+            s12[l] += a * b; s11[l] += a * a; s22[l] += b * b; s1[l] += a; s2[l] += b;
+        }
+    double S1 = s1[0] + s1[1], S2 = s2[0] + s2[1], S11 = s11[0] + s11[1], S12 = s12[0] + s12[1],
+           S22 = s22[0] + s22[1];
+    for (; j < n; j++) {
+        const double a = h1[j], b = h2[j];
+        S12 += a * b; S1 += a; S11 += a * a; S2 += b; S22 += b * b;
+    }
+    const double scale = 1. / n;
+    const double num = S12 - S1 * S2 * scale;
+    const double denom2 = (S11 - S1 * S1 * scale) * (S22 - S2 * S2 * scale);
+    return std::fabs(denom2) > DBL_EPSILON ? num / std::sqrt(denom2) : 1.;
+}
+
+int psd_epilogue_hist_cuts(const psd_frame_scores* recs, int n, const psd_frame_scores* prev_rec,
+                           int64_t first_frame, int64_t fps_num, int64_t fps_den,
+                           const psd_hist_params* p, double* hist_diff, int64_t* cuts, int* n_cuts)
+{
+    if (!recs || n < 0 || !p || !cuts || !n_cuts || p->bins < 1 || p->bins > 256 || !check_fps(fps_num, fps_den)) {
+        psd_set_error("psd_epilogue_hist_cuts: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    const double fps = fps_of(fps_num, fps_den);
+    const MinLen len(p->min_len_frames, p->min_len_secs, fps);
+    const double thr = std::fmax(0.0, std::fmin(1.0, 1.0 - p->threshold));
+    int lut[256];
+    for (int j = 0; j < 256; j++) {
+        int idx = (int)std::floor(j * (p->bins / 256.0));
+        lut[j] = idx < 0 ? 0 : (idx > p->bins - 1 ? p->bins - 1 : idx);
+    }
+    std::vector<float> a((size_t)p->bins), b((size_t)p->bins);
+    float* last = a.data();
+    float* cur = b.data();
+    bool have_last = false;
+    if (prev_rec) { normalized_hist(*prev_rec, p->bins, lut, last); have_last = true; }
+    int nc = 0;
+    int64_t last_cut = first_frame - (prev_rec ? 1 : 0);
+    for (int t = 0; t < n; t++) {
+        const int64_t tc = first_frame + t;
+        normalized_hist(recs[t], p->bins, lut, cur);
+        double d = NAN;
+        if (have_last) {
+            d = correl(last, cur, p->bins);
+            if (d <= thr && len.met(tc, last_cut)) { cuts[nc++] = tc; last_cut = tc; }
+        }
+        if (hist_diff) hist_diff[t] = d;
+        float* tmp = last; last = cur; cur = tmp;
+        have_last = true;
+    }
+    *n_cuts = nc;
+    return PSD_OK;
+}
+
+int psd_epilogue_threshold_cuts(const psd_frame_scores* recs, int n, int height, int width,
+                                int64_t first_frame, int64_t fps_num, int64_t fps_den,
+                                const psd_threshold_params* p, double* average_rgb, int64_t* cuts,
+                                int* n_cuts)
+{
+    if (!recs || n < 0 || height <= 0 || width <= 0 || !p || !cuts || !n_cuts || !check_fps(fps_num, fps_den)) {
+        psd_set_error("psd_epilogue_threshold_cuts: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    const double fps = fps_of(fps_num, fps_den);
+    const MinLen len(p->min_len_frames, p->min_len_secs, fps);
+    const double count = (double)((int64_t)height * (int64_t)width * 3);
+    const double thr = (double)p->threshold;
+    int nc = 0;
+    bool processed = false;
+    int fade_type = -1;  // 0 = in, 1 = out
+    int64_t fade_frame = 0, last_scene_cut = first_frame;
+    for (int t = 0; t < n; t++) {
+        const int64_t tc = first_frame + t;
+        const double avg = (double)recs[t].byte_sum / count;  // numpy.mean: exact sum, one divide
+        if (average_rgb) average_rgb[t] = avg;
+        const bool below = avg < thr;
+        if (processed) {
+            const bool out_now = (p->method == 0) ? below : !below;
+            if (fade_type == 0 && out_now) {
+                fade_type = 1; fade_frame = tc;
+            } else if (fade_type == 1 && !out_now) {
+                if (len.met(tc, last_scene_cut)) {
+                    const int64_t duration = tc - fade_frame;
+                    const int64_t split = fade_frame + (int64_t)std::nearbyint((double)duration * (1.0 + p->fade_bias) / 2.0);
+                    cuts[nc++] = split;
+                    last_scene_cut = tc;
+                }
+                fade_type = 0; fade_frame = tc;
+            }
+        } else {
+            fade_frame = tc;
+            fade_type = below ? 1 : 0;  // first frame always compares with `<` (threshold_detector.py:161-165)
+        }
+        processed = true;
+    }
+    // post_process(last position)
+    if (n > 0 && fade_type == 1 && p->add_final_scene) {
+        const int64_t tc = first_frame + n - 1;
+        if (len.met(tc, last_scene_cut)) cuts[nc++] = fade_frame;
+    }
+    *n_cuts = nc;
+    return PSD_OK;
+}
+
+}  // extern "C"

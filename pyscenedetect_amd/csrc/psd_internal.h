@@ -1,0 +1,43 @@
+// psd_internal.h -- shared declarations between the kernels and the C-ABI engine.
+#ifndef PSD_INTERNAL_H
+#define PSD_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "psd_engine.h"
+
+namespace psd {
+
+constexpr int kScoreWG = 1024;  // threads per workgroup of the scoring kernel (16 waves)
+constexpr int kScoreG = 1;      // 16-pixel groups per lane per frame
+
+struct ScoreParams {
+    const uint8_t* frames;   // device, frame t at frames + t*frame_stride
+    const uint8_t* prev;     // device, frame preceding frame 0, or nullptr
+    psd_frame_scores* out;   // device, n records, zero-initialised
+    const uint32_t* lut;     // device, [0..255] = sdiv, [256..511] = hdiv180
+    size_t frame_stride;
+    size_t row_stride;
+    long npix;               // height*width
+    int width;
+    int n;
+    // filled in by the launcher
+    int group_begin;         // 16-px groups [group_begin, group_end) of every frame
+    int group_end;
+    int n_tiles;
+    int groups_per_tile;
+    int frames_per_chunk;
+};
+
+hipError_t launch_score_frames(ScoreParams p, bool hsv, bool luma, bool fast, int target_blocks,
+                               hipStream_t stream, int* launches);
+
+// Edge term (Canny + dilate + XOR count); psd_edge_kernels.hip.
+struct EdgeWorkspace;
+size_t edge_workspace_bytes(int height, int width, int frames_per_pass);
+
+}  // namespace psd
+
+#endif

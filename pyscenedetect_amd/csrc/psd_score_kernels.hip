@@ -1,0 +1,385 @@
+// psd_score_kernels.hip -- fused per-frame scoring kernels for gfx950 (MI355X, CDNA4).
+//
+// One pass over packed BGR frames produces, per frame, the exact integer reductions that
+// PySceneDetect's detectors derive from cv2/numpy (reference paths relative to its tree):
+//   sad_h/s/v : sum |HSV_t - HSV_{t-1}|     content_detector.py:29-36,155,166-169
+//   hist[256] : histogram of BT.601 luma Y   histogram_detector.py:156-159
+//   byte_sum  : sum of all B,G,R bytes       threshold_detector.py:127
+//
+// Design:
+//  * A workgroup owns a fixed spatial tile of the frame and WALKS THE TIME AXIS over a chunk of
+//    T frames, carrying the previous frame's H,S,V for its pixels in registers (packed 4 px per
+//    dword).  Every pixel of the batch is therefore read from HBM once (3 B/px algorithmic) and
+//    converted to HSV once; only the one halo frame in front of each chunk is read twice.
+//  * A lane handles groups of 16 pixels = 48 contiguous bytes = three dwordx4 loads.
+//  * The two fixed-point division tables of the 8-bit HSV conversion live in LDS, replicated 32x
+//    so that lane l always reads bank l%32 (conflict-free for any data; a wave64 ds_read_b32 is
+//    serviced in two 32-lane groups).  The luma histogram is replicated the same way, so the
+//    LDS atomics never collide -- flat frames (all pixels in one bin) cost the same as noise.
+//  * Per-frame results leave the workgroup as one global atomic per non-empty bin / sum.
+//    Everything is integer, so the result is independent of scheduling order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "psd_internal.h"
+
+namespace psd {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int COPIES = 32;           // replication factor of LUTs / accumulators (= b32 LDS banks)
+constexpr int NACC = 260;            // 256 luma bins + sad_h, sad_s, sad_v, byte_sum
+constexpr int ACC_SAD_H = 256, ACC_SAD_S = 257, ACC_SAD_V = 258, ACC_BYTES = 259;
+
+// BT.601 luma in OpenCV's 14-bit fixed point (color_yuv.simd.hpp RGB2YCrCb_i).
+constexpr u32 kB2Y = 1868, kG2Y = 9617, kR2Y = 4899;
+
+struct Group {
+    u32 w[12];  // 16 packed BGR pixels
+};
+struct Hsv16 {
+    u32 h[4], s[4], v[4];  // 4 pixels per dword
+};
+
+// 24-bit multiply-adds, pinned to the full-rate VALU forms (left to itself hipcc widens the hue
+// product to a quarter-rate v_mad_u64_u32).  All operands are provably within 24 bits:
+// |hraw| <= 1275, hdiv180 <= 122880, diff <= 255, sdiv <= 1044480, BGR coefficients < 2^14.
+__device__ __forceinline__ int mad_i24(int a, int b, int c)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ u32 mad_u24(u32 a, u32 b, u32 c)
+{
+    u32 d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// ---- loads ---------------------------------------------------------------------------------
+
+template <bool FAST>
+__device__ __forceinline__ void load_group(const ScoreParams& p, const uint8_t* __restrict__ frame,
+                                           int group, Group& g)
+{
+    if (FAST) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(frame + (size_t)group * 48);
+        u32x4 a = __builtin_nontemporal_load(src + 0);
+        u32x4 b = __builtin_nontemporal_load(src + 1);
+        u32x4 c = __builtin_nontemporal_load(src + 2);
+        g.w[0] = a.x; g.w[1] = a.y; g.w[2] = a.z; g.w[3] = a.w;
+        g.w[4] = b.x; g.w[5] = b.y; g.w[6] = b.z; g.w[7] = b.w;
+        g.w[8] = c.x; g.w[9] = c.y; g.w[10] = c.z; g.w[11] = c.w;
+        return;
+    }
+    // Generic path: any alignment, padded rows, ragged tail.  Pixels past the end read as 0.
+    const int first_px = group * 16;
+#pragma unroll
+    for (int i = 0; i < 12; i++) g.w[i] = 0;
+#pragma unroll 1
+    for (int j = 0; j < 16; j++) {
+        const int px = first_px + j;
+        if (px < p.npix) {
+            const int row = px / p.width, col = px - row * p.width;
+            const uint8_t* s = frame + (size_t)row * p.row_stride + (size_t)col * 3;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int bi = 3 * j + c;
+                g.w[bi >> 2] |= (u32)s[c] << ((bi & 3) * 8);
+            }
+        }
+    }
+}
+
+// ---- per-group arithmetic ------------------------------------------------------------------
+
+// 8-bit BGR -> HSV exactly as OpenCV's RGB2HSV_b (hsv_shift = 12, hue range 180), plus luma
+// histogram and byte sum.  lut_s/lut_h/hist are already offset by the lane's replica index.
+template <bool HSV, bool LUMA>
+__device__ __forceinline__ void convert_group(const Group& g, Hsv16& o, const u32* __restrict__ lut_s,
+                                              const u32* __restrict__ lut_h, u32* __restrict__ hist,
+                                              u32& byte_sum)
+{
+    if (LUMA) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) byte_sum = __builtin_amdgcn_sad_u8(g.w[i], 0u, byte_sum);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        u32 hq = 0, sq = 0, vq = 0;
+        // The 4 pixels of this quad live in 3 dwords.  Tie them to the previous quad's results so
+        // the 16 pixels are processed quad by quad: fully interleaved (what the scheduler does when
+        // left alone) the live temporaries exceed the 128-VGPR budget of a 16-wave workgroup and
+        // spill.  Latency is hidden by the other 3 waves of the SIMD, not by ILP across quads.
+        u32 d[3] = {g.w[3 * q], g.w[3 * q + 1], g.w[3 * q + 2]};
+        if (HSV && q > 0)
+            asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]) : "v"(o.h[q - 1]), "v"(o.s[q - 1]), "v"(o.v[q - 1]));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int ib = 3 * k, ig = 3 * k + 1, ir = 3 * k + 2;
+            const u32 b = (d[ib >> 2] >> ((ib & 3) * 8)) & 0xffu;
+            const u32 gg = (d[ig >> 2] >> ((ig & 3) * 8)) & 0xffu;
+            const u32 r = (d[ir >> 2] >> ((ir & 3) * 8)) & 0xffu;
+            if (LUMA) {
+                const u32 y = mad_u24(r, kR2Y, mad_u24(gg, kG2Y, mad_u24(b, kB2Y, 8192u))) >> 14;
+                __hip_atomic_fetch_add(&hist[y * COPIES], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (HSV) {
+                const u32 v = max(max(b, gg), r);
+                const u32 vmin = min(min(b, gg), r);
+                const u32 diff = v - vmin;
+                const u32 sdiv = lut_s[v * COPIES];
+                const int hdiv = (int)lut_h[diff * COPIES];
+                const u32 s = mad_u24(diff, sdiv, 2048u) >> 12;
+                const int d = (int)diff;
+                const int hraw = (v == r) ? ((int)gg - (int)b)
+                               : (v == gg) ? ((int)b - (int)r + 2 * d)
+                                           : ((int)r - (int)gg + 4 * d);
+                const int hh = mad_i24(hraw, hdiv, 2048) >> 12;  // arithmetic shift, as in OpenCV
+                // hh < 0 ? hh + 180 : hh   (hh >= -180, so the unsigned min picks the right one)
+                const u32 h = min((u32)hh, (u32)(hh + 180));
+                hq |= h << (8 * k);
+                sq |= s << (8 * k);
+                vq |= v << (8 * k);
+            }
+        }
+        if (HSV) { o.h[q] = hq; o.s[q] = sq; o.v[q] = vq; }
+    }
+}
+
+__device__ __forceinline__ void sad_group(const Hsv16& a, const Hsv16& b, u32& sh, u32& ss, u32& sv)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        sh = __builtin_amdgcn_sad_u8(a.h[q], b.h[q], sh);
+        ss = __builtin_amdgcn_sad_u8(a.s[q], b.s[q], ss);
+        sv = __builtin_amdgcn_sad_u8(a.v[q], b.v[q], sv);
+    }
+}
+
+// ---- workgroup flush of one frame's accumulators -------------------------------------------
+
+// acc: [NACC][COPIES] u32 in LDS.  Sums the replicas, zeroes them, and adds the totals to the
+// frame's record in global memory.  Called by all WG threads after a __syncthreads().
+template <bool LUMA, int WG>
+__device__ __forceinline__ void flush_frame(u32* acc, psd_frame_scores* rec, int tid)
+{
+    static_assert(WG % 4 == 0, "");
+    const int part = tid & 3;
+    const u32x4 zero = {0, 0, 0, 0};
+    if (LUMA) {
+        for (int a = tid >> 2; a < 256; a += WG / 4) {
+            u32x4* p = reinterpret_cast<u32x4*>(acc + a * COPIES + part * 8);
+            u32x4 v0 = p[0], v1 = p[1];
+            p[0] = zero; p[1] = zero;
+            u32 s = v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w;
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            if (part == 0 && s) atomicAdd(&rec->hist[a], s);
+        }
+    }
+    if (tid < 16) {
+        const int a = 256 + (tid >> 2);
+        u32x4* p = reinterpret_cast<u32x4*>(acc + a * COPIES + part * 8);
+        u32x4 v0 = p[0], v1 = p[1];
+        p[0] = zero; p[1] = zero;
+        u32 s = v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w;
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (part == 0 && s) {
+            unsigned long long* dst =
+                a == ACC_SAD_H ? (unsigned long long*)&rec->sad_h
+              : a == ACC_SAD_S ? (unsigned long long*)&rec->sad_s
+              : a == ACC_SAD_V ? (unsigned long long*)&rec->sad_v
+                               : (unsigned long long*)&rec->byte_sum;
+            atomicAdd(dst, (unsigned long long)s);
+        }
+    }
+}
+
+// ---- the kernel ----------------------------------------------------------------------------
+
+// grid.x = n_tiles * n_chunks.  Block (tile, chunk) scores frames [chunk*T, chunk*T+T) of its
+// spatial tile.  G = 16-pixel groups per lane per frame.
+template <bool HSV, bool LUMA, int G, bool FAST, int WG>
+__global__ __launch_bounds__(WG) void score_frames_kernel(const ScoreParams p)
+{
+    __shared__ __attribute__((aligned(16))) u32 lut_s[HSV ? 256 * COPIES : 4];
+    __shared__ __attribute__((aligned(16))) u32 lut_h[HSV ? 256 * COPIES : 4];
+    __shared__ __attribute__((aligned(16))) u32 acc[2][NACC * COPIES];
+
+    const int tid = threadIdx.x;
+    const int l32 = tid & 31;
+    const int tile = blockIdx.x % p.n_tiles;
+    const int chunk = blockIdx.x / p.n_tiles;
+
+    // Fill the replicated LUTs and clear the accumulators.
+    if (HSV) {
+        for (int i = tid; i < 256 * COPIES; i += WG) {
+            lut_s[i] = p.lut[i / COPIES];
+            lut_h[i] = p.lut[256 + i / COPIES];
+        }
+    }
+    for (int i = tid; i < 2 * NACC * COPIES; i += WG) (&acc[0][0])[i] = 0;
+    __syncthreads();
+
+    const int t0 = chunk * p.frames_per_chunk;
+    const int t1 = min(p.n, t0 + p.frames_per_chunk);
+    const int g0 = p.group_begin + tile * p.groups_per_tile;
+    const int g1 = min(p.group_end, g0 + p.groups_per_tile);
+
+    int grp[G];
+    bool live[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        grp[k] = g0 + k * WG + tid;
+        live[k] = grp[k] < g1;
+    }
+
+    const u32* my_lut_s = lut_s + l32;
+    const u32* my_lut_h = lut_h + l32;
+
+    Hsv16 prev[G];
+    bool have_prev = false;
+    if (HSV) {
+        const uint8_t* halo = (t0 > 0) ? p.frames + (size_t)(t0 - 1) * p.frame_stride : p.prev;
+        if (halo != nullptr) {
+            have_prev = true;
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                if (live[k]) {
+                    Group g;
+                    load_group<FAST>(p, halo, grp[k], g);
+                    u32 dummy = 0;
+                    convert_group<true, false>(g, prev[k], my_lut_s, my_lut_h, nullptr, dummy);
+                }
+            }
+        }
+    }
+
+    Group cur[G];
+    if (t0 < t1) {
+        const uint8_t* f = p.frames + (size_t)t0 * p.frame_stride;
+#pragma unroll
+        for (int k = 0; k < G; k++)
+            if (live[k]) load_group<FAST>(p, f, grp[k], cur[k]);
+    }
+
+    // Pixels past the end of the frame in the last group read as black: Y = 0.
+    const int last_group = (int)((p.npix + 15) / 16) - 1;
+    const int pad_px = FAST ? 0 : (last_group + 1) * 16 - (int)p.npix;
+
+    for (int t = t0; t < t1; t++) {
+        const int buf = (t - t0) & 1;
+        u32* my_hist = &acc[buf][0] + l32;
+        // Prefetch the next frame of the chunk while this one is being scored.
+        Group nxt[G];
+        if (t + 1 < t1) {
+            const uint8_t* f = p.frames + (size_t)(t + 1) * p.frame_stride;
+#pragma unroll
+            for (int k = 0; k < G; k++)
+                if (live[k]) load_group<FAST>(p, f, grp[k], nxt[k]);
+        }
+        u32 sh = 0, ss = 0, sv = 0, bs = 0;
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            if (live[k]) {
+                Hsv16 c;
+                convert_group<HSV, LUMA>(cur[k], c, my_lut_s, my_lut_h, my_hist, bs);
+                if (HSV) {
+                    if (have_prev) sad_group(c, prev[k], sh, ss, sv);
+                    prev[k] = c;
+                }
+                if (!FAST && LUMA && pad_px && grp[k] == last_group)
+                    __hip_atomic_fetch_add(&my_hist[0], (u32)(0 - pad_px), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (HSV) {
+            __hip_atomic_fetch_add(&my_hist[ACC_SAD_H * COPIES], sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&my_hist[ACC_SAD_S * COPIES], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&my_hist[ACC_SAD_V * COPIES], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (LUMA)
+            __hip_atomic_fetch_add(&my_hist[ACC_BYTES * COPIES], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        have_prev = true;
+        __syncthreads();
+        // Frame t is complete in acc[buf]; frame t+1 accumulates into the other buffer, so no
+        // second barrier is needed (the barrier of frame t+1 orders this flush before reuse).
+        flush_frame<LUMA, WG>(&acc[buf][0], p.out + t, tid);
+        if (t + 1 < t1) {
+#pragma unroll
+            for (int k = 0; k < G; k++) cur[k] = nxt[k];
+        }
+    }
+}
+
+// ---- host-side launcher ---------------------------------------------------------------------
+
+template <bool HSV, bool LUMA, int G, bool FAST>
+static hipError_t launch_one(const ScoreParams& p, int grid, hipStream_t stream)
+{
+    constexpr int WG = kScoreWG;
+    hipLaunchKernelGGL((score_frames_kernel<HSV, LUMA, G, FAST, WG>), dim3(grid), dim3(WG), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <bool FAST>
+static hipError_t launch_flags(const ScoreParams& p, int grid, bool hsv, bool luma, hipStream_t s)
+{
+    constexpr int G = kScoreG;
+    if (hsv && luma) return launch_one<true, true, G, FAST>(p, grid, s);
+    if (hsv) return launch_one<true, false, G, FAST>(p, grid, s);
+    return launch_one<false, true, G, FAST>(p, grid, s);
+}
+
+static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bool hsv, bool luma,
+                               bool fast, int target_blocks, hipStream_t stream)
+{
+    // Tile geometry: spread the 16-px groups evenly over the fewest tiles that fit.
+    const int cap = kScoreWG * kScoreG;
+    const int n_groups = group_end - group_begin;
+    if (n_groups <= 0) return hipSuccess;
+    p.group_begin = group_begin;
+    p.group_end = group_end;
+    p.n_tiles = (n_groups + cap - 1) / cap;
+    p.groups_per_tile = (n_groups + p.n_tiles - 1) / p.n_tiles;
+    // Time chunks: enough workgroups to keep every CU busy for several rounds, but chunks long
+    // enough that the re-read halo frame stays a small fraction.
+    int chunks = (target_blocks + p.n_tiles - 1) / p.n_tiles;
+    if (chunks > p.n) chunks = p.n;
+    if (chunks < 1) chunks = 1;
+    p.frames_per_chunk = (p.n + chunks - 1) / chunks;
+    chunks = (p.n + p.frames_per_chunk - 1) / p.frames_per_chunk;
+    const int grid = p.n_tiles * chunks;
+    return fast ? launch_flags<true>(p, grid, hsv, luma, stream)
+                : launch_flags<false>(p, grid, hsv, luma, stream);
+}
+
+hipError_t launch_score_frames(ScoreParams p, bool hsv, bool luma, bool fast, int target_blocks,
+                               hipStream_t stream, int* launches)
+{
+    const int total_groups = (int)((p.npix + 15) / 16);
+    const int full_groups = (int)(p.npix / 16);
+    if (!fast) {
+        *launches += 1;
+        return launch_range(p, 0, total_groups, hsv, luma, false, target_blocks, stream);
+    }
+    // Fast kernel over the full 48-byte groups; the ragged tail (< 16 px per frame), if any, goes
+    // through the generic kernel.  Both add into the same records.
+    hipError_t err = hipSuccess;
+    if (full_groups > 0) {
+        *launches += 1;
+        err = launch_range(p, 0, full_groups, hsv, luma, true, target_blocks, stream);
+    }
+    if (err == hipSuccess && total_groups > full_groups) {
+        *launches += 1;
+        err = launch_range(p, full_groups, total_groups, hsv, luma, false, 1, stream);
+    }
+    return err;
+}
+
+}  // namespace psd

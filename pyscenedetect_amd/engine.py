@@ -1,0 +1,186 @@
+"""Python face of the scoring engine: device-resident or host frame batches -> integer records.
+
+Thin wrapper over the C-ABI (``include/psd_engine.h``); torch is optional and only used as a
+device-memory owner (``data_ptr()``), never for arithmetic.
+"""
+
+import ctypes
+import threading
+
+import numpy as np
+
+from pyscenedetect_amd import _native
+from pyscenedetect_amd._native import (  # noqa: F401  (re-exported)
+    RECORD_DTYPE,
+    SCORE_ALL,
+    SCORE_BYTE_SUM,
+    SCORE_EDGES,
+    SCORE_HSV_SAD,
+    SCORE_LUMA_HIST,
+)
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    _native.load().psd_device_count(ctypes.byref(n))
+    return n.value
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned by an engine (for hosts without torch)."""
+
+    def __init__(self, engine: "ScoringEngine", nbytes: int):
+        self._engine = engine
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        _native.check(engine._lib.psd_device_alloc(engine._h, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, host: np.ndarray, offset: int = 0) -> None:
+        host = np.ascontiguousarray(host)
+        if offset + host.nbytes > self.nbytes:
+            raise ValueError("upload out of range")
+        _native.check(self._engine._lib.psd_memcpy_h2d(self._engine._h, self.ptr + offset, host.ctypes.data, host.nbytes))
+
+    def download(self, nbytes: int | None = None, offset: int = 0) -> np.ndarray:
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        out = np.empty(nbytes, np.uint8)
+        _native.check(self._engine._lib.psd_memcpy_d2h(self._engine._h, out.ctypes.data, self.ptr + offset, nbytes))
+        return out
+
+    def free(self) -> None:
+        if self.ptr and self._engine._h:
+            self._engine._lib.psd_device_free(self._engine._h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ScoringEngine:
+    """One HIP device + stream.  Not thread-safe per instance; use one engine per thread/GPU."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _native.load()
+        h = ctypes.c_void_p()
+        rc = self._lib.psd_create(int(device), ctypes.byref(h))
+        if rc == _native.PSD_ERR_NO_DEVICE:
+            raise RuntimeError(
+                "pyscenedetect_amd needs an AMD GPU (MI355X / gfx950): " + _native.last_error() + ". There is no CPU fallback."
+            )
+        _native.check(rc)
+        self._h = h
+        self.device = int(device)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.psd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- host frames -----------------------------------------------------------------------
+    def score_host(self, frames: np.ndarray, prev: np.ndarray | None = None, flags: int = SCORE_ALL & ~SCORE_EDGES,
+                   edge_kernel: int = 0) -> np.ndarray:
+        """Score ``frames`` uint8[N,H,W,3] (BGR, any row/frame strides) held in host memory."""
+        frames = np.asarray(frames)
+        if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[3] != 3:
+            raise ValueError("frames must be uint8[N,H,W,3]")
+        if frames.strides[3] != 1 or frames.strides[2] != 3:
+            frames = np.ascontiguousarray(frames)
+        n, h, w, _ = frames.shape
+        pp = None
+        if prev is not None:
+            prev = np.asarray(prev)
+            if prev.dtype != np.uint8 or prev.shape != (h, w, 3):
+                raise ValueError("prev must be uint8[H,W,3] of the same size")
+            if prev.strides != (frames.strides[1], 3, 1):
+                tmp = np.empty((h, frames.strides[1]), np.uint8)
+                tmp[:, : w * 3] = prev.reshape(h, w * 3)
+                prev = tmp
+            pp = prev.ctypes.data
+        out = np.zeros(n, RECORD_DTYPE)
+        if n == 0:
+            return out
+        _native.check(
+            self._lib.psd_score_batch(self._h, frames.ctypes.data, n, h, w, frames.strides[1], frames.strides[0], pp,
+                                      int(flags), int(edge_kernel), out.ctypes.data)
+        )
+        return out
+
+    # -- device frames ---------------------------------------------------------------------
+    def score_device(self, d_frames: int, n: int, height: int, width: int, row_stride: int | None = None,
+                     frame_stride: int | None = None, d_prev: int | None = None,
+                     flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0, stream: int | None = None) -> np.ndarray:
+        """Score ``n`` frames resident in HBM at device address ``d_frames`` (synchronous)."""
+        self.submit_device(d_frames, n, height, width, row_stride, frame_stride, d_prev, flags, edge_kernel, stream)
+        return self.collect(n)
+
+    def submit_device(self, d_frames: int, n: int, height: int, width: int, row_stride: int | None = None,
+                      frame_stride: int | None = None, d_prev: int | None = None,
+                      flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0, stream: int | None = None) -> None:
+        row_stride = width * 3 if row_stride is None else row_stride
+        frame_stride = height * row_stride if frame_stride is None else frame_stride
+        _native.check(
+            self._lib.psd_score_submit_device(self._h, d_frames, int(n), int(height), int(width), row_stride, frame_stride,
+                                              d_prev, int(flags), int(edge_kernel), stream)
+        )
+
+    def collect(self, n: int) -> np.ndarray:
+        out = np.zeros(n, RECORD_DTYPE)
+        _native.check(self._lib.psd_score_collect(self._h, out.ctypes.data if n else None, int(n)))
+        return out
+
+    def last_kernel_ms(self) -> tuple[float, int]:
+        ms, launches = ctypes.c_float(0), ctypes.c_int(0)
+        _native.check(self._lib.psd_last_kernel_ms(self._h, ctypes.byref(ms), ctypes.byref(launches)))
+        return ms.value, launches.value
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def edge_map(self, d_frame: int, height: int, width: int, row_stride: int | None = None, edge_kernel: int = 0) -> np.ndarray:
+        out = np.empty((height, width), np.uint8)
+        _native.check(self._lib.psd_edge_map_device(self._h, d_frame, height, width, width * 3 if row_stride is None else row_stride,
+                                                    int(edge_kernel), out.ctypes.data))
+        return out
+
+
+_default_lock = threading.Lock()
+_default_engines: dict[int, ScoringEngine] = {}
+
+
+def default_engine(device: int | None = None) -> ScoringEngine:
+    """Process-wide engine for ``device`` (default: ``LOCAL_RANK`` or 0).  Raises without a GPU."""
+    import os
+
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+        if device >= max(device_count(), 1):
+            device = 0
+    with _default_lock:
+        eng = _default_engines.get(device)
+        if eng is None:
+            eng = ScoringEngine(device)
+            _default_engines[device] = eng
+        return eng
+
+
+def hsv_tables() -> tuple[np.ndarray, np.ndarray]:
+    s = np.zeros(256, np.int32)
+    h = np.zeros(256, np.int32)
+    _native.check(_native.load().psd_hsv_tables(s.ctypes.data, h.ctypes.data))
+    return s, h
