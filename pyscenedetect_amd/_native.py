@@ -124,6 +124,35 @@ class NativeLibraryError(RuntimeError):
     """libpsd_hip.so is missing or unusable.  There is no CPU fallback."""
 
 
+def _preload_torch_hip_runtime() -> None:
+    """Make this process use ONE HIP/HSA runtime.
+
+    PyTorch-ROCm wheels bundle their own ``libamdhip64.so.7``/``libhsa-runtime64`` next to
+    ``libtorch_hip.so``; ``libpsd_hip.so`` links against the same SONAME.  If ``/opt/rocm``'s copy
+    were loaded first and torch initialised later (torch owns device memory and RCCL in
+    ``bench.py``), two HSA runtimes would fight over the GPU ("No HIP GPUs are available").
+    So when torch is installed, load *its* runtime first (without importing torch); the dynamic
+    linker then binds our DT_NEEDED entry to it.
+    """
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return  # torch already brought its runtime in
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
@@ -133,6 +162,7 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C pyscenedetect_amd/csrc`).  pyscenedetect_amd has no CPU fallback."
         )
+    _preload_torch_hip_runtime()
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as ex:  # e.g. libamdhip64 missing
