@@ -1,0 +1,151 @@
+"""Detector plug-in interface and the minimum-scene-length filter.
+
+Same surface as the reference's ``scenedetect/detector.py`` (``SceneDetector`` :37-103,
+``FlashFilter`` :106-224) so a detector written against PySceneDetect's plug-in API drops in.
+What is new is :meth:`SceneDetector.process_record`: GPU-backed detectors split every
+``process_frame`` into *pixel work* (done once per frame on the device, possibly for a whole
+batch and for several detectors at once) and the *decision* made from the resulting integer
+record.  ``process_frame(timecode, frame)`` remains and is just "score one frame, then decide".
+"""
+
+import math
+from abc import ABC, abstractmethod
+from enum import Enum
+
+import numpy as np
+
+from pyscenedetect_amd.timecode import FrameTimecode, parse_timecode_seconds
+
+
+class SceneDetector(ABC):
+    """Base class of all detectors (reference ``detector.py:37-103``)."""
+
+    def __init__(self):
+        self._stats_manager = None
+
+    @abstractmethod
+    def process_frame(self, timecode: FrameTimecode, frame_img: np.ndarray) -> list[FrameTimecode]:
+        """Process the next frame (24-bit BGR image); returns the cuts detected, if any."""
+
+    def post_process(self, timecode: FrameTimecode) -> list[FrameTimecode]:
+        """Called once after the last frame."""
+        return []
+
+    @property
+    def event_buffer_length(self) -> int:
+        """How many frames in the past an emitted cut can lie."""
+        return 0
+
+    @property
+    def stats_manager(self):
+        return self._stats_manager
+
+    @stats_manager.setter
+    def stats_manager(self, value):
+        self._stats_manager = value
+
+    def get_metrics(self) -> list[str]:
+        return []
+
+    # -- extension used by the batched GPU path --------------------------------------------------
+    def score_flags(self) -> int:
+        """Bit-or of ``PSD_SCORE_*`` terms this detector needs per frame (0 = not GPU-backed)."""
+        return 0
+
+    def edge_kernel_size(self) -> int:
+        """Dilation size for the edge term, 0 = derive from the frame size."""
+        return 0
+
+    def process_record(self, timecode: FrameTimecode, record, height: int, width: int) -> list[FrameTimecode]:
+        """Decide from a precomputed per-frame score record (``psd_frame_scores``)."""
+        raise NotImplementedError
+
+
+class FlashFilter:
+    """Enforces a minimum scene length on a stream of above/below-threshold decisions.
+
+    MERGE collapses bursts of cuts closer than ``length`` into the last one of the burst (emitted
+    late, once the burst is over); SUPPRESS drops cuts until ``length`` has passed since the last
+    one.  Behaviour follows the reference (``detector.py:160-224``), including its quirks: the
+    filter arms only after the first emitted cut, and an integer length is converted to seconds
+    with the first frame's rate and back to frames for every comparison.
+    """
+
+    class Mode(Enum):
+        MERGE = 0
+        SUPPRESS = 1
+
+    def __init__(self, mode: "FlashFilter.Mode", length):
+        self._mode = mode
+        self._length_frames = 0
+        self._length_secs = None
+        if isinstance(length, float):
+            self._length_secs = length
+        elif isinstance(length, str) and not length.strip().isdigit():
+            self._length_secs = parse_timecode_seconds(length, 100)
+        elif isinstance(length, FrameTimecode):
+            self._length_secs = length.seconds
+        else:
+            self._length_frames = int(length)
+        self._threshold_frames = None  # resolved on the first frame
+        self._last_above = None
+        self._armed = False
+        self._merging = False
+        self._merge_start = None
+
+    @property
+    def max_behind(self) -> int:
+        if self._mode == FlashFilter.Mode.SUPPRESS:
+            return 0
+        if self._length_secs is not None:
+            return math.ceil(self._length_secs * 240.0)
+        return self._length_frames
+
+    @property
+    def _disabled(self) -> bool:
+        if self._length_secs is not None:
+            return self._length_secs <= 0.0
+        return self._length_frames <= 0
+
+    def _resolve(self, timecode: FrameTimecode) -> int:
+        if self._threshold_frames is None:
+            rate = timecode.frame_rate
+            secs = self._length_secs
+            if secs is None:
+                secs = self._length_frames / float(rate)
+                self._length_secs = secs
+            self._threshold_frames = round(secs * rate)
+        return self._threshold_frames
+
+    def filter(self, timecode: FrameTimecode, above_threshold: bool) -> list[FrameTimecode]:
+        if self._disabled:
+            return [timecode] if above_threshold else []
+        need = self._resolve(timecode)
+        now = timecode.frame_num
+        if self._last_above is None:
+            self._last_above = timecode
+        gap_ok = max(0, now - self._last_above.frame_num) >= need
+        if self._mode == FlashFilter.Mode.SUPPRESS:
+            if above_threshold and gap_ok:
+                self._last_above = timecode
+                return [timecode]
+            return []
+        if self._mode != FlashFilter.Mode.MERGE:
+            raise RuntimeError("Unhandled FlashFilter mode.")
+        if above_threshold:
+            self._last_above = timecode
+        if self._merging:
+            burst_len = max(0, self._last_above.frame_num - self._merge_start.frame_num)
+            if gap_ok and not above_threshold and burst_len >= need:
+                self._merging = False
+                return [self._last_above]
+            return []
+        if not above_threshold:
+            return []
+        if gap_ok:
+            self._armed = True
+            return [timecode]
+        if self._armed:
+            self._merging = True
+            self._merge_start = timecode
+        return []

@@ -94,8 +94,11 @@ class ScoringEngine:
 
     # -- host frames -----------------------------------------------------------------------
     def score_host(self, frames: np.ndarray, prev: np.ndarray | None = None, flags: int = SCORE_ALL & ~SCORE_EDGES,
-                   edge_kernel: int = 0) -> np.ndarray:
+                   edge_kernel: int = 0, downscale: float = 1.0) -> np.ndarray:
         """Score ``frames`` uint8[N,H,W,3] (BGR, any row/frame strides) held in host memory."""
+        if downscale > 1.0:
+            raise NotImplementedError("device-side downscale (cv2.resize INTER_LINEAR) is not implemented yet; "
+                                      "set SceneManager.auto_downscale = False")
         frames = np.asarray(frames)
         if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[3] != 3:
             raise ValueError("frames must be uint8[N,H,W,3]")

@@ -1,0 +1,314 @@
+"""SceneManager: runs detectors over a frame source, batching the pixel work onto the GPU.
+
+API surface follows the reference's ``scenedetect/scene_manager.py`` (``SceneManager`` :218-745,
+``get_scenes_from_cuts`` :171-210, ``compute_downscale_factor`` :123-140).  The difference is
+inside ``detect_scenes``: instead of calling ``detector.process_frame`` once per frame per detector
+(:578-597, :426-428), frames are gathered into batches by a decode thread, each batch is scored
+ONCE on the device for the union of what all registered detectors need, and every detector then
+replays its decision logic over the per-frame records in frame order -- so cut lists, metrics and
+callback order are those of the sequential loop.
+"""
+
+import logging
+import queue
+import sys
+import threading
+import typing as ty
+
+import numpy as np
+
+from pyscenedetect_amd.detector import SceneDetector
+from pyscenedetect_amd.stats_manager import StatsManager
+from pyscenedetect_amd.timecode import FrameTimecode
+
+logger = logging.getLogger("pyscenedetect")
+
+DEFAULT_MIN_WIDTH: int = 256
+MAX_FRAME_QUEUE_LENGTH: int = 4
+MAX_FRAME_SIZE_ERRORS: int = 16
+DEFAULT_BATCH_FRAMES: int = 64
+
+
+def compute_downscale_factor(frame_width: int, effective_width: int = DEFAULT_MIN_WIDTH) -> float:
+    """Downscale factor that brings ``frame_width`` to about ``effective_width`` pixels."""
+    assert frame_width > 0 and effective_width > 0
+    if frame_width < effective_width:
+        return 1
+    return frame_width / float(effective_width)
+
+
+def get_scenes_from_cuts(cut_list, start_pos, end_pos):
+    """Contiguous (start, end) pairs from a sorted cut list; one scene if there are no cuts."""
+    bounds = [start_pos, *cut_list, end_pos]
+    return list(zip(bounds[:-1], bounds[1:]))
+
+
+class SceneManager:
+    def __init__(self, stats_manager: StatsManager | None = None, engine=None,
+                 batch_frames: int = DEFAULT_BATCH_FRAMES):
+        self._cutting_list: list[FrameTimecode] = []
+        self._detector_list: list[SceneDetector] = []
+        self._stats_manager = stats_manager
+        self._engine = engine
+        self._batch_frames = max(1, int(batch_frames))
+        self._start_pos = None
+        self._last_pos = None
+        self._frame_size = None
+        self._frame_size_errors = 0
+        self._base_timecode = None
+        self._downscale = 1
+        self._auto_downscale = True
+        self._exception_info = None
+        self._stop = threading.Event()
+        self._frame_buffer: list[tuple[FrameTimecode, np.ndarray]] = []
+        self._frame_buffer_size = 0
+        self._crop = None
+
+    # -- configuration (reference :265-335) ---------------------------------------------------------
+    @property
+    def stats_manager(self):
+        return self._stats_manager
+
+    @property
+    def crop(self):
+        if self._crop is None:
+            return None
+        x0, y0, x1, y1 = self._crop
+        return (x0, y0, x1 - 1, y1 - 1)
+
+    @crop.setter
+    def crop(self, value):
+        if value is None:
+            self._crop = None
+            return
+        if not (len(value) == 4 and all(isinstance(v, int) for v in value)):
+            raise TypeError("crop region must be tuple of 4 ints")
+        if any(c < 0 for c in value):
+            raise ValueError("crop coordinates must be >= 0")
+        x0, y0, x1, y1 = value
+        self._crop = (min(x0, x1), min(y0, y1), max(x0, x1) + 1, max(y0, y1) + 1)
+
+    @property
+    def downscale(self) -> int:
+        return self._downscale
+
+    @downscale.setter
+    def downscale(self, value: int):
+        if value < 1:
+            raise ValueError("Downscale factor must be a positive integer >= 1!")
+        if self.auto_downscale:
+            logger.warning("Downscale factor will be ignored because auto_downscale=True!")
+        self._downscale = int(value)
+
+    @property
+    def auto_downscale(self) -> bool:
+        return self._auto_downscale
+
+    @auto_downscale.setter
+    def auto_downscale(self, value: bool):
+        self._auto_downscale = value
+
+    # -- detectors ---------------------------------------------------------------------------------
+    def add_detector(self, detector: SceneDetector) -> None:
+        detector.stats_manager = self._stats_manager
+        if self._stats_manager is not None:
+            self._stats_manager.register_metrics(detector.get_metrics())
+        self._detector_list.append(detector)
+        self._frame_buffer_size = max(detector.event_buffer_length, self._frame_buffer_size)
+
+    def get_num_detectors(self) -> int:
+        return len(self._detector_list)
+
+    def clear(self) -> None:
+        self._cutting_list.clear()
+        self._last_pos = None
+        self._start_pos = None
+        self._frame_size = None
+        self.clear_detectors()
+
+    def clear_detectors(self) -> None:
+        self._detector_list.clear()
+
+    # -- results -----------------------------------------------------------------------------------
+    def _get_cutting_list(self) -> list[FrameTimecode]:
+        return sorted(set(self._cutting_list))
+
+    def get_cut_list(self, show_warning: bool = False) -> list[FrameTimecode]:
+        return self._get_cutting_list()
+
+    def get_scene_list(self, start_in_scene: bool = False):
+        if self._base_timecode is None or self._start_pos is None or self._last_pos is None:
+            return []
+        cuts = self._get_cutting_list()
+        if not cuts and not start_in_scene:
+            return []
+        return sorted(get_scenes_from_cuts(cuts, self._start_pos, self._last_pos + 1))
+
+    def stop(self) -> None:
+        self._stop.set()
+
+    # -- the loop ----------------------------------------------------------------------------------
+    def _engine_or_default(self):
+        if self._engine is None:
+            from pyscenedetect_amd.engine import default_engine
+
+            self._engine = default_engine()
+        return self._engine
+
+    def _dispatch(self, position, frame_im, record, callback, scored_size=None) -> bool:
+        """One frame's worth of decisions for every detector (reference ``_process_frame`` :410-435)."""
+        new_cuts = False
+        self._frame_buffer.append((position, frame_im))
+        self._frame_buffer = self._frame_buffer[-(self._frame_buffer_size + 1):]
+        h, w = scored_size if scored_size is not None else (frame_im.shape[0], frame_im.shape[1])
+        for detector in self._detector_list:
+            if record is not None and detector.score_flags():
+                cuts = detector.process_record(position, record, h, w)
+            else:
+                cuts = detector.process_frame(position, frame_im)
+            self._cutting_list += cuts
+            new_cuts = bool(cuts)
+            if callback:
+                for cut in cuts:
+                    for buffered_pos, buffered in self._frame_buffer:
+                        if cut == buffered_pos:
+                            callback(buffered, buffered_pos)
+        return new_cuts
+
+    def detect_scenes(self, video=None, duration=None, end_time=None, frame_skip: int = 0,
+                      show_progress: bool = False,
+                      callback: ty.Callable[[np.ndarray, FrameTimecode], None] | None = None) -> int:
+        if video is None:
+            raise TypeError("detect_scenes() missing 1 required positional argument: 'video'")
+        if frame_skip > 0 and self.stats_manager is not None:
+            raise ValueError("frame_skip must be 0 when using a StatsManager.")
+        if duration is not None and end_time is not None:
+            raise ValueError("duration and end_time cannot be set at the same time!")
+        if duration is not None and isinstance(duration, (int, float)) and duration < 0:
+            raise ValueError("duration must be greater than or equal to 0!")
+        if end_time is not None and isinstance(end_time, (int, float)) and end_time < 0:
+            raise ValueError("end_time must be greater than or equal to 0!")
+
+        effective_frame_size = video.frame_size
+        if self._crop:
+            x0, y0, x1, y1 = self._crop
+            frame_width, frame_height = video.frame_size
+            if x0 >= frame_width or y0 >= frame_height:
+                raise ValueError("crop starts outside video boundary")
+            if x1 > frame_width or y1 > frame_height:
+                logger.warning("Warning: crop ends outside of video boundary.")
+            effective_frame_size = (min(x1, frame_width) - x0, min(y1, frame_height) - y0)
+        factor = compute_downscale_factor(max(effective_frame_size)) if self.auto_downscale else self.downscale
+
+        self._base_timecode = video.base_timecode
+        if self._stats_manager is not None:
+            self._stats_manager._base_timecode = self._base_timecode
+        start_frame_num = video.frame_number
+        if end_time is not None:
+            end_time = self._base_timecode + end_time
+        elif duration is not None:
+            end_time = (self._base_timecode + duration) + start_frame_num
+
+        flags = 0
+        edge_kernel = 0
+        for det in self._detector_list:
+            flags |= det.score_flags()
+            edge_kernel = edge_kernel or det.edge_kernel_size()
+        engine = self._engine_or_default() if flags else None
+
+        batches: queue.Queue = queue.Queue(2)
+        self._stop.clear()
+        self._exception_info = None
+        worker = threading.Thread(target=self._decode_thread, args=(video, frame_skip, end_time, batches), daemon=True)
+        worker.start()
+        last_frame = None
+        try:
+            while not self._stop.is_set():
+                batch = batches.get()
+                if batch is None:
+                    break
+                frames, positions = batch
+                records = None
+                scored_size = None
+                if engine is not None:
+                    stacked = np.stack(frames)
+                    if factor > 1.0:
+                        # Same target size as the reference's cv2.resize call (:670-678).
+                        scored_size = (max(1, round(stacked.shape[1] / factor)), max(1, round(stacked.shape[2] / factor)))
+                    if last_frame is not None and last_frame.shape != stacked.shape[1:]:
+                        last_frame = None
+                    records = engine.score_host(stacked, prev=last_frame, flags=flags, edge_kernel=edge_kernel,
+                                                **({"downscale": factor} if factor > 1.0 else {}))
+                    last_frame = stacked[-1]
+                for i, (frame_im, position) in enumerate(zip(frames, positions)):
+                    self._dispatch(position, frame_im, records[i] if records is not None else None, callback, scored_size)
+        finally:
+            self._stop.set()
+            while worker.is_alive():
+                while not batches.empty():
+                    batches.get_nowait()
+                worker.join(timeout=0.1)
+        if self._exception_info is not None:
+            exc = self._exception_info[1]
+            raise exc.with_traceback(self._exception_info[2])
+        self._last_pos = video.position
+        for detector in self._detector_list:
+            self._cutting_list += detector.post_process(video.position)
+        return video.frame_number - start_frame_num
+
+    def _decode_thread(self, video, frame_skip: int, end_time, out_queue: queue.Queue) -> None:
+        """Reads, size-checks and crops frames and hands them over in batches
+        (reference ``_decode_thread`` :625-710; the downscale of :670-678 runs on the device)."""
+        frames: list[np.ndarray] = []
+        positions: list[FrameTimecode] = []
+
+        def flush():
+            nonlocal frames, positions
+            if frames:
+                out_queue.put((frames, positions))
+                frames, positions = [], []
+
+        try:
+            while not self._stop.is_set():
+                frame_im = video.read()
+                if frame_im is False:
+                    break
+                decoded_size = (frame_im.shape[1], frame_im.shape[0])
+                if self._frame_size is None:
+                    self._frame_size = decoded_size
+                    if video.frame_size != decoded_size:
+                        logger.warning(f"WARNING: Decoded frame size ({decoded_size}) does not match "
+                                       f" video resolution {video.frame_size}, possible corrupt input.")
+                elif self._frame_size != decoded_size:
+                    self._frame_size_errors += 1
+                    if self._frame_size_errors <= MAX_FRAME_SIZE_ERRORS:
+                        logger.error(f"ERROR: Frame at {video.position!s} has incorrect size and cannot be "
+                                     f"processed: decoded size = {decoded_size}, expected = {self._frame_size}. "
+                                     "Video may be corrupt.")
+                    continue
+                if self._crop:
+                    x0, y0, x1, y1 = self._crop
+                    frame_im = frame_im[y0:y1, x0:x1]
+                if self._start_pos is None:
+                    self._start_pos = video.position
+                frames.append(frame_im)
+                positions.append(video.position)
+                if len(frames) >= self._batch_frames:
+                    flush()
+                if frame_skip > 0:
+                    for _ in range(frame_skip):
+                        if not video.read(decode=False):
+                            break
+                if end_time is not None and not (video.position + 1) < end_time:
+                    break
+            flush()
+        except KeyboardInterrupt:
+            self._stop.set()
+        except BaseException:
+            logger.critical("Fatal error: Exception raised in decode thread.")
+            self._exception_info = sys.exc_info()
+            self._stop.set()
+        finally:
+            if self._start_pos is None:
+                self._start_pos = video.position
+            out_queue.put(None)

@@ -1,0 +1,175 @@
+"""CPU: the host mirror (detectors + SceneManager + C epilogues) fed by the ORACLE's integer
+records must reproduce the reference's own runs (tests/golden/reference_runs.json, produced by
+oracle/gen_golden.py from the unmodified reference): identical cut lists, scene lists and
+bit-identical float metrics."""
+import math
+
+import numpy as np
+import pytest
+
+import pyscenedetect_amd as psd
+from pyscenedetect_amd import FlashFilter, FrameTimecode, epilogue
+from tests._helpers import assert_same_run, run_config
+from tests.conftest import golden_clip
+
+SMALL_CLIPS = ["scenes_a", "fades_b", "ragged_c", "uniform_u"]
+
+
+def _configs(golden, clip):
+    res = golden["clips"][clip]["results"]
+    return [(name, golden["configs"][name]) for name in res]
+
+
+@pytest.mark.parametrize("clip", SMALL_CLIPS)
+def test_scene_manager_matches_reference(golden, oracle_engine, clip):
+    frames = golden_clip(golden, clip)
+    for name, (cls_name, kwargs, with_stats) in _configs(golden, clip):
+        got = run_config(frames, cls_name, kwargs, with_stats, oracle_engine)
+        assert_same_run(got, golden["clips"][clip]["results"][name], f"{clip}/{name}")
+
+
+def test_batch_size_does_not_matter(golden, oracle_engine):
+    frames = golden_clip(golden, "ragged_c")
+    for name in ("content_stats", "adaptive_default", "hist_default", "threshold_final"):
+        cls_name, kwargs, with_stats = golden["configs"][name]
+        for bf in (1, 7, 1000):
+            got = run_config(frames, cls_name, kwargs, with_stats, oracle_engine, batch_frames=bf)
+            assert_same_run(got, golden["clips"]["ragged_c"]["results"][name], f"ragged_c/{name}/batch{bf}")
+
+
+def test_process_frame_api_matches_reference(golden, oracle_engine):
+    """The one-frame-at-a-time plug-in API (SceneDetector.process_frame) gives the same cuts."""
+    frames = golden_clip(golden, "fades_b")
+    for name in ("content_default", "adaptive_default", "hist_default", "threshold_final"):
+        cls_name, kwargs, _ = golden["configs"][name]
+        from tests._helpers import build_detector
+
+        det = build_detector(cls_name, kwargs, oracle_engine)
+        cuts = []
+        for i, f in enumerate(frames):
+            cuts += det.process_frame(FrameTimecode(i, 25.0), f)
+        cuts += det.post_process(FrameTimecode(len(frames) - 1, 25.0))
+        assert sorted({c.frame_num for c in cuts}) == golden["clips"]["fades_b"]["results"][name]["cuts"], name
+
+
+def test_all_detectors_share_one_pass(golden, oracle_engine):
+    """Four detectors on one SceneManager (one fused device pass) == four separate runs."""
+    frames = golden_clip(golden, "scenes_a")
+    names = ["content_default", "adaptive_default", "hist_default", "threshold_default"]
+    want = set()
+    for n in names:
+        want |= set(golden["clips"]["scenes_a"]["results"][n]["cuts"])
+    from tests._helpers import build_detector
+
+    sm = psd.SceneManager(engine=oracle_engine)
+    sm.auto_downscale = False
+    for n in names:
+        cls_name, kwargs, _ = golden["configs"][n]
+        sm.add_detector(build_detector(cls_name, kwargs, oracle_engine))
+    sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+    assert [c.frame_num for c in sm.get_cut_list()] == sorted(want)
+
+
+# ---- pure state machines: known-answer traces generated from the reference ----------------------
+
+def test_flash_filter_kats(golden):
+    for key, kat in golden["kats"].items():
+        if not key.startswith("flash_"):
+            continue
+        _, mode, length = key.split("_", 2)
+        length = eval(length)  # repr of int/float/str written by gen_golden.py
+        f = FlashFilter(FlashFilter.Mode[mode], length)
+        emitted = []
+        above = set(kat["above"])
+        for i in range(kat["n"]):
+            emitted += [[i, c.frame_num] for c in f.filter(FrameTimecode(i, 25.0), i in above)]
+        assert emitted == kat["emitted"], key
+        # (recorded after the run: an int length has been converted to seconds by then, detector.py:176)
+        assert f.max_behind == kat["max_behind"]
+        # native epilogue: same cuts (emission time is not part of its output)
+        cv = np.array([30.0 if i in above else 0.0 for i in range(kat["n"])])
+        cuts = epilogue.content_cuts(cv, 25.0, threshold=27.0, min_scene_len=length, filter_mode=0 if mode == "MERGE" else 1)
+        assert cuts == [c for _, c in kat["emitted"]], key
+
+
+def test_injected_score_kats(golden, oracle_engine):
+    kat = golden["kats"]["content_injected"]
+    scores = np.full(kat["n"], kat["default"])
+    for k, v in kat["scores"].items():
+        scores[int(k)] = v
+    assert epilogue.content_cuts(scores, 25.0) == kat["cuts"]
+
+    class Injected(psd.ContentDetector):
+        def _score_from_record(self, timecode, record, height, width):
+            return float(scores[timecode.frame_num])
+
+    d = Injected(engine=oracle_engine)
+    got = []
+    for i in range(kat["n"]):
+        got += [c.frame_num for c in d.process_record(FrameTimecode(i, 25.0), None, 4, 4)]
+    assert got == kat["cuts"]
+
+    kat = golden["kats"]["adaptive_injected"]
+    scores = np.full(kat["n"], kat["default"])
+    for k, v in kat["scores"].items():
+        scores[int(k)] = v
+    cuts, _ = epilogue.adaptive_cuts(scores, 25.0)
+    assert cuts == kat["cuts"]
+
+    class InjectedA(psd.AdaptiveDetector):
+        def _score_from_record(self, timecode, record, height, width):
+            return float(scores[timecode.frame_num])
+
+    d = InjectedA(engine=oracle_engine)
+    got = []
+    for i in range(kat["n"]):
+        got += [c.frame_num for c in d.process_record(FrameTimecode(i, 25.0), None, 4, 4)]
+    assert got == kat["cuts"]
+
+
+# ---- native (C++) epilogues vs the reference runs ------------------------------------------------
+
+def _nan_to_none(a):
+    return [None if math.isnan(x) else float(x) for x in a]
+
+
+@pytest.mark.parametrize("clip", SMALL_CLIPS)
+def test_native_epilogues_match_reference(golden, oracle_engine, clip):
+    frames = golden_clip(golden, clip)
+    h, w = frames.shape[1:3]
+    res = golden["clips"][clip]["results"]
+    recs_e = oracle_engine.score_host(frames, flags=15)
+    for name in res:
+        cls_name, kwargs, _ = golden["configs"][name]
+        want = res[name]
+        kw = dict(kwargs)
+        if cls_name in ("ContentDetector", "AdaptiveDetector"):
+            weights = kw.get("weights", [1.0, 1.0, 1.0, 0.0])
+            if kw.get("luma_only"):
+                weights = [0.0, 0.0, 1.0, 0.0]
+            recs = recs_e
+            if kw.get("kernel_size"):
+                recs = oracle_engine.score_host(frames, flags=15, edge_kernel=kw["kernel_size"])
+            sc = epilogue.content_scores(recs, h, w, weights)
+            if cls_name == "ContentDetector":
+                cuts = epilogue.content_cuts(sc["content_val"], 25.0, kw.get("threshold", 27.0), kw.get("min_scene_len", 15),
+                                             1 if kw.get("filter_mode") == "SUPPRESS" else 0)
+                if want["metrics"]:
+                    for key in ("content_val", "delta_hue", "delta_sat", "delta_lum", "delta_edges"):
+                        assert [None] + [float(x) for x in sc[key][1:]] == want["metrics"][key], f"{clip}/{name}/{key}"
+            else:
+                cuts, ratio = epilogue.adaptive_cuts(sc["content_val"], 25.0, kw.get("adaptive_threshold", 3.0),
+                                                     kw.get("min_scene_len", 15), kw.get("window_width", 2),
+                                                     kw.get("min_content_val", 15.0))
+                key = [k for k in want["metrics"] if k.startswith("adaptive_ratio")][0]
+                assert _nan_to_none(ratio) == want["metrics"][key], f"{clip}/{name}"
+        elif cls_name == "HistogramDetector":
+            cuts, diff = epilogue.hist_cuts(recs_e, 25.0, kw.get("threshold", 0.2), kw.get("bins", 128), kw.get("min_scene_len", 15))
+            key = list(want["metrics"])[0]
+            assert _nan_to_none(diff) == want["metrics"][key], f"{clip}/{name}"
+        else:
+            cuts, avg = epilogue.threshold_cuts(recs_e, h, w, 25.0, kw.get("threshold", 12), kw.get("min_scene_len", 15),
+                                                kw.get("fade_bias", 0.0), kw.get("add_final_scene", False),
+                                                1 if kw.get("method") == "CEILING" else 0)
+            assert [float(x) for x in avg] == want["metrics"]["average_rgb"], f"{clip}/{name}"
+        assert sorted(set(cuts)) == want["cuts"], f"{clip}/{name}: {cuts} vs {want['cuts']}"
