@@ -454,15 +454,26 @@ typedef struct {
     uint32_t hist[256];
 } orc_frame_scores;
 
+/* flags: 1 = HSV SADs, 2|4 = luma histogram + byte sum (as PSD_SCORE_* in include/psd_engine.h). */
+void orc_score_batch_flags(const uint8_t* frames, int n, int h, int w, size_t row_stride, size_t frame_stride,
+                           const uint8_t* prev, orc_frame_scores* out, unsigned flags);
+
 void orc_score_batch(const uint8_t* frames, int n, int h, int w, size_t row_stride, size_t frame_stride,
                      const uint8_t* prev, orc_frame_scores* out)
 {
+    orc_score_batch_flags(frames, n, h, w, row_stride, frame_stride, prev, out, 7u);
+}
+
+void orc_score_batch_flags(const uint8_t* frames, int n, int h, int w, size_t row_stride, size_t frame_stride,
+                           const uint8_t* prev, orc_frame_scores* out, unsigned flags)
+{
+    const int do_hsv = (flags & 1u) != 0, do_luma = (flags & 6u) != 0;
     init_tables();
     size_t np = (size_t)h * w;
     uint8_t* cur = (uint8_t*)malloc(np * 3);
     uint8_t* last = (uint8_t*)malloc(np * 3);
     int have_last = 0;
-    if (prev) {
+    if (prev && do_hsv) {
         orc_bgr2hsv_planes(prev, row_stride, last, last + np, last + 2 * np, h, w);
         have_last = 1;
     }
@@ -470,8 +481,8 @@ void orc_score_batch(const uint8_t* frames, int n, int h, int w, size_t row_stri
         const uint8_t* f = frames + (size_t)t * frame_stride;
         orc_frame_scores* o = out + t;
         memset(o, 0, sizeof(*o));
-        orc_bgr2hsv_planes(f, row_stride, cur, cur + np, cur + 2 * np, h, w);
-        if (have_last) {
+        if (do_hsv) orc_bgr2hsv_planes(f, row_stride, cur, cur + np, cur + 2 * np, h, w);
+        if (do_hsv && have_last) {
             uint64_t a = 0, b = 0, c = 0;
             for (size_t i = 0; i < np; i++) {
                 a += (uint64_t)abs((int)cur[i] - (int)last[i]);
@@ -481,7 +492,7 @@ void orc_score_batch(const uint8_t* frames, int n, int h, int w, size_t row_stri
             o->sad_h = a; o->sad_s = b; o->sad_v = c;
         }
         uint64_t bs = 0;
-        for (int y = 0; y < h; y++) {
+        for (int y = 0; do_luma && y < h; y++) {
             const uint8_t* s = f + (size_t)y * row_stride;
             for (int x = 0; x < w; x++, s += 3) {
                 bs += (uint64_t)s[0] + s[1] + s[2];
@@ -490,7 +501,7 @@ void orc_score_batch(const uint8_t* frames, int n, int h, int w, size_t row_stri
         }
         o->byte_sum = bs;
         uint8_t* tsw = cur; cur = last; last = tsw;
-        have_last = 1;
+        have_last = do_hsv;
     }
     free(cur); free(last);
 }

@@ -70,6 +70,7 @@ def lib() -> ctypes.CDLL:
         L.orc_dilate_rect.argtypes = [vp, sz, i, i, i, i, vp]
         L.orc_resize_linear_u8.argtypes = [vp, sz, i, i, i, vp, sz, i, i]
         L.orc_score_batch.argtypes = [vp, i, i, i, sz, sz, vp, vp]
+        L.orc_score_batch_flags.argtypes = [vp, i, i, i, sz, sz, vp, vp, ctypes.c_uint]
         _lib = L
     return _lib
 
@@ -85,7 +86,7 @@ def hsv_tables():
     return s, h
 
 
-def score_batch(frames: np.ndarray, prev: np.ndarray | None = None) -> np.ndarray:
+def score_batch(frames: np.ndarray, prev: np.ndarray | None = None, flags: int = 7) -> np.ndarray:
     """Oracle per-frame integer records for ``frames`` uint8[N,H,W,3] (BGR).
 
     Returns a structured array (RECORD_DTYPE).  ``edge_xor`` is left 0 here; see
@@ -101,5 +102,5 @@ def score_batch(frames: np.ndarray, prev: np.ndarray | None = None) -> np.ndarra
         assert prev.shape == (h, w, 3)
         pp = _p(prev)
     if n:
-        lib().orc_score_batch(_p(frames), n, h, w, w * 3, h * w * 3, pp, _p(out))
+        lib().orc_score_batch_flags(_p(frames), n, h, w, w * 3, h * w * 3, pp, _p(out), int(flags) & 7)
     return out

@@ -1,0 +1,79 @@
+"""CPU, world_size 2 over gloo: sharding by frame range (1-frame halo) and by clip, with the
+all-gather of score records, gives the same records and cut lists as a single process."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pyscenedetect_amd import distributed as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 64, 4097):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+def test_assign_clips_balances():
+    plan = D.assign_clips([100, 90, 50, 40, 10, 10], 2)
+    assert sorted(sum(plan, [])) == list(range(6))
+    loads = [sum([100, 90, 50, 40, 10, 10][i] for i in p) for p in plan]
+    assert abs(loads[0] - loads[1]) <= 20
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.detectors_np import OracleEngine
+    from pyscenedetect_amd import epilogue
+    from pyscenedetect_amd.synth import make_clip
+
+    eng = OracleEngine()
+    frames, _ = make_clip(31, 75, 36, 64, shot_len=(8, 16))
+    recs = D.score_clip_sharded(eng, lambda a, b: frames[a:b], len(frames), flags=7)
+    clips = [make_clip(40 + i, n, 24, 40, shot_len=(5, 9))[0] for i, n in enumerate((30, 11, 22, 5))]
+    per_clip = D.score_clips_distributed(eng, clips, flags=7)
+    sc = epilogue.content_scores(recs, 36, 64)
+    cuts = epilogue.content_cuts(sc["content_val"], 25.0, min_scene_len=5)
+    np.save(os.path.join(tmp, f"recs{rank}.npy"), recs)
+    np.save(os.path.join(tmp, f"cuts{rank}.npy"), np.array(cuts))
+    for i, r in enumerate(per_clip):
+        np.save(os.path.join(tmp, f"clip{i}_{rank}.npy"), r)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one(tmp_path):
+    from oracle.detectors_np import OracleEngine
+    from pyscenedetect_amd import epilogue
+    from pyscenedetect_amd.synth import make_clip
+
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    eng = OracleEngine()
+    frames, _ = make_clip(31, 75, 36, 64, shot_len=(8, 16))
+    want = eng.score_host(frames, flags=7)
+    sc = epilogue.content_scores(want, 36, 64)
+    want_cuts = epilogue.content_cuts(sc["content_val"], 25.0, min_scene_len=5)
+    assert want_cuts
+    for r in range(world):
+        got = np.load(tmp_path / f"recs{r}.npy")
+        assert got.tobytes() == want.tobytes()
+        assert np.load(tmp_path / f"cuts{r}.npy").tolist() == want_cuts
+    clips = [make_clip(40 + i, n, 24, 40, shot_len=(5, 9))[0] for i, n in enumerate((30, 11, 22, 5))]
+    for i, c in enumerate(clips):
+        ref = eng.score_host(c, flags=7)
+        for r in range(world):
+            assert np.load(tmp_path / f"clip{i}_{r}.npy").tobytes() == ref.tobytes()
