@@ -99,7 +99,7 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU batch")
     ap.add_argument("--dist", default="U", choices=["U", "K", "S"])
     ap.add_argument("--detector", default="content", choices=["content", "all"])
-    ap.add_argument("--cpu-sample", type=int, default=64)
+    ap.add_argument("--cpu-sample", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

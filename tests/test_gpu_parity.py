@@ -121,7 +121,9 @@ def test_full_size_properties_1080p(hip_engine):
     # idempotence
     same(hip_engine.score_device(x.data_ptr(), n, h, w, flags=NOEDGE), whole)
     # symmetry of |a-b|: reversing time moves each SAD to its neighbour
-    rev = hip_engine.score_device(torch.flip(x, dims=[0]).contiguous().data_ptr(), n, h, w, flags=NOEDGE)
+    xr = torch.flip(x, dims=[0]).contiguous()
+    torch.cuda.synchronize()                       # the engine launches on its own stream
+    rev = hip_engine.score_device(xr.data_ptr(), n, h, w, flags=NOEDGE)
     assert np.array_equal(rev["sad_s"][1:], whole["sad_s"][1:][::-1])
     # oracle on a sample
     sample = x[:3].cpu().numpy()
