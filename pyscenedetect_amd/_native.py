@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpsd_hip.so")
+LIB_PATH = os.environ.get("PSD_LIB_PATH") or os.path.join(_HERE, "libpsd_hip.so")  # override: experiments only
 
 PSD_OK = 0
 PSD_ERR_INVALID = -1

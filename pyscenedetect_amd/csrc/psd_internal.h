@@ -11,7 +11,7 @@
 namespace psd {
 
 constexpr int kScoreWG = 1024;  // threads per workgroup of the scoring kernel (16 waves)
-constexpr int kScoreG = 1;      // 16-pixel groups per lane per frame
+constexpr int kScoreG = 2;      // 16-pixel groups per lane per frame
 
 struct ScoreParams {
     const uint8_t* frames;   // device, frame t at frames + t*frame_stride

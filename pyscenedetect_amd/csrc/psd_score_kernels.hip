@@ -20,8 +20,16 @@
 //    Everything is integer, so the result is independent of scheduling order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "psd_internal.h"
+
+// PSD_ABLATE (build-time, experiments only -- results are WRONG when non-zero):
+//   1 = no LDS table reads, 2 = no per-frame barrier/flush, 4 = no global loads inside the time loop,
+//   8 = no HSV arithmetic (loads + byte SAD only).  tools/ablate.sh builds and times the variants.
+#ifndef PSD_ABLATE
+#define PSD_ABLATE 0
+#endif
 
 namespace psd {
 
@@ -49,13 +57,35 @@ struct Hsv16 {
 __device__ __forceinline__ int mad_i24(int a, int b, int c)
 {
     int d;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
     return d;
 }
 __device__ __forceinline__ u32 mad_u24(u32 a, u32 b, u32 c)
 {
     u32 d;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+__device__ __forceinline__ u32 mad_u24_vsv(u32 a, u32 b, u32 c)
+{
+    u32 d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ u32 mul_u24_vs(u32 a, u32 b)
+{
+    u32 d;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "s"(b), "v"(a));
+    return d;
+}
+
+// (a == b) ? x : y as compare + v_cndmask.  Spelled in asm because hipcc otherwise turns the hue
+// sector selection into real branches (s_and_saveexec / s_xor / s_or per pixel), which costs more
+// scalar instructions than the three candidate subtractions it tries to skip.
+__device__ __forceinline__ int sel_eq(u32 a, u32 b, int x, int y)
+{
+    int d;
+    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %4, %3, vcc" : "=v"(d) : "v"(a), "v"(b), "v"(x), "v"(y) : "vcc");
     return d;
 }
 
@@ -98,7 +128,7 @@ __device__ __forceinline__ void load_group(const ScoreParams& p, const uint8_t* 
 
 // 8-bit BGR -> HSV exactly as OpenCV's RGB2HSV_b (hsv_shift = 12, hue range 180), plus luma
 // histogram and byte sum.  lut_s/lut_h/hist are already offset by the lane's replica index.
-template <bool HSV, bool LUMA>
+template <bool HSV, bool LUMA, int LC = COPIES, int AC = COPIES>
 __device__ __forceinline__ void convert_group(const Group& g, Hsv16& o, const u32* __restrict__ lut_s,
                                               const u32* __restrict__ lut_h, u32* __restrict__ hist,
                                               u32& byte_sum)
@@ -124,20 +154,30 @@ __device__ __forceinline__ void convert_group(const Group& g, Hsv16& o, const u3
             const u32 gg = (d[ig >> 2] >> ((ig & 3) * 8)) & 0xffu;
             const u32 r = (d[ir >> 2] >> ((ir & 3) * 8)) & 0xffu;
             if (LUMA) {
-                const u32 y = mad_u24(r, kR2Y, mad_u24(gg, kG2Y, mad_u24(b, kB2Y, 8192u))) >> 14;
-                __hip_atomic_fetch_add(&hist[y * COPIES], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // (B2Y*b + G2Y*g + R2Y*r + 8192) >> 14; the rounding term rides on the first product
+                const u32 y = mad_u24_vsv(r, kR2Y, mad_u24_vsv(gg, kG2Y, mul_u24_vs(b, kB2Y) + 8192u)) >> 14;
+                __hip_atomic_fetch_add(&hist[y * AC], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+#if PSD_ABLATE & 8
+            if (HSV) { hq += b + (gg << 8); sq += r; vq ^= b; }
+#else
             if (HSV) {
                 const u32 v = max(max(b, gg), r);
                 const u32 vmin = min(min(b, gg), r);
                 const u32 diff = v - vmin;
-                const u32 sdiv = lut_s[v * COPIES];
-                const int hdiv = (int)lut_h[diff * COPIES];
+#if PSD_ABLATE & 1
+                const u32 sdiv = v + 4097u;
+                const int hdiv = (int)diff + 480;
+#else
+                const u32 sdiv = lut_s[v * LC];
+                const int hdiv = (int)lut_h[diff * LC];
+#endif
                 const u32 s = mad_u24(diff, sdiv, 2048u) >> 12;
                 const int d = (int)diff;
-                const int hraw = (v == r) ? ((int)gg - (int)b)
-                               : (v == gg) ? ((int)b - (int)r + 2 * d)
-                                           : ((int)r - (int)gg + 4 * d);
+                const int c_r = (int)gg - (int)b;
+                const int c_g = (int)b - (int)r + 2 * d;
+                const int c_b = (int)r - (int)gg + 4 * d;
+                const int hraw = sel_eq(v, r, c_r, sel_eq(v, gg, c_g, c_b));
                 const int hh = mad_i24(hraw, hdiv, 2048) >> 12;  // arithmetic shift, as in OpenCV
                 // hh < 0 ? hh + 180 : hh   (hh >= -180, so the unsigned min picks the right one)
                 const u32 h = min((u32)hh, (u32)(hh + 180));
@@ -145,6 +185,7 @@ __device__ __forceinline__ void convert_group(const Group& g, Hsv16& o, const u3
                 sq |= s << (8 * k);
                 vq |= v << (8 * k);
             }
+#endif
         }
         if (HSV) { o.h[q] = hq; o.s[q] = sq; o.v[q] = vq; }
     }
@@ -277,12 +318,21 @@ __global__ __launch_bounds__(WG) void score_frames_kernel(const ScoreParams p)
         u32* my_hist = &acc[buf][0] + l32;
         // Prefetch the next frame of the chunk while this one is being scored.
         Group nxt[G];
+#if PSD_ABLATE & 4
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            nxt[k] = cur[k];
+#pragma unroll
+            for (int i = 0; i < 12; i++) asm volatile("" : "+v"(nxt[k].w[i]));
+        }
+#else
         if (t + 1 < t1) {
             const uint8_t* f = p.frames + (size_t)(t + 1) * p.frame_stride;
 #pragma unroll
             for (int k = 0; k < G; k++)
                 if (live[k]) load_group<FAST>(p, f, grp[k], nxt[k]);
         }
+#endif
         u32 sh = 0, ss = 0, sv = 0, bs = 0;
 #pragma unroll
         for (int k = 0; k < G; k++) {
@@ -306,10 +356,12 @@ __global__ __launch_bounds__(WG) void score_frames_kernel(const ScoreParams p)
         if (LUMA)
             __hip_atomic_fetch_add(&my_hist[ACC_BYTES * COPIES], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         have_prev = true;
+#if !(PSD_ABLATE & 2)
         __syncthreads();
         // Frame t is complete in acc[buf]; frame t+1 accumulates into the other buffer, so no
         // second barrier is needed (the barrier of frame t+1 orders this flush before reuse).
         flush_frame<LUMA, WG>(&acc[buf][0], p.out + t, tid);
+#endif
         if (t + 1 < t1) {
 #pragma unroll
             for (int k = 0; k < G; k++) cur[k] = nxt[k];
@@ -317,30 +369,249 @@ __global__ __launch_bounds__(WG) void score_frames_kernel(const ScoreParams p)
     }
 }
 
+// ---- fast path: LDS-DMA staged loads ----------------------------------------------------------
+//
+// Same tiling and time walk as score_frames_kernel, but the frame bytes travel
+// HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip, issued one frame ahead) and are
+// then picked up by each lane as its 48 contiguous bytes with three ds_read_b128.
+//   * global side: lane i of a wave moves bytes [16 i, 16 i + 16) of each 1 KiB piece, so every
+//     128-byte line is touched by exactly one instruction (the direct kernel's 48-byte lane stride
+//     makes three instructions touch every line and tops out near 4.2 TB/s);
+//   * LDS side: the wave-private 3 KiB slot is a linear image of its 64 groups; lane l reads
+//     dwords [12 l, 12 l + 12) -- a 12-dword stride is conflict-free for ds_read_b128.
+// A wave only ever reads the slot it filled itself, so the hand-off needs no barrier: the wave's
+// own s_waitcnt vmcnt(0) covers the DMA, lgkmcnt(0) covers the reads before the slot is refilled.
+// Accumulators: HSV-only keeps 2 x F frames of {sad_h,sad_s,sad_v} so the workgroup barrier and
+// flush happen once per F frames; with the luma histogram it is one frame per barrier (F = 1).
+
+constexpr int LCD = 16;  // LUT replicas in the staged kernel (2-way conflicts at worst, 32 KiB for both tables)
+constexpr int ACD = 16;  // accumulator replicas
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <int G, int NW>
+__device__ __forceinline__ void dma_issue(const ScoreParams& p, const uint8_t* frame, int wave_group0, int wave,
+                                          int lane, uint8_t* stage)
+{
+    // wave_group0[k] = first group of this wave's k-th slot; 64 groups = 3072 contiguous bytes.
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        const long gfirst = (long)wave_group0 + (long)k * NW * 64;
+        const long limit = (long)p.group_end * 48;  // never read past the last full group of the range
+        uint8_t* slot = stage + (size_t)(k * NW + wave) * 3072;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const long off = gfirst * 48 + j * 1024 + lane * 16;
+            if (off + 16 <= limit)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + off), (lds_ptr_t)(slot + j * 1024), 16, 0, 0);
+        }
+    }
+}
+
+template <int G, int NW>
+__device__ __forceinline__ void stage_read(const uint8_t* stage, int wave, int lane, Group (&out)[G])
+{
+#pragma unroll
+    for (int k = 0; k < G; k++) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(stage + (size_t)(k * NW + wave) * 3072 + lane * 48);
+        const u32x4 a = src[0], b = src[1], c = src[2];
+        out[k].w[0] = a.x; out[k].w[1] = a.y; out[k].w[2] = a.z; out[k].w[3] = a.w;
+        out[k].w[4] = b.x; out[k].w[5] = b.y; out[k].w[6] = b.z; out[k].w[7] = b.w;
+        out[k].w[8] = c.x; out[k].w[9] = c.y; out[k].w[10] = c.z; out[k].w[11] = c.w;
+    }
+}
+
+// Sum the ACD replicas of accumulators [a0, a0+count) of one slot, zero them, add to the record.
+template <bool LUMA>
+__device__ __forceinline__ void flush_slot(u32* slot_acc, psd_frame_scores* rec, int idx)
+{
+    // idx in [0, 2*NA): accumulator a = idx >> 1, half = idx & 1 (8 replicas each)
+    const int a = idx >> 1, half = idx & 1;
+    u32x4* q = reinterpret_cast<u32x4*>(slot_acc + a * ACD + half * 8);
+    const u32x4 v0 = q[0], v1 = q[1];
+    const u32x4 zero = {0, 0, 0, 0};
+    q[0] = zero; q[1] = zero;
+    u32 s = v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w;
+    s += __shfl_xor(s, 1);
+    if (half == 0 && s) {
+        if (LUMA && a < 256) {
+            atomicAdd(&rec->hist[a], s);
+        } else {
+            const int e = LUMA ? a - 256 : a;
+            unsigned long long* dst = e == 0 ? (unsigned long long*)&rec->sad_h
+                                    : e == 1 ? (unsigned long long*)&rec->sad_s
+                                    : e == 2 ? (unsigned long long*)&rec->sad_v
+                                             : (unsigned long long*)&rec->byte_sum;
+            atomicAdd(dst, (unsigned long long)s);
+        }
+    }
+}
+
+template <bool HSV, bool LUMA, int G, int WG>
+__global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams p)
+{
+    constexpr int NW = WG / 64;
+    constexpr int NA = LUMA ? NACC : 4;       // accumulators per frame slot
+    constexpr int F = LUMA ? 1 : 8;           // frames per barrier
+    constexpr int SLOTS = 2 * F;
+    __shared__ __attribute__((aligned(16))) u32 lut_s[HSV ? 256 * LCD : 4];
+    __shared__ __attribute__((aligned(16))) u32 lut_h[HSV ? 256 * LCD : 4];
+    __shared__ __attribute__((aligned(16))) u32 acc[SLOTS][NA * ACD];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[G * NW * 3072];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l16 = tid & 15;
+    const int tile = blockIdx.x % p.n_tiles;
+    const int chunk = blockIdx.x / p.n_tiles;
+
+    if (HSV) {
+        for (int i = tid; i < 256 * LCD; i += WG) {
+            lut_s[i] = p.lut[i / LCD];
+            lut_h[i] = p.lut[256 + i / LCD];
+        }
+    }
+    for (int i = tid; i < SLOTS * NA * ACD; i += WG) (&acc[0][0])[i] = 0;
+    __syncthreads();
+
+    const int t0 = chunk * p.frames_per_chunk;
+    const int t1 = min(p.n, t0 + p.frames_per_chunk);
+    const int g0 = p.group_begin + tile * p.groups_per_tile;
+    const int g1 = min(p.group_end, g0 + p.groups_per_tile);
+    const int wave_group0 = g0 + wave * 64;
+
+    bool live[G];
+#pragma unroll
+    for (int k = 0; k < G; k++) live[k] = (wave_group0 + k * NW * 64 + lane) < g1;
+
+    const u32* my_lut_s = lut_s + l16;
+    const u32* my_lut_h = lut_h + l16;
+
+    Hsv16 prev[G];
+    bool have_prev = false;
+    Group cur[G];
+    if (HSV) {
+        const uint8_t* halo = (t0 > 0) ? p.frames + (size_t)(t0 - 1) * p.frame_stride : p.prev;
+        if (halo != nullptr) {
+            have_prev = true;
+            dma_issue<G, NW>(p, halo, wave_group0, wave, lane, stage);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stage_read<G, NW>(stage, wave, lane, cur);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                u32 dummy = 0;
+                if (live[k]) convert_group<true, false, LCD, ACD>(cur[k], prev[k], my_lut_s, my_lut_h, nullptr, dummy);
+            }
+        }
+    }
+    if (t0 < t1) dma_issue<G, NW>(p, p.frames + (size_t)t0 * p.frame_stride, wave_group0, wave, lane, stage);
+
+    for (int t = t0; t < t1; t++) {
+        const int slot = (t - t0) % SLOTS;
+        u32* my_acc = &acc[slot][0] + l16;
+        // Frame t has been in flight since the previous step; take it out of the staging slot and
+        // immediately refill the slot with frame t+1.
+#if !(PSD_ABLATE & 4)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stage_read<G, NW>(stage, wave, lane, cur);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t + 1 < t1) dma_issue<G, NW>(p, p.frames + (size_t)(t + 1) * p.frame_stride, wave_group0, wave, lane, stage);
+#else
+#pragma unroll
+        for (int k = 0; k < G; k++)
+#pragma unroll
+            for (int i = 0; i < 12; i++) asm volatile("" : "+v"(cur[k].w[i]));
+#endif
+        u32 sh = 0, ss = 0, sv = 0, bs = 0;
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            if (live[k]) {
+                Hsv16 c;
+                convert_group<HSV, LUMA, LCD, ACD>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs);
+                if (HSV) {
+                    if (have_prev) sad_group(c, prev[k], sh, ss, sv);
+                    prev[k] = c;
+                }
+            }
+        }
+        constexpr int E0 = LUMA ? 256 : 0;  // index of sad_h among the slot's accumulators
+        if (HSV) {
+            __hip_atomic_fetch_add(&my_acc[(E0 + 0) * ACD], sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&my_acc[(E0 + 1) * ACD], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&my_acc[(E0 + 2) * ACD], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (LUMA)
+            __hip_atomic_fetch_add(&my_acc[(E0 + 3) * ACD], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        have_prev = true;
+#if !(PSD_ABLATE & 2)
+        // Every F frames (and at the end of the chunk) the block's sums for the last <= F frames
+        // are complete in one half of the slot ring: flush that half while the other half fills.
+        const int done = t - t0 + 1;
+        if (done % F == 0 || t + 1 == t1) {
+            __syncthreads();
+            const int nf = (done % F == 0) ? F : done % F;       // frames in this half
+            const int first = done - nf;                          // chunk-relative index of the first
+            for (int i = tid; i < nf * 2 * NA; i += WG) {
+                const int fi = i / (2 * NA), idx = i - fi * 2 * NA;
+                flush_slot<LUMA>(&acc[(first + fi) % SLOTS][0], p.out + t0 + first + fi, idx);
+            }
+        }
+#endif
+    }
+}
+
 // ---- host-side launcher ---------------------------------------------------------------------
+
+// PSD_SCORE_DIRECT=1 selects the register-staged loads on the fast path too (experiments).
+static bool direct_loads()
+{
+    static const bool d = [] { const char* e = getenv("PSD_SCORE_DIRECT"); return e && atoi(e) != 0; }();
+    return d;
+}
 
 template <bool HSV, bool LUMA, int G, bool FAST>
 static hipError_t launch_one(const ScoreParams& p, int grid, hipStream_t stream)
 {
     constexpr int WG = kScoreWG;
+    if constexpr (FAST && !(HSV && LUMA && G == 2)) {  // (the fused G=2 variant would need 160.5 KiB of LDS)
+        if (!direct_loads()) {
+            hipLaunchKernelGGL((score_frames_dma_kernel<HSV, LUMA, G, WG>), dim3(grid), dim3(WG), 0, stream, p);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((score_frames_kernel<HSV, LUMA, G, FAST, WG>), dim3(grid), dim3(WG), 0, stream, p);
     return hipGetLastError();
 }
 
-template <bool FAST>
+template <bool FAST, int G>
 static hipError_t launch_flags(const ScoreParams& p, int grid, bool hsv, bool luma, hipStream_t s)
 {
-    constexpr int G = kScoreG;
     if (hsv && luma) return launch_one<true, true, G, FAST>(p, grid, s);
     if (hsv) return launch_one<true, false, G, FAST>(p, grid, s);
     return launch_one<false, true, G, FAST>(p, grid, s);
+}
+
+// Groups of 16 pixels per lane per frame.  Tunable for experiments with PSD_SCORE_G=1|2.
+static int groups_per_lane()
+{
+    static const int g = [] {
+        const char* e = getenv("PSD_SCORE_G");
+        const int v = e ? atoi(e) : kScoreG;
+        return v == 2 ? 2 : 1;
+    }();
+    return g;
 }
 
 static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bool hsv, bool luma,
                                bool fast, int target_blocks, hipStream_t stream)
 {
     // Tile geometry: spread the 16-px groups evenly over the fewest tiles that fit.
-    const int cap = kScoreWG * kScoreG;
+    int gpl = fast ? groups_per_lane() : 1;
+    if (fast && hsv && luma && !direct_loads()) gpl = 1;  // fused staged kernel: one group per lane (LDS budget)
+    const int cap = kScoreWG * gpl;
     const int n_groups = group_end - group_begin;
     if (n_groups <= 0) return hipSuccess;
     p.group_begin = group_begin;
@@ -355,8 +626,9 @@ static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bo
     p.frames_per_chunk = (p.n + chunks - 1) / chunks;
     chunks = (p.n + p.frames_per_chunk - 1) / p.frames_per_chunk;
     const int grid = p.n_tiles * chunks;
-    return fast ? launch_flags<true>(p, grid, hsv, luma, stream)
-                : launch_flags<false>(p, grid, hsv, luma, stream);
+    if (!fast) return launch_flags<false, 1>(p, grid, hsv, luma, stream);
+    return gpl == 2 ? launch_flags<true, 2>(p, grid, hsv, luma, stream)
+                    : launch_flags<true, 1>(p, grid, hsv, luma, stream);
 }
 
 hipError_t launch_score_frames(ScoreParams p, bool hsv, bool luma, bool fast, int target_blocks,

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Build ablated variants of the scoring kernel (timing experiments; wrong results by design).
+set -e
+cd "$(dirname "$0")/../pyscenedetect_amd/csrc"
+mkdir -p build/abl
+for a in "$@"; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -DPSD_ABLATE=$a -c psd_score_kernels.hip -o build/abl/score_$a.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/abl/libpsd_abl$a.so build/abl/score_$a.o build/psd_edge_kernels.hip.o build/psd_engine.cpp.o build/psd_epilogue.cpp.o
+  echo built abl$a
+done

@@ -47,12 +47,12 @@ print("PARITY", "GREEN" if ok else "RED")
 # ---- timing on device-resident batches -------------------------------------------------------
 import torch
 H, W = 1080, 1920
-for N in (64, 512, 2048):
+for N in (int(os.environ.get('PROBE_N', '1024')),):
     x = torch.randint(0, 256, (N, H, W, 3), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     for name, fl in (("hsv", E.SCORE_HSV_SAD), ("luma", E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM), ("all", FL)):
         best = 1e9
-        for it in range(4):
+        for it in range(6):
             t0 = time.perf_counter()
             r = eng.score_device(x.data_ptr(), N, H, W, flags=fl)
             wall = (time.perf_counter() - t0) * 1e3
