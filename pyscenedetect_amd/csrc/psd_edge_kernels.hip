@@ -1,26 +1,646 @@
-// psd_edge_kernels.hip -- edge term of ContentDetector (placeholder until the Canny pipeline lands).
+// psd_edge_kernels.hip -- the edge term of ContentDetector and the bilinear downscale, for gfx950.
+//
+// Edge term (reference scenedetect/detectors/content_detector.py:170-174,213-239):
+//     edges_t   = cv2.dilate(cv2.Canny(V_t, low, high), ones(k,k))   with low/high from numpy.median(V_t)
+//     delta_edges = mean |edges_t - edges_{t-1}| = 255 * popcount(edges_t XOR edges_{t-1}) / (H*W)
+// Device pipeline per chunk of frames (everything integer, so the result is exact):
+//   K1 value_plane_hist   V = max(B,G,R) -> u8 plane + per-frame 256-bin histogram (for the median)
+//   K2 median_thresholds  exact numpy.median from the histogram -> (low, high) via a host-built table
+//   K3 sobel_nms          Sobel 3x3 (replicate border), |dx|+|dy|, non-maximum suppression with
+//                         OpenCV's TG22 fixed point -> map {0 none, 1 weak, 2 strong}; LDS tiles with halo
+//   K4 hysteresis         8-connected growth of strong into weak: in-LDS fix point per 64x64 tile,
+//                         relaunched until no tile changes (the result is order independent)
+//   K5 pack_hdilate       strong pixels -> bit rows, horizontal OR over the k-window (bit shifts)
+//   K6 vdilate_xor        vertical OR over the k-window, XOR with the previous frame's dilated bits,
+//                         popcount -> edge_xor; the dilated bits stay resident for the next frame
+// Algorithmic traffic is 5 B/px (3 read + edge map write + previous edge map read);
+// the intermediate planes are implementation overhead.
+//
+// Downscale (reference scenedetect/scene_manager.py:666-678): cv2.resize(..., INTER_LINEAR) with
+// OpenCV's 11-bit fixed-point coefficients; exact 2x decimation takes OpenCV's INTER_AREA shortcut.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
 #include "psd_internal.h"
 
 extern "C" void psd_set_error(const char* fmt, ...);
 
 namespace psd {
 
-int edges_score(psd_engine*, const uint8_t*, int, int, int, size_t, size_t, const uint8_t*, int,
-                psd_frame_scores*, hipStream_t)
+void** engine_edge_ws(psd_engine* e);
+size_t* engine_edge_ws_bytes(psd_engine* e);
+int engine_num_cus(psd_engine* e);
+hipStream_t engine_stream(psd_engine* e);
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define HIP_TRY(expr)                                                                                \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            psd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PSD_ERR_HIP;                                                                      \
+        }                                                                                            \
+    } while (0)
+
+// ---- K1: V plane + histogram -------------------------------------------------------------------
+
+struct EdgeGeom {
+    int height, width;
+    long npix;
+    size_t row_stride, frame_stride;
+    int words_per_row;  // ceil(width/32)
+};
+
+// virtual frame j of a chunk -> source pointer
+struct ChunkSrc {
+    const uint8_t* frames;  // batch base
+    const uint8_t* prev;    // frame preceding the batch (may be null)
+    int start;              // batch index of virtual frame `first_is_prev`
+    int first_is_prev;      // virtual frame 0 is `prev`
+};
+
+__device__ __forceinline__ const uint8_t* chunk_frame(const ChunkSrc& c, size_t frame_stride, int j)
 {
-    psd_set_error("PSD_SCORE_EDGES is not implemented yet");
-    return PSD_ERR_UNSUPPORTED;
+    if (c.first_is_prev && j == 0) return c.prev;
+    return c.frames + (size_t)(c.start + j - c.first_is_prev) * frame_stride;
 }
-int edges_map(psd_engine*, const uint8_t*, int, int, size_t, int, uint8_t*)
+
+// One thread = 4 pixels.  grid = (ceil(npix/4/256), frames)
+__global__ __launch_bounds__(256) void value_plane_hist_kernel(ChunkSrc src, EdgeGeom g, uint8_t* vplane, u32* hist)
 {
-    psd_set_error("PSD_SCORE_EDGES is not implemented yet");
-    return PSD_ERR_UNSUPPORTED;
+    __shared__ u32 lh[256 * 8];
+    for (int i = threadIdx.x; i < 256 * 8; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int j = blockIdx.y;
+    const uint8_t* frame = chunk_frame(src, g.frame_stride, j);
+    const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int rep = threadIdx.x & 7;
+    if (p0 < g.npix) {
+        u32 packed = 0;
+        const bool packed_rows = g.row_stride == (size_t)g.width * 3;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long p = p0 + k;
+            if (p < g.npix) {
+                const uint8_t* s;
+                if (packed_rows) s = frame + (size_t)p * 3;
+                else {
+                    const int row = (int)(p / g.width), col = (int)(p - (long)row * g.width);
+                    s = frame + (size_t)row * g.row_stride + (size_t)col * 3;
+                }
+                const u32 v = max(max((u32)s[0], (u32)s[1]), (u32)s[2]);
+                packed |= v << (8 * k);
+                atomicAdd(&lh[v * 8 + rep], 1u);
+            }
+        }
+        uint8_t* dst = vplane + (size_t)j * g.npix + p0;
+        if (p0 + 4 <= g.npix && ((g.npix & 3) == 0)) *reinterpret_cast<u32*>(dst) = packed;
+        else
+            for (int k = 0; k < 4 && p0 + k < g.npix; k++) dst[k] = (uint8_t)(packed >> (8 * k));
+    }
+    __syncthreads();
+    {
+        const int b = threadIdx.x;
+        u32 s = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) s += lh[b * 8 + r];
+        if (s) atomicAdd(&hist[(size_t)j * 256 + b], s);
+    }
 }
-void edges_release(psd_engine*) {}
-int resize_linear(const uint8_t*, int, int, int, size_t, uint8_t*, int, int, size_t, hipStream_t)
+
+// ---- K2: median -> Canny thresholds ------------------------------------------------------------
+
+// numpy.median of the V plane: for an even count the mean of the two middle order statistics, so
+// 2*median = a + b is an integer in [0, 510]; thr_tab[a+b] = (low, high) computed on the host with
+// the reference's float64 expression (content_detector.py:229-233).
+__global__ __launch_bounds__(256) void median_thresholds_kernel(const u32* hist, long npix, const int2* thr_tab, int2* thr)
 {
-    psd_set_error("psd_resize_linear_device is not implemented yet");
-    return PSD_ERR_UNSUPPORTED;
+    __shared__ u32 cum[256];
+    const int j = blockIdx.x, b = threadIdx.x;
+    cum[b] = hist[(size_t)j * 256 + b];
+    __syncthreads();
+    if (b == 0) {
+        const long ka = (npix - 1) / 2, kb = npix / 2;  // 0-based ranks of the two middle elements
+        long run = 0;
+        int a = -1, bb = -1;
+        for (int v = 0; v < 256; v++) {
+            run += cum[v];
+            if (a < 0 && run > ka) a = v;
+            if (bb < 0 && run > kb) { bb = v; break; }
+        }
+        thr[j] = thr_tab[a + bb];
+    }
+}
+
+// ---- K3: Sobel + non-maximum suppression -------------------------------------------------------
+
+constexpr int NT_W = 64, NT_H = 16;  // tile of the NMS kernel (256 threads x 4 px)
+
+// grid = (tiles_x, tiles_y, frames)
+__global__ __launch_bounds__(256) void sobel_nms_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, uint8_t* map)
+{
+    __shared__ uint8_t sv[NT_H + 4][NT_W + 4 + 4];        // V with a 2-px halo (replicated at the image border)
+    __shared__ unsigned short smag[NT_H + 2][NT_W + 2 + 2];  // |dx|+|dy| with a 1-px halo (0 outside the image)
+    __shared__ short sdx[NT_H][NT_W], sdy[NT_H][NT_W];
+    const int j = blockIdx.z;
+    const uint8_t* V = vplane + (size_t)j * g.npix;
+    const int x0 = blockIdx.x * NT_W, y0 = blockIdx.y * NT_H;
+    const int H = g.height, W = g.width;
+    for (int i = threadIdx.x; i < (NT_H + 4) * (NT_W + 4); i += 256) {
+        const int ly = i / (NT_W + 4), lx = i - ly * (NT_W + 4);
+        const int y = min(max(y0 + ly - 2, 0), H - 1), x = min(max(x0 + lx - 2, 0), W - 1);
+        sv[ly][lx] = V[(size_t)y * W + x];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (NT_H + 2) * (NT_W + 2); i += 256) {
+        const int ly = i / (NT_W + 2), lx = i - ly * (NT_W + 2);
+        const int y = y0 + ly - 1, x = x0 + lx - 1;
+        unsigned short m = 0;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            // sv index of (y, x) is [ly+1][lx+1]
+            const int cy = ly + 1, cx = lx + 1;
+            const int a00 = sv[cy - 1][cx - 1], a01 = sv[cy - 1][cx], a02 = sv[cy - 1][cx + 1];
+            const int a10 = sv[cy][cx - 1], a12 = sv[cy][cx + 1];
+            const int a20 = sv[cy + 1][cx - 1], a21 = sv[cy + 1][cx], a22 = sv[cy + 1][cx + 1];
+            const int dx = (a02 - a00) + 2 * (a12 - a10) + (a22 - a20);
+            const int dy = (a20 - a00) + 2 * (a21 - a01) + (a22 - a02);
+            m = (unsigned short)(abs(dx) + abs(dy));
+            if (ly >= 1 && ly <= NT_H && lx >= 1 && lx <= NT_W) {
+                sdx[ly - 1][lx - 1] = (short)dx;
+                sdy[ly - 1][lx - 1] = (short)dy;
+            }
+        }
+        smag[ly][lx] = m;
+    }
+    __syncthreads();
+    const int low = thr[j].x, high = thr[j].y;
+    for (int i = threadIdx.x; i < NT_H * NT_W; i += 256) {
+        const int ly = i / NT_W, lx = i - ly * NT_W;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= H || x >= W) continue;
+        const int m = smag[ly + 1][lx + 1];
+        uint8_t out = 0;
+        if (m > low) {
+            const int xs = sdx[ly][lx], ys = sdy[ly][lx];
+            const int ax = abs(xs), ay = abs(ys) << 15;
+            const int tg22x = ax * 13573;  // TG22 = round(tan(22.5 deg) * 2^15)
+            bool is_max;
+            if (ay < tg22x) {
+                is_max = m > smag[ly + 1][lx] && m >= smag[ly + 1][lx + 2];
+            } else {
+                const int tg67x = tg22x + (ax << 16);
+                if (ay > tg67x) {
+                    is_max = m > smag[ly][lx + 1] && m >= smag[ly + 2][lx + 1];
+                } else {
+                    const int s = (xs ^ ys) < 0 ? -1 : 1;
+                    is_max = m > smag[ly][lx + 1 - s] && m > smag[ly + 2][lx + 1 + s];
+                }
+            }
+            if (is_max) out = m > high ? 2 : 1;
+        }
+        map[(size_t)j * g.npix + (size_t)y * W + x] = out;
+    }
+}
+
+// ---- K4: hysteresis -----------------------------------------------------------------------------
+
+constexpr int HT = 64;  // hysteresis tile edge
+
+// grid = (tiles_x, tiles_y, frames).  Grows strong (2) into 8-connected weak (1) pixels inside the
+// tile until nothing changes, using the neighbouring tiles' current state as a read-only halo.
+// Sets *changed when the tile promoted anything.
+__global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom g, int* changed)
+{
+    __shared__ uint8_t t[HT + 2][HT + 2 + 2];
+    __shared__ int any_weak, tile_changed, round_changed;
+    const int j = blockIdx.z;
+    uint8_t* M = map + (size_t)j * g.npix;
+    const int x0 = blockIdx.x * HT, y0 = blockIdx.y * HT, H = g.height, W = g.width;
+    if (threadIdx.x == 0) { any_weak = 0; tile_changed = 0; }
+    __syncthreads();
+    int weak_here = 0;
+    for (int i = threadIdx.x; i < (HT + 2) * (HT + 2); i += 256) {
+        const int ly = i / (HT + 2), lx = i - ly * (HT + 2);
+        const int y = y0 + ly - 1, x = x0 + lx - 1;
+        uint8_t v = 0;
+        if (y >= 0 && y < H && x >= 0 && x < W) v = M[(size_t)y * W + x];
+        t[ly][lx] = v;
+        if (v == 1 && ly >= 1 && ly <= HT && lx >= 1 && lx <= HT) weak_here = 1;
+    }
+    if (weak_here) any_weak = 1;
+    __syncthreads();
+    if (!any_weak) return;
+    // each thread owns a 4x4 patch of the 64x64 tile
+    const int py = (threadIdx.x >> 4) * 4 + 1, px = (threadIdx.x & 15) * 4 + 1;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) round_changed = 0;
+        __syncthreads();
+        int ch = 0;
+#pragma unroll
+        for (int dy = 0; dy < 4; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 4; dx++) {
+                const int y = py + dy, x = px + dx;
+                if (t[y][x] == 1) {
+                    const int s = (t[y - 1][x - 1] | t[y - 1][x] | t[y - 1][x + 1] | t[y][x - 1] | t[y][x + 1] |
+                                   t[y + 1][x - 1] | t[y + 1][x] | t[y + 1][x + 1]) & 2;
+                    if (s) { t[y][x] = 2; ch = 1; }   // racing writers only ever store 2: benign
+                }
+            }
+        if (ch) round_changed = 1;
+        __syncthreads();
+        if (!round_changed) break;
+        if (threadIdx.x == 0) tile_changed = 1;
+    }
+    __syncthreads();
+    if (tile_changed) {
+        for (int i = threadIdx.x; i < HT * HT; i += 256) {
+            const int ly = i / HT, lx = i - ly * HT;
+            const int y = y0 + ly, x = x0 + lx;
+            if (y < H && x < W && t[ly + 1][lx + 1] == 2) M[(size_t)y * W + x] = 2;
+        }
+        if (threadIdx.x == 0) atomicOr(changed, 1);
+    }
+}
+
+// ---- K5: pack strong pixels into bit rows + horizontal dilation ---------------------------------
+
+// grid = (height, frames); one block per image row.  anchor = k/2; window [x-anchor, x-anchor+k-1].
+__global__ __launch_bounds__(256) void pack_hdilate_kernel(const uint8_t* map, EdgeGeom g, int k, u32* hbits)
+{
+    extern __shared__ u32 rowbits[];  // words_per_row + 2 (one zero word of padding on each side)
+    const int j = blockIdx.y, y = blockIdx.x, W = g.width, nw = g.words_per_row;
+    const uint8_t* M = map + (size_t)j * g.npix + (size_t)y * W;
+    for (int w = threadIdx.x; w < nw + 2; w += 256) {
+        u32 bits = 0;
+        if (w >= 1 && w <= nw) {
+            const int xb = (w - 1) * 32;
+#pragma unroll 8
+            for (int b = 0; b < 32; b++) {
+                const int x = xb + b;
+                if (x < W && M[x] == 2) bits |= 1u << b;
+            }
+        }
+        rowbits[w] = bits;
+    }
+    __syncthreads();
+    const int left = k / 2, right = k - 1 - k / 2;  // output x is set if any input in [x-left, x+right] is set
+    for (int w = threadIdx.x; w < nw; w += 256) {
+        const u32 lo = rowbits[w], mid = rowbits[w + 1], hi = rowbits[w + 2];
+        u32 out = mid;
+        // input at x+s (s>0) contributes: shift the (mid,hi) pair right by s
+        for (int s = 1; s <= right; s++) out |= s < 32 ? (u32)((((u64)hi << 32) | mid) >> s) : (hi >> (s - 32));
+        // input at x-s contributes: shift the (lo,mid) pair left by s
+        for (int s = 1; s <= left; s++) out |= s < 32 ? (u32)(((((u64)mid << 32) | lo) << s) >> 32) : (lo << (s - 32));
+        const int xb = w * 32;
+        if (xb + 32 > W) out &= (W - xb >= 32) ? 0xffffffffu : ((1u << (W - xb)) - 1u);
+        hbits[((size_t)j * g.height + y) * nw + w] = out;
+    }
+}
+
+// ---- K6: vertical dilation, then XOR count ------------------------------------------------------
+
+// grid = (ceil(words_per_frame/256), frames).  dil[j] = OR of hbits rows [y-anchor, y-anchor+k-1].
+__global__ __launch_bounds__(256) void vdilate_kernel(const u32* hbits, EdgeGeom g, int k, u32* dil)
+{
+    const int j = blockIdx.y, nw = g.words_per_row;
+    const long words = (long)g.height * nw;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= words) return;
+    const int y = (int)(i / nw), w = (int)(i - (long)y * nw);
+    const int ytop = max(y - k / 2, 0), ybot = min(y - k / 2 + k - 1, g.height - 1);
+    const u32* hb = hbits + (size_t)j * words;
+    u32 v = 0;
+    for (int yy = ytop; yy <= ybot; yy++) v |= hb[(size_t)yy * nw + w];
+    dil[(size_t)j * words + i] = v;
+}
+
+// Number of pixels whose dilated edge bit differs between virtual frame j and its predecessor
+// (dil[j-1], or `carry` = last frame of the previous chunk for j == 0).
+__global__ __launch_bounds__(256) void xor_count_kernel(const u32* dil, long words, const u32* carry, int have_carry,
+                                                         unsigned long long* out_xor)
+{
+    const int j = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    u32 diff = 0;
+    if (i < words) {
+        const u32 v = dil[(size_t)j * words + i];
+        if (j > 0) diff = __popc(v ^ dil[(size_t)(j - 1) * words + i]);
+        else if (have_carry) diff = __popc(v ^ carry[i]);
+    }
+    __shared__ u32 red[4];
+    for (int o = 32; o > 0; o >>= 1) diff += __shfl_down(diff, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = diff;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 s = red[0] + red[1] + red[2] + red[3];
+        if (s) atomicAdd(&out_xor[j], (unsigned long long)s);
+    }
+}
+
+// Copy the chunk's XOR counts into the batch records (virtual frame j -> batch frame first_t + j).
+__global__ void store_xor_kernel(const unsigned long long* xr, int count, int skip_first, int first_has_pred,
+                                 int first_t, psd_frame_scores* out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    if (skip_first && j == 0) return;          // virtual frame 0 is `prev`, not part of the batch
+    if (j == 0 && !first_has_pred) return;     // no predecessor: edge_xor stays 0
+    out[first_t + j - skip_first].edge_xor = xr[j];
+}
+
+// ---- host orchestration ---------------------------------------------------------------------------
+
+static int estimated_kernel_size(int width, int height)
+{
+    // 4 + round(sqrt(w*h)/192), made odd (content_detector.py:39-46; Python round = half to even)
+    int size = 4 + (int)nearbyint(sqrt((double)width * (double)height) / 192.0);
+    if (size % 2 == 0) size += 1;
+    return size;
+}
+
+struct EdgeBuffers {
+    uint8_t* vplane; uint8_t* map; u32* hist; int2* thr; u32* hbits; u32* dil; u32* carry;
+    unsigned long long* xr; int* flags; int2* thr_tab;
+    int cap_frames;
+};
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeBuffers* b)
+{
+    const size_t words = (size_t)g.height * g.words_per_row;
+    const size_t per_frame = align_up((size_t)g.npix) * 2 + align_up(256 * 4) + align_up(sizeof(int2)) +
+                             align_up(words * 4) * 2 + align_up(8);
+    // bound the workspace to ~1 GiB unless a single frame needs more
+    int frames = (int)std::max<size_t>(1, std::min<size_t>((size_t)want_frames, ((size_t)1 << 30) / per_frame));
+    const size_t fixed = align_up(words * 4) + align_up(64 * sizeof(int)) + align_up(511 * sizeof(int2));
+    const size_t need = per_frame * (size_t)frames + fixed;
+    void** ws = engine_edge_ws(e);
+    size_t* ws_bytes = engine_edge_ws_bytes(e);
+    if (*ws_bytes < need) {
+        if (*ws) HIP_TRY(hipFree(*ws));
+        *ws = nullptr; *ws_bytes = 0;
+        HIP_TRY(hipMalloc(ws, need));
+        *ws_bytes = need;
+    } else {
+        // the cached workspace may fit more frames than computed for `want_frames`; keep `frames`
+    }
+    uint8_t* p = (uint8_t*)*ws;
+    auto take = [&](size_t bytes) { uint8_t* r = p; p += align_up(bytes); return r; };
+    b->vplane = take((size_t)g.npix * frames);
+    b->map = take((size_t)g.npix * frames);
+    b->hist = (u32*)take((size_t)frames * 256 * 4);
+    b->thr = (int2*)take((size_t)frames * sizeof(int2));
+    b->hbits = (u32*)take(words * 4 * frames);
+    b->dil = (u32*)take(words * 4 * frames);
+    b->xr = (unsigned long long*)take((size_t)frames * 8);
+    b->carry = (u32*)take(words * 4);
+    b->flags = (int*)take(64 * sizeof(int));
+    b->thr_tab = (int2*)take(511 * sizeof(int2));
+    b->cap_frames = frames;
+    if ((size_t)(p - (uint8_t*)*ws) > *ws_bytes) { psd_set_error("edge workspace layout overflow"); return PSD_ERR_NOMEM; }
+    return PSD_OK;
+}
+
+static void threshold_table(int2* tab)
+{
+    // low = int(max(0, (1-sigma)*median)), high = int(min(255, (1+sigma)*median)), sigma = 1/3, in the
+    // reference's float64 arithmetic (content_detector.py:229-233); median = m2/2 for m2 = a+b.
+    const double sigma = 1.0 / 3.0;
+    for (int m2 = 0; m2 <= 510; m2++) {
+        const double median = m2 / 2.0;
+        const double lo = (1.0 - sigma) * median, hi = (1.0 + sigma) * median;
+        int low = (int)(lo > 0 ? lo : 0), high = (int)(hi < 255 ? hi : 255);
+        // cv2.Canny swaps the thresholds if they are out of order and floors them (already ints here)
+        if (low > high) { const int t = low; low = high; high = t; }
+        tab[m2] = make_int2(low, high);
+    }
+}
+
+// Runs K1..K6a for `count` virtual frames; on return (stream-ordered) b.dil holds their dilated bits.
+static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, const EdgeBuffers& b, hipStream_t stream)
+{
+    const size_t words = (size_t)g.height * g.words_per_row;
+    HIP_TRY(hipMemsetAsync(b.hist, 0, (size_t)count * 256 * 4, stream));
+    hipLaunchKernelGGL(value_plane_hist_kernel, dim3((unsigned)((g.npix + 1023) / 1024), count), dim3(256), 0, stream, src, g,
+                       b.vplane, b.hist);
+    hipLaunchKernelGGL(median_thresholds_kernel, dim3(count), dim3(256), 0, stream, b.hist, g.npix, b.thr_tab, b.thr);
+    hipLaunchKernelGGL(sobel_nms_kernel, dim3((g.width + NT_W - 1) / NT_W, (g.height + NT_H - 1) / NT_H, count), dim3(256), 0,
+                       stream, b.vplane, g, b.thr, b.map);
+    HIP_TRY(hipGetLastError());
+    // hysteresis to the fix point: rounds of 8 launches, each with its own flag; stop when the last
+    // launch of a round changed nothing.
+    const dim3 hgrid((g.width + HT - 1) / HT, (g.height + HT - 1) / HT, count);
+    for (int round = 0; round < 4096; round++) {
+        constexpr int R = 8;
+        HIP_TRY(hipMemsetAsync(b.flags, 0, R * sizeof(int), stream));
+        for (int i = 0; i < R; i++) hipLaunchKernelGGL(hysteresis_kernel, hgrid, dim3(256), 0, stream, b.map, g, b.flags + i);
+        int flags[R];
+        HIP_TRY(hipMemcpyAsync(flags, b.flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (!flags[R - 1]) break;
+    }
+    hipLaunchKernelGGL(pack_hdilate_kernel, dim3(g.height, count), dim3(256), (g.words_per_row + 2) * sizeof(u32), stream, b.map, g,
+                       k, b.hbits);
+    hipLaunchKernelGGL(vdilate_kernel, dim3((unsigned)((words + 255) / 256), count), dim3(256), 0, stream, b.hbits, g, k, b.dil);
+    HIP_TRY(hipGetLastError());
+    return PSD_OK;
+}
+
+static EdgeGeom make_geom(int height, int width, size_t row_stride, size_t frame_stride)
+{
+    EdgeGeom g;
+    g.height = height; g.width = width; g.npix = (long)height * width;
+    g.row_stride = row_stride; g.frame_stride = frame_stride;
+    g.words_per_row = (width + 31) / 32;
+    return g;
+}
+
+int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
+                size_t frame_stride, const uint8_t* d_prev, int edge_kernel, psd_frame_scores* d_out,
+                hipStream_t stream)
+{
+    const EdgeGeom g = make_geom(height, width, row_stride, frame_stride);
+    const int k = edge_kernel ? edge_kernel : estimated_kernel_size(width, height);
+    const int total = n + (d_prev ? 1 : 0);
+    EdgeBuffers b;
+    int rc = edge_buffers(e, g, total, &b);
+    if (rc != PSD_OK) return rc;
+    int2 tab[511];
+    threshold_table(tab);
+    HIP_TRY(hipMemcpyAsync(b.thr_tab, tab, sizeof(tab), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));  // `tab` lives on this stack frame
+    const size_t words = (size_t)g.height * g.words_per_row;
+    int done = 0;          // virtual frames processed
+    bool have_carry = false;
+    while (done < total) {
+        const int count = std::min(b.cap_frames, total - done);
+        ChunkSrc src;
+        src.frames = d_frames;
+        src.prev = d_prev;
+        src.first_is_prev = (done == 0 && d_prev) ? 1 : 0;
+        src.start = done - (d_prev ? 1 : 0) + src.first_is_prev;  // batch index of the first non-prev virtual frame
+        rc = edge_chunk(g, src, count, k, b, stream);
+        if (rc != PSD_OK) return rc;
+        HIP_TRY(hipMemsetAsync(b.xr, 0, (size_t)count * 8, stream));
+        hipLaunchKernelGGL(xor_count_kernel, dim3((unsigned)((words + 255) / 256), count), dim3(256), 0, stream, b.dil, (long)words,
+                           b.carry, have_carry ? 1 : 0, b.xr);
+        hipLaunchKernelGGL(store_xor_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, b.xr, count, src.first_is_prev,
+                           have_carry ? 1 : 0, src.start, d_out);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(b.carry, b.dil + (size_t)(count - 1) * words, words * 4, hipMemcpyDeviceToDevice, stream));
+        have_carry = true;
+        done += count;
+    }
+    return PSD_OK;
+}
+
+int edges_map(psd_engine* e, const uint8_t* d_frame, int height, int width, size_t row_stride, int edge_kernel,
+              uint8_t* h_edges)
+{
+    const EdgeGeom g = make_geom(height, width, row_stride, 0);
+    const int k = edge_kernel ? edge_kernel : estimated_kernel_size(width, height);
+    hipStream_t stream = engine_stream(e);
+    EdgeBuffers b;
+    int rc = edge_buffers(e, g, 1, &b);
+    if (rc != PSD_OK) return rc;
+    int2 tab[511];
+    threshold_table(tab);
+    HIP_TRY(hipMemcpyAsync(b.thr_tab, tab, sizeof(tab), hipMemcpyHostToDevice, stream));
+    ChunkSrc src;
+    src.frames = d_frame; src.prev = nullptr; src.start = 0; src.first_is_prev = 0;
+    rc = edge_chunk(g, src, 1, k, b, stream);
+    if (rc != PSD_OK) return rc;
+    const size_t words = (size_t)g.height * g.words_per_row;
+    std::vector<u32> bits(words);
+    HIP_TRY(hipMemcpyAsync(bits.data(), b.dil, words * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++)
+            h_edges[(size_t)y * width + x] = (bits[(size_t)y * g.words_per_row + (x >> 5)] >> (x & 31)) & 1u ? 255 : 0;
+    return PSD_OK;
+}
+
+void edges_release(psd_engine* e)
+{
+    void** ws = engine_edge_ws(e);
+    if (*ws) (void)hipFree(*ws);
+    *ws = nullptr;
+    *engine_edge_ws_bytes(e) = 0;
+}
+
+// ---- cv2.resize(INTER_LINEAR), 8-bit, 3 channels --------------------------------------------------
+
+struct ResizeTabs {
+    const int* xofs; const short* ialpha; const int* yofs; const short* ibeta;
+};
+
+// grid = (ceil(dst_w/64), dst_h, frames), block 64: one destination pixel (3 channels) per thread.
+__global__ __launch_bounds__(64) void resize_linear_kernel(const uint8_t* src, int sh, int sw, size_t sstride, uint8_t* dst, int dh,
+                                                           int dw, size_t dstride, ResizeTabs t)
+{
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y;
+    if (dx >= dw) return;
+    const uint8_t* S = src + (size_t)blockIdx.z * sstride;
+    uint8_t* D = dst + (size_t)blockIdx.z * dstride + ((size_t)dy * dw + dx) * 3;
+    const int sy0 = min(max(t.yofs[dy], 0), sh - 1), sy1 = min(max(t.yofs[dy] + 1, 0), sh - 1);
+    const int sx = t.xofs[dx], sx1 = min(sx + 1, sw - 1);
+    const int a0 = t.ialpha[2 * dx], a1 = t.ialpha[2 * dx + 1], b0 = t.ibeta[2 * dy], b1 = t.ibeta[2 * dy + 1];
+    const uint8_t* r0 = S + (size_t)sy0 * sw * 3;
+    const uint8_t* r1 = S + (size_t)sy1 * sw * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int h0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+        const int h1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+        D[c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+// exact 2x2 decimation: OpenCV routes INTER_LINEAR to INTER_AREA, i.e. the rounded box mean
+__global__ __launch_bounds__(64) void resize_area2_kernel(const uint8_t* src, int sw, size_t sstride, uint8_t* dst, int dh, int dw,
+                                                          size_t dstride)
+{
+    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y;
+    if (dx >= dw) return;
+    const uint8_t* p = src + (size_t)blockIdx.z * sstride + ((size_t)(2 * dy) * sw + 2 * dx) * 3;
+    uint8_t* D = dst + (size_t)blockIdx.z * dstride + ((size_t)dy * dw + dx) * 3;
+    const size_t row = (size_t)sw * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) D[c] = (uint8_t)((p[c] + p[3 + c] + p[row + c] + p[row + 3 + c] + 2) >> 2);
+}
+
+static short sat_s16_round(float v)
+{
+    long r = lrintf(v);
+    return (short)(r > 32767 ? 32767 : (r < -32768 ? -32768 : r));
+}
+
+int resize_linear(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
+                  int dst_w, size_t dst_frame_stride, hipStream_t stream)
+{
+    if (n == 0) return PSD_OK;
+    const double scale_x = 1. / ((double)dst_w / src_w), scale_y = 1. / ((double)dst_h / src_h);
+    const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
+    const bool area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+    const dim3 grid((dst_w + 63) / 64, dst_h, n);
+    if (area_fast && iscale_x == 2 && iscale_y == 2) {
+        hipLaunchKernelGGL(resize_area2_kernel, grid, dim3(64), 0, stream, d_src, src_w, src_frame_stride, d_dst, dst_h, dst_w,
+                           dst_frame_stride);
+        HIP_TRY(hipGetLastError());
+        return PSD_OK;
+    }
+    // OpenCV's coefficient tables (resize.cpp, INTER_LINEAR, 11-bit fixed point), built on the host
+    // in the same float arithmetic.
+    std::vector<int> xofs(dst_w), yofs(dst_h);
+    std::vector<short> ialpha(2 * (size_t)dst_w), ibeta(2 * (size_t)dst_h);
+    for (int dx = 0; dx < dst_w; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= src_w - 1) { fx = 0; sx = src_w - 1; }
+        xofs[dx] = sx;
+        ialpha[2 * dx] = sat_s16_round((1.f - fx) * 2048);
+        ialpha[2 * dx + 1] = sat_s16_round(fx * 2048);
+    }
+    for (int dy = 0; dy < dst_h; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        ibeta[2 * dy] = sat_s16_round((1.f - fy) * 2048);
+        ibeta[2 * dy + 1] = sat_s16_round(fy * 2048);
+    }
+    const size_t bx = align_up(dst_w * sizeof(int)), ba = align_up(2 * (size_t)dst_w * sizeof(short));
+    const size_t by = align_up(dst_h * sizeof(int)), bb = align_up(2 * (size_t)dst_h * sizeof(short));
+    uint8_t* tabs = nullptr;
+    HIP_TRY(hipMalloc((void**)&tabs, bx + ba + by + bb));
+    ResizeTabs t;
+    t.xofs = (const int*)tabs; t.ialpha = (const short*)(tabs + bx);
+    t.yofs = (const int*)(tabs + bx + ba); t.ibeta = (const short*)(tabs + bx + ba + by);
+    hipError_t err = hipMemcpyAsync((void*)t.xofs, xofs.data(), dst_w * sizeof(int), hipMemcpyHostToDevice, stream);
+    if (err == hipSuccess) err = hipMemcpyAsync((void*)t.ialpha, ialpha.data(), 2 * (size_t)dst_w * sizeof(short), hipMemcpyHostToDevice, stream);
+    if (err == hipSuccess) err = hipMemcpyAsync((void*)t.yofs, yofs.data(), dst_h * sizeof(int), hipMemcpyHostToDevice, stream);
+    if (err == hipSuccess) err = hipMemcpyAsync((void*)t.ibeta, ibeta.data(), 2 * (size_t)dst_h * sizeof(short), hipMemcpyHostToDevice, stream);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(resize_linear_kernel, grid, dim3(64), 0, stream, d_src, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w,
+                           dst_frame_stride, t);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(stream);  // the tables are freed below
+    (void)hipFree(tabs);
+    if (err != hipSuccess) { psd_set_error("resize failed: %s", hipGetErrorString(err)); return PSD_ERR_HIP; }
+    return PSD_OK;
 }
 
 }  // namespace psd

@@ -206,6 +206,10 @@ static int validate(const void* frames, int n, int height, int width, size_t row
         psd_set_error("kernel_size must be odd integer >= 3");
         return PSD_ERR_INVALID;
     }
+    if ((flags & PSD_SCORE_EDGES) && edge_kernel > 63) {
+        psd_set_error("kernel_size %d not supported on the device (max 63)", edge_kernel);
+        return PSD_ERR_UNSUPPORTED;
+    }
     if ((long long)height * width > 0x7fffffffLL / 4) {
         psd_set_error("frame too large");
         return PSD_ERR_UNSUPPORTED;

@@ -76,6 +76,8 @@ class ScoringEngine:
         self.device = int(device)
 
     def close(self) -> None:
+        for buf in self.__dict__.pop("_scratch_bufs", {}).values():
+            buf.free()
         if getattr(self, "_h", None):
             self._lib.psd_destroy(self._h)
             self._h = None
@@ -97,8 +99,7 @@ class ScoringEngine:
                    edge_kernel: int = 0, downscale: float = 1.0) -> np.ndarray:
         """Score ``frames`` uint8[N,H,W,3] (BGR, any row/frame strides) held in host memory."""
         if downscale > 1.0:
-            raise NotImplementedError("device-side downscale (cv2.resize INTER_LINEAR) is not implemented yet; "
-                                      "set SceneManager.auto_downscale = False")
+            return self._score_host_downscaled(frames, prev, flags, edge_kernel, downscale)
         frames = np.asarray(frames)
         if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[3] != 3:
             raise ValueError("frames must be uint8[N,H,W,3]")
@@ -123,6 +124,54 @@ class ScoringEngine:
                                       int(flags), int(edge_kernel), out.ctypes.data)
         )
         return out
+
+    def _score_host_downscaled(self, frames, prev, flags, edge_kernel, factor):
+        """Upload, ``cv2.resize(INTER_LINEAR)`` on the device to the reference's target size
+        (``scene_manager.py:670-678``), then score the small frames.  ``prev`` is resized too."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if frames.ndim != 4 or frames.shape[3] != 3:
+            raise ValueError("frames must be uint8[N,H,W,3]")
+        n, h, w, _ = frames.shape
+        dw, dh = max(1, round(w / factor)), max(1, round(h / factor))
+        out = np.zeros(n, RECORD_DTYPE)
+        if n == 0:
+            return out
+        sstride = h * w * 3
+        dstride = (dh * dw * 3 + 15) & ~15
+        per_chunk = max(1, min(n, (256 << 20) // sstride))
+        src = self._scratch("rs_src", (per_chunk + 1) * sstride)
+        dst = self._scratch("rs_dst", (per_chunk + 1) * dstride)
+        last = None if prev is None else np.ascontiguousarray(prev, dtype=np.uint8)
+        done = 0
+        while done < n:
+            cnt = min(per_chunk, n - done)
+            p = 0
+            if last is not None:
+                src.upload(last.reshape(-1), 0)
+                p = 1
+            src.upload(frames[done:done + cnt].reshape(-1), p * sstride)
+            self.resize_device(src.ptr, cnt + p, h, w, dst.ptr, dh, dw, dst_frame_stride=dstride)
+            out[done:done + cnt] = self.score_device(dst.ptr + p * dstride, cnt, dh, dw, dw * 3, dstride,
+                                                     d_prev=dst.ptr if p else None, flags=flags, edge_kernel=edge_kernel)
+            last = frames[done + cnt - 1]
+            done += cnt
+        return out
+
+    def _scratch(self, name: str, nbytes: int) -> "DeviceBuffer":
+        cache = self.__dict__.setdefault("_scratch_bufs", {})
+        buf = cache.get(name)
+        if buf is None or buf.nbytes < nbytes:
+            if buf is not None:
+                buf.free()
+            buf = cache[name] = DeviceBuffer(self, nbytes)
+        return buf
+
+    def resize_device(self, d_src: int, n: int, src_h: int, src_w: int, d_dst: int, dst_h: int, dst_w: int,
+                      src_frame_stride: int | None = None, dst_frame_stride: int | None = None, stream: int | None = None):
+        """``cv2.resize(frame, (dst_w, dst_h), interpolation=INTER_LINEAR)`` for n packed BGR frames in HBM."""
+        _native.check(self._lib.psd_resize_linear_device(
+            self._h, d_src, int(n), int(src_h), int(src_w), src_h * src_w * 3 if src_frame_stride is None else src_frame_stride,
+            d_dst, int(dst_h), int(dst_w), dst_h * dst_w * 3 if dst_frame_stride is None else dst_frame_stride, stream))
 
     # -- device frames ---------------------------------------------------------------------
     def score_device(self, d_frames: int, n: int, height: int, width: int, row_stride: int | None = None,

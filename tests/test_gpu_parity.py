@@ -166,3 +166,69 @@ def test_edges_match_oracle(hip_engine):
         pytest.xfail("edge term not implemented on the device yet")
     want = oracle_score(frames, edges=True)
     same(got, want, FIELDS + ("edge_xor",))
+
+
+def test_edge_maps_match_oracle(hip_engine):
+    """Dilated Canny edge maps, pixel for pixel (several sizes, kernels, flat and noisy content)."""
+    from oracle.detectors_np import edge_map
+    from pyscenedetect_amd.synth import make_clip
+
+    cases = []
+    frames, _ = make_clip(17, 3, 90, 160, shot_len=(1, 1))
+    cases += [(f, 0) for f in frames] + [(frames[0], 3), (frames[1], 9)]
+    frames, _ = make_clip(18, 2, 131, 197, shot_len=(1, 1), noise=6.0)   # odd size, > 1 hysteresis tile
+    cases += [(f, 0) for f in frames]
+    rng = np.random.default_rng(5)
+    cases.append((rng.integers(0, 256, (70, 100, 3), dtype=np.uint8), 5))
+    cases.append((np.full((40, 50, 3), 77, np.uint8), 0))
+    cases.append((np.zeros((9, 9, 3), np.uint8), 3))
+    for frame, k in cases:
+        h, w, _ = frame.shape
+        buf = hip_engine.alloc(frame.nbytes)
+        buf.upload(frame.reshape(-1))
+        got = hip_engine.edge_map(buf.ptr, h, w, edge_kernel=k)
+        want = edge_map(frame, k)
+        assert np.array_equal(got, want), f"edge map differs for {h}x{w} k={k}: {np.count_nonzero(got != want)} px"
+        buf.free()
+
+
+def test_edges_with_prev_and_chunks(hip_engine):
+    from pyscenedetect_amd.synth import make_clip
+
+    frames, _ = make_clip(23, 20, 72, 128, shot_len=(4, 7))
+    want = oracle_score(frames, edges=True)
+    got = hip_engine.score_host(frames, flags=E.SCORE_ALL)
+    same(got, want, FIELDS + ("edge_xor",))
+    # split with a halo: identical
+    a = hip_engine.score_host(frames[:9], flags=E.SCORE_EDGES)
+    b = hip_engine.score_host(frames[9:], prev=frames[8], flags=E.SCORE_EDGES)
+    assert np.array_equal(np.concatenate([a, b])["edge_xor"], want["edge_xor"])
+    with pytest.raises(ValueError):
+        hip_engine.score_host(frames[:2], flags=E.SCORE_EDGES, edge_kernel=4)
+
+
+@pytest.mark.parametrize("shape", [((180, 320), (144, 256)), ((200, 300), (100, 150)), ((97, 131), (41, 77)),
+                                   ((1080, 1920), (144, 256)), ((64, 64), (64, 64))])
+def test_resize_matches_oracle(hip_engine, shape):
+    import cv2  # the oracle shim
+
+    (sh, sw), (dh, dw) = shape
+    rng = np.random.default_rng(sh + dw)
+    src = rng.integers(0, 256, (3, sh, sw, 3), dtype=np.uint8)
+    a = hip_engine.alloc(src.nbytes)
+    a.upload(src.reshape(-1))
+    b = hip_engine.alloc(3 * dh * dw * 3)
+    hip_engine.resize_device(a.ptr, 3, sh, sw, b.ptr, dh, dw)
+    got = b.download().reshape(3, dh, dw, 3)
+    for i in range(3):
+        want = cv2.resize(src[i], (dw, dh))
+        assert np.array_equal(got[i], want), f"resize {sh}x{sw}->{dh}x{dw}: {np.count_nonzero(got[i] != want)} bytes differ"
+
+
+def test_auto_downscale_golden_through_hip(golden, hip_engine):
+    """Reference default pipeline: frames wider than 256 px are downscaled before scoring."""
+    frames = golden_clip(golden, "wide_d")
+    for name in golden["clips"]["wide_d"]["results"]:
+        cls_name, kwargs, with_stats = golden["configs"][name]
+        got = run_config(frames, cls_name, kwargs, with_stats, hip_engine, auto_downscale=True)
+        assert_same_run(got, golden["clips"]["wide_d"]["results"][name], f"wide_d/{name}")

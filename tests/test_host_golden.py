@@ -173,3 +173,12 @@ def test_native_epilogues_match_reference(golden, oracle_engine, clip):
                                                 1 if kw.get("method") == "CEILING" else 0)
             assert [float(x) for x in avg] == want["metrics"]["average_rgb"], f"{clip}/{name}"
         assert sorted(set(cuts)) == want["cuts"], f"{clip}/{name}: {cuts} vs {want['cuts']}"
+
+
+def test_auto_downscale_matches_reference(golden, oracle_engine):
+    """> 256 px wide: the SceneManager asks the engine to downscale to the reference's target size."""
+    frames = golden_clip(golden, "wide_d")
+    for name in golden["clips"]["wide_d"]["results"]:
+        cls_name, kwargs, with_stats = golden["configs"][name]
+        got = run_config(frames, cls_name, kwargs, with_stats, oracle_engine, auto_downscale=True)
+        assert_same_run(got, golden["clips"]["wide_d"]["results"][name], f"wide_d/{name}")
