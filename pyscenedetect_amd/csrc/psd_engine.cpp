@@ -405,6 +405,7 @@ int psd_memcpy_h2d(psd_engine* e, void* d_dst, const void* h_src, size_t bytes)
 {
     if (!e || (bytes && (!d_dst || !h_src))) { psd_set_error("psd_memcpy_h2d: null argument"); return PSD_ERR_INVALID; }
     HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));  // order against work queued on the engine's (non-blocking) stream
     HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
     return PSD_OK;
 }
@@ -413,6 +414,7 @@ int psd_memcpy_d2h(psd_engine* e, void* h_dst, const void* d_src, size_t bytes)
 {
     if (!e || (bytes && (!h_dst || !d_src))) { psd_set_error("psd_memcpy_d2h: null argument"); return PSD_ERR_INVALID; }
     HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
     return PSD_OK;
 }
