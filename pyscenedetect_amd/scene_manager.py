@@ -292,7 +292,7 @@ class SceneManager:
                 if self._start_pos is None:
                     self._start_pos = video.position
                 frames.append(frame_im)
-                positions.append(video.position)
+                positions.append(FrameTimecode(video.position))  # also accepts the reference's FrameTimecode
                 if len(frames) >= self._batch_frames:
                     flush()
                 if frame_skip > 0:

@@ -66,6 +66,8 @@ class FrameTimecode:
     __slots__ = ("_frames", "_secs", "_rate")
 
     def __init__(self, timecode, fps=None):
+        if _is_foreign_timecode(timecode):
+            timecode = FrameTimecode(int(timecode.frame_num), framerate_to_fraction(timecode.frame_rate))
         if isinstance(timecode, FrameTimecode):
             self._frames, self._secs = timecode._frames, timecode._secs
             self._rate = timecode._rate if fps is None else _as_rate(fps)
@@ -128,6 +130,8 @@ class FrameTimecode:
 
     # -- conversions of the other operand --------------------------------------------------------
     def _frames_of(self, other) -> int:
+        if _is_foreign_timecode(other):
+            other = FrameTimecode(other)
         if isinstance(other, int):
             return other
         if isinstance(other, float):
@@ -141,6 +145,8 @@ class FrameTimecode:
         raise TypeError("Cannot obtain frame number for this timecode.")
 
     def _seconds_of(self, other) -> float:
+        if _is_foreign_timecode(other):
+            other = FrameTimecode(other)
         if isinstance(other, int):
             return float(other) / float(self._rate)
         if isinstance(other, float):
@@ -153,6 +159,8 @@ class FrameTimecode:
 
     def _cmp_key(self, other):
         """(mine, theirs) in the unit the reference would compare in."""
+        if _is_foreign_timecode(other):
+            other = FrameTimecode(other)
         if isinstance(other, FrameTimecode):
             return self.frame_num, other.frame_num
         if isinstance(other, int):
@@ -223,9 +231,16 @@ class FrameTimecode:
         return f"{self.get_timecode()} [frame_num={self._frames}, fps={self._rate}]"
 
 
+def _is_foreign_timecode(obj) -> bool:
+    """Another library's frame timecode (e.g. ``scenedetect.FrameTimecode``): duck-typed."""
+    return not isinstance(obj, FrameTimecode) and hasattr(obj, "frame_num") and hasattr(obj, "frame_rate")
+
+
 def _as_rate(fps) -> Fraction:
     if isinstance(fps, FrameTimecode):
         return fps._rate
+    if _is_foreign_timecode(fps):
+        return framerate_to_fraction(fps.frame_rate)
     if isinstance(fps, (float, Fraction)):
         return framerate_to_fraction(fps)
     raise TypeError(f"Wrong type for fps: {type(fps)} - expected float, Fraction, or FrameTimecode")
