@@ -86,7 +86,7 @@ def cpu_baseline(sample: np.ndarray, flags: int, threads: int) -> dict:
         parts = list(ex.map(work, bounds))
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} frames of the same 1920x1080 batch through oracle/cv2_restate.c (gcc -O3), "
+            "sample": f"{n} frames of the same batch through oracle/cv2_restate.c (gcc -O3), "
                       f"{threads} threads; single thread: {single:.2f} frames/s; real OpenCV is not installed",
             "_records": np.concatenate(parts)}
 
@@ -98,10 +98,15 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU batch")
     ap.add_argument("--dist", default="U", choices=["U", "K", "S"])
-    ap.add_argument("--detector", default="content", choices=["content", "all"])
+    ap.add_argument("--detector", default="content", choices=["content", "hist", "all"],
+                    help="content = ContentDetector (headline); hist = Histogram+Threshold; all = all four fused")
+    ap.add_argument("--res", default="1080p", choices=["1080p", "4k"])
     ap.add_argument("--cpu-sample", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    global H, W
+    if args.res == "4k":
+        H, W = 2160, 3840
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,7 +125,8 @@ def main() -> None:
     from pyscenedetect_amd._native import RECORD_DTYPE
 
     eng = E.ScoringEngine(local_rank)
-    flags = E.SCORE_HSV_SAD if args.detector == "content" else (E.SCORE_HSV_SAD | E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM)
+    flags = {"content": E.SCORE_HSV_SAD, "hist": E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM,
+             "all": E.SCORE_HSV_SAD | E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM}[args.detector]
     n = args.frames
     batch = make_batch(n, args.dist, 20250921 + rank, device)
     ptr = batch.data_ptr()
@@ -143,12 +149,16 @@ def main() -> None:
             allv = recv.cpu().numpy().astype(np.uint64)
             mine = allv[rank]
             assert np.array_equal(mine[:, 0], recs["sad_h"])
-        sc = epilogue.content_scores(recs, H, W)
-        state["cuts"] = epilogue.content_cuts(sc["content_val"], 25.0, threshold=27.0, min_scene_len=15)
         state["recs"] = recs
-        if args.detector == "all":
-            epilogue.hist_cuts(recs, 25.0)
+        if args.detector in ("content", "all"):
+            sc = epilogue.content_scores(recs, H, W)
+            state["cuts"] = epilogue.content_cuts(sc["content_val"], 25.0, threshold=27.0, min_scene_len=15)
+        if args.detector in ("hist", "all"):
+            cuts, _ = epilogue.hist_cuts(recs, 25.0)
             epilogue.threshold_cuts(recs, H, W, 25.0)
+            if args.detector == "hist":
+                state["cuts"] = cuts
+        if args.detector == "all":
             epilogue.adaptive_cuts(sc["content_val"], 25.0)
 
     def run(steps: int, timing: bool):
@@ -193,12 +203,13 @@ def main() -> None:
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
-                key = f"{args.detector}_{args.dist}_{n}"
+                key = f"{args.detector}_{args.res}_{args.dist}_{n}"
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "frames/sec (1080p ContentDetector)",
+            "metric": "frames/sec (1080p ContentDetector)" if (args.detector, args.res) == ("content", "1080p")
+                      else f"frames/sec ({args.res} {args.detector})",
             "value": round(fps, 1),
             "unit": "frames/s",
             "n_gpus": world,
@@ -211,8 +222,11 @@ def main() -> None:
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"ContentDetector(threshold=27) on {n} x 1920x1080 BGR frames per GPU, device-resident "
-                            f"(BASELINE.json configs[1]); distribution {args.dist}; detector set '{args.detector}'",
+                "workload": (f"ContentDetector(threshold=27) on {n} x 1920x1080 BGR frames per GPU, device-resident "
+                             f"(BASELINE.json configs[1]); distribution {args.dist}")
+                            if (args.detector, args.res) == ("content", "1080p") else
+                            f"detector set '{args.detector}' on {n} x {W}x{H} BGR frames per GPU, device-resident; "
+                            f"distribution {args.dist}",
                 "frames_per_gpu": n, "height": H, "width": W, "distribution": args.dist,
                 "parallelism": f"clips sharded over {world} GPU(s), all-gather of score vectors" if world > 1 else "1 GPU",
                 "pipeline_depth": 2,
