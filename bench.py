@@ -111,12 +111,16 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # Under torchrun (RANK set) the RCCL process group is always created, even for one rank, so the
+    # exchange path below is the same code for N = 1 (launched that way) and N = 8.
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -138,7 +142,7 @@ def main() -> None:
         recs = eng.collect(n)
         if collect_timing:
             kernel_ms.append(eng.last_kernel_ms()[0])
-        if world > 1:
+        if use_dist:
             # score vectors only: 4 x u64 per frame
             import torch.distributed as dist
 
@@ -169,10 +173,10 @@ def main() -> None:
         finish(timing)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
 
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize(device)
 
     if args.warmup > 0:
@@ -182,7 +186,7 @@ def main() -> None:
     run(args.steps, True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
 
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -228,7 +232,7 @@ def main() -> None:
                             f"detector set '{args.detector}' on {n} x {W}x{H} BGR frames per GPU, device-resident; "
                             f"distribution {args.dist}",
                 "frames_per_gpu": n, "height": H, "width": W, "distribution": args.dist,
-                "parallelism": f"clips sharded over {world} GPU(s), all-gather of score vectors" if world > 1 else "1 GPU",
+                "parallelism": f"clips sharded over {world} GPU(s), RCCL all-gather of score vectors" if use_dist else "1 GPU",
                 "pipeline_depth": 2,
             },
             "roofline": {
@@ -238,7 +242,7 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "kernel": "psd::score_frames_kernel",
+                "kernel": "psd::score_frames_dma_kernel",
                 "avg_launch_ms": round(avg_kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
@@ -256,10 +260,10 @@ def main() -> None:
         else:
             out["cpu_baseline"] = None
     eng.close()
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
 
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
