@@ -120,7 +120,19 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when the communicator comes up; stdout must carry
+        # exactly one JSON line, so point fd 1 at stderr until the first collective has run.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier(device_ids=[local_rank])
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -136,7 +148,19 @@ def main() -> None:
     ptr = batch.data_ptr()
 
     kernel_ms: list[float] = []
-    state = {"cuts": None}
+    state = {"cuts": None, "pending_gather": None, "gathered": None}
+
+    def consume_gather():
+        """Finish the score-vector all-gather issued one step earlier (keeps ranks loosely coupled)."""
+        pend = state["pending_gather"]
+        if pend is None:
+            return
+        work, recv, mine = pend
+        work.wait()
+        allv = recv.cpu().numpy().astype(np.uint64)      # [world, n, 4]: every clip's score vectors
+        assert np.array_equal(allv[rank, :, 0], mine)
+        state["gathered"] = allv
+        state["pending_gather"] = None
 
     def finish(collect_timing: bool):
         recs = eng.collect(n)
@@ -146,13 +170,12 @@ def main() -> None:
             # score vectors only: 4 x u64 per frame
             import torch.distributed as dist
 
+            consume_gather()
             vec = np.stack([recs["sad_h"], recs["sad_s"], recs["sad_v"], recs["edge_xor"]], axis=1)
-            send = torch.from_numpy(vec.astype(np.int64)).to(device)
+            send = torch.from_numpy(vec.astype(np.int64)).to(device, non_blocking=True)
             recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=device)
-            dist.all_gather_into_tensor(recv, send)
-            allv = recv.cpu().numpy().astype(np.uint64)
-            mine = allv[rank]
-            assert np.array_equal(mine[:, 0], recs["sad_h"])
+            work = dist.all_gather_into_tensor(recv, send, async_op=True)
+            state["pending_gather"] = (work, recv, recs["sad_h"].copy())
         state["recs"] = recs
         if args.detector in ("content", "all"):
             sc = epilogue.content_scores(recs, H, W)
@@ -171,6 +194,8 @@ def main() -> None:
             eng.submit_device(ptr, n, H, W, flags=flags)
             finish(timing)
         finish(timing)
+        if use_dist:
+            consume_gather()   # the last step's exchange completes inside the timed region
 
     def barrier():
         if use_dist:
