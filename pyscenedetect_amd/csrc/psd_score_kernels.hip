@@ -385,7 +385,7 @@ __global__ __launch_bounds__(WG) void score_frames_kernel(const ScoreParams p)
 // flush happen once per F frames; with the luma histogram it is one frame per barrier (F = 1).
 
 constexpr int LCD = 16;  // LUT replicas in the staged kernel (2-way conflicts at worst, 32 KiB for both tables)
-constexpr int ACD = 16;  // accumulator replicas
+constexpr int ACD_MAX = 16;  // accumulator replicas (8 in the fused HSV+luma variant, to fit G=2 in LDS)
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -422,17 +422,27 @@ __device__ __forceinline__ void stage_read(const uint8_t* stage, int wave, int l
     }
 }
 
-// Sum the ACD replicas of accumulators [a0, a0+count) of one slot, zero them, add to the record.
-template <bool LUMA>
+// Sum the AC replicas of one accumulator of one slot, zero them, add to the record.
+template <bool LUMA, int AC>
 __device__ __forceinline__ void flush_slot(u32* slot_acc, psd_frame_scores* rec, int idx)
 {
-    // idx in [0, 2*NA): accumulator a = idx >> 1, half = idx & 1 (8 replicas each)
+    // idx in [0, 2*NA): accumulator a = idx >> 1, half = idx & 1 (AC/2 replicas each)
     const int a = idx >> 1, half = idx & 1;
-    u32x4* q = reinterpret_cast<u32x4*>(slot_acc + a * ACD + half * 8);
-    const u32x4 v0 = q[0], v1 = q[1];
-    const u32x4 zero = {0, 0, 0, 0};
-    q[0] = zero; q[1] = zero;
-    u32 s = v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w;
+    u32 s;
+    if (AC == 16) {
+        u32x4* q = reinterpret_cast<u32x4*>(slot_acc + a * AC + half * 8);
+        const u32x4 v0 = q[0], v1 = q[1];
+        const u32x4 zero = {0, 0, 0, 0};
+        q[0] = zero; q[1] = zero;
+        s = v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w;
+    } else {
+        static_assert(AC == 16 || AC == 8, "");
+        u32x4* q = reinterpret_cast<u32x4*>(slot_acc + a * AC + half * 4);
+        const u32x4 v0 = q[0];
+        const u32x4 zero = {0, 0, 0, 0};
+        q[0] = zero;
+        s = v0.x + v0.y + v0.z + v0.w;
+    }
     s += __shfl_xor(s, 1);
     if (half == 0 && s) {
         if (LUMA && a < 256) {
@@ -452,6 +462,7 @@ template <bool HSV, bool LUMA, int G, int WG>
 __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams p)
 {
     constexpr int NW = WG / 64;
+    constexpr int ACD = (HSV && LUMA) ? 8 : ACD_MAX;
     constexpr int NA = LUMA ? NACC : 4;       // accumulators per frame slot
     constexpr int F = LUMA ? 1 : 8;           // frames per barrier
     constexpr int SLOTS = 2 * F;
@@ -464,6 +475,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int l16 = tid & 15;
+    const int lacc = tid & (ACD - 1);
     const int tile = blockIdx.x % p.n_tiles;
     const int chunk = blockIdx.x / p.n_tiles;
 
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
 
     for (int t = t0; t < t1; t++) {
         const int slot = (t - t0) % SLOTS;
-        u32* my_acc = &acc[slot][0] + l16;
+        u32* my_acc = &acc[slot][0] + lacc;
         // Frame t has been in flight since the previous step; take it out of the staging slot and
         // immediately refill the slot with frame t+1.
 #if !(PSD_ABLATE & 4)
@@ -556,7 +568,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
             const int first = done - nf;                          // chunk-relative index of the first
             for (int i = tid; i < nf * 2 * NA; i += WG) {
                 const int fi = i / (2 * NA), idx = i - fi * 2 * NA;
-                flush_slot<LUMA>(&acc[(first + fi) % SLOTS][0], p.out + t0 + first + fi, idx);
+                flush_slot<LUMA, ACD>(&acc[(first + fi) % SLOTS][0], p.out + t0 + first + fi, idx);
             }
         }
 #endif
@@ -576,7 +588,7 @@ template <bool HSV, bool LUMA, int G, bool FAST>
 static hipError_t launch_one(const ScoreParams& p, int grid, hipStream_t stream)
 {
     constexpr int WG = kScoreWG;
-    if constexpr (FAST && !(HSV && LUMA && G == 2)) {  // (the fused G=2 variant would need 160.5 KiB of LDS)
+    if constexpr (FAST) {
         if (!direct_loads()) {
             hipLaunchKernelGGL((score_frames_dma_kernel<HSV, LUMA, G, WG>), dim3(grid), dim3(WG), 0, stream, p);
             return hipGetLastError();
@@ -609,8 +621,7 @@ static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bo
                                bool fast, int target_blocks, hipStream_t stream)
 {
     // Tile geometry: spread the 16-px groups evenly over the fewest tiles that fit.
-    int gpl = fast ? groups_per_lane() : 1;
-    if (fast && hsv && luma && !direct_loads()) gpl = 1;  // fused staged kernel: one group per lane (LDS budget)
+    const int gpl = fast ? groups_per_lane() : 1;
     const int cap = kScoreWG * gpl;
     const int n_groups = group_end - group_begin;
     if (n_groups <= 0) return hipSuccess;
