@@ -179,6 +179,64 @@ def kats():
     return out
 
 
+def scenarios():
+    """SceneManager behaviours around the per-frame loop (seek/end_time/duration, start_in_scene,
+    callbacks with look-behind, crop, frame_skip), again from the unmodified reference."""
+    frames, _ = make_clip(*CLIPS["scenes_a"][:4], **CLIPS["scenes_a"][4])
+    out = {}
+
+    def manager(det, stats=False, **attrs):
+        sm = SceneManager(StatsManager() if stats else None)
+        sm.auto_downscale = False
+        for k, v in attrs.items():
+            setattr(sm, k, v)
+        sm.add_detector(det)
+        return sm
+
+    def scene_nums(sm, **kw):
+        return [[a.frame_num, b.frame_num] for a, b in sm.get_scene_list(**kw)]
+
+    # window: seek + end_time
+    video = MemoryStream(frames)
+    video.seek(40)
+    sm = manager(ContentDetector())
+    n = sm.detect_scenes(video, end_time=200)
+    out["window_seek40_end200"] = {"frames_processed": n, "scenes": scene_nums(sm),
+                                   "cuts": [c.frame_num for c in sm.get_cut_list(show_warning=False)]}
+    # duration
+    video = MemoryStream(frames)
+    sm = manager(ContentDetector())
+    n = sm.detect_scenes(video, duration=100)
+    out["duration_100"] = {"frames_processed": n, "scenes": scene_nums(sm)}
+    # no cuts -> empty list unless start_in_scene
+    video = MemoryStream(frames)
+    sm = manager(ContentDetector())
+    n = sm.detect_scenes(video, end_time=10)
+    out["short_no_cuts"] = {"frames_processed": n, "scenes": scene_nums(sm), "scenes_start_in_scene": scene_nums(sm, start_in_scene=True)}
+    # callbacks
+    for name, det in (("content", ContentDetector()), ("adaptive", AdaptiveDetector()),
+                      ("content_suppress", ContentDetector(filter_mode=FlashFilter.Mode.SUPPRESS, min_scene_len=6, threshold=20.0))):
+        calls = []
+        video = MemoryStream(frames)
+        sm = manager(det)
+        sm.detect_scenes(video, callback=lambda img, pos: calls.append([pos.frame_num, int(img.sum())]))
+        out[f"callback_{name}"] = {"calls": calls, "cuts": [c.frame_num for c in sm.get_cut_list(show_warning=False)]}
+    # crop (inclusive coordinates)
+    video = MemoryStream(frames)
+    sm = manager(ContentDetector(), stats=True, crop=(10, 5, 100, 60))
+    sm.detect_scenes(video)
+    cv = [sm.stats_manager.get_metrics(i, ["content_val"])[0] for i in range(len(frames))]
+    out["crop_10_5_100_60"] = {"cuts": [c.frame_num for c in sm.get_cut_list(show_warning=False)],
+                               "content_val": [None if v is None else float(v) for v in cv]}
+    # frame_skip
+    video = MemoryStream(frames)
+    sm = manager(ContentDetector())
+    n = sm.detect_scenes(video, frame_skip=1)
+    out["frame_skip_1"] = {"frames_processed": n, "cuts": [c.frame_num for c in sm.get_cut_list(show_warning=False)],
+                           "scenes": scene_nums(sm)}
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     golden = {"reference_version": scenedetect.__version__, "numpy": np.__version__, "clips": {}, "configs": CONFIGS}
@@ -198,6 +256,7 @@ def main():
         entry["results"][cname] = run(fr, cls_name, kwargs, with_stats, False)
     golden["clips"]["uniform_u"] = entry
     golden["kats"] = kats()
+    golden["scenarios"] = scenarios()
     path = os.path.join(OUT, "reference_runs.json")
     with open(path, "w") as f:
         json.dump(golden, f, indent=None, separators=(",", ":"))

@@ -1,0 +1,151 @@
+"""CPU (+ one GPU pass): SceneManager behaviour around the per-frame loop -- seek/end_time/duration
+windows, start_in_scene, callbacks with look-behind, crop, frame_skip, stats CSV -- against runs of
+the unmodified reference (tests/golden/reference_runs.json["scenarios"]; the reference's own
+versions of these tests are tests/test_scene_manager.py:28-196 and need video files)."""
+import io
+
+import numpy as np
+import pytest
+
+import pyscenedetect_amd as psd
+from pyscenedetect_amd import FlashFilter
+from tests.conftest import golden_clip
+
+
+def _manager(det, engine, stats=False, **attrs):
+    sm = psd.SceneManager(psd.StatsManager() if stats else None, engine=engine, batch_frames=32)
+    sm.auto_downscale = False
+    for k, v in attrs.items():
+        setattr(sm, k, v)
+    sm.add_detector(det)
+    return sm
+
+
+def _scenes(sm, **kw):
+    return [[a.frame_num, b.frame_num] for a, b in sm.get_scene_list(**kw)]
+
+
+def _run_scenarios(golden, engine):
+    frames = golden_clip(golden, "scenes_a")
+    want = golden["scenarios"]
+
+    video = psd.ArrayVideoStream(frames, 25.0)
+    video.seek(40)
+    sm = _manager(psd.ContentDetector(engine=engine), engine)
+    assert sm.detect_scenes(video, end_time=200) == want["window_seek40_end200"]["frames_processed"]
+    assert _scenes(sm) == want["window_seek40_end200"]["scenes"]
+    assert [c.frame_num for c in sm.get_cut_list()] == want["window_seek40_end200"]["cuts"]
+    scenes = sm.get_scene_list()
+    assert all(a.frame_num < b.frame_num for a, b in scenes) and all(x[1] == y[0] for x, y in zip(scenes, scenes[1:]))
+
+    sm = _manager(psd.ContentDetector(engine=engine), engine)
+    assert sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), duration=100) == want["duration_100"]["frames_processed"]
+    assert _scenes(sm) == want["duration_100"]["scenes"]
+
+    sm = _manager(psd.ContentDetector(engine=engine), engine)
+    assert sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), end_time=10) == want["short_no_cuts"]["frames_processed"]
+    assert _scenes(sm) == [] and _scenes(sm, start_in_scene=True) == want["short_no_cuts"]["scenes_start_in_scene"]
+
+    dets = {"content": lambda: psd.ContentDetector(engine=engine),
+            "adaptive": lambda: psd.AdaptiveDetector(engine=engine),
+            "content_suppress": lambda: psd.ContentDetector(filter_mode=FlashFilter.Mode.SUPPRESS, min_scene_len=6,
+                                                            threshold=20.0, engine=engine)}
+    for name, make in dets.items():
+        calls = []
+        sm = _manager(make(), engine)
+        sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), callback=lambda img, pos: calls.append([pos.frame_num, int(img.sum())]))
+        assert calls == want[f"callback_{name}"]["calls"], name
+        assert [c.frame_num for c in sm.get_cut_list()] == want[f"callback_{name}"]["cuts"]
+
+    sm = _manager(psd.ContentDetector(engine=engine), engine, stats=True, crop=(10, 5, 100, 60))
+    assert sm.crop == (10, 5, 100, 60)
+    sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+    assert [c.frame_num for c in sm.get_cut_list()] == want["crop_10_5_100_60"]["cuts"]
+    cv = [sm.stats_manager.get_metrics(i, ["content_val"])[0] for i in range(len(frames))]
+    assert [None if v is None else float(v) for v in cv] == want["crop_10_5_100_60"]["content_val"]
+
+    sm = _manager(psd.ContentDetector(engine=engine), engine)
+    assert sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), frame_skip=1) == want["frame_skip_1"]["frames_processed"]
+    assert [c.frame_num for c in sm.get_cut_list()] == want["frame_skip_1"]["cuts"]
+    assert _scenes(sm) == want["frame_skip_1"]["scenes"]
+
+
+def test_scenarios_match_reference(golden, oracle_engine):
+    _run_scenarios(golden, oracle_engine)
+
+
+@pytest.mark.gpu
+def test_scenarios_match_reference_on_gpu(golden, hip_engine):
+    _run_scenarios(golden, hip_engine)
+
+
+def test_argument_validation(oracle_engine):
+    sm = psd.SceneManager(psd.StatsManager(), engine=oracle_engine)
+    sm.add_detector(psd.ThresholdDetector(engine=oracle_engine))
+    video = psd.ArrayVideoStream(np.zeros((4, 8, 8, 3), np.uint8), 25.0)
+    with pytest.raises(ValueError):
+        sm.detect_scenes(video, frame_skip=1)              # not allowed with a StatsManager
+    with pytest.raises(ValueError):
+        sm.detect_scenes(video, duration=1, end_time=2)
+    with pytest.raises(ValueError):
+        sm.detect_scenes(video, end_time=-1)
+    with pytest.raises(TypeError):
+        sm.detect_scenes()
+    with pytest.raises(ValueError):
+        sm.crop = (0, 0, -1, 4)
+    with pytest.raises(TypeError):
+        sm.crop = (0, 0, 1.5, 4)
+    sm2 = psd.SceneManager(engine=oracle_engine)
+    sm2.crop = (100, 100, 120, 120)
+    sm2.add_detector(psd.ThresholdDetector(engine=oracle_engine))
+    with pytest.raises(ValueError, match="outside video boundary"):
+        sm2.detect_scenes(psd.ArrayVideoStream(np.zeros((4, 8, 8, 3), np.uint8), 25.0))
+    with pytest.raises(ValueError):
+        psd.ContentDetector(kernel_size=4)
+    with pytest.raises(ValueError):
+        psd.AdaptiveDetector(window_width=0)
+    with pytest.raises(ValueError):
+        psd.HistogramDetector(engine=oracle_engine).process_frame(psd.FrameTimecode(0, 25.0), np.zeros((4, 4, 3), np.float32))
+
+
+def test_decode_errors_surface_in_caller(oracle_engine):
+    """An exception in the frame source is re-raised by detect_scenes after the worker stopped
+    (reference scene_manager.py:598-618)."""
+
+    class Broken(psd.ArrayVideoStream):
+        def read(self, decode=True):
+            if self.frame_number == 5:
+                raise OSError("decoder blew up")
+            return super().read(decode)
+
+    sm = psd.SceneManager(engine=oracle_engine, batch_frames=2)
+    sm.add_detector(psd.ThresholdDetector(engine=oracle_engine))
+    with pytest.raises(OSError, match="decoder blew up"):
+        sm.detect_scenes(Broken(np.zeros((9, 8, 8, 3), np.uint8), 25.0))
+
+
+def test_stats_csv_and_cached_threshold_metric(golden, oracle_engine):
+    frames = golden_clip(golden, "fades_b")
+    stats = psd.StatsManager()
+    sm = psd.SceneManager(stats, engine=oracle_engine)
+    sm.auto_downscale = False
+    sm.add_detector(psd.ThresholdDetector(engine=oracle_engine))
+    sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+    cuts = [c.frame_num for c in sm.get_cut_list()]
+    assert cuts == golden["clips"]["fades_b"]["results"]["threshold_default"]["cuts"]
+    buf = io.StringIO()
+    stats.save_to_csv(buf)
+    lines = buf.getvalue().strip().split("\n")
+    assert lines[0] == "Frame Number,Timecode,average_rgb" and len(lines) == len(frames) + 1
+    assert lines[1].startswith("1,00:00:00.000,")
+    # second pass over cached metrics: no pixel work at all (threshold_detector.py:122-125)
+    class NoEngine:
+        def score_host(self, *a, **k):
+            raise AssertionError("cached average_rgb must be used")
+
+    det = psd.ThresholdDetector(engine=NoEngine())
+    det.stats_manager = stats
+    again = []
+    for i, f in enumerate(frames):
+        again += det.process_frame(psd.FrameTimecode(i, 25.0), f)
+    assert [c.frame_num for c in again] == cuts
