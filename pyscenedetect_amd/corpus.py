@@ -1,0 +1,79 @@
+"""Whole-corpus detection: many clips (mixed resolutions), several detectors, one or many GPUs.
+
+This is the batch face of the engine for BASELINE.json configs 4-5: clips are packed onto the
+GPUs of a node (one process per GPU, sharded by clip), every clip is scored ONCE for the union of
+what the requested detectors need, the per-frame records are all-gathered (RCCL), and every rank
+runs the native decision epilogues -- so the result does not depend on the number of GPUs.
+"""
+
+import numpy as np
+
+from pyscenedetect_amd import _native, epilogue
+
+#: detector name -> (score flags, default parameters); parameters mirror the reference constructors.
+DETECTORS = {
+    "content": (_native.SCORE_HSV_SAD, dict(threshold=27.0, min_scene_len=15, weights=(1.0, 1.0, 1.0, 0.0), filter_mode=0)),
+    "adaptive": (_native.SCORE_HSV_SAD, dict(adaptive_threshold=3.0, min_scene_len=15, window_width=2, min_content_val=15.0,
+                                            weights=(1.0, 1.0, 1.0, 0.0))),
+    "hist": (_native.SCORE_LUMA_HIST, dict(threshold=0.20, bins=128, min_scene_len=15)),
+    "threshold": (_native.SCORE_BYTE_SUM, dict(threshold=12, min_scene_len=15, fade_bias=0.0, add_final_scene=False, method=0)),
+}
+
+
+def required_flags(detectors: dict) -> int:
+    flags = 0
+    for name, params in detectors.items():
+        base, defaults = DETECTORS[name]
+        flags |= base
+        w = (params or {}).get("weights", defaults.get("weights"))
+        if w is not None and len(w) == 4 and w[3] > 0.0:
+            flags |= _native.SCORE_EDGES
+    return flags
+
+
+def decide(records: np.ndarray, height: int, width: int, fps, detectors: dict) -> dict:
+    """Cut lists of one clip from its records: ``{detector name: [frame numbers]}``."""
+    out = {}
+    scores = None
+    for name, params in detectors.items():
+        p = dict(DETECTORS[name][1])
+        p.update(params or {})
+        if name in ("content", "adaptive"):
+            weights = p.pop("weights")
+            scores = epilogue.content_scores(records, height, width, weights)
+            if name == "content":
+                out[name] = epilogue.content_cuts(scores["content_val"], fps, p["threshold"], p["min_scene_len"], p["filter_mode"])
+            else:
+                out[name] = epilogue.adaptive_cuts(scores["content_val"], fps, p["adaptive_threshold"], p["min_scene_len"],
+                                                   p["window_width"], p["min_content_val"])[0]
+        elif name == "hist":
+            out[name] = epilogue.hist_cuts(records, fps, p["threshold"], p["bins"], p["min_scene_len"])[0]
+        elif name == "threshold":
+            out[name] = epilogue.threshold_cuts(records, height, width, fps, p["threshold"], p["min_scene_len"], p["fade_bias"],
+                                                p["add_final_scene"], p["method"])[0]
+        else:
+            raise KeyError(name)
+    return out
+
+
+def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: int = 0) -> list[dict]:
+    """Detect cuts in every clip of ``clips`` (each ``uint8[n,H,W,3]``, sizes may differ).
+
+    With an initialised ``torch.distributed`` process group the clips are sharded over the ranks
+    (``distributed.score_clips_distributed``) and every rank returns the full result."""
+    flags = required_flags(detectors)
+    use_dist = False
+    try:
+        import torch.distributed as dist
+
+        use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    except ImportError:
+        pass
+    if use_dist:
+        from pyscenedetect_amd.distributed import score_clips_distributed
+
+        records = score_clips_distributed(engine, clips, flags, edge_kernel, group)
+    else:
+        records = [engine.score_host(c[0:len(c)], flags=flags, edge_kernel=edge_kernel) for c in clips]
+    fps_list = fps if isinstance(fps, (list, tuple)) else [fps] * len(clips)
+    return [decide(r, c.shape[1], c.shape[2], f, detectors) for r, c, f in zip(records, clips, fps_list)]

@@ -29,6 +29,10 @@ def test_assign_clips_balances():
     assert abs(loads[0] - loads[1]) <= 20
 
 
+CORPUS = [(70, 36, 64), (50, 54, 96), (33, 24, 40), (90, 36, 64), (41, 48, 80)]
+ALL_FOUR = {"content": {"min_scene_len": 8}, "adaptive": {"min_scene_len": 8}, "hist": {}, "threshold": {"threshold": 40}}
+
+
 def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -45,6 +49,15 @@ def _worker(rank, world, port, tmp):
     per_clip = D.score_clips_distributed(eng, clips, flags=7)
     sc = epilogue.content_scores(recs, 36, 64)
     cuts = epilogue.content_cuts(sc["content_val"], 25.0, min_scene_len=5)
+    # mixed-resolution corpus, all four detectors (BASELINE.json config 5 in miniature)
+    import json
+
+    from pyscenedetect_amd.corpus import detect_corpus
+
+    corpus = [make_clip(60 + i, n, h, w, shot_len=(16, 24))[0] for i, (n, h, w) in enumerate(CORPUS)]
+    res = detect_corpus(eng, corpus, 25.0, ALL_FOUR)
+    with open(os.path.join(tmp, f"corpus{rank}.json"), "w") as f:
+        json.dump(res, f)
     np.save(os.path.join(tmp, f"recs{rank}.npy"), recs)
     np.save(os.path.join(tmp, f"cuts{rank}.npy"), np.array(cuts))
     for i, r in enumerate(per_clip):
@@ -77,3 +90,20 @@ def test_two_ranks_equal_one(tmp_path):
         ref = eng.score_host(c, flags=7)
         for r in range(world):
             assert np.load(tmp_path / f"clip{i}_{r}.npy").tobytes() == ref.tobytes()
+    # corpus: 2 ranks == 1 process == the per-frame detectors through SceneManager
+    import json
+
+    import pyscenedetect_amd as psd
+    from pyscenedetect_amd.corpus import detect_corpus
+
+    corpus = [make_clip(60 + i, n, h, w, shot_len=(16, 24))[0] for i, (n, h, w) in enumerate(CORPUS)]
+    single = detect_corpus(eng, corpus, 25.0, ALL_FOUR)
+    assert any(any(v for v in clip.values()) for clip in single)
+    for r in range(world):
+        assert json.load(open(tmp_path / f"corpus{r}.json")) == single
+    for clip, res in zip(corpus, single):
+        sm = psd.SceneManager(engine=eng)
+        sm.auto_downscale = False
+        sm.add_detector(psd.ContentDetector(min_scene_len=8, engine=eng))
+        sm.detect_scenes(psd.ArrayVideoStream(clip, 25.0))
+        assert [c.frame_num for c in sm.get_cut_list()] == res["content"]
