@@ -142,43 +142,66 @@ __global__ __launch_bounds__(256) void median_thresholds_kernel(const u32* hist,
 
 // ---- K3: Sobel + non-maximum suppression -------------------------------------------------------
 
-constexpr int NT_W = 64, NT_H = 16;  // tile of the NMS kernel (256 threads x 4 px)
+constexpr int NT_W = 64, NT_H = 32;  // tile of the NMS kernel (256 threads x 8 px)
 
 // grid = (tiles_x, tiles_y, frames)
 __global__ __launch_bounds__(256) void sobel_nms_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, uint8_t* map)
 {
-    __shared__ uint8_t sv[NT_H + 4][NT_W + 4 + 4];        // V with a 2-px halo (replicated at the image border)
-    __shared__ unsigned short smag[NT_H + 2][NT_W + 2 + 2];  // |dx|+|dy| with a 1-px halo (0 outside the image)
-    __shared__ short sdx[NT_H][NT_W], sdy[NT_H][NT_W];
+    constexpr int SVW = NT_W + 8;                       // V rows cover x0-4 .. x0+67 (dword aligned)
+    __shared__ __attribute__((aligned(16))) uint8_t sv[NT_H + 4][SVW];   // rows y0-2 .. y0+NT_H+1
+    __shared__ unsigned short smag[NT_H + 2][NT_W + 2 + 2];              // |dx|+|dy|, 1-px halo, 0 outside the image
+    __shared__ u32 sdxy[NT_H][NT_W];                                     // (dy << 16) | (dx & 0xffff) of interior pixels
     const int j = blockIdx.z;
     const uint8_t* V = vplane + (size_t)j * g.npix;
     const int x0 = blockIdx.x * NT_W, y0 = blockIdx.y * NT_H;
     const int H = g.height, W = g.width;
-    for (int i = threadIdx.x; i < (NT_H + 4) * (NT_W + 4); i += 256) {
-        const int ly = i / (NT_W + 4), lx = i - ly * (NT_W + 4);
-        const int y = min(max(y0 + ly - 2, 0), H - 1), x = min(max(x0 + lx - 2, 0), W - 1);
-        sv[ly][lx] = V[(size_t)y * W + x];
+    // Load V with the border replicated.  Interior tiles of frames whose width is a multiple of 4
+    // use aligned dword loads, everything else clamps per byte.
+    const bool inner = (W & 3) == 0 && ((g.npix & 3) == 0) && x0 >= 4 && x0 + NT_W + 4 <= W && y0 >= 2 && y0 + NT_H + 2 <= H;
+    if (inner) {
+        for (int i = threadIdx.x; i < (NT_H + 4) * (SVW / 4); i += 256) {
+            const int ly = i / (SVW / 4), lw = i - ly * (SVW / 4);
+            const u32 v = *reinterpret_cast<const u32*>(V + (size_t)(y0 + ly - 2) * W + x0 - 4 + lw * 4);
+            *reinterpret_cast<u32*>(&sv[ly][lw * 4]) = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < (NT_H + 4) * SVW; i += 256) {
+            const int ly = i / SVW, lx = i - ly * SVW;
+            const int y = min(max(y0 + ly - 2, 0), H - 1), x = min(max(x0 + lx - 4, 0), W - 1);
+            sv[ly][lx] = V[(size_t)y * W + x];
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (NT_H + 2) * (NT_W + 2); i += 256) {
-        const int ly = i / (NT_W + 2), lx = i - ly * (NT_W + 2);
-        const int y = y0 + ly - 1, x = x0 + lx - 1;
-        unsigned short m = 0;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-            // sv index of (y, x) is [ly+1][lx+1]
-            const int cy = ly + 1, cx = lx + 1;
-            const int a00 = sv[cy - 1][cx - 1], a01 = sv[cy - 1][cx], a02 = sv[cy - 1][cx + 1];
-            const int a10 = sv[cy][cx - 1], a12 = sv[cy][cx + 1];
-            const int a20 = sv[cy + 1][cx - 1], a21 = sv[cy + 1][cx], a22 = sv[cy + 1][cx + 1];
-            const int dx = (a02 - a00) + 2 * (a12 - a10) + (a22 - a20);
-            const int dy = (a20 - a00) + 2 * (a21 - a01) + (a22 - a02);
-            m = (unsigned short)(abs(dx) + abs(dy));
-            if (ly >= 1 && ly <= NT_H && lx >= 1 && lx <= NT_W) {
-                sdx[ly - 1][lx - 1] = (short)dx;
-                sdy[ly - 1][lx - 1] = (short)dy;
-            }
+    // Separable Sobel down columns: per V row, h1 = right - left and h2 = left + 2*mid + right;
+    // dx = h1[-1] + 2 h1[0] + h1[+1], dy = h2[+1] - h2[-1].  One work item = one column of the
+    // (NT_W+2)-wide magnitude halo region x a quarter of its rows.
+    constexpr int MW = NT_W + 2, MH = NT_H + 2, QR = (MH + 3) / 4;
+    for (int item = threadIdx.x; item < MW * 4; item += 256) {
+        const int lx = item % MW, q = item / MW;
+        const int r0 = q * QR, r1 = min(MH, r0 + QR);          // magnitude rows [r0, r1)
+        // magnitude (ly, lx) is centred on sv[ly + 1][lx + 3]
+        const int cx = lx + 3;
+        int h1a, h1b, h2a, h2b;
+        {
+            const int a = sv[r0][cx - 1], b = sv[r0][cx], c = sv[r0][cx + 1];
+            h1a = c - a; h2a = a + 2 * b + c;
+            const int a1 = sv[r0 + 1][cx - 1], b1 = sv[r0 + 1][cx], c1 = sv[r0 + 1][cx + 1];
+            h1b = c1 - a1; h2b = a1 + 2 * b1 + c1;
         }
-        smag[ly][lx] = m;
+        const int x = x0 + lx - 1;
+        for (int ly = r0; ly < r1; ly++) {
+            const int a = sv[ly + 2][cx - 1], b = sv[ly + 2][cx], c = sv[ly + 2][cx + 1];
+            const int h1c = c - a, h2c = a + 2 * b + c;
+            const int dx = h1a + 2 * h1b + h1c, dy = h2c - h2a;
+            const int y = y0 + ly - 1;
+            unsigned short m = 0;
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                m = (unsigned short)(abs(dx) + abs(dy));
+                if (ly >= 1 && ly <= NT_H && lx >= 1 && lx <= NT_W) sdxy[ly - 1][lx - 1] = ((u32)dy << 16) | ((u32)dx & 0xffffu);
+            }
+            smag[ly][lx] = m;
+            h1a = h1b; h1b = h1c; h2a = h2b; h2b = h2c;
+        }
     }
     __syncthreads();
     const int low = thr[j].x, high = thr[j].y;
@@ -189,7 +212,8 @@ __global__ __launch_bounds__(256) void sobel_nms_kernel(const uint8_t* vplane, E
         const int m = smag[ly + 1][lx + 1];
         uint8_t out = 0;
         if (m > low) {
-            const int xs = sdx[ly][lx], ys = sdy[ly][lx];
+            const u32 pk = sdxy[ly][lx];
+            const int xs = (int)(short)(pk & 0xffffu), ys = (int)pk >> 16;
             const int ax = abs(xs), ay = abs(ys) << 15;
             const int tg22x = ax * 13573;  // TG22 = round(tan(22.5 deg) * 2^15)
             bool is_max;
@@ -216,15 +240,21 @@ constexpr int HT = 64;  // hysteresis tile edge
 
 // grid = (tiles_x, tiles_y, frames).  Grows strong (2) into 8-connected weak (1) pixels inside the
 // tile until nothing changes, using the neighbouring tiles' current state as a read-only halo.
-// Sets *changed when the tile promoted anything.
-__global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom g, int* changed)
+// Work list: a tile is only looked at when `dirty_in` says one of its neighbours promoted a pixel
+// on the shared border in the previous launch (all tiles are dirty for the first launch); when it
+// promotes border pixels itself it marks its neighbours in `dirty_out` and raises *changed.
+__global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom g, const uint8_t* dirty_in, uint8_t* dirty_out,
+                                                         int* changed)
 {
     __shared__ uint8_t t[HT + 2][HT + 2 + 2];
-    __shared__ int any_weak, tile_changed, round_changed;
+    __shared__ int any_weak, tile_changed, border_changed, round_changed;
     const int j = blockIdx.z;
+    const int tiles_x = gridDim.x, tiles_y = gridDim.y;
+    const size_t tile_base = (size_t)j * tiles_x * tiles_y;
+    if (!dirty_in[tile_base + (size_t)blockIdx.y * tiles_x + blockIdx.x]) return;
     uint8_t* M = map + (size_t)j * g.npix;
     const int x0 = blockIdx.x * HT, y0 = blockIdx.y * HT, H = g.height, W = g.width;
-    if (threadIdx.x == 0) { any_weak = 0; tile_changed = 0; }
+    if (threadIdx.x == 0) { any_weak = 0; tile_changed = 0; border_changed = 0; }
     __syncthreads();
     int weak_here = 0;
     for (int i = threadIdx.x; i < (HT + 2) * (HT + 2); i += 256) {
@@ -244,7 +274,7 @@ __global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom 
         __syncthreads();
         if (threadIdx.x == 0) round_changed = 0;
         __syncthreads();
-        int ch = 0;
+        int ch = 0, bch = 0;
 #pragma unroll
         for (int dy = 0; dy < 4; dy++)
 #pragma unroll
@@ -253,10 +283,15 @@ __global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom 
                 if (t[y][x] == 1) {
                     const int s = (t[y - 1][x - 1] | t[y - 1][x] | t[y - 1][x + 1] | t[y][x - 1] | t[y][x + 1] |
                                    t[y + 1][x - 1] | t[y + 1][x] | t[y + 1][x + 1]) & 2;
-                    if (s) { t[y][x] = 2; ch = 1; }   // racing writers only ever store 2: benign
+                    if (s) {
+                        t[y][x] = 2;  // racing writers only ever store 2: benign
+                        ch = 1;
+                        if (y == 1 || y == HT || x == 1 || x == HT) bch = 1;
+                    }
                 }
             }
         if (ch) round_changed = 1;
+        if (bch) border_changed = 1;
         __syncthreads();
         if (!round_changed) break;
         if (threadIdx.x == 0) tile_changed = 1;
@@ -268,7 +303,11 @@ __global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom 
             const int y = y0 + ly, x = x0 + lx;
             if (y < H && x < W && t[ly + 1][lx + 1] == 2) M[(size_t)y * W + x] = 2;
         }
-        if (threadIdx.x == 0) atomicOr(changed, 1);
+        if (border_changed && threadIdx.x < 9 && threadIdx.x != 4) {
+            const int ny = (int)blockIdx.y + (int)threadIdx.x / 3 - 1, nx = (int)blockIdx.x + (int)threadIdx.x % 3 - 1;
+            if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) dirty_out[tile_base + (size_t)ny * tiles_x + nx] = 1;
+        }
+        if (border_changed && threadIdx.x == 0) atomicOr(changed, 1);
     }
 }
 
@@ -370,8 +409,8 @@ static int estimated_kernel_size(int width, int height)
 
 struct EdgeBuffers {
     uint8_t* vplane; uint8_t* map; u32* hist; int2* thr; u32* hbits; u32* dil; u32* carry;
-    unsigned long long* xr; int* flags; int2* thr_tab;
-    int cap_frames;
+    unsigned long long* xr; int* flags; int2* thr_tab; uint8_t* dirty[2];
+    int cap_frames; size_t tiles_per_frame;
 };
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -379,8 +418,9 @@ static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeBuffers* b)
 {
     const size_t words = (size_t)g.height * g.words_per_row;
+    const size_t tiles = (size_t)((g.width + HT - 1) / HT) * ((g.height + HT - 1) / HT);
     const size_t per_frame = align_up((size_t)g.npix) * 2 + align_up(256 * 4) + align_up(sizeof(int2)) +
-                             align_up(words * 4) * 2 + align_up(8);
+                             align_up(words * 4) * 2 + align_up(8) + 2 * align_up(tiles);
     // bound the workspace to ~1 GiB unless a single frame needs more
     int frames = (int)std::max<size_t>(1, std::min<size_t>((size_t)want_frames, ((size_t)1 << 30) / per_frame));
     const size_t fixed = align_up(words * 4) + align_up(64 * sizeof(int)) + align_up(511 * sizeof(int2));
@@ -404,6 +444,9 @@ static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeB
     b->hbits = (u32*)take(words * 4 * frames);
     b->dil = (u32*)take(words * 4 * frames);
     b->xr = (unsigned long long*)take((size_t)frames * 8);
+    b->dirty[0] = take(tiles * frames);
+    b->dirty[1] = take(tiles * frames);
+    b->tiles_per_frame = tiles;
     b->carry = (u32*)take(words * 4);
     b->flags = (int*)take(64 * sizeof(int));
     b->thr_tab = (int2*)take(511 * sizeof(int2));
@@ -438,17 +481,26 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
     hipLaunchKernelGGL(sobel_nms_kernel, dim3((g.width + NT_W - 1) / NT_W, (g.height + NT_H - 1) / NT_H, count), dim3(256), 0,
                        stream, b.vplane, g, b.thr, b.map);
     HIP_TRY(hipGetLastError());
-    // hysteresis to the fix point: rounds of 8 launches, each with its own flag; stop when the last
-    // launch of a round changed nothing.
+    // hysteresis to the fix point: rounds of R launches (ping-pong dirty-tile lists, one flag per
+    // launch); done when a launch promoted nothing on any tile border.
     const dim3 hgrid((g.width + HT - 1) / HT, (g.height + HT - 1) / HT, count);
+    const size_t dirty_bytes = b.tiles_per_frame * (size_t)count;
+    HIP_TRY(hipMemsetAsync(b.dirty[0], 1, dirty_bytes, stream));
+    int launch = 0;
     for (int round = 0; round < 4096; round++) {
-        constexpr int R = 8;
+        constexpr int R = 3;
         HIP_TRY(hipMemsetAsync(b.flags, 0, R * sizeof(int), stream));
-        for (int i = 0; i < R; i++) hipLaunchKernelGGL(hysteresis_kernel, hgrid, dim3(256), 0, stream, b.map, g, b.flags + i);
+        for (int i = 0; i < R; i++, launch++) {
+            HIP_TRY(hipMemsetAsync(b.dirty[(launch + 1) & 1], 0, dirty_bytes, stream));
+            hipLaunchKernelGGL(hysteresis_kernel, hgrid, dim3(256), 0, stream, b.map, g, b.dirty[launch & 1], b.dirty[(launch + 1) & 1],
+                               b.flags + i);
+        }
         int flags[R];
         HIP_TRY(hipMemcpyAsync(flags, b.flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (!flags[R - 1]) break;
+        bool done = false;
+        for (int i = 0; i < R; i++) done = done || !flags[i];   // a launch with nothing to pass on ends it
+        if (done) break;
     }
     hipLaunchKernelGGL(pack_hdilate_kernel, dim3(g.height, count), dim3(256), (g.words_per_row + 2) * sizeof(u32), stream, b.map, g,
                        k, b.hbits);
