@@ -3,8 +3,9 @@
 set -e
 cd "$(dirname "$0")/../pyscenedetect_amd/csrc"
 mkdir -p build/abl
+MACRO=PSD_ABLATE; TAG=abl
 for a in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -DPSD_ABLATE=$a -c psd_score_kernels.hip -o build/abl/score_$a.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/abl/libpsd_abl$a.so build/abl/score_$a.o build/psd_edge_kernels.hip.o build/psd_engine.cpp.o build/psd_epilogue.cpp.o
-  echo built abl$a
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -D$MACRO=$a -c psd_score_kernels.hip -o build/abl/score_$TAG$a.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/abl/libpsd_$TAG$a.so build/abl/score_$TAG$a.o build/psd_edge_kernels.hip.o build/psd_engine.cpp.o build/psd_epilogue.cpp.o
+  echo built $TAG$a
 done
