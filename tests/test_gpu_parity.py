@@ -232,3 +232,48 @@ def test_auto_downscale_golden_through_hip(golden, hip_engine):
         cls_name, kwargs, with_stats = golden["configs"][name]
         got = run_config(frames, cls_name, kwargs, with_stats, hip_engine, auto_downscale=True)
         assert_same_run(got, golden["clips"]["wide_d"]["results"][name], f"wide_d/{name}")
+
+
+def test_4k_batch_properties_and_oracle_sample(hip_engine):
+    """BASELINE config 3 size (3840x2160): fused luma pass + HSV pass, checked by properties and a sample."""
+    import torch
+
+    n, h, w = 24, 2160, 3840
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    x = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
+    x[5] = 255                                   # byte_sum = 6.3e9 > 2^32: the u64 path
+    x[6] = 0
+    x[7] = x[6]
+    torch.cuda.synchronize()
+    r = hip_engine.score_device(x.data_ptr(), n, h, w, flags=NOEDGE)
+    assert (r["hist"].sum(axis=1) == h * w).all()
+    assert r["byte_sum"][5] == 255 * 3 * h * w and r["byte_sum"][6] == 0 and r["hist"][5][255] == h * w
+    assert r["sad_v"][6] == 255 * h * w and r["sad_s"][6] == 0 and r["sad_h"][7] == 0 and r["sad_v"][7] == 0
+    sums = x.view(n, -1).to(torch.int64).sum(dim=1).cpu().numpy()
+    assert np.array_equal(r["byte_sum"], sums.astype(np.uint64))
+    same(r[:2], orc.score_batch(x[:2].cpu().numpy()))
+    luma = hip_engine.score_device(x.data_ptr(), n, h, w, flags=E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM)
+    same(luma, r, ("hist", "byte_sum"))
+
+
+def test_shot_like_1080p_content_matches_oracle_and_finds_the_cuts(hip_engine):
+    """Realistic content at full size: smooth shots + noise with hard cuts every 12 frames."""
+    import torch
+
+    from pyscenedetect_amd import epilogue
+
+    n, h, w, shot = 48, 1080, 1920, 12
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    x = torch.empty((n, h, w, 3), dtype=torch.uint8, device="cuda")
+    for s0 in range(0, n, shot):
+        grid = torch.rand((1, 3, 9, 16), device="cuda", generator=g) * 255.0
+        base = torch.nn.functional.interpolate(grid, size=(h, w), mode="bilinear", align_corners=True)[0].permute(1, 2, 0)
+        for i in range(s0, s0 + shot):
+            x[i] = (base + torch.randn((h, w, 3), device="cuda", generator=g) * 2.0).round().clamp(0, 255).to(torch.uint8)
+    torch.cuda.synchronize()
+    r = hip_engine.score_device(x.data_ptr(), n, h, w, flags=NOEDGE)
+    same(r[10:14], orc.score_batch(x[10:14].cpu().numpy(), x[9].cpu().numpy()))
+    sc = epilogue.content_scores(r, h, w)
+    assert epilogue.content_cuts(sc["content_val"], 25.0, min_scene_len=5) == [12, 24, 36]
