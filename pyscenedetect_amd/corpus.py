@@ -56,6 +56,17 @@ def decide(records: np.ndarray, height: int, width: int, fps, detectors: dict) -
     return out
 
 
+def score_clip(engine, clip, flags: int, edge_kernel: int = 0) -> np.ndarray:
+    """Records of one clip held either in host memory (ndarray) or in HBM (anything with
+    ``data_ptr()``/``shape``, e.g. a torch uint8 tensor on this engine's device)."""
+    if hasattr(clip, "data_ptr"):
+        n, h, w, c = clip.shape
+        if c != 3 or not clip.is_contiguous():
+            raise ValueError("device clips must be contiguous uint8[n,H,W,3]")
+        return engine.score_device(clip.data_ptr(), n, h, w, flags=flags, edge_kernel=edge_kernel)
+    return engine.score_host(clip[0:len(clip)], flags=flags, edge_kernel=edge_kernel)
+
+
 def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: int = 0) -> list[dict]:
     """Detect cuts in every clip of ``clips`` (each ``uint8[n,H,W,3]``, sizes may differ).
 
@@ -74,6 +85,6 @@ def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: 
 
         records = score_clips_distributed(engine, clips, flags, edge_kernel, group)
     else:
-        records = [engine.score_host(c[0:len(c)], flags=flags, edge_kernel=edge_kernel) for c in clips]
+        records = [score_clip(engine, c, flags, edge_kernel) for c in clips]
     fps_list = fps if isinstance(fps, (list, tuple)) else [fps] * len(clips)
     return [decide(r, c.shape[1], c.shape[2], f, detectors) for r, c, f in zip(records, clips, fps_list)]

@@ -90,9 +90,11 @@ def score_clips_distributed(engine, clips, flags: int, edge_kernel: int = 0, gro
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    costs = [len(c) * int(np.prod(c[0:1].shape[1:3])) if len(c) else 0 for c in clips]
+    costs = [int(c.shape[0]) * int(c.shape[1]) * int(c.shape[2]) for c in clips]
     plan = assign_clips(costs, world)
-    mine = [engine.score_host(clips[i][0:len(clips[i])], flags=flags, edge_kernel=edge_kernel) for i in plan[rank]]
+    from pyscenedetect_amd.corpus import score_clip
+
+    mine = [score_clip(engine, clips[i], flags, edge_kernel) for i in plan[rank]]
     local = np.concatenate(mine) if mine else np.zeros(0, RECORD_DTYPE)
     parts = all_gather_records(local, group)
     out: list = [None] * len(clips)
