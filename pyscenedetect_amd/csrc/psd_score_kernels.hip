@@ -95,6 +95,40 @@ __device__ __forceinline__ int sel_eq(u32 a, u32 b, int x, int y)
 // 16-bit unsigned min (VOP2, fast class; the upper halves are ignored and the result is zero-extended).
 __device__ __forceinline__ u32 min_u16(u32 a, u32 b) { u32 d; asm("v_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
+// Packing without separate shift/or instructions:
+//  * pack_byte2<K>: byte 2 of `src` -> byte K of the packed dword (v_perm_b32; K = 0 zero-fills the rest);
+//    used for S (the table holds sdiv << 4, so the product's bits 16..23 are S) and for V.
+//  * min_u16_to_byte<K>: the 16-bit hue-wrap min written straight into byte K (SDWA dst_sel).
+template <int K>
+__device__ __forceinline__ u32 pack_byte2(u32 src, u32 packed)
+{
+    constexpr u32 sel = K == 0 ? 0x0c0c0c06u : K == 1 ? 0x03020600u : K == 2 ? 0x03060100u : 0x06020100u;
+    u32 d;
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(src), "v"(K == 0 ? src : packed), "s"(sel));
+    return d;
+}
+template <int K>
+__device__ __forceinline__ u32 pack_byte0(u32 src, u32 packed)
+{
+    constexpr u32 sel = K == 0 ? 0x0c0c0c04u : K == 1 ? 0x03020400u : K == 2 ? 0x03040100u : 0x04020100u;
+    u32 d;
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(src), "v"(K == 0 ? src : packed), "s"(sel));
+    return d;
+}
+template <int K>
+__device__ __forceinline__ u32 min_u16_to_byte(u32 a, u32 b, u32 packed)
+{
+    if (K == 0) {
+        u32 d;
+        asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(d) : "v"(a), "v"(b));
+        return d;
+    }
+    if (K == 1) asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(packed) : "v"(a), "v"(b));
+    if (K == 2) asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(packed) : "v"(a), "v"(b));
+    if (K == 3) asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(packed) : "v"(a), "v"(b));
+    return packed;
+}
+
 // ---- loads ---------------------------------------------------------------------------------
 
 template <bool FAST>
@@ -132,6 +166,51 @@ __device__ __forceinline__ void load_group(const ScoreParams& p, const uint8_t* 
 
 // ---- per-group arithmetic ------------------------------------------------------------------
 
+// One pixel (K-th of a quad held in d[0..2]): exact 8-bit HSV as OpenCV's RGB2HSV_b, packed into
+// byte K of hq/sq/vq, plus the luma histogram.  The sdiv table is stored pre-shifted by 4 so that
+// S sits byte-aligned in the product (255 * (sdiv << 4) + (2048 << 4) < 2^32).
+template <bool HSV, bool LUMA, int LC, int AC, int K>
+__device__ __forceinline__ void pixel(const u32 (&d)[3], u32& hq, u32& sq, u32& vq, const u32* __restrict__ lut_s,
+                                      const u32* __restrict__ lut_h, u32* __restrict__ hist)
+{
+    constexpr int ib = 3 * K, ig = 3 * K + 1, ir = 3 * K + 2;
+    const u32 b = (d[ib >> 2] >> ((ib & 3) * 8)) & 0xffu;
+    const u32 gg = (d[ig >> 2] >> ((ig & 3) * 8)) & 0xffu;
+    const u32 r = (d[ir >> 2] >> ((ir & 3) * 8)) & 0xffu;
+    if (LUMA) {
+        // (B2Y*b + G2Y*g + R2Y*r + 8192) >> 14; the rounding term rides on the first product
+        const u32 y = mad_u24_vsv(r, kR2Y, mad_u24_vsv(gg, kG2Y, mul_u24_vs(b, kB2Y) + 8192u)) >> 14;
+        __hip_atomic_fetch_add(&hist[y * AC], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#if PSD_ABLATE & 8
+    if (HSV) { hq += b + (gg << 8); sq += r; vq ^= b; }
+#else
+    if (HSV) {
+        const u32 v = max(max(b, gg), r);
+        const u32 vmin = min(min(b, gg), r);
+        const u32 diff = v - vmin;
+#if PSD_ABLATE & 1
+        const u32 sdiv16 = (v + 4097u) << 4;
+        const int hdiv = (int)diff + 480;
+#else
+        const u32 sdiv16 = lut_s[v * LC];
+        const int hdiv = (int)lut_h[diff * LC];
+#endif
+        const u32 s16 = mad_u24(diff, sdiv16, 2048u << 4);   // S in bits 16..23
+        const int dd = (int)diff;
+        const int c_r = (int)gg - (int)b;
+        const int c_g = (int)b - (int)r + 2 * dd;
+        const int c_b = (int)r - (int)gg + 4 * dd;
+        const int hraw = sel_eq(v, r, c_r, sel_eq(v, gg, c_g, c_b));
+        const int hh = mad_i24(hraw, hdiv, 2048) >> 12;  // arithmetic shift, as in OpenCV
+        // hh < 0 ? hh + 180 : hh: as 16-bit unsigned values a negative hh is huge, so the min picks right
+        hq = min_u16_to_byte<K>((u32)hh, (u32)(hh + 180), hq);
+        sq = pack_byte2<K>(s16, sq);
+        vq = pack_byte0<K>(v, vq);
+    }
+#endif
+}
+
 // 8-bit BGR -> HSV exactly as OpenCV's RGB2HSV_b (hsv_shift = 12, hue range 180), plus luma
 // histogram and byte sum.  lut_s/lut_h/hist are already offset by the lane's replica index.
 template <bool HSV, bool LUMA, int LC = COPIES, int AC = COPIES>
@@ -153,47 +232,10 @@ __device__ __forceinline__ void convert_group(const Group& g, Hsv16& o, const u3
         u32 d[3] = {g.w[3 * q], g.w[3 * q + 1], g.w[3 * q + 2]};
         if (HSV && q > 0)
             asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]) : "v"(o.h[q - 1]), "v"(o.s[q - 1]), "v"(o.v[q - 1]));
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int ib = 3 * k, ig = 3 * k + 1, ir = 3 * k + 2;
-            const u32 b = (d[ib >> 2] >> ((ib & 3) * 8)) & 0xffu;
-            const u32 gg = (d[ig >> 2] >> ((ig & 3) * 8)) & 0xffu;
-            const u32 r = (d[ir >> 2] >> ((ir & 3) * 8)) & 0xffu;
-            if (LUMA) {
-                // (B2Y*b + G2Y*g + R2Y*r + 8192) >> 14; the rounding term rides on the first product
-                const u32 y = mad_u24_vsv(r, kR2Y, mad_u24_vsv(gg, kG2Y, mul_u24_vs(b, kB2Y) + 8192u)) >> 14;
-                __hip_atomic_fetch_add(&hist[y * AC], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-#if PSD_ABLATE & 8
-            if (HSV) { hq += b + (gg << 8); sq += r; vq ^= b; }
-#else
-            if (HSV) {
-                const u32 v = max(max(b, gg), r);
-                const u32 vmin = min(min(b, gg), r);
-                const u32 diff = v - vmin;
-#if PSD_ABLATE & 1
-                const u32 sdiv = v + 4097u;
-                const int hdiv = (int)diff + 480;
-#else
-                const u32 sdiv = lut_s[v * LC];
-                const int hdiv = (int)lut_h[diff * LC];
-#endif
-                const u32 s = mad_u24(diff, sdiv, 2048u) >> 12;
-                const int d = (int)diff;
-                const int c_r = (int)gg - (int)b;
-                const int c_g = (int)b - (int)r + 2 * d;
-                const int c_b = (int)r - (int)gg + 4 * d;
-                const int hraw = sel_eq(v, r, c_r, sel_eq(v, gg, c_g, c_b));
-                const int hh = mad_i24(hraw, hdiv, 2048) >> 12;  // arithmetic shift, as in OpenCV
-                // hh < 0 ? hh + 180 : hh   (hh >= -180, so the unsigned min picks the right one)
-                // (as 16-bit unsigned values a negative hh is huge, so the min picks hh or hh + 180 correctly)
-                const u32 h = min_u16((u32)hh, (u32)(hh + 180));
-                hq |= h << (8 * k);
-                sq |= s << (8 * k);
-                vq |= v << (8 * k);
-            }
-#endif
-        }
+        pixel<HSV, LUMA, LC, AC, 0>(d, hq, sq, vq, lut_s, lut_h, hist);
+        pixel<HSV, LUMA, LC, AC, 1>(d, hq, sq, vq, lut_s, lut_h, hist);
+        pixel<HSV, LUMA, LC, AC, 2>(d, hq, sq, vq, lut_s, lut_h, hist);
+        pixel<HSV, LUMA, LC, AC, 3>(d, hq, sq, vq, lut_s, lut_h, hist);
         if (HSV) { o.h[q] = hq; o.s[q] = sq; o.v[q] = vq; }
     }
 }
