@@ -148,8 +148,9 @@ int psd_create(int device, psd_engine** out)
         if (hipMalloc((void**)&e->d_lut, 512 * sizeof(uint32_t)) != hipSuccess) { rc = PSD_ERR_HIP; break; }
         int32_t tab[512];
         fill_tables(tab, tab + 256);
-        // The kernels keep sdiv pre-shifted by 4 so that S lands byte-aligned in diff*sdiv (see pixel<>).
-        for (int i = 0; i < 256; i++) tab[i] <<= 4;
+        // The kernels keep both tables pre-shifted by 4 so that S and H land 16-bit aligned in the
+        // products (see pixel<> in psd_score_kernels.hip).
+        for (int i = 0; i < 512; i++) tab[i] <<= 4;
         if (hipMemcpy(e->d_lut, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) { rc = PSD_ERR_HIP; break; }
         for (auto& s : e->slots) {
             if (hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess ||

@@ -98,7 +98,8 @@ __device__ __forceinline__ u32 min_u16(u32 a, u32 b) { u32 d; asm("v_min_u16 %0,
 // Packing without separate shift/or instructions:
 //  * pack_byte2<K>: byte 2 of `src` -> byte K of the packed dword (v_perm_b32; K = 0 zero-fills the rest);
 //    used for S (the table holds sdiv << 4, so the product's bits 16..23 are S) and for V.
-//  * min_u16_to_byte<K>: the 16-bit hue-wrap min written straight into byte K (SDWA dst_sel).
+//  * min_hi16_to_byte<K>: the hue-wrap min taken on the upper halves (the hdiv table is pre-shifted by 4
+//    as well, so the hue sits in bits 16..31 of the product) and written straight into byte K (SDWA).
 template <int K>
 __device__ __forceinline__ u32 pack_byte2(u32 src, u32 packed)
 {
@@ -115,17 +116,18 @@ __device__ __forceinline__ u32 pack_byte0(u32 src, u32 packed)
     asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(src), "v"(K == 0 ? src : packed), "s"(sel));
     return d;
 }
+// min of the UPPER 16-bit halves of a and b (as unsigned), written into byte K of `packed`.
 template <int K>
-__device__ __forceinline__ u32 min_u16_to_byte(u32 a, u32 b, u32 packed)
+__device__ __forceinline__ u32 min_hi16_to_byte(u32 a, u32 b, u32 packed)
 {
     if (K == 0) {
         u32 d;
-        asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(d) : "v"(a), "v"(b));
+        asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(d) : "v"(a), "v"(b));
         return d;
     }
-    if (K == 1) asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(packed) : "v"(a), "v"(b));
-    if (K == 2) asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(packed) : "v"(a), "v"(b));
-    if (K == 3) asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(packed) : "v"(a), "v"(b));
+    if (K == 1) asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(packed) : "v"(a), "v"(b));
+    if (K == 2) asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(packed) : "v"(a), "v"(b));
+    if (K == 3) asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(packed) : "v"(a), "v"(b));
     return packed;
 }
 
@@ -167,8 +169,8 @@ __device__ __forceinline__ void load_group(const ScoreParams& p, const uint8_t* 
 // ---- per-group arithmetic ------------------------------------------------------------------
 
 // One pixel (K-th of a quad held in d[0..2]): exact 8-bit HSV as OpenCV's RGB2HSV_b, packed into
-// byte K of hq/sq/vq, plus the luma histogram.  The sdiv table is stored pre-shifted by 4 so that
-// S sits byte-aligned in the product (255 * (sdiv << 4) + (2048 << 4) < 2^32).
+// byte K of hq/sq/vq, plus the luma histogram.  Both division tables are stored pre-shifted by 4 so
+// that S and H sit 16-bit aligned in the products (255 * (sdiv << 4) + (2048 << 4) < 2^32).
 template <bool HSV, bool LUMA, int LC, int AC, int K>
 __device__ __forceinline__ void pixel(const u32 (&d)[3], u32& hq, u32& sq, u32& vq, const u32* __restrict__ lut_s,
                                       const u32* __restrict__ lut_h, u32* __restrict__ hist)
@@ -191,10 +193,10 @@ __device__ __forceinline__ void pixel(const u32 (&d)[3], u32& hq, u32& sq, u32& 
         const u32 diff = v - vmin;
 #if PSD_ABLATE & 1
         const u32 sdiv16 = (v + 4097u) << 4;
-        const int hdiv = (int)diff + 480;
+        const int hdiv16 = ((int)diff + 480) << 4;
 #else
         const u32 sdiv16 = lut_s[v * LC];
-        const int hdiv = (int)lut_h[diff * LC];
+        const int hdiv16 = (int)lut_h[diff * LC];
 #endif
         const u32 s16 = mad_u24(diff, sdiv16, 2048u << 4);   // S in bits 16..23
         const int dd = (int)diff;
@@ -202,9 +204,11 @@ __device__ __forceinline__ void pixel(const u32 (&d)[3], u32& hq, u32& sq, u32& 
         const int c_g = (int)b - (int)r + 2 * dd;
         const int c_b = (int)r - (int)gg + 4 * dd;
         const int hraw = sel_eq(v, r, c_r, sel_eq(v, gg, c_g, c_b));
-        const int hh = mad_i24(hraw, hdiv, 2048) >> 12;  // arithmetic shift, as in OpenCV
+        // hh16 = (hraw*hdiv + 2048) << 4, so its upper half is OpenCV's (hraw*hdiv + 2048) >> 12 (arithmetic);
+        // |hraw*hdiv| <= 5*122880 + 3*255, far inside 32 bits after the shift.
+        const int hh16 = mad_i24(hraw, hdiv16, 2048 << 4);
         // hh < 0 ? hh + 180 : hh: as 16-bit unsigned values a negative hh is huge, so the min picks right
-        hq = min_u16_to_byte<K>((u32)hh, (u32)(hh + 180), hq);
+        hq = min_hi16_to_byte<K>((u32)hh16, (u32)hh16 + (180u << 16), hq);
         sq = pack_byte2<K>(s16, sq);
         vq = pack_byte0<K>(v, vq);
     }
