@@ -75,10 +75,10 @@ __device__ __forceinline__ u32 mad_u24_vsv(u32 a, u32 b, u32 c)
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
     return d;
 }
-__device__ __forceinline__ u32 mul_u24_vs(u32 a, u32 b)
+__device__ __forceinline__ u32 mad_u24_vvs(u32 a, u32 b, u32 c)
 {
     u32 d;
-    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "s"(b), "v"(a));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
     return d;
 }
 
@@ -181,7 +181,7 @@ __device__ __forceinline__ void pixel(const u32 (&d)[3], u32& hq, u32& sq, u32& 
     const u32 r = (d[ir >> 2] >> ((ir & 3) * 8)) & 0xffu;
     if (LUMA) {
         // (B2Y*b + G2Y*g + R2Y*r + 8192) >> 14; the rounding term rides on the first product
-        const u32 y = mad_u24_vsv(r, kR2Y, mad_u24_vsv(gg, kG2Y, mul_u24_vs(b, kB2Y) + 8192u)) >> 14;
+        const u32 y = mad_u24_vsv(r, kR2Y, mad_u24_vsv(gg, kG2Y, mad_u24_vvs(b, kB2Y, 8192u))) >> 14;
         __hip_atomic_fetch_add(&hist[y * AC], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #if PSD_ABLATE & 8
