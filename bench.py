@@ -56,7 +56,8 @@ def make_batch(n: int, dist: str, seed: int, device) -> torch.Tensor:
                 x[i] = (base + noise).round().clamp(0, 255).to(torch.uint8)
     else:
         raise ValueError(dist)
-    torch.cuda.synchronize(device)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
     return x
 
 
@@ -91,7 +92,10 @@ def cpu_baseline(sample: np.ndarray, flags: int, threads: int) -> dict:
             "_records": np.concatenate(parts)}
 
 
-def main() -> None:
+def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
+    """``engine_factory``/``cpu_dry_run`` exist for tests/test_bench_plumbing.py only: they run this very
+    control flow (pipelining, exchange, JSON) on CPU tensors over gloo with a stand-in engine, so the
+    N > 1 path is exercised without GPUs.  The measured path always uses the HIP engine on cuda."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -103,10 +107,15 @@ def main() -> None:
     ap.add_argument("--res", default="1080p", choices=["1080p", "4k"])
     ap.add_argument("--cpu-sample", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--height", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--width", type=int, default=0, help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
     global H, W
     if args.res == "4k":
         H, W = 2160, 3840
+    if args.height and args.width:
+        H, W = args.height, args.width
+    on_gpu = not cpu_dry_run
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -119,28 +128,33 @@ def main() -> None:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
+        if on_gpu:
+            torch.cuda.set_device(local_rank)
         # RCCL prints a version banner on stdout when the communicator comes up; stdout must carry
         # exactly one JSON line, so point fd 1 at stderr until the first collective has run.
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            dist.barrier(device_ids=[local_rank])
-            torch.cuda.synchronize()
+            if on_gpu:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                dist.barrier(device_ids=[local_rank])
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(device)
 
     from pyscenedetect_amd import engine as E
     from pyscenedetect_amd import epilogue
     from pyscenedetect_amd._native import RECORD_DTYPE
 
-    eng = E.ScoringEngine(local_rank)
+    eng = engine_factory(local_rank) if engine_factory else E.ScoringEngine(local_rank)
     flags = {"content": E.SCORE_HSV_SAD, "hist": E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM,
              "all": E.SCORE_HSV_SAD | E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM}[args.detector]
     n = args.frames
@@ -157,7 +171,7 @@ def main() -> None:
             return
         work, recv, mine = pend
         work.wait()
-        allv = recv.cpu().numpy().astype(np.uint64)      # [world, n, 4]: every clip's score vectors
+        allv = recv.cpu().numpy().astype(np.uint64).reshape(world, -1, 4)   # every clip's score vectors
         assert np.array_equal(allv[rank, :, 0], mine)
         state["gathered"] = allv
         state["pending_gather"] = None
@@ -173,7 +187,7 @@ def main() -> None:
             consume_gather()
             vec = np.stack([recs["sad_h"], recs["sad_s"], recs["sad_v"], recs["edge_xor"]], axis=1)
             send = torch.from_numpy(vec.astype(np.int64)).to(device, non_blocking=True)
-            recv = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=device)
+            recv = torch.empty((world * send.shape[0], send.shape[1]), dtype=send.dtype, device=device)  # rank-major concat
             work = dist.all_gather_into_tensor(recv, send, async_op=True)
             state["pending_gather"] = (work, recv, recs["sad_h"].copy())
         state["recs"] = recs
@@ -201,8 +215,9 @@ def main() -> None:
         if use_dist:
             import torch.distributed as dist
 
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize(device)
+            dist.barrier(device_ids=[local_rank]) if on_gpu else dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize(device)
 
     if args.warmup > 0:
         run(args.warmup, False)
@@ -288,7 +303,7 @@ def main() -> None:
     if use_dist:
         import torch.distributed as dist
 
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(device_ids=[local_rank]) if on_gpu else dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))

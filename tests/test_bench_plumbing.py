@@ -1,0 +1,47 @@
+"""CPU: bench.py's control flow (2-deep pipelining, the score-vector exchange, max-over-ranks
+timing, exactly one JSON line on stdout) run for real over gloo with world_size 1 and 2, with a
+stand-in engine.  The numbers mean nothing here; the N > 1 code path must simply work."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "tests", "_bench_dry_driver.py")
+ARGS = ["--steps", "3", "--warmup", "1", "--frames", "12", "--height", "36", "--width", "64", "--cpu-sample", "8"]
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _check(stdout: str, n_gpus: int):
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must be exactly one JSON line, got: {lines!r}"
+    j = json.loads(lines[0])
+    assert KEYS <= set(j)
+    assert j["n_gpus"] == n_gpus and j["steps"] == 3 and j["warmup"] == 1 and j["value"] > 0
+    assert j["scaling"] == "weak" and j["higher_is_better"] is True and j["vs_baseline"] is None and j["dtype"] == "u8"
+    assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert "workload" in j["config"] and "model" not in j["config"]
+    return j
+
+
+@pytest.mark.timeout(300)
+def test_single_process():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, DRIVER, *ARGS], capture_output=True, text=True, env=env, cwd=ROOT, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = _check(out.stdout, 1)
+    assert j["cpu_baseline"]["kind"] == "port" and "identical" in j["parity_sample"]
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_over_gloo():
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), DRIVER, "--gpus", "2", *ARGS]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = _check(out.stdout, 2)
+    assert j["cpu_baseline"] is None and "RCCL all-gather" in j["config"]["parallelism"]
