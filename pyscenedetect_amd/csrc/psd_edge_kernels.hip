@@ -73,32 +73,51 @@ __device__ __forceinline__ const uint8_t* chunk_frame(const ChunkSrc& c, size_t 
     return c.frames + (size_t)(c.start + j - c.first_is_prev) * frame_stride;
 }
 
-// One thread = 4 pixels.  grid = (ceil(npix/4/256), frames)
+constexpr int VP_ITER = 16;  // 4-pixel packets per thread: amortises the histogram clear/flush of a block
+
+// One thread = VP_ITER packets of 4 pixels.  grid = (ceil(npix/(1024*VP_ITER)), frames)
 __global__ __launch_bounds__(256) void value_plane_hist_kernel(ChunkSrc src, EdgeGeom g, uint8_t* vplane, u32* hist)
 {
-    __shared__ u32 lh[256 * 8];
-    for (int i = threadIdx.x; i < 256 * 8; i += 256) lh[i] = 0;
+    // 32 replicas, lane l uses replica l%32: the LDS atomics of a wave never collide, whatever the content
+    __shared__ u32 lh[256 * 32];
+    for (int i = threadIdx.x; i < 256 * 32; i += 256) lh[i] = 0;
     __syncthreads();
     const int j = blockIdx.y;
     const uint8_t* frame = chunk_frame(src, g.frame_stride, j);
-    const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    const int rep = threadIdx.x & 7;
+    const int rep = threadIdx.x & 31;
+    for (int it = 0; it < VP_ITER; it++) {
+    const long p0 = (((long)blockIdx.x * VP_ITER + it) * 256 + threadIdx.x) * 4;
     if (p0 < g.npix) {
         u32 packed = 0;
         const bool packed_rows = g.row_stride == (size_t)g.width * 3;
+        if (packed_rows && p0 + 4 <= g.npix && (((uintptr_t)frame) & 3) == 0) {
+            // 4 pixels = 12 contiguous bytes = 3 aligned dwords: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+            const u32* w = reinterpret_cast<const u32*>(frame + (size_t)p0 * 3);
+            const u32 w0 = w[0], w1 = w[1], w2 = w[2];
+            const u32 v0 = max(max(w0 & 0xffu, (w0 >> 8) & 0xffu), (w0 >> 16) & 0xffu);
+            const u32 v1 = max(max(w0 >> 24, w1 & 0xffu), (w1 >> 8) & 0xffu);
+            const u32 v2 = max(max((w1 >> 16) & 0xffu, w1 >> 24), w2 & 0xffu);
+            const u32 v3 = max(max((w2 >> 8) & 0xffu, (w2 >> 16) & 0xffu), w2 >> 24);
+            packed = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+            atomicAdd(&lh[v0 * 32 + rep], 1u);
+            atomicAdd(&lh[v1 * 32 + rep], 1u);
+            atomicAdd(&lh[v2 * 32 + rep], 1u);
+            atomicAdd(&lh[v3 * 32 + rep], 1u);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const long p = p0 + k;
-            if (p < g.npix) {
-                const uint8_t* s;
-                if (packed_rows) s = frame + (size_t)p * 3;
-                else {
-                    const int row = (int)(p / g.width), col = (int)(p - (long)row * g.width);
-                    s = frame + (size_t)row * g.row_stride + (size_t)col * 3;
+            for (int k = 0; k < 4; k++) {
+                const long p = p0 + k;
+                if (p < g.npix) {
+                    const uint8_t* s;
+                    if (packed_rows) s = frame + (size_t)p * 3;
+                    else {
+                        const int row = (int)(p / g.width), col = (int)(p - (long)row * g.width);
+                        s = frame + (size_t)row * g.row_stride + (size_t)col * 3;
+                    }
+                    const u32 v = max(max((u32)s[0], (u32)s[1]), (u32)s[2]);
+                    packed |= v << (8 * k);
+                    atomicAdd(&lh[v * 32 + rep], 1u);
                 }
-                const u32 v = max(max((u32)s[0], (u32)s[1]), (u32)s[2]);
-                packed |= v << (8 * k);
-                atomicAdd(&lh[v * 8 + rep], 1u);
             }
         }
         uint8_t* dst = vplane + (size_t)j * g.npix + p0;
@@ -106,12 +125,13 @@ __global__ __launch_bounds__(256) void value_plane_hist_kernel(ChunkSrc src, Edg
         else
             for (int k = 0; k < 4 && p0 + k < g.npix; k++) dst[k] = (uint8_t)(packed >> (8 * k));
     }
+    }
     __syncthreads();
     {
         const int b = threadIdx.x;
         u32 s = 0;
 #pragma unroll
-        for (int r = 0; r < 8; r++) s += lh[b * 8 + r];
+        for (int r = 0; r < 32; r++) s += lh[b * 32 + ((r + b) & 31)];   // rotated: conflict-free across lanes
         if (s) atomicAdd(&hist[(size_t)j * 256 + b], s);
     }
 }
@@ -319,14 +339,23 @@ __global__ __launch_bounds__(256) void pack_hdilate_kernel(const uint8_t* map, E
     extern __shared__ u32 rowbits[];  // words_per_row + 2 (one zero word of padding on each side)
     const int j = blockIdx.y, y = blockIdx.x, W = g.width, nw = g.words_per_row;
     const uint8_t* M = map + (size_t)j * g.npix + (size_t)y * W;
+    const bool wide = (((uintptr_t)M) & 15) == 0;
     for (int w = threadIdx.x; w < nw + 2; w += 256) {
         u32 bits = 0;
         if (w >= 1 && w <= nw) {
             const int xb = (w - 1) * 32;
+            if (wide && xb + 32 <= W) {
+                // 32 map bytes (values 0,1,2): bit 1 marks "strong"; gather one bit per byte with a multiply
+                const uint4 a = *reinterpret_cast<const uint4*>(M + xb), c = *reinterpret_cast<const uint4*>(M + xb + 16);
+                const u32 q[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int i = 0; i < 8; i++) bits |= ((((q[i] >> 1) & 0x01010101u) * 0x01020408u) >> 24) << (4 * i);
+            } else {
 #pragma unroll 8
-            for (int b = 0; b < 32; b++) {
-                const int x = xb + b;
-                if (x < W && M[x] == 2) bits |= 1u << b;
+                for (int b = 0; b < 32; b++) {
+                    const int x = xb + b;
+                    if (x < W && M[x] == 2) bits |= 1u << b;
+                }
             }
         }
         rowbits[w] = bits;
@@ -475,7 +504,7 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
 {
     const size_t words = (size_t)g.height * g.words_per_row;
     HIP_TRY(hipMemsetAsync(b.hist, 0, (size_t)count * 256 * 4, stream));
-    hipLaunchKernelGGL(value_plane_hist_kernel, dim3((unsigned)((g.npix + 1023) / 1024), count), dim3(256), 0, stream, src, g,
+    hipLaunchKernelGGL(value_plane_hist_kernel, dim3((unsigned)((g.npix + 1024 * VP_ITER - 1) / (1024 * VP_ITER)), count), dim3(256), 0, stream, src, g,
                        b.vplane, b.hist);
     hipLaunchKernelGGL(median_thresholds_kernel, dim3(count), dim3(256), 0, stream, b.hist, g.npix, b.thr_tab, b.thr);
     hipLaunchKernelGGL(sobel_nms_kernel, dim3((g.width + NT_W - 1) / NT_W, (g.height + NT_H - 1) / NT_H, count), dim3(256), 0,
