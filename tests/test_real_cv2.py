@@ -1,0 +1,61 @@
+"""If a REAL OpenCV build is importable (it is not in the build/bench image), pin the oracle to it.
+
+The oracle is a restatement of OpenCV's published 8-bit algorithms ("parity unpinned at the cv2
+boundary").  On any machine that does have ``cv2`` these tests close that gap:
+every primitive of the hot path is compared with the real library on seeded inputs, and
+``tools/dump_cv2_vectors.py`` can freeze the vectors into tests/golden/ for machines without it.
+Skipped (not failed) when only the oracle shim is on the path.
+"""
+import numpy as np
+import pytest
+
+cv2 = pytest.importorskip("cv2")
+if "oracle-shim" in getattr(cv2, "__version__", ""):
+    pytest.skip("only the oracle's cv2 shim is importable: nothing to pin against", allow_module_level=True)
+
+from oracle import lib as orc  # noqa: E402
+from oracle.detectors_np import edge_map, hsv_planes  # noqa: E402
+
+
+def _img(seed, h=97, w=131):
+    return np.random.default_rng(seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def test_hsv_and_yuv_all_triples():
+    g8 = np.arange(256, dtype=np.uint8)
+    for b0 in range(0, 256, 64):
+        bb, gg, rr = np.meshgrid(g8[b0:b0 + 64], g8, g8, indexing="ij")
+        img = np.ascontiguousarray(np.stack([bb, gg, rr], axis=-1).reshape(64 * 256, 256, 3))
+        hsv = cv2.cvtColor(img, cv2.COLOR_BGR2HSV)
+        hp, sp, vp = hsv_planes(img)
+        assert np.array_equal(hsv[..., 0], hp) and np.array_equal(hsv[..., 1], sp) and np.array_equal(hsv[..., 2], vp)
+        y = np.empty(img.shape[:2], np.uint8)
+        orc.lib().orc_bgr2y(img.ctypes.data, img.shape[1] * 3, y.ctypes.data, img.shape[0], img.shape[1])
+        assert np.array_equal(cv2.cvtColor(img, cv2.COLOR_BGR2YUV)[..., 0], y)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_canny_dilate_hist_resize(seed):
+    img = _img(seed)
+    lum = np.ascontiguousarray(cv2.cvtColor(img, cv2.COLOR_BGR2HSV)[..., 2])
+    med = np.median(lum)
+    low, high = int(max(0, (1 - 1 / 3) * med)), int(min(255, (1 + 1 / 3) * med))
+    want = cv2.dilate(cv2.Canny(lum, low, high), np.ones((5, 5), np.uint8))
+    assert np.array_equal(edge_map(img, 5), want)
+    # histogram chain
+    y = np.ascontiguousarray(cv2.cvtColor(img, cv2.COLOR_BGR2YUV)[..., 0])
+    for bins in (256, 128, 100):
+        h = cv2.calcHist([y], [0], None, [bins], [0, 256])
+        n = cv2.normalize(h, h).flatten()
+        ref = np.zeros((bins, 1), np.float32)
+        orc.lib().orc_calc_hist_u8(y.ctypes.data, y.shape[1], y.shape[0], y.shape[1], bins, 0.0, 256.0, ref.ctypes.data)
+        flat = ref.reshape(-1).copy()
+        orc.lib().orc_normalize_l2_f32(flat.ctypes.data, bins)
+        assert np.array_equal(n, flat)
+        other = np.roll(flat, 3).copy()
+        got = orc.lib().orc_compare_hist_correl(flat.ctypes.data, other.ctypes.data, bins)
+        assert abs(got - cv2.compareHist(flat, other, cv2.HISTCMP_CORREL)) <= 4e-16   # lane order may differ by an ulp
+    for dw, dh in ((64, 48), (65, 48), (131 // 2, 97 // 2)):
+        out = np.empty((dh, dw, 3), np.uint8)
+        orc.lib().orc_resize_linear_u8(img.ctypes.data, img.shape[1] * 3, img.shape[0], img.shape[1], 3, out.ctypes.data, dw * 3, dh, dw)
+        assert np.array_equal(out, cv2.resize(img, (dw, dh), interpolation=cv2.INTER_LINEAR))
