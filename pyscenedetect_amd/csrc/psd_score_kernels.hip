@@ -75,6 +75,15 @@ __device__ __forceinline__ u32 mad_u24_vsv(u32 a, u32 b, u32 c)
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
     return d;
 }
+// B2Y held in a VGPR the compiler cannot rematerialise as a literal move per pixel (the asm is pure,
+// so it is hoisted out of the frame loop); VOP3 on gfx9 takes only one scalar/literal operand.
+__device__ __forceinline__ u32 vgpr_b2y()
+{
+    u32 x;
+    asm("v_mov_b32 %0, 0x74c" : "=v"(x));
+    static_assert(kB2Y == 0x74c, "");
+    return x;
+}
 __device__ __forceinline__ u32 mad_u24_vvs(u32 a, u32 b, u32 c)
 {
     u32 d;
@@ -173,7 +182,7 @@ __device__ __forceinline__ void load_group(const ScoreParams& p, const uint8_t* 
 // that S and H sit 16-bit aligned in the products (255 * (sdiv << 4) + (2048 << 4) < 2^32).
 template <bool HSV, bool LUMA, int LC, int AC, int K>
 __device__ __forceinline__ void pixel(const u32 (&d)[3], u32& hq, u32& sq, u32& vq, const u32* __restrict__ lut_s,
-                                      const u32* __restrict__ lut_h, u32* __restrict__ hist)
+                                      const u32* __restrict__ lut_h, u32* __restrict__ hist, u32 inc)
 {
     constexpr int ib = 3 * K, ig = 3 * K + 1, ir = 3 * K + 2;
     const u32 b = (d[ib >> 2] >> ((ib & 3) * 8)) & 0xffu;
@@ -181,8 +190,9 @@ __device__ __forceinline__ void pixel(const u32 (&d)[3], u32& hq, u32& sq, u32& 
     const u32 r = (d[ir >> 2] >> ((ir & 3) * 8)) & 0xffu;
     if (LUMA) {
         // (B2Y*b + G2Y*g + R2Y*r + 8192) >> 14; the rounding term rides on the first product
-        const u32 y = mad_u24_vsv(r, kR2Y, mad_u24_vsv(gg, kG2Y, mad_u24_vvs(b, kB2Y, 8192u))) >> 14;
-        __hip_atomic_fetch_add(&hist[y * AC], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u32 y = mad_u24_vsv(r, kR2Y, mad_u24_vsv(gg, kG2Y, mad_u24_vvs(b, vgpr_b2y(), 8192u))) >> 14;
+        // inc is 1, or 0 for a lane that owns no group here (cheaper than predicating every atomic)
+        __hip_atomic_fetch_add(&hist[y * AC], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #if PSD_ABLATE & 8
     if (HSV) { hq += b + (gg << 8); sq += r; vq ^= b; }
@@ -218,28 +228,32 @@ __device__ __forceinline__ void pixel(const u32 (&d)[3], u32& hq, u32& sq, u32& 
 // 8-bit BGR -> HSV exactly as OpenCV's RGB2HSV_b (hsv_shift = 12, hue range 180), plus luma
 // histogram and byte sum.  lut_s/lut_h/hist are already offset by the lane's replica index.
 template <bool HSV, bool LUMA, int LC = COPIES, int AC = COPIES>
-__device__ __forceinline__ void convert_group(const Group& g, Hsv16& o, const u32* __restrict__ lut_s,
+__device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __restrict__ lut_s,
                                               const u32* __restrict__ lut_h, u32* __restrict__ hist,
-                                              u32& byte_sum)
+                                              u32& byte_sum, u32 inc = 1u)
 {
     if (LUMA) {
+        u32 local = 0;
 #pragma unroll
-        for (int i = 0; i < 12; i++) byte_sum = __builtin_amdgcn_sad_u8(g.w[i], 0u, byte_sum);
+        for (int i = 0; i < 12; i++) local = __builtin_amdgcn_sad_u8(g.w[i], 0u, local);
+        byte_sum += local * inc;   // 16 px * 3 * 255 < 2^24: a 24-bit multiply
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        u32 hq = 0, sq = 0, vq = 0;
+        u32 hq, sq, vq;
+        if (!HSV) { hq = 0; sq = 0; vq = 0; }
         // The 4 pixels of this quad live in 3 dwords.  Tie them to the previous quad's results so
         // the 16 pixels are processed quad by quad: fully interleaved (what the scheduler does when
         // left alone) the live temporaries exceed the 128-VGPR budget of a 16-wave workgroup and
         // spill.  Latency is hidden by the other 3 waves of the SIMD, not by ILP across quads.
-        u32 d[3] = {g.w[3 * q], g.w[3 * q + 1], g.w[3 * q + 2]};
+        // (in place on g: the group's input registers are dead after this call, a copy would cost 3 v_mov)
         if (HSV && q > 0)
-            asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]) : "v"(o.h[q - 1]), "v"(o.s[q - 1]), "v"(o.v[q - 1]));
-        pixel<HSV, LUMA, LC, AC, 0>(d, hq, sq, vq, lut_s, lut_h, hist);
-        pixel<HSV, LUMA, LC, AC, 1>(d, hq, sq, vq, lut_s, lut_h, hist);
-        pixel<HSV, LUMA, LC, AC, 2>(d, hq, sq, vq, lut_s, lut_h, hist);
-        pixel<HSV, LUMA, LC, AC, 3>(d, hq, sq, vq, lut_s, lut_h, hist);
+            asm volatile("" : "+v"(g.w[3 * q]), "+v"(g.w[3 * q + 1]), "+v"(g.w[3 * q + 2]) : "v"(o.h[q - 1]), "v"(o.s[q - 1]), "v"(o.v[q - 1]));
+        const u32 d[3] = {g.w[3 * q], g.w[3 * q + 1], g.w[3 * q + 2]};
+        pixel<HSV, LUMA, LC, AC, 0>(d, hq, sq, vq, lut_s, lut_h, hist, inc);
+        pixel<HSV, LUMA, LC, AC, 1>(d, hq, sq, vq, lut_s, lut_h, hist, inc);
+        pixel<HSV, LUMA, LC, AC, 2>(d, hq, sq, vq, lut_s, lut_h, hist, inc);
+        pixel<HSV, LUMA, LC, AC, 3>(d, hq, sq, vq, lut_s, lut_h, hist, inc);
         if (HSV) { o.h[q] = hq; o.s[q] = sq; o.v[q] = vq; }
     }
 }
@@ -437,21 +451,35 @@ __global__ __launch_bounds__(WG) void score_frames_kernel(const ScoreParams p)
 // Accumulators: HSV-only keeps 2 x F frames of {sad_h,sad_s,sad_v} so the workgroup barrier and
 // flush happen once per F frames; with the luma histogram it is one frame per barrier (F = 1).
 
-constexpr int LCD = 16;  // LUT replicas in the staged kernel (2-way conflicts at worst, 32 KiB for both tables)
-constexpr int ACD_MAX = 16;  // accumulator replicas (8 in the fused HSV+luma variant, to fit G=2 in LDS)
+constexpr int LCD_MAX = 16;  // LUT replicas in the staged kernel (2-way conflicts at worst, 32 KiB for both tables)
+constexpr int ACD_MAX = 16;  // accumulator replicas
+// The fused HSV+luma variant has to fit two tables, the histogram slots and G=2 staging in 160 KiB:
+#ifndef PSD_FUSED_LC
+#define PSD_FUSED_LC 16
+#endif
+#ifndef PSD_FUSED_AC
+#define PSD_FUSED_AC 8
+#endif
+#ifndef PSD_FUSED_F
+#define PSD_FUSED_F 1
+#endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
 template <int G, int NW>
-__device__ __forceinline__ void dma_issue(const ScoreParams& p, const uint8_t* frame, int wave_group0, int wave,
+__device__ __forceinline__ void dma_issue(const ScoreParams& p, const uint8_t* frame, int wave_group0, int tile_end, int wave,
                                           int lane, uint8_t* stage)
 {
     // wave_group0[k] = first group of this wave's k-th slot; 64 groups = 3072 contiguous bytes.
 #pragma unroll
     for (int k = 0; k < G; k++) {
         const long gfirst = (long)wave_group0 + (long)k * NW * 64;
-        const long limit = (long)p.group_end * 48;  // never read past the last full group of the range
+        // Never load past the tile: lanes of the last wave that own no group then keep whatever bytes
+        // their staging area holds -- the SAME bytes every frame, so their HSV never changes, their SADs
+        // are 0 and the HSV arithmetic needs no per-lane predicate (which would turn `prev = cur` into
+        // 12 real moves per group).  Their luma side effects are predicated instead.
+        const long limit = (long)tile_end * 48;
         uint8_t* slot = stage + (size_t)(k * NW + wave) * 3072;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -488,13 +516,17 @@ __device__ __forceinline__ void flush_slot(u32* slot_acc, psd_frame_scores* rec,
         const u32x4 zero = {0, 0, 0, 0};
         q[0] = zero; q[1] = zero;
         s = v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w;
-    } else {
-        static_assert(AC == 16 || AC == 8, "");
+    } else if (AC == 8) {
         u32x4* q = reinterpret_cast<u32x4*>(slot_acc + a * AC + half * 4);
         const u32x4 v0 = q[0];
         const u32x4 zero = {0, 0, 0, 0};
         q[0] = zero;
         s = v0.x + v0.y + v0.z + v0.w;
+    } else {
+        static_assert(AC == 16 || AC == 8 || AC == 4, "");
+        u32* q = slot_acc + a * AC + half * 2;
+        s = q[0] + q[1];
+        q[0] = 0; q[1] = 0;
     }
     s += __shfl_xor(s, 1);
     if (half == 0 && s) {
@@ -515,9 +547,10 @@ template <bool HSV, bool LUMA, int G, int WG>
 __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams p)
 {
     constexpr int NW = WG / 64;
-    constexpr int ACD = (HSV && LUMA) ? 8 : ACD_MAX;
+    constexpr int ACD = (HSV && LUMA) ? PSD_FUSED_AC : ACD_MAX;
+    constexpr int LCD = (HSV && LUMA) ? PSD_FUSED_LC : LCD_MAX;
     constexpr int NA = LUMA ? NACC : 4;       // accumulators per frame slot
-    constexpr int F = LUMA ? 1 : 8;           // frames per barrier
+    constexpr int F = LUMA ? (HSV ? PSD_FUSED_F : 1) : 8;   // frames per barrier
     constexpr int SLOTS = 2 * F;
     __shared__ __attribute__((aligned(16))) u32 lut_s[HSV ? 256 * LCD : 4];
     __shared__ __attribute__((aligned(16))) u32 lut_h[HSV ? 256 * LCD : 4];
@@ -527,7 +560,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int l16 = tid & 15;
+    const int l16 = tid & (LCD - 1);
     const int lacc = tid & (ACD - 1);
     const int tile = blockIdx.x % p.n_tiles;
     const int chunk = blockIdx.x / p.n_tiles;
@@ -561,18 +594,18 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
         const uint8_t* halo = (t0 > 0) ? p.frames + (size_t)(t0 - 1) * p.frame_stride : p.prev;
         if (halo != nullptr) {
             have_prev = true;
-            dma_issue<G, NW>(p, halo, wave_group0, wave, lane, stage);
+            dma_issue<G, NW>(p, halo, wave_group0, g1, wave, lane, stage);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stage_read<G, NW>(stage, wave, lane, cur);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int k = 0; k < G; k++) {
                 u32 dummy = 0;
-                if (live[k]) convert_group<true, false, LCD, ACD>(cur[k], prev[k], my_lut_s, my_lut_h, nullptr, dummy);
+                convert_group<true, false, LCD, ACD>(cur[k], prev[k], my_lut_s, my_lut_h, nullptr, dummy);
             }
         }
     }
-    if (t0 < t1) dma_issue<G, NW>(p, p.frames + (size_t)t0 * p.frame_stride, wave_group0, wave, lane, stage);
+    if (t0 < t1) dma_issue<G, NW>(p, p.frames + (size_t)t0 * p.frame_stride, wave_group0, g1, wave, lane, stage);
 
     for (int t = t0; t < t1; t++) {
         const int slot = (t - t0) % SLOTS;
@@ -583,7 +616,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stage_read<G, NW>(stage, wave, lane, cur);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (t + 1 < t1) dma_issue<G, NW>(p, p.frames + (size_t)(t + 1) * p.frame_stride, wave_group0, wave, lane, stage);
+        if (t + 1 < t1) dma_issue<G, NW>(p, p.frames + (size_t)(t + 1) * p.frame_stride, wave_group0, g1, wave, lane, stage);
 #else
 #pragma unroll
         for (int k = 0; k < G; k++)
@@ -593,9 +626,9 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
         u32 sh = 0, ss = 0, sv = 0, bs = 0;
 #pragma unroll
         for (int k = 0; k < G; k++) {
-            if (live[k]) {
+            if (HSV || live[k]) {
                 Hsv16 c;
-                convert_group<HSV, LUMA, LCD, ACD>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs);
+                convert_group<HSV, LUMA, LCD, ACD>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs, live[k] ? 1u : 0u);
                 if (HSV) {
                     if (have_prev) sad_group(c, prev[k], sh, ss, sv);
                     prev[k] = c;

@@ -5,7 +5,10 @@ import torch
 from pyscenedetect_amd import engine as E
 N = int(os.environ.get("KT_N", "1024")); H, W = 1080, 1920
 eng = E.ScoringEngine(0)
-x = torch.randint(0, 256, (N, H, W, 3), dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+x = torch.randint(0, 256, (N, H, W, 3), dtype=torch.uint8, device="cuda")
+if os.environ.get("KT_DIST") == "K":
+    x.copy_(torch.randint(0, 256, (N, 1, 1, 1), dtype=torch.uint8, device="cuda").expand_as(x))
+torch.cuda.synchronize()
 names = {"hsv": E.SCORE_HSV_SAD, "luma": E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM, "all": 7}
 for name in os.environ.get("KT_FLAGS", "hsv").split(","):
     best = 1e9
