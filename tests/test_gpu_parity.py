@@ -277,3 +277,34 @@ def test_shot_like_1080p_content_matches_oracle_and_finds_the_cuts(hip_engine):
     same(r[10:14], orc.score_batch(x[10:14].cpu().numpy(), x[9].cpu().numpy()))
     sc = epilogue.content_scores(r, h, w)
     assert epilogue.content_cuts(sc["content_val"], 25.0, min_scene_len=5) == [12, 24, 36]
+
+
+def test_randomised_shapes_flags_and_halos(hip_engine):
+    """Seeded sweep: 48 random (n, H, W), with/without a preceding frame, random flag sets incl. edges."""
+    rng = np.random.default_rng(2025)
+    for case in range(48):
+        n = int(rng.integers(1, 14))
+        h = int(rng.choice([1, 2, 3, 7, 16, 33, 64, 90, 131]))
+        w = int(rng.choice([1, 2, 5, 16, 31, 64, 97, 160, 257]))
+        flags = int(rng.integers(1, 16))
+        kernel = int(rng.choice([0, 3, 5, 7])) if flags & E.SCORE_EDGES else 0
+        style = case % 3
+        if style == 0:
+            fr = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        elif style == 1:   # smooth + noise (long weak edge chains)
+            yy, xx = np.mgrid[0:h, 0:w]
+            base = 128 + 90 * np.sin(xx / 6.0 + case) * np.cos(yy / 5.0)
+            fr = np.clip(base[None, :, :, None] + rng.normal(0, 5, (n, h, w, 3)), 0, 255).astype(np.uint8)
+        else:              # few distinct values (ties in max/min, flat regions)
+            fr = (rng.integers(0, 3, (n, h, w, 3)) * 127).astype(np.uint8)
+        pv = rng.integers(0, 256, (h, w, 3), dtype=np.uint8) if case % 2 else None
+        want = oracle_score(fr, pv, edges=bool(flags & E.SCORE_EDGES), kernel_size=kernel)
+        got = hip_engine.score_host(fr, prev=pv, flags=flags, edge_kernel=kernel)
+        tag = f"case {case}: n={n} {h}x{w} flags={flags} k={kernel} prev={pv is not None}"
+        if flags & E.SCORE_HSV_SAD:
+            for f in ("sad_h", "sad_s", "sad_v"):
+                assert np.array_equal(got[f], want[f]), f"{tag}: {f}"
+        if flags & (E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM):
+            assert np.array_equal(got["hist"], want["hist"]) and np.array_equal(got["byte_sum"], want["byte_sum"]), tag
+        if flags & E.SCORE_EDGES:
+            assert np.array_equal(got["edge_xor"], want["edge_xor"]), f"{tag}: edge_xor {got['edge_xor']} vs {want['edge_xor']}"
