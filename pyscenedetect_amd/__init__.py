@@ -15,8 +15,28 @@ from pyscenedetect_amd.video_stream import ArrayVideoStream
 
 __version__ = "0.1.0"
 
+
+def detect(video, detector, stats_file_path=None, show_progress=False, start_time=None, end_time=None,
+           start_in_scene=False, fps=25.0, engine=None):
+    """Counterpart of ``scenedetect.detect()`` (reference ``scenedetect/__init__.py:160-219``) for
+    already-decoded frames: ``video`` is a frame source (anything with the ``VideoStream`` members
+    ``SceneManager.detect_scenes`` uses, e.g. one of the reference's backends) or an array
+    ``uint8[N,H,W,3]`` of BGR frames.  Returns the scene list ``[(start, end), ...]``."""
+    import numpy as _np
+
+    if isinstance(video, _np.ndarray):
+        video = ArrayVideoStream(video, fps)
+    if start_time is not None:
+        video.seek(start_time if isinstance(start_time, (int, FrameTimecode)) else FrameTimecode(start_time, video.frame_rate))
+    manager = SceneManager(StatsManager() if stats_file_path else None, engine=engine)
+    manager.add_detector(detector)
+    manager.detect_scenes(video, end_time=end_time, show_progress=show_progress)
+    if manager.stats_manager is not None:
+        manager.stats_manager.save_to_csv(stats_file_path)
+    return manager.get_scene_list(start_in_scene=start_in_scene)
+
 __all__ = [
     "AdaptiveDetector", "ArrayVideoStream", "ContentDetector", "FlashFilter", "FrameTimecode", "HistogramDetector",
-    "SceneDetector", "SceneManager", "StatsManager", "ThresholdDetector", "compute_downscale_factor",
+    "SceneDetector", "SceneManager", "StatsManager", "ThresholdDetector", "compute_downscale_factor", "detect",
     "get_scenes_from_cuts",
 ]

@@ -149,3 +149,17 @@ def test_stats_csv_and_cached_threshold_metric(golden, oracle_engine):
     for i, f in enumerate(frames):
         again += det.process_frame(psd.FrameTimecode(i, 25.0), f)
     assert [c.frame_num for c in again] == cuts
+
+
+def test_detect_convenience(golden, oracle_engine, tmp_path):
+    """``detect()`` = open -> SceneManager -> scene list (reference scenedetect/__init__.py:160-219)."""
+    frames = golden_clip(golden, "wide_d")           # > 256 px wide: default auto-downscale applies
+    want = golden["clips"]["wide_d"]["results"]["content_default"]["scenes"]
+    scenes = psd.detect(frames, psd.ContentDetector(engine=oracle_engine), engine=oracle_engine)
+    assert [[a.frame_num, b.frame_num] for a, b in scenes] == want
+    csv_path = tmp_path / "stats.csv"
+    psd.detect(frames, psd.ThresholdDetector(engine=oracle_engine), stats_file_path=str(csv_path), engine=oracle_engine)
+    assert csv_path.read_text().startswith("Frame Number,Timecode,average_rgb")
+    empty = psd.detect(frames[:5], psd.ContentDetector(engine=oracle_engine), engine=oracle_engine)
+    assert empty == [] and len(psd.detect(frames[:5], psd.ContentDetector(engine=oracle_engine), start_in_scene=True,
+                                          engine=oracle_engine)) == 1
