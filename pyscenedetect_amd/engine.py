@@ -157,6 +157,37 @@ class ScoringEngine:
             done += cnt
         return out
 
+    def score_frames(self, frames, prev=None, flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0,
+                     downscale: float = 1.0) -> np.ndarray:
+        """Score a list of separately allocated host frames (what a decoder hands out) without first
+        stacking them on the host: every frame is uploaded straight into one device batch."""
+        n = len(frames)
+        out = np.zeros(n, RECORD_DTYPE)
+        if n == 0:
+            return out
+        first = np.asarray(frames[0])
+        if first.dtype != np.uint8 or first.ndim != 3 or first.shape[2] != 3:
+            raise ValueError("frames must be uint8[H,W,3]")
+        h, w, _ = first.shape
+        sstride = (h * w * 3 + 15) & ~15
+        p = 0 if prev is None else 1
+        src = self._scratch("fr_src", (n + 1) * sstride)
+        items = ([prev] if p else []) + list(frames)
+        for i, f in enumerate(items):
+            f = np.ascontiguousarray(f, dtype=np.uint8)
+            if f.shape != (h, w, 3):
+                raise ValueError("all frames of a batch must have the same size")
+            src.upload(f.reshape(-1), i * sstride)
+        if downscale > 1.0:
+            dw, dh = max(1, round(w / downscale)), max(1, round(h / downscale))
+            dstride = (dh * dw * 3 + 15) & ~15
+            dst = self._scratch("fr_dst", (n + 1) * dstride)
+            self.resize_device(src.ptr, n + p, h, w, dst.ptr, dh, dw, src_frame_stride=sstride, dst_frame_stride=dstride)
+            return self.score_device(dst.ptr + p * dstride, n, dh, dw, dw * 3, dstride, d_prev=dst.ptr if p else None,
+                                     flags=flags, edge_kernel=edge_kernel)
+        return self.score_device(src.ptr + p * sstride, n, h, w, w * 3, sstride, d_prev=src.ptr if p else None,
+                                 flags=flags, edge_kernel=edge_kernel)
+
     def _scratch(self, name: str, nbytes: int) -> "DeviceBuffer":
         cache = self.__dict__.setdefault("_scratch_bufs", {})
         buf = cache.get(name)

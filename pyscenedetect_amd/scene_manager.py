@@ -231,15 +231,20 @@ class SceneManager:
                 records = None
                 scored_size = None
                 if engine is not None:
-                    stacked = np.stack(frames)
+                    shape = frames[0].shape
+                    if last_frame is not None and last_frame.shape != shape:
+                        last_frame = None
                     if factor > 1.0:
                         # Same target size as the reference's cv2.resize call (:670-678).
-                        scored_size = (max(1, round(stacked.shape[1] / factor)), max(1, round(stacked.shape[2] / factor)))
-                    if last_frame is not None and last_frame.shape != stacked.shape[1:]:
-                        last_frame = None
-                    records = engine.score_host(stacked, prev=last_frame, flags=flags, edge_kernel=edge_kernel,
-                                                **({"downscale": factor} if factor > 1.0 else {}))
-                    last_frame = stacked[-1]
+                        scored_size = (max(1, round(shape[0] / factor)), max(1, round(shape[1] / factor)))
+                    kwargs = {"downscale": factor} if factor > 1.0 else {}
+                    if hasattr(engine, "score_frames"):
+                        # frames go to the device one by one: no host-side stacking copy
+                        records = engine.score_frames(frames, prev=last_frame, flags=flags, edge_kernel=edge_kernel, **kwargs)
+                    else:
+                        records = engine.score_host(np.stack(frames), prev=last_frame, flags=flags,
+                                                    edge_kernel=edge_kernel, **kwargs)
+                    last_frame = frames[-1]
                 for i, (frame_im, position) in enumerate(zip(frames, positions)):
                     self._dispatch(position, frame_im, records[i] if records is not None else None, callback, scored_size)
         finally:

@@ -43,6 +43,14 @@ t0 = time.perf_counter()
 for i in range(32):
     det.process_frame(psd.FrameTimecode(i, 25.0), hf[i])
 out["process_frame_1080p_ms"] = round((time.perf_counter() - t0) / 32 * 1e3, 3)
+# 3b. SceneManager end to end from host frames (decode thread -> batches -> device -> decisions)
+for name, auto in (("full_res", False), ("auto_downscale", True)):
+    sm = psd.SceneManager(engine=eng)
+    sm.auto_downscale = auto
+    sm.add_detector(psd.ContentDetector(engine=eng))
+    t0 = time.perf_counter()
+    nproc = sm.detect_scenes(psd.ArrayVideoStream(hf, 25.0))
+    out[f"scene_manager_1080p_{name}_fps"] = round(nproc / (time.perf_counter() - t0), 1)
 # 4. mixed corpus, all four detectors, one GPU
 corpus = [hf[:96], hf[96:], rng.integers(0, 256, (24, 2160, 3840, 3), dtype=np.uint8), hf[:64]]
 t0 = time.perf_counter()
