@@ -308,3 +308,11 @@ def test_randomised_shapes_flags_and_halos(hip_engine):
             assert np.array_equal(got["hist"], want["hist"]) and np.array_equal(got["byte_sum"], want["byte_sum"]), tag
         if flags & E.SCORE_EDGES:
             assert np.array_equal(got["edge_xor"], want["edge_xor"]), f"{tag}: edge_xor {got['edge_xor']} vs {want['edge_xor']}"
+
+
+def test_8k_frames(hip_engine):
+    """7680x4320: sums exceed 32 bits (u64 records), 2 M groups per frame."""
+    rng = np.random.default_rng(8)
+    fr = rng.integers(0, 256, (3, 4320, 7680, 3), dtype=np.uint8)
+    fr[2] = 255 - fr[1]
+    same(hip_engine.score_host(fr, flags=NOEDGE), orc.score_batch(fr))
