@@ -316,3 +316,51 @@ def test_8k_frames(hip_engine):
     fr = rng.integers(0, 256, (3, 4320, 7680, 3), dtype=np.uint8)
     fr[2] = 255 - fr[1]
     same(hip_engine.score_host(fr, flags=NOEDGE), orc.score_batch(fr))
+
+
+def test_pipelined_submissions_and_limits(hip_engine):
+    rng = np.random.default_rng(4)
+    clips = [rng.integers(0, 256, (5 + i, 40, 64, 3), dtype=np.uint8) for i in range(4)]
+    bufs = []
+    for c in clips:
+        b = hip_engine.alloc(c.nbytes)
+        b.upload(c.reshape(-1))
+        bufs.append(b)
+    for c, b in zip(clips, bufs):
+        hip_engine.submit_device(b.ptr, len(c), 40, 64, flags=NOEDGE)
+    with pytest.raises(ValueError, match="in flight"):
+        hip_engine.submit_device(bufs[0].ptr, len(clips[0]), 40, 64, flags=NOEDGE)     # PSD_MAX_INFLIGHT = 4
+    with pytest.raises(ValueError, match="expected n"):
+        hip_engine.collect(99)                                                          # a bad collect consumes nothing
+    for c in clips:                                                                     # results come back in order
+        same(hip_engine.collect(len(c)), orc.score_batch(c))
+    with pytest.raises(ValueError, match="nothing submitted"):
+        hip_engine.collect(1)
+    same(hip_engine.score_device(bufs[0].ptr, len(clips[0]), 40, 64, flags=NOEDGE), orc.score_batch(clips[0]))
+
+
+def test_two_engines_in_two_threads():
+    """Distinct engines may be driven from distinct threads concurrently (include/psd_engine.h)."""
+    import threading
+
+    rng = np.random.default_rng(6)
+    clips = [rng.integers(0, 256, (40, 90, 160, 3), dtype=np.uint8) for _ in range(2)]
+    want = [orc.score_batch(c) for c in clips]
+    errors = []
+
+    def work(i):
+        try:
+            with E.ScoringEngine(0) as eng:
+                for _ in range(5):
+                    got = eng.score_host(clips[i], flags=NOEDGE)
+                    for f in FIELDS:
+                        assert np.array_equal(got[f], want[i][f]), f
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
