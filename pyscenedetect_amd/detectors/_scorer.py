@@ -30,9 +30,30 @@ class FrameScorer:
             raise ValueError("Image must be 8-bit BGR")
         if frame.ndim != 3 or frame.shape[2] != 3:
             raise ValueError("Image must have three color channels")
+        engine = self.engine
+        if hasattr(engine, "alloc") and hasattr(engine, "score_device"):
+            return self._score_resident(engine, frame, flags, edge_kernel)
         prev = self._last
         if prev is not None and prev.shape != frame.shape:
             prev = None
-        rec = self.engine.score_host(frame[None], prev=prev, flags=flags, edge_kernel=edge_kernel)[0]
+        rec = engine.score_host(frame[None], prev=prev, flags=flags, edge_kernel=edge_kernel)[0]
         self._last = np.array(frame, copy=True)
+        return rec
+
+    def _score_resident(self, engine, frame: np.ndarray, flags: int, edge_kernel: int):
+        """Keep the previous frame in HBM (two ping-pong buffers): one upload per call instead of two."""
+        h, w, _ = frame.shape
+        nbytes = (h * w * 3 + 15) & ~15
+        state = getattr(self, "_resident", None)
+        if state is None or state["shape"] != frame.shape or state["engine"] is not engine:
+            state = {"shape": frame.shape, "engine": engine, "bufs": [engine.alloc(nbytes), engine.alloc(nbytes)],
+                     "cur": 0, "have_prev": False}
+            self._resident = state
+        cur = state["cur"]
+        buf, other = state["bufs"][cur], state["bufs"][cur ^ 1]
+        buf.upload(np.ascontiguousarray(frame).reshape(-1))
+        rec = engine.score_device(buf.ptr, 1, h, w, d_prev=other.ptr if state["have_prev"] else None, flags=flags,
+                                  edge_kernel=edge_kernel)[0]
+        state["cur"] = cur ^ 1
+        state["have_prev"] = True
         return rec
