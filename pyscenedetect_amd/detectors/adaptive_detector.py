@@ -44,36 +44,42 @@ class AdaptiveDetector(ContentDetector):
         return [*super().get_metrics(), self._adaptive_ratio_key]
 
     def process_record(self, timecode: FrameTimecode, record, height: int, width: int) -> list[FrameTimecode]:
-        super().process_record(timecode, record, height, width)
-        if self._frame_score is None:
+        """Decide about the frame ``window_width`` frames back, now that its right-hand neighbours are known."""
+        super().process_record(timecode, record, height, width)   # updates self._frame_score / the stats
+        score_now = self._frame_score
+        if score_now is None:
             return []
         if self._last_cut is None:
-            self._last_cut = timecode
-        need = 1 + 2 * self.window_width
-        self._buffer.append((timecode, self._frame_score))
-        if len(self._buffer) < need:
+            self._last_cut = timecode            # scene length is measured from the first frame seen
+        w = self.window_width
+        window = self._buffer
+        window.append((timecode, score_now))
+        if len(window) < 2 * w + 1:
             return []
-        self._buffer = self._buffer[-need:]
-        target_timecode, target_score = self._buffer[self.window_width]
-        average = sum(score for i, (_tc, score) in enumerate(self._buffer) if i != self.window_width) / (
-            2.0 * self.window_width
-        )
-        average_is_zero = abs(average) < 0.00001
-        adaptive_ratio = 0.0
-        if not average_is_zero:
-            adaptive_ratio = min(target_score / average, 255.0)
-        elif target_score >= self.min_content_val:
-            adaptive_ratio = 255.0
-        if self.stats_manager is not None:
-            self.stats_manager.set_metrics(target_timecode, {self._adaptive_ratio_key: adaptive_ratio})
-        threshold_met = adaptive_ratio >= self.adaptive_threshold and target_score >= self.min_content_val
-        # Note: the *current* position is compared with the last cut, the *target* is emitted
-        # (adaptive_detector.py:139-142).
-        min_length_met = (timecode - self._last_cut) >= self.min_scene_len
-        if threshold_met and min_length_met:
-            self._last_cut = target_timecode
-            return [target_timecode]
-        return []
+        del window[: len(window) - (2 * w + 1)]  # keep exactly w neighbours on each side of the candidate
+        candidate_tc, candidate = window[w]
+        # Mean of the 2w neighbours; accumulated left to right from 0 so that the float result is the
+        # reference's sum(...) / (2.0 * w) bit for bit.
+        neighbours = 0
+        for pos, (_tc, value) in enumerate(window):
+            if pos != w:
+                neighbours = neighbours + value
+        mean = neighbours / (2.0 * w)
+        if abs(mean) < 0.00001:
+            ratio = 255.0 if candidate >= self.min_content_val else 0.0
+        else:
+            ratio = min(candidate / mean, 255.0)
+        stats = self.stats_manager
+        if stats is not None:
+            stats.set_metrics(candidate_tc, {self._adaptive_ratio_key: ratio})
+        is_peak = ratio >= self.adaptive_threshold and candidate >= self.min_content_val
+        # The reference measures the gap from the CURRENT position but reports the candidate
+        # (adaptive_detector.py:139-142); kept as is.
+        long_enough = (timecode - self._last_cut) >= self.min_scene_len
+        if not (is_peak and long_enough):
+            return []
+        self._last_cut = candidate_tc
+        return [candidate_tc]
 
     def process_frame(self, timecode: FrameTimecode, frame_img: np.ndarray) -> list[FrameTimecode]:
         record = self._scorer.score(frame_img, self.score_flags(), self.edge_kernel_size())
