@@ -34,10 +34,6 @@ struct ScoreParams {
 hipError_t launch_score_frames(ScoreParams p, bool hsv, bool luma, bool fast, int target_blocks,
                                hipStream_t stream, int* launches);
 
-// Edge term (Canny + dilate + XOR count); psd_edge_kernels.hip.
-struct EdgeWorkspace;
-size_t edge_workspace_bytes(int height, int width, int frames_per_pass);
-
 }  // namespace psd
 
 #endif

@@ -23,7 +23,6 @@ for (n, h, w) in [(5, 36, 64), (7, 37, 53), (3, 144, 256), (4, 1, 1), (9, 16, 16
     fr = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
     ref = O.score_batch(fr)
     cmp(eng.score_host(fr, flags=FL), ref, f"host all {n}x{h}x{w}")
-    cmp(eng.score_host(fr, flags=E.SCORE_HSV_SAD), np.where(True, ref, ref), f"host hsv-only(+others ignored) {n}x{h}x{w}") if False else None
     pv = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
     cmp(eng.score_host(fr, prev=pv, flags=FL), O.score_batch(fr, pv), f"host prev {n}x{h}x{w}")
     # device path, packed (unaligned when h*w*3 % 16 != 0 -> generic kernel)
