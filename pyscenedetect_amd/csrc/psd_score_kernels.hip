@@ -463,6 +463,13 @@ constexpr int ACD_MAX = 16;  // accumulator replicas
 #ifndef PSD_FUSED_F
 #define PSD_FUSED_F 1
 #endif
+// luma-only variant (histogram + byte sum): replicas of the accumulators and frames per barrier
+#ifndef PSD_LUMA_AC
+#define PSD_LUMA_AC 16
+#endif
+#ifndef PSD_LUMA_F
+#define PSD_LUMA_F 1
+#endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -547,10 +554,10 @@ template <bool HSV, bool LUMA, int G, int WG>
 __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams p)
 {
     constexpr int NW = WG / 64;
-    constexpr int ACD = (HSV && LUMA) ? PSD_FUSED_AC : ACD_MAX;
+    constexpr int ACD = (HSV && LUMA) ? PSD_FUSED_AC : (LUMA ? PSD_LUMA_AC : ACD_MAX);
     constexpr int LCD = (HSV && LUMA) ? PSD_FUSED_LC : LCD_MAX;
     constexpr int NA = LUMA ? NACC : 4;       // accumulators per frame slot
-    constexpr int F = LUMA ? (HSV ? PSD_FUSED_F : 1) : 8;   // frames per barrier
+    constexpr int F = LUMA ? (HSV ? PSD_FUSED_F : PSD_LUMA_F) : 8;   // frames per barrier
     constexpr int SLOTS = 2 * F;
     __shared__ __attribute__((aligned(16))) u32 lut_s[HSV ? 256 * LCD : 4];
     __shared__ __attribute__((aligned(16))) u32 lut_h[HSV ? 256 * LCD : 4];
