@@ -516,7 +516,8 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
     const size_t dirty_bytes = b.tiles_per_frame * (size_t)count;
     HIP_TRY(hipMemsetAsync(b.dirty[0], 1, dirty_bytes, stream));
     int launch = 0;
-    for (int round = 0; round < 4096; round++) {
+    bool converged = false;
+    for (int round = 0; round < 4096 && !converged; round++) {
         constexpr int R = 3;
         HIP_TRY(hipMemsetAsync(b.flags, 0, R * sizeof(int), stream));
         for (int i = 0; i < R; i++, launch++) {
@@ -527,9 +528,11 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
         int flags[R];
         HIP_TRY(hipMemcpyAsync(flags, b.flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        bool done = false;
-        for (int i = 0; i < R; i++) done = done || !flags[i];   // a launch with nothing to pass on ends it
-        if (done) break;
+        for (int i = 0; i < R; i++) converged = converged || !flags[i];   // a launch with nothing to pass on ends it
+    }
+    if (!converged) {
+        psd_set_error("edge hysteresis did not converge within %d launches", launch);
+        return PSD_ERR_HIP;
     }
     hipLaunchKernelGGL(pack_hdilate_kernel, dim3(g.height, count), dim3(256), (g.words_per_row + 2) * sizeof(u32), stream, b.map, g,
                        k, b.hbits);
