@@ -79,3 +79,21 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No HIP library -> an exception at first use, never a silent CPU path."""
+    import subprocess
+    import sys
+
+    code = ("import numpy as np, pyscenedetect_amd as psd\n"
+            "try:\n"
+            "    psd.ContentDetector().process_frame(psd.FrameTimecode(0, 25.0), np.zeros((8, 8, 3), np.uint8))\n"
+            "except Exception as ex:\n"
+            "    print(type(ex).__name__, '|', ex)\n"
+            "else:\n"
+            "    print('NO ERROR')\n")
+    env = dict(os.environ, PSD_LIB_PATH=str(tmp_path / "libpsd_missing.so"), PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert out.stdout.startswith("NativeLibraryError"), out.stdout + out.stderr
+    assert "no CPU fallback" in out.stdout
