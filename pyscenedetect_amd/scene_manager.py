@@ -11,6 +11,7 @@ callback order are those of the sequential loop.
 
 import logging
 import queue
+from enum import Enum
 import sys
 import threading
 import typing as ty
@@ -27,6 +28,17 @@ DEFAULT_MIN_WIDTH: int = 256
 MAX_FRAME_QUEUE_LENGTH: int = 4
 MAX_FRAME_SIZE_ERRORS: int = 16
 DEFAULT_BATCH_FRAMES: int = 64
+
+
+class Interpolation(Enum):
+    """Resize filters of the reference (``scenedetect/common.py:148-160``, values = OpenCV's
+    ``INTER_*``).  Only LINEAR -- the reference's default -- is implemented on the device."""
+
+    NEAREST = 0
+    LINEAR = 1
+    CUBIC = 2
+    AREA = 3
+    LANCZOS4 = 4
 
 
 def compute_downscale_factor(frame_width: int, effective_width: int = DEFAULT_MIN_WIDTH) -> float:
@@ -58,6 +70,7 @@ class SceneManager:
         self._base_timecode = None
         self._downscale = 1
         self._auto_downscale = True
+        self._interpolation = Interpolation.LINEAR
         self._exception_info = None
         self._stop = threading.Event()
         self._frame_buffer: list[tuple[FrameTimecode, np.ndarray]] = []
@@ -87,6 +100,18 @@ class SceneManager:
             raise ValueError("crop coordinates must be >= 0")
         x0, y0, x1, y1 = value
         self._crop = (min(x0, x1), min(y0, y1), max(x0, x1) + 1, max(y0, y1) + 1)
+
+    @property
+    def interpolation(self) -> Interpolation:
+        """Filter used when downscaling frames (reference ``scene_manager.py:265-272``)."""
+        return self._interpolation
+
+    @interpolation.setter
+    def interpolation(self, value: Interpolation):
+        value = Interpolation(value)
+        if value != Interpolation.LINEAR:
+            raise NotImplementedError(f"only Interpolation.LINEAR is implemented on the device, not {value.name}")
+        self._interpolation = value
 
     @property
     def downscale(self) -> int:
