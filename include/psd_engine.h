@@ -134,6 +134,16 @@ int psd_resize_linear_device(psd_engine* e, const uint8_t* d_src, int n, int src
                              size_t src_frame_stride, uint8_t* d_dst, int dst_h, int dst_w,
                              size_t dst_frame_stride, void* stream);
 
+/* HashDetector.hash_frame, front half (hash_detector.py:125-129): cv2.cvtColor(BGR2GRAY) followed by
+ * cv2.resize(gray, (size, size), INTER_AREA) for n frames; `size` is the detector's size*lowpass.
+ * h_thumbs: host array uint8[n][size][size].  Decimation only (size <= width, height), size <= 256.
+ * The *_device form takes frames resident in HBM (same layout rules as psd_score_batch_device) and, like
+ * it, reports the kernel time through psd_last_kernel_ms(). */
+int psd_hash_thumbs_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width,
+                           size_t row_stride, size_t frame_stride, int size, uint8_t* h_thumbs);
+int psd_hash_thumbs(psd_engine* e, const uint8_t* h_frames, int n, int height, int width,
+                    size_t row_stride, size_t frame_stride, int size, uint8_t* h_thumbs);
+
 /* ---- host epilogues (no device involved) -------------------------------------------------
  * Frame positions are frame numbers first_frame .. first_frame+n-1 at a constant frame rate
  * fps_num/fps_den.  min_scene_len is given either in frames (min_len_frames >= 0 and
@@ -198,6 +208,25 @@ int psd_epilogue_threshold_cuts(const psd_frame_scores* recs, int n, int height,
                                 int64_t first_frame, int64_t fps_num, int64_t fps_den,
                                 const psd_threshold_params* p, double* average_rgb, int64_t* cuts,
                                 int* n_cuts);
+
+/* HashDetector.hash_frame, back half (hash_detector.py:131-151): scale by the maximum, 2-D DCT-II, keep
+ * the hash_size x hash_size low frequencies, threshold at their median.  bits: uint8[n][hash_size^2] of 0/1.
+ * The DCT is evaluated in float64 and rounded once to float32 (cv2.dct's own float32 operation order
+ * depends on the OpenCV build and is not restatable). */
+int psd_epilogue_hash_bits(const uint8_t* thumbs, int n, int size, int hash_size, uint8_t* bits);
+
+typedef struct psd_hash_params {
+    double threshold; /* HashDetector(threshold=0.35): cut iff hamming/hash_size^2 >= threshold */
+    int hash_size;    /* 8 */
+    int64_t min_len_frames;
+    double min_len_secs;
+} psd_hash_params;
+
+/* hash_dist[t] (t>=1, or t>=0 when prev_bits != NULL) = normalised Hamming distance of consecutive hashes
+ * (hash_detector.py:97-116). */
+int psd_epilogue_hash_cuts(const uint8_t* bits, int n, const uint8_t* prev_bits, int64_t first_frame,
+                           int64_t fps_num, int64_t fps_den, const psd_hash_params* p,
+                           double* hash_dist, int64_t* cuts, int* n_cuts);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@
  *   cv2.normalize                   scenedetect/detectors/histogram_detector.py:163
  *   cv2.compareHist(CORREL)         scenedetect/detectors/histogram_detector.py:98
  *   cv2.resize(INTER_LINEAR)        scenedetect/scene_manager.py:670-678
+ *   cv2.cvtColor(BGR2GRAY) / cv2.resize(INTER_AREA) / cv2.dct   scenedetect/detectors/hash_detector.py:125,129,139
  *
  * PARITY UNPINNED at the cv2 boundary: no real cv2 build and none of the
  * reference's video fixtures exist in this environment, so
@@ -439,6 +440,160 @@ void orc_resize_linear_u8(const uint8_t* src, size_t sstep, int sh, int sw, int 
             D[x] = (uint8_t)((((b0 * (row0[x] >> 4)) >> 16) + ((b1 * (row1[x] >> 4)) >> 16) + 2) >> 2);
     }
     free(row0); free(row1); free(xofs); free(ialpha); free(yofs); free(ibeta);
+}
+
+/* ---------------------------------------------------------------------------
+ * HashDetector primitives (scenedetect/detectors/hash_detector.py:117-151):
+ *   cv2.cvtColor(BGR2GRAY)  -> orc_bgr2gray      (color_rgb.simd.hpp RGB2Gray<uchar>, 15-bit coefficients)
+ *   cv2.resize(INTER_AREA)  -> orc_resize_area_u8 (resize.cpp: ResizeAreaFast for integer scales,
+ *                                                   computeResizeAreaTab + ResizeArea_ float path otherwise)
+ *   cv2.dct                 -> orc_dct2d_f32     (SEE NOTE)
+ * NOTE on cv2.dct: OpenCV computes the 2-D DCT-II in float32 through its DFT
+ * machinery (and through IPP in the official x86 wheels), so the last bits
+ * of its output depend on the build.  That operation order is not
+ * restatable; this oracle evaluates the orthonormal DCT-II definition in
+ * float64 in a fixed loop order and rounds once to float32.  Hash bits can
+ * therefore differ from a given cv2 build only where a coefficient lies
+ * within float32 rounding noise of the median.
+ * ------------------------------------------------------------------------- */
+void orc_bgr2gray(const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int h, int w)
+{
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src + (size_t)y * src_step;
+        uint8_t* d = dst + (size_t)y * dst_step;
+        for (int x = 0; x < w; x++)
+            d[x] = (uint8_t)((s[3 * x] * 3735 + s[3 * x + 1] * 19235 + s[3 * x + 2] * 9798 + (1 << 14)) >> 15);
+    }
+}
+
+/* One axis of the INTER_AREA decimation table in run-length form.  For every destination index the
+ * source cells are consecutive: an optional fractional head cell, whole cells, an optional fractional
+ * tail cell -- the order computeResizeAreaTab emits them in. */
+typedef struct {
+    int32_t first;      /* source index of the first contributing cell */
+    int32_t count;      /* number of contributing cells */
+    int32_t has_head, has_tail;
+    float a_head, a_mid, a_tail;
+} orc_area_run;
+
+void orc_area_table(int ssize, int dsize, orc_area_run* tab)
+{
+    double scale = 1. / ((double)dsize / ssize);
+    for (int dx = 0; dx < dsize; dx++) {
+        double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        if (sx2 > ssize - 1) sx2 = ssize - 1;
+        if (sx1 > sx2) sx1 = sx2;
+        orc_area_run r;
+        memset(&r, 0, sizeof r);
+        r.first = sx1;
+        if (sx1 - fsx1 > 1e-3) {
+            r.has_head = 1;
+            r.first = sx1 - 1;
+            r.a_head = (float)((sx1 - fsx1) / cell);
+            r.count++;
+        }
+        r.a_mid = (float)(1.0 / cell);
+        r.count += sx2 - sx1;
+        if (fsx2 - sx2 > 1e-3) {
+            double t = fsx2 - sx2 < 1. ? fsx2 - sx2 : 1.;
+            if (t > cell) t = cell;
+            r.has_tail = 1;
+            r.a_tail = (float)(t / cell);
+            r.count++;
+        }
+        tab[dx] = r;
+    }
+}
+
+static inline float area_weight(const orc_area_run* r, int k)
+{
+    if (k == 0 && r->has_head) return r->a_head;
+    if (k == r->count - 1 && r->has_tail) return r->a_tail;
+    return r->a_mid;
+}
+
+/* Single-channel 8-bit, shrinking in both directions (the only way HashDetector uses it).
+ * Returns 0, or -1 if the request is not a pure decimation. */
+int orc_resize_area_u8(const uint8_t* src, size_t sstep, int sh, int sw, uint8_t* dst, size_t dstep, int dh, int dw)
+{
+    if (dw > sw || dh > sh || dw <= 0 || dh <= 0) return -1;
+    double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
+    int is_area_fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
+    if (is_area_fast) {
+        /* integer box: 2x2 uses the rounding shift of the SIMD path, other sizes saturate_cast(sum * (1.f/area)) */
+        int area = iscale_x * iscale_y;
+        float scale = 1.f / area;
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++) {
+                int sum = 0;
+                for (int j = 0; j < iscale_y; j++)
+                    for (int i = 0; i < iscale_x; i++) sum += src[(size_t)(y * iscale_y + j) * sstep + x * iscale_x + i];
+                if (iscale_x == 2 && iscale_y == 2) dst[(size_t)y * dstep + x] = (uint8_t)((sum + 2) >> 2);
+                else {
+                    long v = lrintf((float)sum * scale);
+                    dst[(size_t)y * dstep + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+                }
+            }
+        return 0;
+    }
+    orc_area_run* xt = (orc_area_run*)malloc(sizeof(orc_area_run) * dw);
+    orc_area_run* yt = (orc_area_run*)malloc(sizeof(orc_area_run) * dh);
+    orc_area_table(sw, dw, xt);
+    orc_area_table(sh, dh, yt);
+    float* buf = (float*)malloc(sizeof(float) * dw);
+    float* sum = (float*)malloc(sizeof(float) * dw);
+    for (int dy = 0; dy < dh; dy++) {
+        for (int j = 0; j < yt[dy].count; j++) {
+            const uint8_t* S = src + (size_t)(yt[dy].first + j) * sstep;
+            float beta = area_weight(&yt[dy], j);
+            for (int dx = 0; dx < dw; dx++) {
+                float acc = 0.f;
+                for (int k = 0; k < xt[dx].count; k++) {
+                    float term = (float)S[xt[dx].first + k] * area_weight(&xt[dx], k); /* no fused multiply-add */
+                    acc += term;
+                }
+                buf[dx] = acc;
+            }
+            for (int dx = 0; dx < dw; dx++) {
+                float term = beta * buf[dx];
+                sum[dx] = j == 0 ? term : sum[dx] + term;
+            }
+        }
+        for (int dx = 0; dx < dw; dx++) {
+            long v = lrintf(sum[dx]);
+            dst[(size_t)dy * dstep + dx] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+    }
+    free(xt); free(yt); free(buf); free(sum);
+    return 0;
+}
+
+/* Orthonormal 2-D DCT-II of an n x n float32 block: out = C * in * C^T,
+ * C[0][j] = sqrt(1/n), C[k][j] = sqrt(2/n) * cos(pi*(2j+1)*k/(2n)).  Only the top-left keep x keep block is produced. */
+void orc_dct2d_f32(const float* in, int n, int keep, float* out)
+{
+    double* c = (double*)malloc(sizeof(double) * keep * n);
+    double* t = (double*)malloc(sizeof(double) * keep * n);
+    for (int k = 0; k < keep; k++)
+        for (int j = 0; j < n; j++)
+            c[k * n + j] = k == 0 ? sqrt(1.0 / n) : sqrt(2.0 / n) * cos(3.14159265358979323846 * (2 * j + 1) * k / (2.0 * n));
+    /* t[u][x] = sum_y C[u][y] * in[y][x] */
+    for (int u = 0; u < keep; u++)
+        for (int x = 0; x < n; x++) {
+            double acc = 0.0;
+            for (int y = 0; y < n; y++) acc += c[u * n + y] * (double)in[y * n + x];
+            t[u * n + x] = acc;
+        }
+    for (int u = 0; u < keep; u++)
+        for (int v = 0; v < keep; v++) {
+            double acc = 0.0;
+            for (int x = 0; x < n; x++) acc += t[u * n + x] * c[v * n + x];
+            out[u * keep + v] = (float)acc;
+        }
+    free(c); free(t);
 }
 
 /* ---------------------------------------------------------------------------

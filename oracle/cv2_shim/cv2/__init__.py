@@ -63,6 +63,9 @@ def cvtColor(src, code):
         L.orc_bgr2hsv(src.ctypes.data, w * 3, dst.ctypes.data, w * 3, h, w)
     elif code == COLOR_BGR2YUV:
         L.orc_bgr2yuv(src.ctypes.data, w * 3, dst.ctypes.data, w * 3, h, w)
+    elif code == COLOR_BGR2GRAY:
+        dst = np.empty((h, w), np.uint8)
+        L.orc_bgr2gray(src.ctypes.data, w * 3, dst.ctypes.data, w, h, w)
     else:
         raise NotImplementedError(f"cv2 shim: cvtColor code {code}")
     return dst
@@ -119,12 +122,27 @@ def compareHist(H1, H2, method):
 
 
 def resize(src, dsize, interpolation=INTER_LINEAR):
-    if interpolation != INTER_LINEAR:
-        raise NotImplementedError("cv2 shim: only INTER_LINEAR")
     src = np.ascontiguousarray(src, dtype=np.uint8)
     sh, sw = src.shape[:2]
     cn = 1 if src.ndim == 2 else src.shape[2]
     dw, dh = int(dsize[0]), int(dsize[1])
+    if interpolation == INTER_AREA and cn == 1:
+        dst = np.empty((dh, dw), np.uint8)
+        if _orc.lib().orc_resize_area_u8(src.ctypes.data, sw, sh, sw, dst.ctypes.data, dw, dh, dw) != 0:
+            raise NotImplementedError("cv2 shim: INTER_AREA only for decimation")
+        return dst
+    if interpolation != INTER_LINEAR:
+        raise NotImplementedError("cv2 shim: only INTER_LINEAR (and single-channel INTER_AREA)")
     dst = np.empty((dh, dw) + (() if src.ndim == 2 else (cn,)), np.uint8)
     _orc.lib().orc_resize_linear_u8(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw)
+    return dst
+
+
+def dct(src):
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    n = src.shape[0]
+    if src.ndim != 2 or src.shape[1] != n:
+        raise NotImplementedError("cv2 shim: dct of square float32 blocks only")
+    dst = np.empty((n, n), np.float32)
+    _orc.lib().orc_dct2d_f32(src.ctypes.data, n, n, dst.ctypes.data)
     return dst

@@ -83,3 +83,14 @@ class OracleEngine:
             rec["hist"] = 0
             rec["byte_sum"] = 0
         return rec
+
+    def hash_thumbs_host(self, frames, size, downscale=1.0):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if downscale > 1.0:
+            import cv2  # the shim
+
+            frames = np.stack([cv2.resize(f, (max(1, round(f.shape[1] / downscale)), max(1, round(f.shape[0] / downscale))))
+                               for f in frames])
+        from oracle import lib as _lib
+
+        return _lib.hash_thumbs(frames, size)

@@ -27,7 +27,8 @@ import numpy as np  # noqa: E402
 import scenedetect  # noqa: E402  (the reference)
 from scenedetect import FrameTimecode  # noqa: E402
 from scenedetect.detector import FlashFilter  # noqa: E402
-from scenedetect.detectors import AdaptiveDetector, ContentDetector, HistogramDetector, ThresholdDetector  # noqa: E402
+from scenedetect.detectors import (AdaptiveDetector, ContentDetector, HashDetector, HistogramDetector,  # noqa: E402
+                                   ThresholdDetector)
 from scenedetect.scene_manager import SceneManager  # noqa: E402
 from scenedetect.stats_manager import StatsManager  # noqa: E402
 from scenedetect.video_stream import VideoStream  # noqa: E402
@@ -99,6 +100,9 @@ CONFIGS = {
     "hist_default": ("HistogramDetector", {}, True),
     "hist_256": ("HistogramDetector", {"bins": 256, "threshold": 0.1, "min_scene_len": 5}, True),
     "hist_100": ("HistogramDetector", {"bins": 100, "threshold": 0.3}, True),
+    "hash_default": ("HashDetector", {}, True),
+    "hash_16_lp2": ("HashDetector", {"size": 16, "lowpass": 2, "threshold": 0.3, "min_scene_len": 5}, True),
+    "hash_8_lp4_secs": ("HashDetector", {"size": 8, "lowpass": 4, "threshold": 0.4, "min_scene_len": 0.4}, False),
     "threshold_default": ("ThresholdDetector", {}, True),
     "threshold_final": ("ThresholdDetector", {"threshold": 30, "add_final_scene": True, "fade_bias": 0.5,
                                              "min_scene_len": 4}, True),
@@ -116,7 +120,8 @@ def build_detector(cls_name, kwargs):
     if "method" in kw:
         kw["method"] = ThresholdDetector.Method[kw["method"]]
     return {"ContentDetector": ContentDetector, "AdaptiveDetector": AdaptiveDetector,
-            "HistogramDetector": HistogramDetector, "ThresholdDetector": ThresholdDetector}[cls_name](**kw)
+            "HistogramDetector": HistogramDetector, "ThresholdDetector": ThresholdDetector,
+            "HashDetector": HashDetector}[cls_name](**kw)
 
 
 def run(frames, cls_name, kwargs, with_stats, auto_downscale, fps=25.0):
@@ -251,7 +256,7 @@ def main():
         golden["clips"][name] = entry
     fr = uniform_clip(21, 40, 48, 64)
     entry = {"seed": 21, "n": 40, "h": 48, "w": 64, "uniform": True, "sum_all": int(fr.sum()), "results": {}}
-    for cname in ("content_stats", "content_edges", "hist_default", "threshold_default", "adaptive_default"):
+    for cname in ("content_stats", "content_edges", "hist_default", "threshold_default", "adaptive_default", "hash_default"):
         cls_name, kwargs, with_stats = CONFIGS[cname]
         entry["results"][cname] = run(fr, cls_name, kwargs, with_stats, False)
     golden["clips"]["uniform_u"] = entry

@@ -69,6 +69,9 @@ def lib() -> ctypes.CDLL:
         L.orc_canny.argtypes = [vp, sz, i, i, d, d, vp]
         L.orc_dilate_rect.argtypes = [vp, sz, i, i, i, i, vp]
         L.orc_resize_linear_u8.argtypes = [vp, sz, i, i, i, vp, sz, i, i]
+        L.orc_bgr2gray.argtypes = [vp, sz, vp, sz, i, i]
+        L.orc_resize_area_u8.argtypes = [vp, sz, i, i, vp, sz, i, i]
+        L.orc_dct2d_f32.argtypes = [vp, i, i, vp]
         L.orc_score_batch.argtypes = [vp, i, i, i, sz, sz, vp, vp]
         L.orc_score_batch_flags.argtypes = [vp, i, i, i, sz, sz, vp, vp, ctypes.c_uint]
         _lib = L
@@ -104,3 +107,36 @@ def score_batch(frames: np.ndarray, prev: np.ndarray | None = None, flags: int =
     if n:
         lib().orc_score_batch_flags(_p(frames), n, h, w, w * 3, h * w * 3, pp, _p(out), int(flags) & 7)
     return out
+
+
+def hash_thumbs(frames: np.ndarray, size: int) -> np.ndarray:
+    """Grey ``size x size`` INTER_AREA thumbnails of BGR frames [n,h,w,3] -- the integer/float32 front half
+    of ``HashDetector.hash_frame`` (reference ``hash_detector.py:125-129``)."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, h, w, _ = frames.shape
+    L = lib()
+    gray = np.empty((h, w), np.uint8)
+    out = np.empty((n, size, size), np.uint8)
+    for t in range(n):
+        L.orc_bgr2gray(_p(frames[t]), w * 3, _p(gray), w, h, w)
+        if L.orc_resize_area_u8(_p(gray), w, h, w, _p(out[t]), size, size, size) != 0:
+            raise NotImplementedError("INTER_AREA restated for decimation only")
+    return out
+
+
+def hash_bits(thumbs: np.ndarray, hash_size: int) -> np.ndarray:
+    """Back half of ``hash_frame`` (``hash_detector.py:131-151``): scale by the maximum, DCT, keep the low
+    ``hash_size`` frequencies, threshold at their median.  Returns bool [n, hash_size, hash_size]."""
+    thumbs = np.ascontiguousarray(thumbs, dtype=np.uint8)
+    n, s, _ = thumbs.shape
+    L = lib()
+    bits = np.empty((n, hash_size, hash_size), bool)
+    low = np.empty((hash_size, hash_size), np.float32)
+    for t in range(n):
+        mx = thumbs[t].max()
+        if mx == 0:
+            mx = 1
+        x = np.ascontiguousarray(np.float32(thumbs[t]) / mx)
+        L.orc_dct2d_f32(_p(x), s, hash_size, _p(low))
+        bits[t] = low > np.median(low)
+    return bits

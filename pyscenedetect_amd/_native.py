@@ -82,6 +82,15 @@ class ThresholdParams(ctypes.Structure):
     ]
 
 
+class HashParams(ctypes.Structure):
+    _fields_ = [
+        ("threshold", ctypes.c_double),
+        ("hash_size", ctypes.c_int),
+        ("min_len_frames", ctypes.c_int64),
+        ("min_len_secs", ctypes.c_double),
+    ]
+
+
 #: name -> (restype, argtypes); every symbol ``include/psd_engine.h`` declares.
 _vp, _sz, _i, _u32, _i64, _f = (
     ctypes.c_void_p,
@@ -110,11 +119,15 @@ SYMBOLS = {
     "psd_hsv_tables": (_i, [_vp, _vp]),
     "psd_edge_map_device": (_i, [_vp, _vp, _i, _i, _sz, _i, _vp]),
     "psd_resize_linear_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _sz, _vp]),
+    "psd_hash_thumbs_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp]),
+    "psd_hash_thumbs": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp]),
     "psd_epilogue_content_scores": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "psd_epilogue_content_cuts": (_i, [_vp, _i, _i64, _i64, _i64, _P(ContentParams), _vp, _P(_i)]),
     "psd_epilogue_adaptive_cuts": (_i, [_vp, _i, _i64, _i64, _i64, _P(AdaptiveParams), _vp, _vp, _P(_i)]),
     "psd_epilogue_hist_cuts": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _P(HistParams), _vp, _vp, _P(_i)]),
     "psd_epilogue_threshold_cuts": (_i, [_vp, _i, _i, _i, _i64, _i64, _i64, _P(ThresholdParams), _vp, _vp, _P(_i)]),
+    "psd_epilogue_hash_bits": (_i, [_vp, _i, _i, _i, _vp]),
+    "psd_epilogue_hash_cuts": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _P(HashParams), _vp, _vp, _P(_i)]),
 }
 
 _lib = None

@@ -43,6 +43,11 @@ int edges_map(psd_engine* e, const uint8_t* d_frame, int height, int width, size
 void edges_release(psd_engine* e);
 int resize_linear(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride,
                   uint8_t* d_dst, int dst_h, int dst_w, size_t dst_frame_stride, hipStream_t stream);
+// psd_hash_kernels.hip
+struct AreaRun;
+int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
+                int size, AreaRun* d_tabs, uint8_t* d_thumbs, hipStream_t stream);
+size_t hash_tab_bytes(int size);
 }  // namespace psd
 
 struct psd_slot {
@@ -70,6 +75,9 @@ struct psd_engine {
     size_t stage_bytes = 0;
     void* edge_ws = nullptr;  // owned by psd_edge_kernels.hip
     size_t edge_ws_bytes = 0;
+    uint8_t* d_hash = nullptr;  // thumbnails + run tables of psd_hash_thumbs*
+    size_t hash_bytes = 0;
+    hipEvent_t ev_hash[2] = {nullptr, nullptr};
 };
 
 static void fill_tables(int32_t* sdiv, int32_t* hdiv)
@@ -180,6 +188,8 @@ void psd_destroy(psd_engine* e)
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
     for (auto& d : e->d_stage) if (d) (void)hipFree(d);
+    if (e->d_hash) (void)hipFree(e->d_hash);
+    for (auto& ev : e->ev_hash) if (ev) (void)hipEventDestroy(ev);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -326,16 +336,15 @@ int psd_last_kernel_ms(psd_engine* e, float* ms, int* launches)
     return PSD_OK;
 }
 
-int psd_score_batch(psd_engine* e, const uint8_t* h_frames, int n, int height, int width,
-                    size_t row_stride, size_t frame_stride, const uint8_t* h_prev, uint32_t flags,
-                    int edge_kernel, psd_frame_scores* out)
+}  // extern "C"
+
+// Feeds host frames to `run(d_buf, cnt, packed_row, dstride, d_prev, done)` in bounded chunks through the engine's two device
+// staging buffers (packed rows, 16-byte aligned frames); d_prev is the device copy of the frame preceding
+// the chunk (h_prev for the first one, may be null).
+template <typename Run>
+static int for_each_host_chunk(psd_engine* e, const uint8_t* h_frames, int n, int height, int width, size_t row_stride,
+                               size_t frame_stride, const uint8_t* h_prev, Run run)
 {
-    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
-    int rc = validate(h_frames, n, height, width, row_stride, frame_stride, flags, edge_kernel);
-    if (rc != PSD_OK) return rc;
-    if (e->pending != 0) { psd_set_error("psd_score_batch: asynchronous submissions are still pending"); return PSD_ERR_INVALID; }
-    if (n == 0) return PSD_OK;
-    HIP_TRY(hipSetDevice(e->device));
     const size_t packed_row = (size_t)width * 3;
     const size_t dstride = ((size_t)height * packed_row + 15) & ~(size_t)15;  // 16-B aligned frames
     // Bounded staging: chunks of at most ~256 MiB (and at least one frame) per buffer, plus the
@@ -361,7 +370,7 @@ int psd_score_batch(psd_engine* e, const uint8_t* h_frames, int n, int height, i
         }
         return PSD_OK;
     };
-    int done = 0, chunk_idx = 0;
+    int done = 0, chunk_idx = 0, rc;
     const uint8_t* d_prev = nullptr;
     if (h_prev) {
         rc = upload(e->d_stage[1], h_prev, 1);  // park the halo in the *other* buffer's slot 0
@@ -373,14 +382,94 @@ int psd_score_batch(psd_engine* e, const uint8_t* h_frames, int n, int height, i
         uint8_t* buf = e->d_stage[chunk_idx & 1] + dstride;  // slot 0 is reserved for a halo copy
         rc = upload(buf, h_frames + (size_t)done * frame_stride, (size_t)cnt);
         if (rc != PSD_OK) return rc;
-        rc = psd_score_batch_device(e, buf, cnt, height, width, packed_row, dstride, d_prev, flags, edge_kernel,
-                                    out + done, nullptr);
+        rc = run(buf, cnt, packed_row, dstride, d_prev, done);
         if (rc != PSD_OK) return rc;
         d_prev = buf + (size_t)(cnt - 1) * dstride;
         done += cnt;
         chunk_idx++;
     }
     return PSD_OK;
+}
+
+extern "C" {
+
+int psd_score_batch(psd_engine* e, const uint8_t* h_frames, int n, int height, int width,
+                    size_t row_stride, size_t frame_stride, const uint8_t* h_prev, uint32_t flags,
+                    int edge_kernel, psd_frame_scores* out)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    int rc = validate(h_frames, n, height, width, row_stride, frame_stride, flags, edge_kernel);
+    if (rc != PSD_OK) return rc;
+    if (e->pending != 0) { psd_set_error("psd_score_batch: asynchronous submissions are still pending"); return PSD_ERR_INVALID; }
+    if (n == 0) return PSD_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    return for_each_host_chunk(e, h_frames, n, height, width, row_stride, frame_stride, h_prev,
+                               [&](const uint8_t* buf, int cnt, size_t packed_row, size_t dstride, const uint8_t* d_prev, int done) {
+                                   return psd_score_batch_device(e, buf, cnt, height, width, packed_row, dstride, d_prev, flags,
+                                                                 edge_kernel, out + done, nullptr);
+                               });
+}
+
+static int validate_hash(const void* frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
+                         int size, const void* out)
+{
+    int rc = validate(frames, n, height, width, row_stride, frame_stride, PSD_SCORE_BYTE_SUM, 0);
+    if (rc != PSD_OK) return rc;
+    if (size <= 0) { psd_set_error("hash thumbnail size must be positive, got %d", size); return PSD_ERR_INVALID; }
+    if (n > 0 && !out) { psd_set_error("thumbnail output pointer is null"); return PSD_ERR_INVALID; }
+    return PSD_OK;
+}
+
+int psd_hash_thumbs_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width,
+                           size_t row_stride, size_t frame_stride, int size, uint8_t* h_thumbs)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    int rc = validate_hash(d_frames, n, height, width, row_stride, frame_stride, size, h_thumbs);
+    if (rc != PSD_OK) return rc;
+    if (n == 0) return PSD_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t thumbs_bytes = (((size_t)n * size * size) + 255) & ~(size_t)255;
+    const size_t need = thumbs_bytes + psd::hash_tab_bytes(size);
+    if (e->hash_bytes < need) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->d_hash) HIP_TRY(hipFree(e->d_hash));
+        e->d_hash = nullptr; e->hash_bytes = 0;
+        hipError_t err = hipMalloc((void**)&e->d_hash, need);
+        if (err != hipSuccess) {
+            psd_set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(err));
+            return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
+        }
+        e->hash_bytes = need;
+    }
+    if (!e->ev_hash[0]) { HIP_TRY(hipEventCreate(&e->ev_hash[0])); HIP_TRY(hipEventCreate(&e->ev_hash[1])); }
+    psd::AreaRun* d_tabs = reinterpret_cast<psd::AreaRun*>(e->d_hash + thumbs_bytes);
+    // the run tables are uploaded (and waited for) before the timed region inside hash_thumbs; the events
+    // below bracket that upload too, it is a few hundred bytes
+    HIP_TRY(hipEventRecord(e->ev_hash[0], e->stream));
+    rc = psd::hash_thumbs(d_frames, n, height, width, row_stride, frame_stride, size, d_tabs, e->d_hash, e->stream);
+    if (rc != PSD_OK) return rc;
+    HIP_TRY(hipEventRecord(e->ev_hash[1], e->stream));
+    HIP_TRY(hipMemcpyAsync(h_thumbs, e->d_hash, (size_t)n * size * size, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ev_hash[0], e->ev_hash[1]));
+    e->last_launches = (n + 32767) / 32768;
+    return PSD_OK;
+}
+
+int psd_hash_thumbs(psd_engine* e, const uint8_t* h_frames, int n, int height, int width,
+                    size_t row_stride, size_t frame_stride, int size, uint8_t* h_thumbs)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    int rc = validate_hash(h_frames, n, height, width, row_stride, frame_stride, size, h_thumbs);
+    if (rc != PSD_OK) return rc;
+    if (e->pending != 0) { psd_set_error("psd_hash_thumbs: asynchronous submissions are still pending"); return PSD_ERR_INVALID; }
+    if (n == 0) return PSD_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    return for_each_host_chunk(e, h_frames, n, height, width, row_stride, frame_stride, nullptr,
+                               [&](const uint8_t* buf, int cnt, size_t packed_row, size_t dstride, const uint8_t*, int done) {
+                                   return psd_hash_thumbs_device(e, buf, cnt, height, width, packed_row, dstride, size,
+                                                                 h_thumbs + (size_t)done * size * size);
+                               });
 }
 
 int psd_device_alloc(psd_engine* e, size_t bytes, void** d_ptr)

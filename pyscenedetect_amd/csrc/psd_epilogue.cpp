@@ -9,6 +9,7 @@
 // All floating point is IEEE double (float where OpenCV uses float) in the reference's order, so
 // metrics are bit-identical to the Python host mirror in pyscenedetect_amd/detectors/.
 #include <cfloat>
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -297,6 +298,87 @@ int psd_epilogue_threshold_cuts(const psd_frame_scores* recs, int n, int height,
     if (n > 0 && fade_type == 1 && p->add_final_scene) {
         const int64_t tc = first_frame + n - 1;
         if (len.met(tc, last_scene_cut)) cuts[nc++] = fade_frame;
+    }
+    *n_cuts = nc;
+    return PSD_OK;
+}
+
+int psd_epilogue_hash_bits(const uint8_t* thumbs, int n, int size, int hash_size, uint8_t* bits)
+{
+    if (n < 0 || size <= 0 || hash_size <= 0 || hash_size > size || (n > 0 && (!thumbs || !bits))) {
+        psd_set_error("psd_epilogue_hash_bits: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    const int keep = hash_size;
+    // orthonormal DCT-II basis, rows 0..keep-1
+    std::vector<double> c((size_t)keep * size), tmp((size_t)keep * size);
+    for (int k = 0; k < keep; k++)
+        for (int j = 0; j < size; j++)
+            c[(size_t)k * size + j] = k == 0 ? std::sqrt(1.0 / size)
+                                             : std::sqrt(2.0 / size) * std::cos(3.14159265358979323846 * (2 * j + 1) * k / (2.0 * size));
+    std::vector<float> x((size_t)size * size), low((size_t)keep * keep), sorted((size_t)keep * keep);
+    for (int t = 0; t < n; t++) {
+        const uint8_t* th = thumbs + (size_t)t * size * size;
+        int mx = 0;
+        for (int i = 0; i < size * size; i++) mx = th[i] > mx ? th[i] : mx;
+        if (mx == 0) mx = 1;  // hash_detector.py:132-135
+        const float fmx = (float)mx;
+        for (int i = 0; i < size * size; i++) x[i] = (float)th[i] / fmx;
+        for (int u = 0; u < keep; u++)
+            for (int xx = 0; xx < size; xx++) {
+                double acc = 0.0;
+                for (int y = 0; y < size; y++) acc += c[(size_t)u * size + y] * (double)x[(size_t)y * size + xx];
+                tmp[(size_t)u * size + xx] = acc;
+            }
+        for (int u = 0; u < keep; u++)
+            for (int v = 0; v < keep; v++) {
+                double acc = 0.0;
+                for (int xx = 0; xx < size; xx++) acc += tmp[(size_t)u * size + xx] * c[(size_t)v * size + xx];
+                low[(size_t)u * keep + v] = (float)acc;
+            }
+        // numpy.median of float32: middle element, or the float32 mean of the two middle elements
+        sorted = low;
+        std::sort(sorted.begin(), sorted.end());
+        const size_t m = sorted.size();
+        float med;
+        if (m % 2) med = sorted[m / 2];
+        else {
+            const float two = sorted[m / 2 - 1] + sorted[m / 2];
+            med = two / 2.0f;
+        }
+        uint8_t* b = bits + (size_t)t * keep * keep;
+        for (size_t i = 0; i < m; i++) b[i] = low[i] > med ? 1 : 0;
+    }
+    return PSD_OK;
+}
+
+int psd_epilogue_hash_cuts(const uint8_t* bits, int n, const uint8_t* prev_bits, int64_t first_frame,
+                           int64_t fps_num, int64_t fps_den, const psd_hash_params* p,
+                           double* hash_dist, int64_t* cuts, int* n_cuts)
+{
+    if (n < 0 || (n > 0 && !bits) || !p || !cuts || !n_cuts || p->hash_size <= 0 || !check_fps(fps_num, fps_den)) {
+        psd_set_error("psd_epilogue_hash_cuts: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    const double fps = fps_of(fps_num, fps_den);
+    const MinLen len(p->min_len_frames, p->min_len_secs, fps);
+    const size_t nb = (size_t)p->hash_size * p->hash_size;
+    const double size_sq = (double)nb;
+    int nc = 0;
+    int64_t last_cut = first_frame - (prev_bits ? 1 : 0);
+    const uint8_t* last = prev_bits;
+    for (int t = 0; t < n; t++) {
+        const int64_t tc = first_frame + t;
+        const uint8_t* cur = bits + (size_t)t * nb;
+        double d = NAN;
+        if (last) {
+            int diff = 0;
+            for (size_t i = 0; i < nb; i++) diff += cur[i] != last[i];
+            d = (double)diff / size_sq;
+            if (d >= p->threshold && len.met(tc, last_cut)) { cuts[nc++] = tc; last_cut = tc; }
+        }
+        if (hash_dist) hash_dist[t] = d;
+        last = cur;
     }
     *n_cuts = nc;
     return PSD_OK;

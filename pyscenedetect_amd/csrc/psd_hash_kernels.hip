@@ -1,0 +1,274 @@
+// psd_hash_kernels.hip -- front half of HashDetector.hash_frame for gfx950 (MI355X, CDNA4).
+//
+// Reference (paths relative to its tree): scenedetect/detectors/hash_detector.py:125-129
+//     gray    = cv2.cvtColor(frame, cv2.COLOR_BGR2GRAY)
+//     resized = cv2.resize(gray, (imsize, imsize), interpolation=cv2.INTER_AREA)
+// One fused pass reads every BGR byte once (3 B/px algorithmic) and leaves an imsize x imsize 8-bit
+// thumbnail per frame; the float DCT / median / Hamming distance of 1 KiB per frame is host work
+// (psd_epilogue_hash_*).
+//
+// Arithmetic follows OpenCV's 8-bit paths exactly:
+//   grey      (3735 B + 19235 G + 9798 R + 2^14) >> 15                (RGB2Gray<uchar>, 15-bit coefficients)
+//   INTER_AREA, integer scale in both directions: integer box sums, 2x2 -> (s + 2) >> 2, otherwise
+//             saturate_cast<uchar>(sum * (1.f / area))                   (ResizeAreaFast)
+//   INTER_AREA, fractional scale: float32 run tables (computeResizeAreaTab); per source row
+//             buf[dx] = sum_k S[sx_k] * alpha_k accumulated left to right, per destination row
+//             sum[dx] = beta_0 buf_0 + beta_1 buf_1 + ... top to bottom, every product and sum rounded
+//             to float32 separately, result rounded half-to-even                (ResizeArea_<uchar, float>)
+// The float sums are evaluated in exactly that order (no reassociation, no fused multiply-add), so the
+// thumbnails are bit-identical to the CPU oracle's.
+//
+// Mapping: one workgroup per (frame, destination row).  It walks the ~H/imsize source rows of its cell row
+// in batches of R rows: (A) all threads load the batch with 16-byte loads, convert to grey and park it in
+// LDS; (B) thread (r, dx) reduces its run of one grey row; (C) threads dx < imsize fold the batch's row
+// partials into the running column sums in row order.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "psd_internal.h"
+
+extern "C" void psd_set_error(const char* fmt, ...);
+
+// Every float product and sum below must round separately, as the x86 code it mirrors does.
+#pragma clang fp contract(off)
+
+namespace psd {
+
+typedef uint32_t u32;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+struct AreaRun {
+    int first;       // source index of the first contributing cell
+    int count;       // number of contributing cells (consecutive)
+    int has_head, has_tail;
+    float a_head, a_mid, a_tail;
+    int pad;
+};
+
+struct HashGeom {
+    const uint8_t* frames;
+    size_t frame_stride, row_stride;
+    int height, width, size;
+    int mode;            // 0 = float run tables, 1 = integer box, 2 = 2x2 box
+    float inv_area;      // mode 1
+    int rows_per_batch;  // R
+    int wpad;            // LDS row pitch in bytes (multiple of 16)
+};
+
+constexpr int kHashWG = 256;
+
+__device__ __forceinline__ u32 gray_of(u32 b, u32 g, u32 r)
+{
+    return (__umul24(b, 3735u) + __umul24(g, 19235u) + __umul24(r, 9798u) + (1u << 14)) >> 15;
+}
+
+// 16 packed BGR pixels (12 dwords) -> 16 grey bytes (4 dwords)
+__device__ __forceinline__ u32x4 gray16(const u32 (&w)[12])
+{
+    u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int ib = 3 * i, ig = 3 * i + 1, ir = 3 * i + 2;
+        const u32 b = (w[ib >> 2] >> ((ib & 3) * 8)) & 0xffu;
+        const u32 g = (w[ig >> 2] >> ((ig & 3) * 8)) & 0xffu;
+        const u32 r = (w[ir >> 2] >> ((ir & 3) * 8)) & 0xffu;
+        o[i >> 2] |= gray_of(b, g, r) << ((i & 3) * 8);
+    }
+    u32x4 v;
+    v.x = o[0]; v.y = o[1]; v.z = o[2]; v.w = o[3];
+    return v;
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(kHashWG) void gray_area_kernel(const HashGeom g, const AreaRun* __restrict__ xtab,
+                                                            const AreaRun* __restrict__ ytab,
+                                                            uint8_t* __restrict__ thumbs)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int R = g.rows_per_batch, S = g.size, tid = threadIdx.x;
+    uint8_t* rows = smem;                                               // [R][wpad] grey
+    float* part = reinterpret_cast<float*>(smem + (size_t)R * g.wpad);  // [R][S] row partials
+    AreaRun* xr_lds = reinterpret_cast<AreaRun*>(part + R * S);         // [S]
+    const int dy = blockIdx.x, t = blockIdx.y;
+    const uint8_t* frame = g.frames + (size_t)t * g.frame_stride;
+    for (int i = tid; i < S; i += kHashWG) xr_lds[i] = xtab[i];
+    const AreaRun yr = ytab[dy];
+    float fsum = 0.f;
+    int isum = 0;
+    const int groups_per_row = g.width >> 4;
+    for (int j0 = 0; j0 < yr.count; j0 += R) {
+        const int nrows = min(R, yr.count - j0);
+        // (A) grey rows of this batch -> LDS
+        if (FAST) {
+            for (int item = tid; item < nrows * groups_per_row; item += kHashWG) {
+                const int r = item / groups_per_row, gi = item - r * groups_per_row;
+                const u32x4* src = reinterpret_cast<const u32x4*>(frame + (size_t)(yr.first + j0 + r) * g.row_stride + (size_t)gi * 48);
+                const u32x4 a = __builtin_nontemporal_load(src), b = __builtin_nontemporal_load(src + 1),
+                            c = __builtin_nontemporal_load(src + 2);
+                const u32 w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+                *reinterpret_cast<u32x4*>(rows + (size_t)r * g.wpad + gi * 16) = gray16(w);
+            }
+        } else {
+            for (int item = tid; item < nrows * g.width; item += kHashWG) {
+                const int r = item / g.width, x = item - r * g.width;
+                const uint8_t* s = frame + (size_t)(yr.first + j0 + r) * g.row_stride + (size_t)x * 3;
+                rows[(size_t)r * g.wpad + x] = (uint8_t)gray_of(s[0], s[1], s[2]);
+            }
+        }
+        __syncthreads();
+        // (B) one run of one row per item, accumulated left to right
+        for (int item = tid; item < nrows * S; item += kHashWG) {
+            const int r = item / S, dx = item - r * S;
+            const AreaRun xr = xr_lds[dx];
+            const uint8_t* p = rows + (size_t)r * g.wpad + xr.first;
+            if (g.mode == 0) {
+                float acc = 0.f;
+                int k = 0;
+                const int end = xr.count - xr.has_tail;
+                if (xr.has_head) { acc = __fmul_rn((float)p[0], xr.a_head); k = 1; }
+                for (; k + 4 <= end; k += 4) {  // loads first, then the (ordered) chain
+                    const float f0 = (float)p[k], f1 = (float)p[k + 1], f2 = (float)p[k + 2], f3 = (float)p[k + 3];
+                    acc = __fadd_rn(acc, __fmul_rn(f0, xr.a_mid));
+                    acc = __fadd_rn(acc, __fmul_rn(f1, xr.a_mid));
+                    acc = __fadd_rn(acc, __fmul_rn(f2, xr.a_mid));
+                    acc = __fadd_rn(acc, __fmul_rn(f3, xr.a_mid));
+                }
+                for (; k < end; k++) acc = __fadd_rn(acc, __fmul_rn((float)p[k], xr.a_mid));
+                if (xr.has_tail) acc = __fadd_rn(acc, __fmul_rn((float)p[end], xr.a_tail));
+                part[r * S + dx] = acc;
+            } else {
+                int acc = 0;
+                for (int k = 0; k < xr.count; k++) acc += p[k];
+                part[r * S + dx] = __int_as_float(acc);
+            }
+        }
+        __syncthreads();
+        // (C) fold the batch into the column sums, top to bottom
+        if (tid < S) {
+            if (g.mode == 0) {
+                for (int r = 0; r < nrows; r++) {
+                    const int j = j0 + r;
+                    const float beta = (j == 0 && yr.has_head) ? yr.a_head : (j == yr.count - 1 && yr.has_tail) ? yr.a_tail : yr.a_mid;
+                    const float term = __fmul_rn(beta, part[r * S + tid]);
+                    fsum = j == 0 ? term : __fadd_rn(fsum, term);
+                }
+            } else {
+                for (int r = 0; r < nrows; r++) isum += __float_as_int(part[r * S + tid]);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < S) {
+        int v;
+        if (g.mode == 0) v = __float2int_rn(fsum);
+        else if (g.mode == 2) v = (isum + 2) >> 2;
+        else v = __float2int_rn(__fmul_rn((float)isum, g.inv_area));
+        thumbs[((size_t)t * S + dy) * S + tid] = (uint8_t)min(255, max(0, v));
+    }
+}
+
+// computeResizeAreaTab in run-length form (double arithmetic on the host, like OpenCV)
+static void area_table(int ssize, int dsize, AreaRun* tab)
+{
+    const double scale = 1. / ((double)dsize / ssize);
+    for (int dx = 0; dx < dsize; dx++) {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        if (sx2 > ssize - 1) sx2 = ssize - 1;
+        if (sx1 > sx2) sx1 = sx2;
+        AreaRun r;
+        memset(&r, 0, sizeof r);
+        r.first = sx1;
+        if (sx1 - fsx1 > 1e-3) {
+            r.has_head = 1;
+            r.first = sx1 - 1;
+            r.a_head = (float)((sx1 - fsx1) / cell);
+            r.count++;
+        }
+        r.a_mid = (float)(1.0 / cell);
+        r.count += sx2 - sx1;
+        if (fsx2 - sx2 > 1e-3) {
+            double tl = fsx2 - sx2 < 1. ? fsx2 - sx2 : 1.;
+            if (tl > cell) tl = cell;
+            r.has_tail = 1;
+            r.a_tail = (float)(tl / cell);
+            r.count++;
+        }
+        tab[dx] = r;
+    }
+}
+
+// d_thumbs: device buffer of n*size*size bytes; d_tabs: device buffer of 2*size AreaRun.
+int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
+                int size, AreaRun* d_tabs, uint8_t* d_thumbs, hipStream_t stream)
+{
+    if (size > width || size > height) {
+        psd_set_error("hash thumbnails: INTER_AREA is implemented for decimation only (%dx%d -> %dx%d)", width, height, size, size);
+        return PSD_ERR_UNSUPPORTED;
+    }
+    if (size > kHashWG) {
+        psd_set_error("hash thumbnails: size*lowpass = %d exceeds %d", size, kHashWG);
+        return PSD_ERR_UNSUPPORTED;
+    }
+    const double scale_x = 1. / ((double)size / width), scale_y = 1. / ((double)size / height);
+    const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
+    const bool area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+    std::vector<AreaRun> tabs(2 * (size_t)size);
+    HashGeom g;
+    memset(&g, 0, sizeof g);
+    if (area_fast) {
+        for (int i = 0; i < size; i++) {
+            AreaRun r;
+            memset(&r, 0, sizeof r);
+            r.first = i * iscale_x; r.count = iscale_x;
+            tabs[i] = r;
+            r.first = i * iscale_y; r.count = iscale_y;
+            tabs[size + i] = r;
+        }
+        g.mode = (iscale_x == 2 && iscale_y == 2) ? 2 : 1;
+        g.inv_area = 1.f / (float)(iscale_x * iscale_y);
+    } else {
+        area_table(width, size, tabs.data());
+        area_table(height, size, tabs.data() + size);
+        g.mode = 0;
+    }
+    g.frames = d_frames; g.frame_stride = frame_stride; g.row_stride = row_stride;
+    g.height = height; g.width = width; g.size = size;
+    g.wpad = (width + 15) & ~15;
+    const size_t fixed = (size_t)size * sizeof(AreaRun);
+    const size_t budget = 60 * 1024;
+    int R = kHashWG / size;
+    while (R > 1 && (size_t)R * g.wpad + (size_t)R * size * 4 + fixed > budget) R--;
+    const size_t lds = (size_t)R * g.wpad + (size_t)R * size * 4 + fixed;
+    if (lds > 64 * 1024) {
+        psd_set_error("hash thumbnails: frame width %d too large for the LDS row buffer", width);
+        return PSD_ERR_UNSUPPORTED;
+    }
+    g.rows_per_batch = R;
+    hipError_t err = hipMemcpyAsync(d_tabs, tabs.data(), tabs.size() * sizeof(AreaRun), hipMemcpyHostToDevice, stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(stream);  // `tabs` is pageable and goes out of scope
+    if (err != hipSuccess) { psd_set_error("hash tables upload: %s", hipGetErrorString(err)); return PSD_ERR_HIP; }
+    const bool fast = (width % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0) && ((uintptr_t)d_frames % 16 == 0);
+    // grid.y is limited to 65535: split long batches
+    for (int t0 = 0; t0 < n; t0 += 32768) {
+        const int cnt = n - t0 < 32768 ? n - t0 : 32768;
+        HashGeom gg = g;
+        gg.frames = d_frames + (size_t)t0 * frame_stride;
+        uint8_t* out = d_thumbs + (size_t)t0 * size * size;
+        const dim3 grid(size, cnt);
+        if (fast) hipLaunchKernelGGL(gray_area_kernel<true>, grid, dim3(kHashWG), lds, stream, gg, d_tabs, d_tabs + size, out);
+        else hipLaunchKernelGGL(gray_area_kernel<false>, grid, dim3(kHashWG), lds, stream, gg, d_tabs, d_tabs + size, out);
+    }
+    err = hipGetLastError();
+    if (err != hipSuccess) { psd_set_error("gray_area_kernel launch: %s", hipGetErrorString(err)); return PSD_ERR_HIP; }
+    return PSD_OK;
+}
+
+size_t hash_tab_bytes(int size) { return 2 * (size_t)size * sizeof(AreaRun); }
+
+}  // namespace psd

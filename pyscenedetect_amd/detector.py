@@ -60,6 +60,14 @@ class SceneDetector(ABC):
         """Decide from a precomputed per-frame score record (``psd_frame_scores``)."""
         raise NotImplementedError
 
+    def hash_thumb_size(self) -> int:
+        """Side of the grey INTER_AREA thumbnail this detector needs per frame (0 = none)."""
+        return 0
+
+    def process_thumb(self, timecode: FrameTimecode, thumb) -> list[FrameTimecode]:
+        """Decide from a precomputed thumbnail (``psd_hash_thumbs*``)."""
+        raise NotImplementedError
+
 
 class FlashFilter:
     """Enforces a minimum scene length on a stream of above/below-threshold decisions.

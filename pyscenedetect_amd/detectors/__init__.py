@@ -2,7 +2,8 @@
 
 from pyscenedetect_amd.detectors.content_detector import ContentDetector
 from pyscenedetect_amd.detectors.adaptive_detector import AdaptiveDetector
+from pyscenedetect_amd.detectors.hash_detector import HashDetector
 from pyscenedetect_amd.detectors.histogram_detector import HistogramDetector
 from pyscenedetect_amd.detectors.threshold_detector import ThresholdDetector
 
-__all__ = ["ContentDetector", "AdaptiveDetector", "HistogramDetector", "ThresholdDetector"]
+__all__ = ["ContentDetector", "AdaptiveDetector", "HashDetector", "HistogramDetector", "ThresholdDetector"]

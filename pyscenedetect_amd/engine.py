@@ -161,10 +161,17 @@ class ScoringEngine:
                      downscale: float = 1.0) -> np.ndarray:
         """Score a list of separately allocated host frames (what a decoder hands out) without first
         stacking them on the host: every frame is uploaded straight into one device batch."""
+        return self.analyze_frames(frames, prev, flags, edge_kernel, downscale)[0]
+
+    def analyze_frames(self, frames, prev=None, flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0,
+                       downscale: float = 1.0, hash_size: int = 0):
+        """One upload of a list of host frames, then (records, thumbs): the score records for ``flags``
+        (None if 0) and the grey ``hash_size`` x ``hash_size`` INTER_AREA thumbnails HashDetector needs (None if
+        0), both computed from the (optionally downscaled) frames resident in HBM."""
         n = len(frames)
-        out = np.zeros(n, RECORD_DTYPE)
         if n == 0:
-            return out
+            return (np.zeros(0, RECORD_DTYPE) if flags else None,
+                    np.zeros((0, hash_size, hash_size), np.uint8) if hash_size else None)
         first = np.asarray(frames[0])
         if first.dtype != np.uint8 or first.ndim != 3 or first.shape[2] != 3:
             raise ValueError("frames must be uint8[H,W,3]")
@@ -178,15 +185,45 @@ class ScoringEngine:
             if f.shape != (h, w, 3):
                 raise ValueError("all frames of a batch must have the same size")
             src.upload(f.reshape(-1), i * sstride)
+        buf, fh, fw, stride = src, h, w, sstride
         if downscale > 1.0:
-            dw, dh = max(1, round(w / downscale)), max(1, round(h / downscale))
-            dstride = (dh * dw * 3 + 15) & ~15
-            dst = self._scratch("fr_dst", (n + 1) * dstride)
-            self.resize_device(src.ptr, n + p, h, w, dst.ptr, dh, dw, src_frame_stride=sstride, dst_frame_stride=dstride)
-            return self.score_device(dst.ptr + p * dstride, n, dh, dw, dw * 3, dstride, d_prev=dst.ptr if p else None,
-                                     flags=flags, edge_kernel=edge_kernel)
-        return self.score_device(src.ptr + p * sstride, n, h, w, w * 3, sstride, d_prev=src.ptr if p else None,
-                                 flags=flags, edge_kernel=edge_kernel)
+            fw, fh = max(1, round(w / downscale)), max(1, round(h / downscale))
+            stride = (fh * fw * 3 + 15) & ~15
+            buf = self._scratch("fr_dst", (n + 1) * stride)
+            self.resize_device(src.ptr, n + p, h, w, buf.ptr, fh, fw, src_frame_stride=sstride, dst_frame_stride=stride)
+        records = thumbs = None
+        if flags:
+            records = self.score_device(buf.ptr + p * stride, n, fh, fw, fw * 3, stride, d_prev=buf.ptr if p else None,
+                                        flags=flags, edge_kernel=edge_kernel)
+        if hash_size:
+            thumbs = self.hash_thumbs_device(buf.ptr + p * stride, n, fh, fw, hash_size, fw * 3, stride)
+        return records, thumbs
+
+    # -- HashDetector thumbnails ---------------------------------------------------------------
+    def hash_thumbs_device(self, d_frames: int, n: int, height: int, width: int, size: int,
+                           row_stride: int | None = None, frame_stride: int | None = None) -> np.ndarray:
+        """``cv2.resize(cv2.cvtColor(f, BGR2GRAY), (size, size), INTER_AREA)`` for n frames resident in HBM."""
+        row_stride = width * 3 if row_stride is None else row_stride
+        frame_stride = height * row_stride if frame_stride is None else frame_stride
+        out = np.zeros((n, size, size), np.uint8)
+        _native.check(self._lib.psd_hash_thumbs_device(self._h, d_frames, int(n), int(height), int(width), row_stride,
+                                                       frame_stride, int(size), out.ctypes.data if n else None))
+        return out
+
+    def hash_thumbs_host(self, frames: np.ndarray, size: int, downscale: float = 1.0) -> np.ndarray:
+        """Same for frames uint8[N,H,W,3] in host memory (staged in bounded chunks by the engine)."""
+        frames = np.asarray(frames)
+        if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[3] != 3:
+            raise ValueError("frames must be uint8[N,H,W,3]")
+        if downscale > 1.0:
+            return self.analyze_frames(list(frames), None, 0, 0, downscale, size)[1]
+        if frames.strides[3] != 1 or frames.strides[2] != 3:
+            frames = np.ascontiguousarray(frames)
+        n, h, w, _ = frames.shape
+        out = np.zeros((n, size, size), np.uint8)
+        _native.check(self._lib.psd_hash_thumbs(self._h, frames.ctypes.data, n, h, w, frames.strides[1], frames.strides[0],
+                                                int(size), out.ctypes.data if n else None))
+        return out
 
     def _scratch(self, name: str, nbytes: int) -> "DeviceBuffer":
         cache = self.__dict__.setdefault("_scratch_bufs", {})

@@ -12,7 +12,7 @@ from fractions import Fraction
 import numpy as np
 
 from pyscenedetect_amd import _native
-from pyscenedetect_amd._native import AdaptiveParams, ContentParams, HistParams, ThresholdParams
+from pyscenedetect_amd._native import AdaptiveParams, ContentParams, HashParams, HistParams, ThresholdParams
 from pyscenedetect_amd.timecode import framerate_to_fraction, parse_timecode_seconds
 
 
@@ -128,3 +128,34 @@ def threshold_cuts(records, height: int, width: int, fps, threshold: float = 12,
                                                             ctypes.byref(p), avg.ctypes.data, cuts.ctypes.data,
                                                             ctypes.byref(nc)))
     return cuts[: nc.value].tolist(), avg
+
+
+def hash_bits(thumbs, hash_size: int = 8) -> np.ndarray:
+    """Perceptual hash bits bool[n, hash_size, hash_size] of grey thumbnails uint8[n, S, S] -- the back half of
+    ``HashDetector.hash_frame`` (reference ``hash_detector.py:131-151``)."""
+    thumbs = np.ascontiguousarray(thumbs, dtype=np.uint8)
+    if thumbs.ndim != 3 or thumbs.shape[1] != thumbs.shape[2]:
+        raise ValueError("thumbs must be uint8[n, S, S]")
+    n, size, _ = thumbs.shape
+    bits = np.zeros((n, hash_size, hash_size), np.uint8)
+    _native.check(_native.load().psd_epilogue_hash_bits(thumbs.ctypes.data if n else None, n, size, int(hash_size),
+                                                       bits.ctypes.data if n else None))
+    return bits.astype(bool)
+
+
+def hash_cuts(bits, fps, threshold: float = 0.35, min_scene_len=15, first_frame: int = 0):
+    """(cuts, hash_dist[n] with NaN for the first frame) from hash bits bool[n, size, size]."""
+    rate = _fps(fps)
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    n = len(bits)
+    p = HashParams()
+    p.threshold = float(threshold)
+    p.hash_size = int(bits.shape[1]) if bits.ndim == 3 else 1
+    p.min_len_frames, p.min_len_secs = _min_len(min_scene_len, rate, int_is_frames=False)
+    dist = np.zeros(n, np.float64)
+    cuts = np.zeros(n + 1, np.int64)
+    nc = ctypes.c_int(0)
+    _native.check(_native.load().psd_epilogue_hash_cuts(bits.ctypes.data if n else None, n, None, first_frame,
+                                                       rate.numerator, rate.denominator, ctypes.byref(p),
+                                                       dist.ctypes.data, cuts.ctypes.data, ctypes.byref(nc)))
+    return cuts[: nc.value].tolist(), dist

@@ -180,7 +180,7 @@ class SceneManager:
             self._engine = default_engine()
         return self._engine
 
-    def _dispatch(self, position, frame_im, record, callback, scored_size=None) -> bool:
+    def _dispatch(self, position, frame_im, record, callback, scored_size=None, thumb=None) -> bool:
         """One frame's worth of decisions for every detector (reference ``_process_frame`` :410-435)."""
         new_cuts = False
         self._frame_buffer.append((position, frame_im))
@@ -189,6 +189,8 @@ class SceneManager:
         for detector in self._detector_list:
             if record is not None and detector.score_flags():
                 cuts = detector.process_record(position, record, h, w)
+            elif thumb is not None and detector.hash_thumb_size():
+                cuts = detector.process_thumb(position, thumb)
             else:
                 cuts = detector.process_frame(position, frame_im)
             self._cutting_list += cuts
@@ -236,10 +238,15 @@ class SceneManager:
 
         flags = 0
         edge_kernel = 0
+        thumb_sizes = set()
         for det in self._detector_list:
             flags |= det.score_flags()
             edge_kernel = edge_kernel or det.edge_kernel_size()
-        engine = self._engine_or_default() if flags else None
+            if det.hash_thumb_size():
+                thumb_sizes.add(det.hash_thumb_size())
+        # one thumbnail size per pass; detectors with another size score their own frames in process_frame
+        hash_size = thumb_sizes.pop() if len(thumb_sizes) == 1 else 0
+        engine = self._engine_or_default() if (flags or hash_size) else None
 
         batches: queue.Queue = queue.Queue(2)
         self._stop.clear()
@@ -253,7 +260,7 @@ class SceneManager:
                 if batch is None:
                     break
                 frames, positions = batch
-                records = None
+                records = thumbs = None
                 scored_size = None
                 if engine is not None:
                     shape = frames[0].shape
@@ -263,15 +270,20 @@ class SceneManager:
                         # Same target size as the reference's cv2.resize call (:670-678).
                         scored_size = (max(1, round(shape[0] / factor)), max(1, round(shape[1] / factor)))
                     kwargs = {"downscale": factor} if factor > 1.0 else {}
-                    if hasattr(engine, "score_frames"):
+                    if hasattr(engine, "analyze_frames"):
                         # frames go to the device one by one: no host-side stacking copy
-                        records = engine.score_frames(frames, prev=last_frame, flags=flags, edge_kernel=edge_kernel, **kwargs)
+                        records, thumbs = engine.analyze_frames(frames, prev=last_frame, flags=flags, edge_kernel=edge_kernel,
+                                                                hash_size=hash_size, **kwargs)
                     else:
-                        records = engine.score_host(np.stack(frames), prev=last_frame, flags=flags,
-                                                    edge_kernel=edge_kernel, **kwargs)
+                        stacked = np.stack(frames)
+                        if flags:
+                            records = engine.score_host(stacked, prev=last_frame, flags=flags, edge_kernel=edge_kernel, **kwargs)
+                        if hash_size:
+                            thumbs = engine.hash_thumbs_host(stacked, hash_size, **kwargs)
                     last_frame = frames[-1]
                 for i, (frame_im, position) in enumerate(zip(frames, positions)):
-                    self._dispatch(position, frame_im, records[i] if records is not None else None, callback, scored_size)
+                    self._dispatch(position, frame_im, records[i] if records is not None else None, callback, scored_size,
+                                   thumbs[i] if thumbs is not None else None)
         finally:
             self._stop.set()
             while worker.is_alive():

@@ -364,3 +364,98 @@ def test_two_engines_in_two_threads():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+# ---- HashDetector thumbnails (psd_hash_thumbs*) ---------------------------------------------------
+
+HASH_CASES = [
+    # (n, h, w, size)            what it exercises
+    (3, 72, 128, 16),          # fractional x integer scales -> float run tables, 16-byte fast loads
+    (3, 54, 96, 32),           # fractional both ways
+    (4, 37, 53, 16),           # ragged width: byte-load path
+    (2, 64, 64, 32),           # exact 2x2 -> rounding shift
+    (2, 96, 128, 32),          # integer 3x4 box -> sum * (1.f/area)
+    (2, 144, 256, 16),         # integer 9x16
+    (1, 33, 47, 33),           # 1x identity vertically, fractional horizontally
+    (2, 1080, 1920, 16),       # HashDetector default at 1080p (67.5 x 120)
+    (1, 1080, 1920, 32),       # 33.75 x 60
+    (1, 2160, 3840, 16),
+]
+
+
+@pytest.mark.parametrize("case", HASH_CASES)
+def test_hash_thumbs_match_oracle(hip_engine, case):
+    n, h, w, size = case
+    rng = np.random.default_rng(h * 7 + w + size)
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    frames[0, : h // 2] = 255  # saturated half: rounding at the top of the range
+    want = orc.hash_thumbs(frames, size)
+    got_host = hip_engine.hash_thumbs_host(frames, size)
+    assert np.array_equal(got_host, want), np.argwhere(got_host != want)[:4].tolist()
+    buf = hip_engine.alloc(frames.nbytes)
+    buf.upload(frames.reshape(-1))
+    got_dev = hip_engine.hash_thumbs_device(buf.ptr, n, h, w, size)
+    assert np.array_equal(got_dev, want)
+    # hash bits: native epilogue == oracle's numpy/C back half
+    from pyscenedetect_amd import epilogue
+
+    for hs in (8, size // 2):
+        assert np.array_equal(epilogue.hash_bits(got_dev, hs), orc.hash_bits(want, hs))
+
+
+def test_hash_thumbs_padded_rows_and_smooth_content(hip_engine):
+    """Strided host frames (decoder padding) and low-contrast content, where float rounding order shows."""
+    rng = np.random.default_rng(99)
+    n, h, w = 5, 90, 160
+    base = rng.integers(100, 110, (n, h, w + 6, 3), dtype=np.uint8)
+    frames = base[:, :, 3 : 3 + w]
+    got = hip_engine.hash_thumbs_host(frames, 16)
+    assert np.array_equal(got, orc.hash_thumbs(np.ascontiguousarray(frames), 16))
+
+
+def test_hash_thumbs_invalid_arguments(hip_engine):
+    frames = np.zeros((1, 20, 40, 3), np.uint8)
+    with pytest.raises(NotImplementedError):
+        hip_engine.hash_thumbs_host(frames, 32)  # would need upscaling vertically
+    with pytest.raises(ValueError):
+        hip_engine.hash_thumbs_host(frames, 0)
+    with pytest.raises(ValueError):
+        hip_engine.hash_thumbs_host(np.zeros((1, 20, 40), np.uint8), 8)
+    assert hip_engine.hash_thumbs_host(np.zeros((0, 20, 40, 3), np.uint8), 8).shape == (0, 8, 8)
+
+
+def test_hash_detector_per_frame_api_and_mixed_pass(golden, hip_engine):
+    frames = golden_clip(golden, "fades_b")
+    det = psd.HashDetector(engine=hip_engine)
+    cuts = []
+    for i, f in enumerate(frames):
+        cuts += det.process_frame(psd.FrameTimecode(i, 25.0), f)
+    assert [c.frame_num for c in cuts] == golden["clips"]["fades_b"]["results"]["hash_default"]["cuts"]
+    # hash + content in one SceneManager pass: one upload, two device products
+    sm = psd.SceneManager(engine=hip_engine)
+    sm.auto_downscale = False
+    sm.add_detector(psd.HashDetector(engine=hip_engine))
+    sm.add_detector(psd.ContentDetector(engine=hip_engine))
+    sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+    res = golden["clips"]["fades_b"]["results"]
+    assert [c.frame_num for c in sm.get_cut_list()] == sorted(set(res["hash_default"]["cuts"]) | set(res["content_default"]["cuts"]))
+
+
+def test_hash_thumbs_batch_properties_1080p(hip_engine):
+    """Full-size batch: thumbnails of a batch equal the thumbnails of its frames taken one at a time, a frame
+    and its copy hash identically, and a constant frame gives a constant thumbnail of its grey level."""
+    import torch
+
+    n, h, w = 64, 1080, 1920
+    x = torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda")
+    x[5] = x[4]
+    x[7] = 200
+    torch.cuda.synchronize()
+    all_t = hip_engine.hash_thumbs_device(x.data_ptr(), n, h, w, 16)
+    for i in (0, 4, 63):
+        one = hip_engine.hash_thumbs_device(x[i].data_ptr(), 1, h, w, 16)
+        assert np.array_equal(one[0], all_t[i])
+    assert np.array_equal(all_t[4], all_t[5])
+    assert (all_t[7] == 200).all()
+    sample = x[:2].cpu().numpy()
+    assert np.array_equal(all_t[:2], orc.hash_thumbs(sample, 16))

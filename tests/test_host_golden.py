@@ -40,7 +40,7 @@ def test_batch_size_does_not_matter(golden, oracle_engine):
 def test_process_frame_api_matches_reference(golden, oracle_engine):
     """The one-frame-at-a-time plug-in API (SceneDetector.process_frame) gives the same cuts."""
     frames = golden_clip(golden, "fades_b")
-    for name in ("content_default", "adaptive_default", "hist_default", "threshold_final"):
+    for name in ("content_default", "adaptive_default", "hist_default", "threshold_final", "hash_default", "hash_16_lp2"):
         cls_name, kwargs, _ = golden["configs"][name]
         from tests._helpers import build_detector
 
@@ -53,9 +53,9 @@ def test_process_frame_api_matches_reference(golden, oracle_engine):
 
 
 def test_all_detectors_share_one_pass(golden, oracle_engine):
-    """Four detectors on one SceneManager (one fused device pass) == four separate runs."""
+    """All five detectors on one SceneManager (one upload, one fused scoring pass + one thumbnail pass) == five separate runs."""
     frames = golden_clip(golden, "scenes_a")
-    names = ["content_default", "adaptive_default", "hist_default", "threshold_default"]
+    names = ["content_default", "adaptive_default", "hist_default", "threshold_default", "hash_default"]
     want = set()
     for n in names:
         want |= set(golden["clips"]["scenes_a"]["results"][n]["cuts"])
@@ -167,6 +167,12 @@ def test_native_epilogues_match_reference(golden, oracle_engine, clip):
             cuts, diff = epilogue.hist_cuts(recs_e, 25.0, kw.get("threshold", 0.2), kw.get("bins", 128), kw.get("min_scene_len", 15))
             key = list(want["metrics"])[0]
             assert _nan_to_none(diff) == want["metrics"][key], f"{clip}/{name}"
+        elif cls_name == "HashDetector":
+            thumbs = oracle_engine.hash_thumbs_host(frames, kw.get("size", 8) * kw.get("lowpass", 2))
+            bits = epilogue.hash_bits(thumbs, kw.get("size", 8))
+            cuts, dist = epilogue.hash_cuts(bits, 25.0, kw.get("threshold", 0.35), kw.get("min_scene_len", 15))
+            if want["metrics"]:
+                assert _nan_to_none(dist) == list(want["metrics"].values())[0], f"{clip}/{name}"
         else:
             cuts, avg = epilogue.threshold_cuts(recs_e, h, w, 25.0, kw.get("threshold", 12), kw.get("min_scene_len", 15),
                                                 kw.get("fade_bias", 0.0), kw.get("add_final_scene", False),

@@ -178,3 +178,79 @@ def test_score_batch_is_the_composition_of_the_primitives():
             for name, a, b in zip(("sad_h", "sad_s", "sad_v"), hsv_planes(frames[t]), hsv_planes(frames[t - 1])):
                 assert rec[name][t] == np.abs(a.astype(np.int32) - b.astype(np.int32)).sum()
     assert rec["sad_h"][0] == 0
+
+
+# ---- HashDetector primitives -----------------------------------------------------------------------
+
+def test_gray_formula_and_extremes():
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    img[0, 0] = (255, 255, 255)
+    img[0, 1] = (0, 0, 0)
+    L = orc.lib()
+    g = np.empty((40, 50), np.uint8)
+    L.orc_bgr2gray(img.ctypes.data, 150, g.ctypes.data, 50, 40, 50)
+    b, gr, r = (img[..., c].astype(np.int64) for c in range(3))
+    want = (b * 3735 + gr * 19235 + r * 9798 + (1 << 14)) >> 15
+    assert np.array_equal(g, want)
+    assert g[0, 0] == 255 and g[0, 1] == 0
+    # the three weights are the 15-bit roundings of 0.114 / 0.587 / 0.299 and sum to one
+    assert 3735 + 19235 + 9798 == 1 << 15
+
+
+def _box_weights(ss, ds):
+    sc = ss / ds
+    m = np.zeros((ds, ss))
+    for d in range(ds):
+        a, b = d * sc, (d + 1) * sc
+        for s in range(ss):
+            m[d, s] = max(0.0, min(b, s + 1) - max(a, s)) / sc
+    return m
+
+
+@pytest.mark.parametrize("shape", [(72, 128, 16), (54, 96, 32), (37, 53, 16), (33, 47, 33), (108, 192, 16), (100, 100, 7)])
+def test_area_resize_is_the_box_average(shape):
+    """Fractional INTER_AREA == exact area-weighted mean up to float32 accumulation noise (then rounded)."""
+    h, w, s = shape
+    rng = np.random.default_rng(h + w)
+    g = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    out = np.empty((s, s), np.uint8)
+    assert orc.lib().orc_resize_area_u8(g.ctypes.data, w, h, w, out.ctypes.data, s, s, s) == 0
+    exact = _box_weights(h, s) @ g.astype(np.float64) @ _box_weights(w, s).T
+    assert np.abs(out.astype(np.float64) - exact).max() <= 0.5 + 1e-3
+    flat = np.full((h, w), 173, np.uint8)
+    assert orc.lib().orc_resize_area_u8(flat.ctypes.data, w, h, w, out.ctypes.data, s, s, s) == 0
+    assert (out == 173).all()
+
+
+def test_area_resize_integer_scales():
+    rng = np.random.default_rng(8)
+    g = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    out = np.empty((32, 32), np.uint8)
+    assert orc.lib().orc_resize_area_u8(g.ctypes.data, 64, 64, 64, out.ctypes.data, 32, 32, 32) == 0
+    s = g.astype(np.int64)
+    assert np.array_equal(out, (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2)
+    g = rng.integers(0, 256, (96, 128), dtype=np.uint8)
+    assert orc.lib().orc_resize_area_u8(g.ctypes.data, 128, 96, 128, out.ctypes.data, 32, 32, 32) == 0
+    sums = g.astype(np.int64).reshape(32, 3, 32, 4).sum(axis=(1, 3))
+    want = np.rint((sums.astype(np.float32) * np.float32(1.0 / 12)).astype(np.float64))  # half-to-even
+    assert np.array_equal(out, want.astype(np.uint8))
+    # not a decimation: refused
+    assert orc.lib().orc_resize_area_u8(g.ctypes.data, 128, 96, 128, np.empty((200, 200), np.uint8).ctypes.data, 200, 200, 200) == -1
+
+
+def test_dct_matches_scipy_and_hash_bits_are_balanced():
+    import scipy.fft
+
+    rng = np.random.default_rng(3)
+    x = rng.random((32, 32)).astype(np.float32)
+    low = np.empty((16, 16), np.float32)
+    orc.lib().orc_dct2d_f32(x.ctypes.data, 32, 16, low.ctypes.data)
+    ref = scipy.fft.dctn(x.astype(np.float64), norm="ortho")[:16, :16]
+    assert np.abs(low - ref).max() <= 4e-6
+    thumbs = rng.integers(0, 256, (5, 32, 32), dtype=np.uint8)
+    thumbs[4] = 0  # all-black frame: max_value guard (hash_detector.py:132-135)
+    bits = orc.hash_bits(thumbs, 16)
+    assert bits.shape == (5, 16, 16)
+    assert all(b.sum() == 128 for b in bits[:4])  # strictly-above-median of 256 distinct values
+    assert bits[4].sum() == 0
