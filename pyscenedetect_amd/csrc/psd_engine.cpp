@@ -46,7 +46,7 @@ int resize_linear(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_
 // psd_hash_kernels.hip
 struct AreaRun;
 int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
-                int size, AreaRun* d_tabs, uint8_t* d_thumbs, hipStream_t stream);
+                int size, AreaRun* d_tabs, uint8_t* d_thumbs, hipStream_t stream, hipEvent_t ev_start);
 size_t hash_tab_bytes(int size);
 }  // namespace psd
 
@@ -443,10 +443,8 @@ int psd_hash_thumbs_device(psd_engine* e, const uint8_t* d_frames, int n, int he
     }
     if (!e->ev_hash[0]) { HIP_TRY(hipEventCreate(&e->ev_hash[0])); HIP_TRY(hipEventCreate(&e->ev_hash[1])); }
     psd::AreaRun* d_tabs = reinterpret_cast<psd::AreaRun*>(e->d_hash + thumbs_bytes);
-    // the run tables are uploaded (and waited for) before the timed region inside hash_thumbs; the events
-    // below bracket that upload too, it is a few hundred bytes
-    HIP_TRY(hipEventRecord(e->ev_hash[0], e->stream));
-    rc = psd::hash_thumbs(d_frames, n, height, width, row_stride, frame_stride, size, d_tabs, e->d_hash, e->stream);
+    // ev_hash[0] is recorded inside, after the run tables are on the device
+    rc = psd::hash_thumbs(d_frames, n, height, width, row_stride, frame_stride, size, d_tabs, e->d_hash, e->stream, e->ev_hash[0]);
     if (rc != PSD_OK) return rc;
     HIP_TRY(hipEventRecord(e->ev_hash[1], e->stream));
     HIP_TRY(hipMemcpyAsync(h_thumbs, e->d_hash, (size_t)n * size * size, hipMemcpyDeviceToHost, e->stream));

@@ -205,7 +205,7 @@ static void area_table(int ssize, int dsize, AreaRun* tab)
 
 // d_thumbs: device buffer of n*size*size bytes; d_tabs: device buffer of 2*size AreaRun.
 int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
-                int size, AreaRun* d_tabs, uint8_t* d_thumbs, hipStream_t stream)
+                int size, AreaRun* d_tabs, uint8_t* d_thumbs, hipStream_t stream, hipEvent_t ev_start)
 {
     if (size > width || size > height) {
         psd_set_error("hash thumbnails: INTER_AREA is implemented for decimation only (%dx%d -> %dx%d)", width, height, size, size);
@@ -254,6 +254,7 @@ int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t ro
     if (err == hipSuccess) err = hipStreamSynchronize(stream);  // `tabs` is pageable and goes out of scope
     if (err != hipSuccess) { psd_set_error("hash tables upload: %s", hipGetErrorString(err)); return PSD_ERR_HIP; }
     const bool fast = (width % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0) && ((uintptr_t)d_frames % 16 == 0);
+    if (ev_start) (void)hipEventRecord(ev_start, stream);  // the timed region is the kernel launches only
     // grid.y is limited to 65535: split long batches
     for (int t0 = 0; t0 < n; t0 += 32768) {
         const int cnt = n - t0 < 32768 ? n - t0 : 32768;

@@ -220,7 +220,11 @@ class ScoringEngine:
         if frames.strides[3] != 1 or frames.strides[2] != 3:
             frames = np.ascontiguousarray(frames)
         n, h, w, _ = frames.shape
+        if size <= 0:
+            raise ValueError("thumbnail size must be positive")
         out = np.zeros((n, size, size), np.uint8)
+        if n == 0:
+            return out
         _native.check(self._lib.psd_hash_thumbs(self._h, frames.ctypes.data, n, h, w, frames.strides[1], frames.strides[0],
                                                 int(size), out.ctypes.data if n else None))
         return out
