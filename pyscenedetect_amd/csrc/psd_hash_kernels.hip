@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -171,6 +172,137 @@ __global__ __launch_bounds__(kHashWG) void gray_area_kernel(const HashGeom g, co
     }
 }
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// Packed rows (row_stride == 3*width, width % 16 == 0): the source rows of a cell row are ONE contiguous byte
+// range, so phase (A) can stream it HBM -> LDS with global_load_lds_dwordx4 exactly like the scoring kernel:
+// lane i of a wave moves bytes [16 i, 16 i + 16) of each 1 KiB piece (every 128-byte line is touched by one
+// instruction; the 48-byte lane stride of the register path tops out near 4.4 TB/s), then picks up its 16
+// pixels with three ds_read_b128 at a 12-dword stride.  Each wave owns G slots of 3 KiB and refills them one
+// step ahead -- also across the (B)/(C) phases, so the next batch is in flight while this one is reduced.
+template <int G>
+__global__ __launch_bounds__(kHashWG) void gray_area_dma_kernel(const HashGeom g, const AreaRun* __restrict__ xtab,
+                                                                const AreaRun* __restrict__ ytab,
+                                                                uint8_t* __restrict__ thumbs)
+{
+    constexpr int NW = kHashWG / 64;
+    constexpr int STEP_GROUPS = G * NW * 64;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int R = g.rows_per_batch, S = g.size, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t* stage = smem;                                              // [G*NW][3072] raw BGR
+    uint8_t* rows = smem + G * NW * 3072;                               // [R][width] grey
+    float* part = reinterpret_cast<float*>(rows + (size_t)R * g.wpad);  // [R][S] row partials
+    AreaRun* xr_lds = reinterpret_cast<AreaRun*>(part + R * S);         // [S]
+    const int dy = blockIdx.x, t = blockIdx.y;
+    const uint8_t* frame = g.frames + (size_t)t * g.frame_stride;
+    for (int i = tid; i < S; i += kHashWG) xr_lds[i] = xtab[i];
+    const AreaRun yr = ytab[dy];
+    const int gpr = g.width >> 4;                 // 16-pixel groups per row
+    const size_t row_bytes = (size_t)g.width * 3;
+    float fsum = 0.f;
+    int isum = 0;
+
+    // the stream of DMA steps: (batch first row, step within the batch), issued one ahead of its use
+    int ij0 = 0, istep = 0;
+    bool more = yr.count > 0;
+    auto issue_next = [&]() {
+        const int nrows = min(R, yr.count - ij0);
+        const long limit = (long)nrows * gpr * 48;
+        const uint8_t* base = frame + (size_t)(yr.first + ij0) * row_bytes;
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const long gfirst = (long)istep * STEP_GROUPS + (long)(k * NW + wave) * 64;
+            uint8_t* slot = stage + (size_t)(k * NW + wave) * 3072;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const long off = gfirst * 48 + j * 1024 + lane * 16;
+                if (off + 16 <= limit)
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + off), (lds_ptr_t)(slot + j * 1024), 16, 0, 0);
+            }
+        }
+        istep++;
+        if ((long)istep * STEP_GROUPS >= (long)nrows * gpr) { istep = 0; ij0 += R; more = ij0 < yr.count; }
+    };
+    if (more) issue_next();
+
+    for (int j0 = 0; j0 < yr.count; j0 += R) {
+        const int nrows = min(R, yr.count - j0);
+        const int ngroups = nrows * gpr;
+        // (A) staged BGR -> grey rows
+        for (int sbase = 0; sbase < ngroups; sbase += STEP_GROUPS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            u32 w[G][12];
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                const u32x4* src = reinterpret_cast<const u32x4*>(stage + (size_t)(k * NW + wave) * 3072 + lane * 48);
+                const u32x4 a = src[0], b = src[1], c = src[2];
+                w[k][0] = a.x; w[k][1] = a.y; w[k][2] = a.z; w[k][3] = a.w;
+                w[k][4] = b.x; w[k][5] = b.y; w[k][6] = b.z; w[k][7] = b.w;
+                w[k][8] = c.x; w[k][9] = c.y; w[k][10] = c.z; w[k][11] = c.w;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (more) issue_next();
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                const int gidx = sbase + (k * NW + wave) * 64 + lane;
+                if (gidx < ngroups) *reinterpret_cast<u32x4*>(rows + (size_t)gidx * 16) = gray16(w[k]);
+            }
+        }
+        __syncthreads();
+        // (B) one run of one row per item, accumulated left to right
+        for (int item = tid; item < nrows * S; item += kHashWG) {
+            const int r = item / S, dx = item - r * S;
+            const AreaRun xr = xr_lds[dx];
+            const uint8_t* p = rows + (size_t)r * g.wpad + xr.first;
+            if (g.mode == 0) {
+                float acc = 0.f;
+                int k = 0;
+                const int end = xr.count - xr.has_tail;
+                if (xr.has_head) { acc = __fmul_rn((float)p[0], xr.a_head); k = 1; }
+                for (; k + 4 <= end; k += 4) {  // loads first, then the (ordered) chain
+                    const float f0 = (float)p[k], f1 = (float)p[k + 1], f2 = (float)p[k + 2], f3 = (float)p[k + 3];
+                    acc = __fadd_rn(acc, __fmul_rn(f0, xr.a_mid));
+                    acc = __fadd_rn(acc, __fmul_rn(f1, xr.a_mid));
+                    acc = __fadd_rn(acc, __fmul_rn(f2, xr.a_mid));
+                    acc = __fadd_rn(acc, __fmul_rn(f3, xr.a_mid));
+                }
+                for (; k < end; k++) acc = __fadd_rn(acc, __fmul_rn((float)p[k], xr.a_mid));
+                if (xr.has_tail) acc = __fadd_rn(acc, __fmul_rn((float)p[end], xr.a_tail));
+                part[r * S + dx] = acc;
+            } else {
+                int acc = 0;
+                for (int k = 0; k < xr.count; k++) acc += p[k];
+                part[r * S + dx] = __int_as_float(acc);
+            }
+        }
+        __syncthreads();
+        // (C) fold the batch into the column sums, top to bottom
+        if (tid < S) {
+            if (g.mode == 0) {
+                for (int r = 0; r < nrows; r++) {
+                    const int j = j0 + r;
+                    const float beta = (j == 0 && yr.has_head) ? yr.a_head : (j == yr.count - 1 && yr.has_tail) ? yr.a_tail : yr.a_mid;
+                    const float term = __fmul_rn(beta, part[r * S + tid]);
+                    fsum = j == 0 ? term : __fadd_rn(fsum, term);
+                }
+            } else {
+                for (int r = 0; r < nrows; r++) isum += __float_as_int(part[r * S + tid]);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < S) {
+        int v;
+        if (g.mode == 0) v = __float2int_rn(fsum);
+        else if (g.mode == 2) v = (isum + 2) >> 2;
+        else v = __float2int_rn(__fmul_rn((float)isum, g.inv_area));
+        thumbs[((size_t)t * S + dy) * S + tid] = (uint8_t)min(255, max(0, v));
+    }
+}
+
+constexpr int kHashDmaG = 2;
+
 // computeResizeAreaTab in run-length form (double arithmetic on the host, like OpenCV)
 static void area_table(int ssize, int dsize, AreaRun* tab)
 {
@@ -240,8 +372,13 @@ int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t ro
     g.frames = d_frames; g.frame_stride = frame_stride; g.row_stride = row_stride;
     g.height = height; g.width = width; g.size = size;
     g.wpad = (width + 15) & ~15;
-    const size_t fixed = (size_t)size * sizeof(AreaRun);
-    const size_t budget = 60 * 1024;
+    const bool fast = (width % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0) && ((uintptr_t)d_frames % 16 == 0);
+    static const bool no_dma = [] { const char* e = getenv("PSD_HASH_DIRECT"); return e && atoi(e) != 0; }();
+    const bool dma = fast && row_stride == (size_t)width * 3 && !no_dma;
+    // LDS per workgroup: staging (DMA path) + R grey rows + R*size partials + the x run table.  Three workgroups
+    // per CU (160 KiB) keep enough loads in flight; the register path has no staging and may use up to 60 KiB.
+    const size_t fixed = (size_t)size * sizeof(AreaRun) + (dma ? (size_t)kHashDmaG * (kHashWG / 64) * 3072 : 0);
+    const size_t budget = dma ? 52 * 1024 : 60 * 1024;
     int R = kHashWG / size;
     while (R > 1 && (size_t)R * g.wpad + (size_t)R * size * 4 + fixed > budget) R--;
     const size_t lds = (size_t)R * g.wpad + (size_t)R * size * 4 + fixed;
@@ -253,7 +390,6 @@ int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t ro
     hipError_t err = hipMemcpyAsync(d_tabs, tabs.data(), tabs.size() * sizeof(AreaRun), hipMemcpyHostToDevice, stream);
     if (err == hipSuccess) err = hipStreamSynchronize(stream);  // `tabs` is pageable and goes out of scope
     if (err != hipSuccess) { psd_set_error("hash tables upload: %s", hipGetErrorString(err)); return PSD_ERR_HIP; }
-    const bool fast = (width % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0) && ((uintptr_t)d_frames % 16 == 0);
     if (ev_start) (void)hipEventRecord(ev_start, stream);  // the timed region is the kernel launches only
     // grid.y is limited to 65535: split long batches
     for (int t0 = 0; t0 < n; t0 += 32768) {
@@ -262,7 +398,8 @@ int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t ro
         gg.frames = d_frames + (size_t)t0 * frame_stride;
         uint8_t* out = d_thumbs + (size_t)t0 * size * size;
         const dim3 grid(size, cnt);
-        if (fast) hipLaunchKernelGGL(gray_area_kernel<true>, grid, dim3(kHashWG), lds, stream, gg, d_tabs, d_tabs + size, out);
+        if (dma) hipLaunchKernelGGL(gray_area_dma_kernel<kHashDmaG>, grid, dim3(kHashWG), lds, stream, gg, d_tabs, d_tabs + size, out);
+        else if (fast) hipLaunchKernelGGL(gray_area_kernel<true>, grid, dim3(kHashWG), lds, stream, gg, d_tabs, d_tabs + size, out);
         else hipLaunchKernelGGL(gray_area_kernel<false>, grid, dim3(kHashWG), lds, stream, gg, d_tabs, d_tabs + size, out);
     }
     err = hipGetLastError();
