@@ -194,9 +194,12 @@ __global__ __launch_bounds__(256) void sobel_nms_kernel(const uint8_t* vplane, E
     __syncthreads();
     // Separable Sobel down columns: per V row, h1 = right - left and h2 = left + 2*mid + right;
     // dx = h1[-1] + 2 h1[0] + h1[+1], dy = h2[+1] - h2[-1].  One work item = one column of the
-    // (NT_W+2)-wide magnitude halo region x a quarter of its rows.
-    constexpr int MW = NT_W + 2, MH = NT_H + 2, QR = (MH + 3) / 4;
-    for (int item = threadIdx.x; item < MW * 4; item += 256) {
+    // (NT_W+2)-wide magnitude halo region x a third of its rows.
+    // (three row segments: 66 x 3 = 198 work items fit one pass of the 256 threads; four would need a second
+    //  pass for 8 stragglers)
+    constexpr int MW = NT_W + 2, MH = NT_H + 2, NSEG = 3, QR = (MH + NSEG - 1) / NSEG;
+    static_assert(MW * NSEG <= 256, "one pass");
+    for (int item = threadIdx.x; item < MW * NSEG; item += 256) {
         const int lx = item % MW, q = item / MW;
         const int r0 = q * QR, r1 = min(MH, r0 + QR);          // magnitude rows [r0, r1)
         // magnitude (ly, lx) is centred on sv[ly + 1][lx + 3]
@@ -266,7 +269,9 @@ constexpr int HT = 64;  // hysteresis tile edge
 __global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom g, const uint8_t* dirty_in, uint8_t* dirty_out,
                                                          int* changed)
 {
-    __shared__ uint8_t t[HT + 2][HT + 2 + 2];
+    // tile + 1-px halo; image column x0 sits at LDS column OX + 1 = 4 so interior rows are dword aligned
+    constexpr int OX = 3;
+    __shared__ __attribute__((aligned(16))) uint8_t t[HT + 2][HT + 8];
     __shared__ int any_weak, tile_changed, border_changed, round_changed;
     const int j = blockIdx.z;
     const int tiles_x = gridDim.x, tiles_y = gridDim.y;
@@ -277,19 +282,44 @@ __global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom 
     if (threadIdx.x == 0) { any_weak = 0; tile_changed = 0; border_changed = 0; }
     __syncthreads();
     int weak_here = 0;
-    for (int i = threadIdx.x; i < (HT + 2) * (HT + 2); i += 256) {
-        const int ly = i / (HT + 2), lx = i - ly * (HT + 2);
-        const int y = y0 + ly - 1, x = x0 + lx - 1;
-        uint8_t v = 0;
-        if (y >= 0 && y < H && x >= 0 && x < W) v = M[(size_t)y * W + x];
-        t[ly][lx] = v;
-        if (v == 1 && ly >= 1 && ly <= HT && lx >= 1 && lx <= HT) weak_here = 1;
+    // Tiles whose 64 columns are all inside a frame with 4-byte aligned rows load their interior as dwords
+    // (16 per row) and only the two halo columns as bytes; everything else goes byte by byte.
+    const bool wide = (W & 3) == 0 && (g.npix & 3) == 0 && x0 + HT <= W;
+    if (wide) {
+        for (int i = threadIdx.x; i < (HT + 2) * (HT / 4); i += 256) {
+            const int ly = i / (HT / 4), lw = i - ly * (HT / 4);
+            const int y = y0 + ly - 1;
+            u32 v = 0;
+            if (y >= 0 && y < H) v = *reinterpret_cast<const u32*>(M + (size_t)y * W + x0 + lw * 4);
+            *reinterpret_cast<u32*>(&t[ly][OX + 1 + lw * 4]) = v;
+            // a byte equal to 1 inside the tile rows: (v ^ 0x01010101) has a zero byte there
+            if (ly >= 1 && ly <= HT) {
+                const u32 z = v ^ 0x01010101u;
+                if ((z - 0x01010101u) & ~z & 0x80808080u) weak_here = 1;
+            }
+        }
+        for (int i = threadIdx.x; i < (HT + 2) * 2; i += 256) {
+            const int ly = i >> 1, side = i & 1;
+            const int y = y0 + ly - 1, x = side ? x0 + HT : x0 - 1;
+            uint8_t v = 0;
+            if (y >= 0 && y < H && x >= 0 && x < W) v = M[(size_t)y * W + x];
+            t[ly][side ? OX + HT + 1 : OX] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < (HT + 2) * (HT + 2); i += 256) {
+            const int ly = i / (HT + 2), lx = i - ly * (HT + 2);
+            const int y = y0 + ly - 1, x = x0 + lx - 1;
+            uint8_t v = 0;
+            if (y >= 0 && y < H && x >= 0 && x < W) v = M[(size_t)y * W + x];
+            t[ly][OX + lx] = v;
+            if (v == 1 && ly >= 1 && ly <= HT && lx >= 1 && lx <= HT) weak_here = 1;
+        }
     }
     if (weak_here) any_weak = 1;
     __syncthreads();
     if (!any_weak) return;
     // each thread owns a 4x4 patch of the 64x64 tile
-    const int py = (threadIdx.x >> 4) * 4 + 1, px = (threadIdx.x & 15) * 4 + 1;
+    const int py = (threadIdx.x >> 4) * 4 + 1, px = (threadIdx.x & 15) * 4 + 1 + OX;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) round_changed = 0;
@@ -306,7 +336,7 @@ __global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom 
                     if (s) {
                         t[y][x] = 2;  // racing writers only ever store 2: benign
                         ch = 1;
-                        if (y == 1 || y == HT || x == 1 || x == HT) bch = 1;
+                        if (y == 1 || y == HT || x == OX + 1 || x == OX + HT) bch = 1;
                     }
                 }
             }
@@ -321,7 +351,7 @@ __global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom 
         for (int i = threadIdx.x; i < HT * HT; i += 256) {
             const int ly = i / HT, lx = i - ly * HT;
             const int y = y0 + ly, x = x0 + lx;
-            if (y < H && x < W && t[ly + 1][lx + 1] == 2) M[(size_t)y * W + x] = 2;
+            if (y < H && x < W && t[ly + 1][OX + lx + 1] == 2) M[(size_t)y * W + x] = 2;
         }
         if (border_changed && threadIdx.x < 9 && threadIdx.x != 4) {
             const int ny = (int)blockIdx.y + (int)threadIdx.x / 3 - 1, nx = (int)blockIdx.x + (int)threadIdx.x % 3 - 1;
@@ -450,8 +480,14 @@ static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeB
     const size_t tiles = (size_t)((g.width + HT - 1) / HT) * ((g.height + HT - 1) / HT);
     const size_t per_frame = align_up((size_t)g.npix) * 2 + align_up(256 * 4) + align_up(sizeof(int2)) +
                              align_up(words * 4) * 2 + align_up(8) + 2 * align_up(tiles);
-    // bound the workspace to ~1 GiB unless a single frame needs more
-    int frames = (int)std::max<size_t>(1, std::min<size_t>((size_t)want_frames, ((size_t)1 << 30) / per_frame));
+    // bound the workspace (default 4 GiB of the 288 GB; PSD_EDGE_WS_MB overrides) unless a single frame needs
+    // more: longer chunks amortise the host round trips of the hysteresis rounds
+    static const size_t ws_cap = [] {
+        const char* e = getenv("PSD_EDGE_WS_MB");
+        const long mb = e ? atol(e) : 4096;
+        return (size_t)(mb > 0 ? mb : 4096) << 20;
+    }();
+    int frames = (int)std::max<size_t>(1, std::min<size_t>((size_t)want_frames, ws_cap / per_frame));
     const size_t fixed = align_up(words * 4) + align_up(64 * sizeof(int)) + align_up(511 * sizeof(int2));
     const size_t need = per_frame * (size_t)frames + fixed;
     void** ws = engine_edge_ws(e);
