@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "psd_engine.h"
@@ -311,43 +312,57 @@ int psd_epilogue_hash_bits(const uint8_t* thumbs, int n, int size, int hash_size
     }
     const int keep = hash_size;
     // orthonormal DCT-II basis, rows 0..keep-1
-    std::vector<double> c((size_t)keep * size), tmp((size_t)keep * size);
+    std::vector<double> c((size_t)keep * size);
     for (int k = 0; k < keep; k++)
         for (int j = 0; j < size; j++)
             c[(size_t)k * size + j] = k == 0 ? std::sqrt(1.0 / size)
                                              : std::sqrt(2.0 / size) * std::cos(3.14159265358979323846 * (2 * j + 1) * k / (2.0 * size));
-    std::vector<float> x((size_t)size * size), low((size_t)keep * keep), sorted((size_t)keep * keep);
-    for (int t = 0; t < n; t++) {
-        const uint8_t* th = thumbs + (size_t)t * size * size;
-        int mx = 0;
-        for (int i = 0; i < size * size; i++) mx = th[i] > mx ? th[i] : mx;
-        if (mx == 0) mx = 1;  // hash_detector.py:132-135
-        const float fmx = (float)mx;
-        for (int i = 0; i < size * size; i++) x[i] = (float)th[i] / fmx;
-        for (int u = 0; u < keep; u++)
-            for (int xx = 0; xx < size; xx++) {
-                double acc = 0.0;
-                for (int y = 0; y < size; y++) acc += c[(size_t)u * size + y] * (double)x[(size_t)y * size + xx];
-                tmp[(size_t)u * size + xx] = acc;
+    // frames are independent: split long clips over a few host threads (results do not depend on the split)
+    auto work = [&](int t_begin, int t_end) {
+        std::vector<double> tmp((size_t)keep * size);
+        std::vector<float> x((size_t)size * size), low((size_t)keep * keep), sorted((size_t)keep * keep);
+        for (int t = t_begin; t < t_end; t++) {
+            const uint8_t* th = thumbs + (size_t)t * size * size;
+            int mx = 0;
+            for (int i = 0; i < size * size; i++) mx = th[i] > mx ? th[i] : mx;
+            if (mx == 0) mx = 1;  // hash_detector.py:132-135
+            const float fmx = (float)mx;
+            for (int i = 0; i < size * size; i++) x[i] = (float)th[i] / fmx;
+            for (int u = 0; u < keep; u++)
+                for (int xx = 0; xx < size; xx++) {
+                    double acc = 0.0;
+                    for (int y = 0; y < size; y++) acc += c[(size_t)u * size + y] * (double)x[(size_t)y * size + xx];
+                    tmp[(size_t)u * size + xx] = acc;
+                }
+            for (int u = 0; u < keep; u++)
+                for (int v = 0; v < keep; v++) {
+                    double acc = 0.0;
+                    for (int xx = 0; xx < size; xx++) acc += tmp[(size_t)u * size + xx] * c[(size_t)v * size + xx];
+                    low[(size_t)u * keep + v] = (float)acc;
+                }
+            // numpy.median of float32: middle element, or the float32 mean of the two middle elements
+            sorted = low;
+            std::sort(sorted.begin(), sorted.end());
+            const size_t m = sorted.size();
+            float med;
+            if (m % 2) med = sorted[m / 2];
+            else {
+                const float two = sorted[m / 2 - 1] + sorted[m / 2];
+                med = two / 2.0f;
             }
-        for (int u = 0; u < keep; u++)
-            for (int v = 0; v < keep; v++) {
-                double acc = 0.0;
-                for (int xx = 0; xx < size; xx++) acc += tmp[(size_t)u * size + xx] * c[(size_t)v * size + xx];
-                low[(size_t)u * keep + v] = (float)acc;
-            }
-        // numpy.median of float32: middle element, or the float32 mean of the two middle elements
-        sorted = low;
-        std::sort(sorted.begin(), sorted.end());
-        const size_t m = sorted.size();
-        float med;
-        if (m % 2) med = sorted[m / 2];
-        else {
-            const float two = sorted[m / 2 - 1] + sorted[m / 2];
-            med = two / 2.0f;
+            uint8_t* b = bits + (size_t)t * keep * keep;
+            for (size_t i = 0; i < m; i++) b[i] = low[i] > med ? 1 : 0;
         }
-        uint8_t* b = bits + (size_t)t * keep * keep;
-        for (size_t i = 0; i < m; i++) b[i] = low[i] > med ? 1 : 0;
+    };
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads > 16) nthreads = 16;
+    if (n < 256 || nthreads < 2) {
+        work(0, n);
+    } else {
+        std::vector<std::thread> pool;
+        const int per = (n + (int)nthreads - 1) / (int)nthreads;
+        for (int t0 = 0; t0 < n; t0 += per) pool.emplace_back(work, t0, std::min(n, t0 + per));
+        for (auto& th : pool) th.join();
     }
     return PSD_OK;
 }
