@@ -30,6 +30,9 @@
 #ifndef PSD_ABLATE
 #define PSD_ABLATE 0
 #endif
+#ifndef PSD_PACK3
+#define PSD_PACK3 1
+#endif
 // (Instruction-selection experiments that did NOT pay, measured on the HSV variant, N=1024 1080p:
 //  0xff/180 from SGPRs instead of literals -1.7 %, shift+and instead of v_bfe -1.5 %, 2d/4d by
 //  additions instead of v_lshl_add -4 %; the 16-bit v_min_u16 for the hue wrap +1.3 % is kept.)
@@ -219,10 +222,24 @@ __device__ __forceinline__ void pixel(const u32 (&d)[3], u32& hq, u32& sq, u32& 
         const int hh16 = mad_i24(hraw, hdiv16, 2048 << 4);
         // hh < 0 ? hh + 180 : hh: as 16-bit unsigned values a negative hh is huge, so the min picks right
         hq = min_hi16_to_byte<K>((u32)hh16, (u32)hh16 + (180u << 16), hq);
+#if PSD_PACK3
+        // S and V leave the pixel unpacked; convert_group joins the four of a quad with three v_perm_b32 per
+        // channel (pairwise, then pair of pairs) instead of one insertion per pixel
+        sq = s16;
+        vq = v;
+#else
         sq = pack_byte2<K>(s16, sq);
         vq = pack_byte0<K>(v, vq);
+#endif
     }
 #endif
+}
+
+__device__ __forceinline__ u32 perm_b32(u32 s0, u32 s1, u32 sel)
+{
+    u32 d;
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(s0), "v"(s1), "s"(sel));
+    return d;
 }
 
 // 8-bit BGR -> HSV exactly as OpenCV's RGB2HSV_b (hsv_shift = 12, hue range 180), plus luma
@@ -250,6 +267,21 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
         if (HSV && q > 0)
             asm volatile("" : "+v"(g.w[3 * q]), "+v"(g.w[3 * q + 1]), "+v"(g.w[3 * q + 2]) : "v"(o.h[q - 1]), "v"(o.s[q - 1]), "v"(o.v[q - 1]));
         const u32 d[3] = {g.w[3 * q], g.w[3 * q + 1], g.w[3 * q + 2]};
+#if PSD_PACK3 && !(PSD_ABLATE & 8)
+        if (HSV) {
+            u32 s0, s1, s2, s3, v0, v1, v2, v3;
+            pixel<HSV, LUMA, LC, AC, 0>(d, hq, s0, v0, lut_s, lut_h, hist, inc);
+            pixel<HSV, LUMA, LC, AC, 1>(d, hq, s1, v1, lut_s, lut_h, hist, inc);
+            const u32 s01 = perm_b32(s1, s0, 0x0c0c0602u), v01 = perm_b32(v1, v0, 0x0c0c0400u);
+            pixel<HSV, LUMA, LC, AC, 2>(d, hq, s2, v2, lut_s, lut_h, hist, inc);
+            pixel<HSV, LUMA, LC, AC, 3>(d, hq, s3, v3, lut_s, lut_h, hist, inc);
+            const u32 s23 = perm_b32(s3, s2, 0x0c0c0602u), v23 = perm_b32(v3, v2, 0x0c0c0400u);
+            o.h[q] = hq;
+            o.s[q] = perm_b32(s23, s01, 0x05040100u);
+            o.v[q] = perm_b32(v23, v01, 0x05040100u);
+            continue;
+        }
+#endif
         pixel<HSV, LUMA, LC, AC, 0>(d, hq, sq, vq, lut_s, lut_h, hist, inc);
         pixel<HSV, LUMA, LC, AC, 1>(d, hq, sq, vq, lut_s, lut_h, hist, inc);
         pixel<HSV, LUMA, LC, AC, 2>(d, hq, sq, vq, lut_s, lut_h, hist, inc);
