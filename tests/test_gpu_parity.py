@@ -459,3 +459,24 @@ def test_hash_thumbs_batch_properties_1080p(hip_engine):
     assert (all_t[7] == 200).all()
     sample = x[:2].cpu().numpy()
     assert np.array_equal(all_t[:2], orc.hash_thumbs(sample, 16))
+
+
+def test_hash_thumbs_randomised_shapes(hip_engine):
+    """Random frame sizes, thumbnail sizes and strides: every kernel variant (LDS-DMA stream, register loads,
+    byte loads; float run tables and integer boxes) against the oracle."""
+    rng = np.random.default_rng(20250921)
+    for _ in range(40):
+        size = int(rng.choice([4, 7, 8, 16, 24, 32, 64]))
+        h = int(rng.integers(size, 6 * size + 40))
+        w = int(rng.integers(size, 8 * size + 60))
+        if rng.random() < 0.5:
+            w = max(size, (w + 15) // 16 * 16)          # fast paths need width % 16 == 0
+        if rng.random() < 0.3:
+            h, w = size * int(rng.integers(1, 5)), max(size, size * int(rng.integers(1, 6)))  # integer boxes
+        n = int(rng.integers(1, 5))
+        pad = int(rng.choice([0, 0, 16, 5]))
+        base = rng.integers(0, 256, (n, h, w + pad, 3), dtype=np.uint8)
+        frames = base[:, :, : w]
+        want = orc.hash_thumbs(np.ascontiguousarray(frames), size)
+        got = hip_engine.hash_thumbs_host(frames, size)
+        assert np.array_equal(got, want), (n, h, w, size, pad, np.argwhere(got != want)[:3].tolist())
