@@ -480,3 +480,10 @@ def test_hash_thumbs_randomised_shapes(hip_engine):
         want = orc.hash_thumbs(np.ascontiguousarray(frames), size)
         got = hip_engine.hash_thumbs_host(frames, size)
         assert np.array_equal(got, want), (n, h, w, size, pad, np.argwhere(got != want)[:3].tolist())
+        # the same frames resident in HBM with their padding: strided rows take the register / byte-load kernels
+        buf = hip_engine.alloc(base.nbytes)
+        buf.upload(base.reshape(-1))
+        got_dev = hip_engine.hash_thumbs_device(buf.ptr, n, h, w, size, row_stride=(w + pad) * 3,
+                                                frame_stride=h * (w + pad) * 3)
+        assert np.array_equal(got_dev, want), ("device", n, h, w, size, pad)
+        buf.free()
