@@ -700,6 +700,96 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
     }
 }
 
+// ---- luma histogram + byte sum without the time walk -------------------------------------------
+//
+// HistogramDetector / ThresholdDetector need nothing from the previous frame, so the luma-only pass does not
+// have to walk the time axis: one small workgroup (4 waves) takes one spatial tile of ONE frame, streams it
+// HBM -> LDS exactly like the kernel above (wave-private 3 KiB slots, one step ahead), counts into its 16x
+// replicated LDS histogram and flushes once at the end -- no per-frame workgroup barrier, three workgroups per
+// CU.  grid = (tiles per frame, frames).
+constexpr int kLumaWG = 256, kLumaG = 2, kLumaStepsPerTile = 8;
+
+template <int G>
+__global__ __launch_bounds__(kLumaWG) void luma_hist_kernel(const ScoreParams p)
+{
+    constexpr int WG = kLumaWG, NW = WG / 64, AC = 16, STEP = G * NW * 64;
+    __shared__ __attribute__((aligned(16))) u32 acc[NACC * AC];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[G * NW * 3072];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, t = blockIdx.y;
+    for (int i = tid; i < NACC * AC; i += WG) acc[i] = 0;
+    __syncthreads();
+    const int g0 = p.group_begin + tile * p.groups_per_tile;
+    const int g1 = min(p.group_end, g0 + p.groups_per_tile);
+    const uint8_t* frame = p.frames + (size_t)t * p.frame_stride;
+    const long limit = (long)g1 * 48;
+    auto issue = [&](int sbase) {
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const long gfirst = (long)sbase + (long)(k * NW + wave) * 64;
+            uint8_t* slot = stage + (size_t)(k * NW + wave) * 3072;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const long off = gfirst * 48 + j * 1024 + lane * 16;
+                if (off + 16 <= limit)
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + off), (lds_ptr_t)(slot + j * 1024), 16, 0, 0);
+            }
+        }
+    };
+    u32* my_acc = acc + (tid & (AC - 1));
+    u32 bs = 0;
+    if (g0 < g1) issue(g0);
+    for (int sbase = g0; sbase < g1; sbase += STEP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Group cur[G];
+        stage_read<G, NW>(stage, wave, lane, cur);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (sbase + STEP < g1) issue(sbase + STEP);
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            if (sbase + (k * NW + wave) * 64 + lane < g1) {
+                Hsv16 unused;
+                convert_group<false, true, COPIES, AC>(cur[k], unused, nullptr, nullptr, my_acc, bs, 1u);
+            }
+        }
+    }
+    __hip_atomic_fetch_add(&my_acc[ACC_BYTES * AC], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    for (int i = tid; i < 2 * NACC; i += WG) flush_slot<true, AC>(acc, p.out + t, i);
+}
+
+static hipError_t launch_luma_hist(ScoreParams p, int group_begin, int group_end, hipStream_t stream, int* launches)
+{
+    constexpr int STEP = kLumaG * (kLumaWG / 64) * 64;
+    const int n_groups = group_end - group_begin;
+    if (n_groups <= 0) return hipSuccess;
+    // long batches: 8 steps (4096 groups) per workgroup; short ones (the per-frame API): one step, for parallelism
+    const int cap = STEP * (p.n >= 32 ? kLumaStepsPerTile : 1);
+    p.group_begin = group_begin;
+    p.group_end = group_end;
+    p.n_tiles = (n_groups + cap - 1) / cap;
+    p.groups_per_tile = (n_groups + p.n_tiles - 1) / p.n_tiles;
+    p.frames_per_chunk = 1;
+    const uint8_t* frames = p.frames;
+    psd_frame_scores* out = p.out;
+    const int n = p.n;
+    for (int t0 = 0; t0 < n; t0 += 32768) {   // grid.y limit
+        p.frames = frames + (size_t)t0 * p.frame_stride;
+        p.out = out + t0;
+        p.n = n - t0 < 32768 ? n - t0 : 32768;
+        hipLaunchKernelGGL((luma_hist_kernel<kLumaG>), dim3(p.n_tiles, p.n), dim3(kLumaWG), 0, stream, p);
+        *launches += 1;
+    }
+    return hipGetLastError();
+}
+
+// PSD_LUMA_WALK=1 keeps the luma-only pass on the time-walking kernel (experiments / A-B runs).
+static bool luma_time_walk()
+{
+    static const bool d = [] { const char* e = getenv("PSD_LUMA_WALK"); return e && atoi(e) != 0; }();
+    return d;
+}
+
 // ---- host-side launcher ---------------------------------------------------------------------
 
 // PSD_SCORE_DIRECT=1 selects the register-staged loads on the fast path too (experiments).
@@ -780,8 +870,12 @@ hipError_t launch_score_frames(ScoreParams p, bool hsv, bool luma, bool fast, in
     // through the generic kernel.  Both add into the same records.
     hipError_t err = hipSuccess;
     if (full_groups > 0) {
-        *launches += 1;
-        err = launch_range(p, 0, full_groups, hsv, luma, true, target_blocks, stream);
+        if (luma && !hsv && !direct_loads() && !luma_time_walk()) {
+            err = launch_luma_hist(p, 0, full_groups, stream, launches);
+        } else {
+            *launches += 1;
+            err = launch_range(p, 0, full_groups, hsv, luma, true, target_blocks, stream);
+        }
     }
     if (err == hipSuccess && total_groups > full_groups) {
         *launches += 1;
