@@ -136,6 +136,90 @@ __global__ __launch_bounds__(256) void value_plane_hist_kernel(ChunkSrc src, Edg
     }
 }
 
+// Same result as value_plane_hist_kernel for packed, 16-byte aligned frames whose pixel count is a multiple
+// of 16: one 4-wave workgroup per (tile, frame) streams its tile HBM -> LDS with global_load_lds_dwordx4 into
+// wave-private 3 KiB slots one step ahead (lane i moves bytes [16 i, 16 i + 16) of each 1 KiB piece, then reads
+// its 16 pixels back as 48 contiguous bytes) -- the layout of the scoring kernels, which lifts the 4.1 TB/s
+// ceiling of 12-byte-stride register loads.  grid = (tiles, frames).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+constexpr int VD_G = 2, VD_NW = 4, VD_STEP = VD_G * VD_NW * 64, VD_STEPS_PER_TILE = 8;
+
+__global__ __launch_bounds__(256) void value_plane_hist_dma_kernel(ChunkSrc src, EdgeGeom g, int groups_per_tile, uint8_t* vplane,
+                                                                   u32* hist)
+{
+    constexpr int AC = 16;
+    __shared__ __attribute__((aligned(16))) u32 lh[256 * AC];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[VD_G * VD_NW * 3072];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 256 * AC; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int j = blockIdx.y;
+    const uint8_t* frame = chunk_frame(src, g.frame_stride, j);
+    const int n_groups = (int)(g.npix >> 4);
+    const int g0 = blockIdx.x * groups_per_tile, g1 = min(n_groups, g0 + groups_per_tile);
+    const long limit = (long)g1 * 48;
+    auto issue = [&](int sbase) {
+#pragma unroll
+        for (int k = 0; k < VD_G; k++) {
+            const long gfirst = (long)sbase + (long)(k * VD_NW + wave) * 64;
+            uint8_t* slot = stage + (size_t)(k * VD_NW + wave) * 3072;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const long off = gfirst * 48 + q * 1024 + lane * 16;
+                if (off + 16 <= limit)
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + off), (lds_ptr_t)(slot + q * 1024), 16, 0, 0);
+            }
+        }
+    };
+    u32* my_h = lh + (tid & (AC - 1));
+    uint8_t* vout = vplane + (size_t)j * g.npix;
+    if (g0 < g1) issue(g0);
+    for (int sbase = g0; sbase < g1; sbase += VD_STEP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        u32 w[VD_G][12];
+#pragma unroll
+        for (int k = 0; k < VD_G; k++) {
+            const u32x4* s4 = reinterpret_cast<const u32x4*>(stage + (size_t)(k * VD_NW + wave) * 3072 + lane * 48);
+            const u32x4 a = s4[0], b = s4[1], c = s4[2];
+            w[k][0] = a.x; w[k][1] = a.y; w[k][2] = a.z; w[k][3] = a.w;
+            w[k][4] = b.x; w[k][5] = b.y; w[k][6] = b.z; w[k][7] = b.w;
+            w[k][8] = c.x; w[k][9] = c.y; w[k][10] = c.z; w[k][11] = c.w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (sbase + VD_STEP < g1) issue(sbase + VD_STEP);
+#pragma unroll
+        for (int k = 0; k < VD_G; k++) {
+            const int gidx = sbase + (k * VD_NW + wave) * 64 + lane;
+            if (gidx < g1) {
+                u32 o[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int ib = 3 * i, ig = 3 * i + 1, ir = 3 * i + 2;
+                    const u32 bb = (w[k][ib >> 2] >> ((ib & 3) * 8)) & 0xffu;
+                    const u32 gg = (w[k][ig >> 2] >> ((ig & 3) * 8)) & 0xffu;
+                    const u32 rr = (w[k][ir >> 2] >> ((ir & 3) * 8)) & 0xffu;
+                    const u32 v = max(max(bb, gg), rr);
+                    __hip_atomic_fetch_add(&my_h[v * AC], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    o[i >> 2] |= v << ((i & 3) * 8);
+                }
+                u32x4 pk;
+                pk.x = o[0]; pk.y = o[1]; pk.z = o[2]; pk.w = o[3];
+                *reinterpret_cast<u32x4*>(vout + (size_t)gidx * 16) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int b = tid;
+        u32 sum = 0;
+#pragma unroll
+        for (int r = 0; r < AC; r++) sum += lh[b * AC + ((r + b) & (AC - 1))];
+        if (sum) atomicAdd(&hist[(size_t)j * 256 + b], sum);
+    }
+}
+
 // ---- K2: median -> Canny thresholds ------------------------------------------------------------
 
 // numpy.median of the V plane: for an even count the mean of the two middle order statistics, so
@@ -540,8 +624,20 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
 {
     const size_t words = (size_t)g.height * g.words_per_row;
     HIP_TRY(hipMemsetAsync(b.hist, 0, (size_t)count * 256 * 4, stream));
-    hipLaunchKernelGGL(value_plane_hist_kernel, dim3((unsigned)((g.npix + 1024 * VP_ITER - 1) / (1024 * VP_ITER)), count), dim3(256), 0, stream, src, g,
-                       b.vplane, b.hist);
+    // packed 16-byte aligned frames with a multiple of 16 pixels take the LDS-DMA streaming variant
+    static const bool vp_direct = [] { const char* e = getenv("PSD_EDGE_VP_DIRECT"); return e && atoi(e) != 0; }();
+    const bool vp_dma = !vp_direct && g.row_stride == (size_t)g.width * 3 && (g.npix & 15) == 0 && (g.frame_stride & 15) == 0 &&
+                        ((uintptr_t)src.frames & 15) == 0 && (!src.first_is_prev || ((uintptr_t)src.prev & 15) == 0);
+    if (vp_dma) {
+        const int n_groups = (int)(g.npix >> 4);
+        const int cap = VD_STEP * (count >= 32 ? VD_STEPS_PER_TILE : 1);
+        const int tiles = (n_groups + cap - 1) / cap;
+        const int groups_per_tile = (n_groups + tiles - 1) / tiles;
+        hipLaunchKernelGGL(value_plane_hist_dma_kernel, dim3(tiles, count), dim3(256), 0, stream, src, g, groups_per_tile, b.vplane, b.hist);
+    } else {
+        hipLaunchKernelGGL(value_plane_hist_kernel, dim3((unsigned)((g.npix + 1024 * VP_ITER - 1) / (1024 * VP_ITER)), count), dim3(256), 0, stream, src, g,
+                           b.vplane, b.hist);
+    }
     hipLaunchKernelGGL(median_thresholds_kernel, dim3(count), dim3(256), 0, stream, b.hist, g.npix, b.thr_tab, b.thr);
     hipLaunchKernelGGL(sobel_nms_kernel, dim3((g.width + NT_W - 1) / NT_W, (g.height + NT_H - 1) / NT_H, count), dim3(256), 0,
                        stream, b.vplane, g, b.thr, b.map);
