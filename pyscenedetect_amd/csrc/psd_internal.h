@@ -10,7 +10,11 @@
 
 namespace psd {
 
-constexpr int kScoreWG = 1024;  // threads per workgroup of the scoring kernel (16 waves)
+constexpr int kScoreWG = 1024;  // threads per workgroup of the scoring kernels (16 waves) ...
+#ifndef PSD_HSV_WG
+#define PSD_HSV_WG 256
+#endif
+constexpr int kHsvWG = PSD_HSV_WG;  // ... except the staged HSV-only pass: 4-wave workgroups, four per CU
 constexpr int kScoreG = 2;      // 16-pixel groups per lane per frame
 
 struct ScoreParams {

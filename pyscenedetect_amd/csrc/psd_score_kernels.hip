@@ -495,6 +495,12 @@ constexpr int ACD_MAX = 16;  // accumulator replicas
 #ifndef PSD_FUSED_F
 #define PSD_FUSED_F 1
 #endif
+// HSV-only variant: small workgroups (kHsvWG threads) with fewer table replicas, so that four of them share a CU
+// and their barriers / flushes interleave (A/B on 2048 x 1080p: 3.04 ms vs 3.18 ms for one 1024-thread workgroup
+// with 16 replicas; 512 threads with 8 replicas 3.13 ms; 256 threads with 2 / 8 replicas 3.08 / 3.09 ms; 128 threads 3.4+ ms)
+#ifndef PSD_HSV_LC
+#define PSD_HSV_LC 4
+#endif
 // luma-only variant (histogram + byte sum): replicas of the accumulators and frames per barrier
 #ifndef PSD_LUMA_AC
 #define PSD_LUMA_AC 16
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
 {
     constexpr int NW = WG / 64;
     constexpr int ACD = (HSV && LUMA) ? PSD_FUSED_AC : (LUMA ? PSD_LUMA_AC : ACD_MAX);
-    constexpr int LCD = (HSV && LUMA) ? PSD_FUSED_LC : LCD_MAX;
+    constexpr int LCD = (HSV && LUMA) ? PSD_FUSED_LC : (HSV && WG == kHsvWG ? PSD_HSV_LC : LCD_MAX);
     constexpr int NA = LUMA ? NACC : 4;       // accumulators per frame slot
     constexpr int F = LUMA ? (HSV ? PSD_FUSED_F : PSD_LUMA_F) : 8;   // frames per barrier
     constexpr int SLOTS = 2 * F;
@@ -805,7 +811,8 @@ static hipError_t launch_one(const ScoreParams& p, int grid, hipStream_t stream)
     constexpr int WG = kScoreWG;
     if constexpr (FAST) {
         if (!direct_loads()) {
-            hipLaunchKernelGGL((score_frames_dma_kernel<HSV, LUMA, G, WG>), dim3(grid), dim3(WG), 0, stream, p);
+            constexpr int SWG = (HSV && !LUMA) ? kHsvWG : kScoreWG;
+            hipLaunchKernelGGL((score_frames_dma_kernel<HSV, LUMA, G, SWG>), dim3(grid), dim3(SWG), 0, stream, p);
             return hipGetLastError();
         }
     }
@@ -836,8 +843,12 @@ static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bo
                                bool fast, int target_blocks, hipStream_t stream)
 {
     // Tile geometry: spread the 16-px groups evenly over the fewest tiles that fit.
-    const int gpl = fast ? groups_per_lane() : 1;
-    const int cap = kScoreWG * gpl;
+    const int wg = (fast && hsv && !luma && !direct_loads()) ? kHsvWG : kScoreWG;
+    // The small-workgroup HSV pass takes one group per lane unless PSD_SCORE_G says otherwise: 80 VGPRs and 24 KiB of
+    // LDS, six workgroups (24 waves) per CU.  Sweep on 4096 x 1080p: G=1 5.71 ms, G=2 5.81 ms (1024-thread kernel 5.9-6.0).
+    static const bool g_forced = getenv("PSD_SCORE_G") != nullptr;
+    const int gpl = !fast ? 1 : (wg != kScoreWG && !g_forced) ? 1 : groups_per_lane();
+    const int cap = wg * gpl;
     const int n_groups = group_end - group_begin;
     if (n_groups <= 0) return hipSuccess;
     p.group_begin = group_begin;
@@ -846,6 +857,12 @@ static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bo
     p.groups_per_tile = (n_groups + p.n_tiles - 1) / p.n_tiles;
     // Time chunks: enough workgroups to keep every CU busy for several rounds, but chunks long
     // enough that the re-read halo frame stays a small fraction.
+    if (wg != kScoreWG) {
+        // small workgroups: several share a CU, so ask for proportionally more of them (PSD_HSV_BLOCKS overrides)
+        static const int env_blocks = [] { const char* e = getenv("PSD_HSV_BLOCKS"); return e ? atoi(e) : 0; }();
+        // sweep on 4096 x 1080p (G=1): 2048 blocks 6.13 ms, 8192 5.86, 16384 5.79, 32768 5.71, 65536 5.76
+        target_blocks = env_blocks > 0 ? env_blocks : target_blocks * (kScoreWG / wg) * 4;
+    }
     int chunks = (target_blocks + p.n_tiles - 1) / p.n_tiles;
     if (chunks > p.n) chunks = p.n;
     if (chunks < 1) chunks = 1;
