@@ -501,6 +501,10 @@ constexpr int ACD_MAX = 16;  // accumulator replicas
 #ifndef PSD_HSV_LC
 #define PSD_HSV_LC 4
 #endif
+#ifndef PSD_FUSED_SMALL
+#define PSD_FUSED_SMALL 0   // 1: the fused HSV+luma variant also runs on kHsvWG-thread workgroups (measured: 4.32-4.43 ms
+                            // vs 4.36 ms on 2048 x 1080p with 4 table / 8 histogram replicas -- no gain, off)
+#endif
 // luma-only variant (histogram + byte sum): replicas of the accumulators and frames per barrier
 #ifndef PSD_LUMA_AC
 #define PSD_LUMA_AC 16
@@ -594,6 +598,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
     constexpr int NW = WG / 64;
     constexpr int ACD = (HSV && LUMA) ? PSD_FUSED_AC : (LUMA ? PSD_LUMA_AC : ACD_MAX);
     constexpr int LCD = (HSV && LUMA) ? PSD_FUSED_LC : (HSV && WG == kHsvWG ? PSD_HSV_LC : LCD_MAX);
+    static_assert(!(HSV && LUMA) || WG == kScoreWG || PSD_FUSED_SMALL, "");
     constexpr int NA = LUMA ? NACC : 4;       // accumulators per frame slot
     constexpr int F = LUMA ? (HSV ? PSD_FUSED_F : PSD_LUMA_F) : 8;   // frames per barrier
     constexpr int SLOTS = 2 * F;
@@ -811,7 +816,7 @@ static hipError_t launch_one(const ScoreParams& p, int grid, hipStream_t stream)
     constexpr int WG = kScoreWG;
     if constexpr (FAST) {
         if (!direct_loads()) {
-            constexpr int SWG = (HSV && !LUMA) ? kHsvWG : kScoreWG;
+            constexpr int SWG = (HSV && (!LUMA || PSD_FUSED_SMALL)) ? kHsvWG : kScoreWG;
             hipLaunchKernelGGL((score_frames_dma_kernel<HSV, LUMA, G, SWG>), dim3(grid), dim3(SWG), 0, stream, p);
             return hipGetLastError();
         }
@@ -843,7 +848,7 @@ static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bo
                                bool fast, int target_blocks, hipStream_t stream)
 {
     // Tile geometry: spread the 16-px groups evenly over the fewest tiles that fit.
-    const int wg = (fast && hsv && !luma && !direct_loads()) ? kHsvWG : kScoreWG;
+    const int wg = (fast && hsv && (!luma || PSD_FUSED_SMALL) && !direct_loads()) ? kHsvWG : kScoreWG;
     // The small-workgroup HSV pass takes one group per lane unless PSD_SCORE_G says otherwise: 80 VGPRs and 24 KiB of
     // LDS, six workgroups (24 waves) per CU.  Sweep on 4096 x 1080p: G=1 5.71 ms, G=2 5.81 ms (1024-thread kernel 5.9-6.0).
     static const bool g_forced = getenv("PSD_SCORE_G") != nullptr;
