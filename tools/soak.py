@@ -31,4 +31,16 @@ for name, fl in (("hsv", 1), ("luma", 6), ("all", 7)):
                     bad += 1
                 reps += 1
     print(f"{name}: {reps} repetitions, mismatches so far {bad}")
+# HashDetector thumbnails: same property
+ref_t = eng.hash_thumbs_device(x.data_ptr(), N, H, W, 16)
+assert np.array_equal(ref_t[:3], orc.hash_thumbs(x[:3].cpu().numpy(), 16))
+t0 = time.time(); reps = 0
+while time.time() - t0 < float(os.environ.get("SOAK_SECS", "20")):
+    with torch.cuda.stream(side):
+        noise_a.normal_()
+    for _ in range(16):
+        if eng.hash_thumbs_device(x.data_ptr(), N, H, W, 16).tobytes() != ref_t.tobytes():
+            bad += 1
+        reps += 1
+print(f"hash thumbs: {reps} repetitions, mismatches so far {bad}")
 print("SOAK", "CLEAN" if bad == 0 else f"FAILED ({bad})")
