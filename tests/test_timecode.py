@@ -43,3 +43,116 @@ def test_foreign_timecode_is_accepted():
     assert mine.frame_num == 30 and mine.frame_rate == 25
     assert FrameTimecode(7, fps=RefTimecode(0, Fraction(30000, 1001))).frame_rate == Fraction(30000, 1001)
     assert mine >= RefTimecode(30, Fraction(25, 1)) and (mine - RefTimecode(10, Fraction(25, 1))).frame_num == 20
+
+
+# ---- differential cases evaluated by the reference's own FrameTimecode (oracle/gen_timecode_golden.py) ----------
+
+import json
+import os
+from fractions import Fraction
+
+import pytest
+
+from pyscenedetect_amd.timecode import FrameTimecode as _TC
+from pyscenedetect_amd.timecode import framerate_to_fraction as _f2f
+
+_CASES = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "timecode_cases.json")))
+
+
+def _fps(f):
+    return Fraction(f[0], f[1]) if isinstance(f, list) else f
+
+
+def _field(fn):
+    try:
+        return fn()
+    except Exception as ex:  # noqa: BLE001
+        return "raises:" + type(ex).__name__
+
+
+def _describe(tc):
+    return {"frame_num": _field(lambda: tc.frame_num), "seconds": _field(lambda: tc.seconds),
+            "timecode": _field(tc.get_timecode), "timecode_p1": _field(lambda: tc.get_timecode(precision=1)),
+            "timecode_p0": _field(lambda: tc.get_timecode(precision=0)),
+            "timecode_trunc": _field(lambda: tc.get_timecode(use_rounding=False)), "hash": _field(lambda: hash(tc)),
+            "int": _field(lambda: int(tc)), "float": _field(lambda: float(tc)), "str": _field(lambda: str(tc))}
+
+
+def _outcome(fn):
+    try:
+        return {"ok": fn()}
+    except Exception as ex:  # noqa: BLE001
+        return {"raises": type(ex).__name__}
+
+
+def _same(got, want, tag):
+    if "raises" in want:
+        assert got == want, f"{tag}: reference raises {want['raises']}, got {got}"
+        return
+    assert "ok" in got, f"{tag}: reference gives {want['ok']}, got {got}"
+    if not isinstance(want["ok"], dict):
+        assert got["ok"] == want["ok"], f"{tag}: {got['ok']!r} != {want['ok']!r}"
+        return
+    for key, w in want["ok"].items():
+        g = got["ok"][key]
+        if isinstance(w, float):
+            assert g == pytest.approx(w, rel=0, abs=1e-9), f"{tag}: {key} {g!r} != {w!r}"
+        else:
+            assert g == w, f"{tag}: {key} {g!r} != {w!r}"
+
+
+def test_construction_matches_reference():
+    for c in _CASES["construct"]:
+        v, f = c["value"], c["fps"]
+        if isinstance(v, str) and v.startswith("copy:"):
+            got = _outcome(lambda: _describe(_TC(_TC(int(v[5:]), _fps(f)))))
+        elif isinstance(v, str) and v.startswith("fps_from_tc:"):
+            got = _outcome(lambda: _describe(_TC(int(v[12:]), _TC(100, _fps(f)))))
+        else:
+            got = _outcome(lambda: _describe(_TC(v, _fps(f))))
+        _same(got, {k: c[k] for k in ("ok", "raises") if k in c}, f"FrameTimecode({v!r}, {f!r})")
+
+
+def test_invalid_construction_matches_reference():
+    for c in _CASES["bad"]:
+        v = complex(c["value"]) if c["is_complex"] else c["value"]
+        got = _outcome(lambda: _describe(_TC(v, 25.0)))
+        _same(got, {k: c[k] for k in ("ok", "raises") if k in c}, f"FrameTimecode({v!r})")
+
+
+def test_arithmetic_matches_reference():
+    for c in _CASES["arith"]:
+        def run():
+            x = _TC(c["a"], _fps(c["fps"]))
+            y = _TC(c["b"], _fps(c["fps"])) if c["kind"] == "tc" else c["b"]
+            r = x + y if c["op"] == "add" else x - y
+            return {"frame_num": r.frame_num, "seconds": r.seconds}
+        _same(_outcome(run), {k: c[k] for k in ("ok", "raises") if k in c},
+              f"{c['a']!r} {c['op']} {c['b']!r} ({c['kind']}) @ {c['fps']!r}")
+
+
+def test_comparisons_match_reference():
+    for c in _CASES["compare"]:
+        def run():
+            x = _TC(c["a"], _fps(c["fps"]))
+            y = _TC(c["b"], _fps(c["fps"])) if c["kind"] == "tc" else c["b"]
+            return {"eq": x == y, "ne": x != y, "lt": x < y, "le": x <= y, "gt": x > y, "ge": x >= y}
+        _same(_outcome(run), {k: c[k] for k in ("ok", "raises") if k in c},
+              f"{c['a']!r} vs {c['b']!r} ({c['kind']}) @ {c['fps']!r}")
+
+
+def test_framerate_to_fraction_matches_reference():
+    for c in _CASES["framerate"]:
+        def run():
+            q = _f2f(c["fps"])
+            return [q.numerator, q.denominator]
+        _same(_outcome(run), {k: c[k] for k in ("ok", "raises") if k in c}, f"framerate_to_fraction({c['fps']!r})")
+
+
+def test_cross_rate_behaviour_matches_reference():
+    for c in _CASES["cross_rate"]:
+        def run():
+            a, b = _TC(10, 25.0), _TC(10, 30.0)
+            op = c["op"]
+            return {"eq": a == b} if op == "eq" else {"frame_num": (a + b).frame_num} if op == "add" else {"lt": a < b}
+        _same(_outcome(run), {k: c[k] for k in ("ok", "raises") if k in c}, f"cross-rate {c['op']}")
