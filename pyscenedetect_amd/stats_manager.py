@@ -6,6 +6,7 @@ Detectors write the same metric keys as the reference (``content_val``, ``delta_
 """
 
 import csv
+import os
 
 from pyscenedetect_amd.timecode import FrameTimecode
 
@@ -19,6 +20,13 @@ class FrameMetricRegistered(Exception):
     def __init__(self, metric_key: str, message: str = "Attempted to re-register frame metric key."):
         super().__init__(message)
         self.metric_key = metric_key
+
+
+class StatsFileCorrupt(Exception):
+    """The stats file is not one this class wrote (reference ``stats_manager.py:60-70``)."""
+
+    def __init__(self, message: str = "Could not load frame metric data data from passed CSV file."):
+        super().__init__(message)
 
 
 class StatsManager:
@@ -75,3 +83,50 @@ class StatsManager:
         finally:
             if close:
                 csv_file.close()
+
+    @staticmethod
+    def valid_header(row) -> bool:
+        """``Frame Number, Timecode, ...`` (reference ``stats_manager.py:205-216``)."""
+        return bool(row) and len(row) >= 2 and row[0] == COLUMN_NAME_FRAME_NUMBER and row[1] == COLUMN_NAME_TIMECODE
+
+    def load_from_csv(self, csv_file):
+        """Read metrics written by :meth:`save_to_csv` back (reference ``stats_manager.py:220-296``, deprecated
+        there but still what lets ``ThresholdDetector`` reuse a cached ``average_rgb``).  Rows are keyed by 0-based
+        frame number.  Returns the number of rows, or None for a missing / empty file; raises
+        :class:`StatsFileCorrupt` for anything that is not a stats file."""
+        if isinstance(csv_file, (str, bytes, os.PathLike)):
+            if not os.path.exists(csv_file):
+                return None
+            with open(csv_file) as handle:
+                return self.load_from_csv(handle)
+        reader = csv.reader(csv_file, lineterminator="\n")
+        try:
+            row = next(reader)
+            if not self.valid_header(row):   # older files carried one extra header line
+                row = next(reader)
+        except StopIteration:
+            return None
+        if not self.valid_header(row):
+            raise StatsFileCorrupt()
+        num_cols = len(row)
+        if num_cols - 2 <= 0:
+            raise StatsFileCorrupt("No metrics defined in CSV file.")
+        keys = list(row[2:])
+        num_frames = 0
+        for row in reader:
+            if len(row) != num_cols:
+                raise StatsFileCorrupt("Wrong number of columns detected in stats file row.")
+            frame_number = int(row[0])
+            if frame_number > 0:
+                frame_number -= 1
+            self.set_metrics(frame_number, {})
+            for key, text in zip(keys, row[2:]):
+                if text and text != "None":
+                    try:
+                        self._frame_metrics[frame_number][key] = float(text)
+                    except ValueError:
+                        raise StatsFileCorrupt(f"Corrupted value in stats file: {text}") from ValueError
+            num_frames += 1
+        self.register_metrics(keys)
+        self._metrics_updated = False
+        return num_frames

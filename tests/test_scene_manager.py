@@ -163,3 +163,45 @@ def test_detect_convenience(golden, oracle_engine, tmp_path):
     empty = psd.detect(frames[:5], psd.ContentDetector(engine=oracle_engine), engine=oracle_engine)
     assert empty == [] and len(psd.detect(frames[:5], psd.ContentDetector(engine=oracle_engine), start_in_scene=True,
                                           engine=oracle_engine)) == 1
+
+
+def test_stats_manager_csv_round_trip_and_corrupt_files(golden, oracle_engine, tmp_path):
+    """save_to_csv -> load_from_csv (reference stats_manager.py:164-296): same metric values back, keyed by 0-based
+    frame number; blank / missing files give None; anything else that is not a stats file raises StatsFileCorrupt."""
+    frames = golden_clip(golden, "scenes_a")
+    stats = psd.StatsManager()
+    sm = psd.SceneManager(stats, engine=oracle_engine)
+    sm.auto_downscale = False
+    sm.add_detector(psd.ContentDetector(engine=oracle_engine))
+    sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+    path = tmp_path / "stats.csv"
+    stats.save_to_csv(str(path))
+    loaded = psd.StatsManager()
+    assert loaded.load_from_csv(str(path)) == len(frames) - 1      # frame 0 has no metrics (nothing to compare with)
+    assert not loaded.is_save_required()
+    keys = ["content_val", "delta_hue", "delta_sat", "delta_lum"]
+    for i in range(1, len(frames)):
+        assert loaded.metrics_exist(i, keys)
+        assert loaded.get_metrics(i, keys) == [float(str(v)) for v in stats.get_metrics(i, keys)]
+    assert not loaded.metrics_exist(0, keys)
+    assert set(keys) <= set(loaded.metric_keys)
+    # blank and missing files
+    blank = tmp_path / "blank.csv"
+    blank.write_text("")
+    assert psd.StatsManager().load_from_csv(str(blank)) is None
+    assert psd.StatsManager().load_from_csv(str(tmp_path / "nope.csv")) is None
+    # an older layout with one extra line in front of the header still loads
+    legacy = tmp_path / "legacy.csv"
+    legacy.write_text("Video Framerate,25.0\nFrame Number,Timecode,content_val\n1,00:00:00.000,3.5\n2,00:00:00.040,None\n")
+    old = psd.StatsManager()
+    assert old.load_from_csv(str(legacy)) == 2
+    assert old.get_metrics(0, ["content_val"]) == [3.5] and not old.metrics_exist(1, ["content_val"])
+    # corrupt files
+    for text in ("a,b,c\n1,2,3\n",                                              # not a stats header
+                 "Frame Number,Timecode\n1,00:00:00.000\n",                      # no metrics
+                 "Frame Number,Timecode,content_val\n1,00:00:00.000\n",          # short row
+                 "Frame Number,Timecode,content_val\n1,00:00:00.000,abc\n"):     # not a number
+        bad = tmp_path / "bad.csv"
+        bad.write_text(text)
+        with pytest.raises(psd.StatsFileCorrupt):
+            psd.StatsManager().load_from_csv(str(bad))
