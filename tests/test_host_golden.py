@@ -188,3 +188,51 @@ def test_auto_downscale_matches_reference(golden, oracle_engine):
         cls_name, kwargs, with_stats = golden["configs"][name]
         got = run_config(frames, cls_name, kwargs, with_stats, oracle_engine, auto_downscale=True)
         assert_same_run(got, golden["clips"]["wide_d"]["results"][name], f"wide_d/{name}")
+
+
+# ---- plug-in surface: constructor validation, metric keys, look-behind (oracle/gen_api_golden.py) -------------------
+
+def _api_cases():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "api_cases.json")) as fh:
+        return json.load(fh)
+
+
+def _outcome(fn):
+    try:
+        return {"ok": fn()}
+    except Exception as ex:  # noqa: BLE001
+        return {"raises": type(ex).__name__}
+
+
+def test_constructors_and_plugin_properties_match_reference(oracle_engine):
+    from tests._helpers import build_detector
+
+    for c in _api_cases()["ctor"]:
+        def describe():
+            det = build_detector(c["cls"], c["kwargs"], oracle_engine)
+            return {"metrics": list(det.get_metrics()), "event_buffer_length": int(det.event_buffer_length),
+                    "stats_manager_is_none": det.stats_manager is None}
+        want = {k: c[k] for k in ("ok", "raises") if k in c}
+        assert _outcome(describe) == want, f"{c['cls']}({c['kwargs']})"
+
+
+def test_rejected_frames_and_manager_properties_match_reference(oracle_engine):
+    cases = _api_cases()
+    tc = FrameTimecode(0, 25.0)
+    for name, c in cases["bad_frames"].items():
+        frame = np.zeros(c["shape"], np.dtype(c["dtype"]))
+        got = _outcome(lambda: [x.frame_num for x in getattr(psd, c["cls"])(engine=oracle_engine).process_frame(tc, frame)])
+        assert got == {k: c[k] for k in ("ok", "raises") if k in c}, name
+    for c in cases["downscale_factor"]:
+        got = _outcome(lambda: psd.compute_downscale_factor(c["width"], c["effective"]))
+        assert got == {k: c[k] for k in ("ok", "raises") if k in c}, c
+    sm = psd.SceneManager(engine=oracle_engine)
+    sizes = []
+    for cls, kw in (("ThresholdDetector", {}), ("ContentDetector", {}), ("AdaptiveDetector", {"window_width": 4}),
+                    ("ContentDetector", {"min_scene_len": 40})):
+        sm.add_detector(getattr(psd, cls)(engine=oracle_engine, **kw))
+        sizes.append(sm._frame_buffer_size)
+    assert {"ok": sizes} == cases["frame_buffer_sizes"]
