@@ -129,7 +129,15 @@ int psd_hsv_tables(int32_t sdiv[256], int32_t hdiv180[256]);
 int psd_edge_map_device(psd_engine* e, const uint8_t* d_frame, int height, int width,
                         size_t row_stride, int edge_kernel, uint8_t* h_edges);
 
-/* cv2.resize(src,(dst_w,dst_h),INTER_LINEAR) for n device-resident BGR frames (packed rows). */
+/* cv2.resize(src, (dst_w, dst_h), interpolation) for n device-resident BGR frames (packed rows): the downscale
+ * SceneManager applies in front of the detectors (scene_manager.py:666-678).  `interpolation` takes cv2's values
+ * as the reference's Interpolation enum does (common.py:148-160): NEAREST, LINEAR (the default) and AREA are
+ * implemented, AREA for decimation only; CUBIC / LANCZOS4 return PSD_ERR_UNSUPPORTED. */
+enum psd_interpolation { PSD_INTER_NEAREST = 0, PSD_INTER_LINEAR = 1, PSD_INTER_CUBIC = 2, PSD_INTER_AREA = 3, PSD_INTER_LANCZOS4 = 4 };
+int psd_resize_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w,
+                      size_t src_frame_stride, uint8_t* d_dst, int dst_h, int dst_w,
+                      size_t dst_frame_stride, int interpolation, void* stream);
+/* psd_resize_device(..., PSD_INTER_LINEAR, ...) */
 int psd_resize_linear_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w,
                              size_t src_frame_stride, uint8_t* d_dst, int dst_h, int dst_w,
                              size_t dst_frame_stride, void* stream);

@@ -17,7 +17,7 @@
  *   cv2.calcHist                    scenedetect/detectors/histogram_detector.py:159
  *   cv2.normalize                   scenedetect/detectors/histogram_detector.py:163
  *   cv2.compareHist(CORREL)         scenedetect/detectors/histogram_detector.py:98
- *   cv2.resize(INTER_LINEAR)        scenedetect/scene_manager.py:670-678
+ *   cv2.resize(INTER_LINEAR | INTER_NEAREST | INTER_AREA)   scenedetect/scene_manager.py:670-678 (Interpolation, common.py:148-160)
  *   cv2.cvtColor(BGR2GRAY) / cv2.resize(INTER_AREA) / cv2.dct   scenedetect/detectors/hash_detector.py:125,129,139
  *
  * PARITY UNPINNED at the cv2 boundary: no real cv2 build and none of the
@@ -514,11 +514,11 @@ static inline float area_weight(const orc_area_run* r, int k)
     return r->a_mid;
 }
 
-/* Single-channel 8-bit, shrinking in both directions (the only way HashDetector uses it).
- * Returns 0, or -1 if the request is not a pure decimation. */
-int orc_resize_area_u8(const uint8_t* src, size_t sstep, int sh, int sw, uint8_t* dst, size_t dstep, int dh, int dw)
+/* 8-bit, cn interleaved channels, shrinking in both directions (HashDetector uses cn = 1; SceneManager's
+ * Interpolation.AREA downscale uses cn = 3).  Returns 0, or -1 if the request is not a pure decimation. */
+int orc_resize_area_u8_cn(const uint8_t* src, size_t sstep, int sh, int sw, int cn, uint8_t* dst, size_t dstep, int dh, int dw)
 {
-    if (dw > sw || dh > sh || dw <= 0 || dh <= 0) return -1;
+    if (dw > sw || dh > sh || dw <= 0 || dh <= 0 || cn <= 0) return -1;
     double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
     int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
     int is_area_fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
@@ -527,48 +527,73 @@ int orc_resize_area_u8(const uint8_t* src, size_t sstep, int sh, int sw, uint8_t
         int area = iscale_x * iscale_y;
         float scale = 1.f / area;
         for (int y = 0; y < dh; y++)
-            for (int x = 0; x < dw; x++) {
-                int sum = 0;
-                for (int j = 0; j < iscale_y; j++)
-                    for (int i = 0; i < iscale_x; i++) sum += src[(size_t)(y * iscale_y + j) * sstep + x * iscale_x + i];
-                if (iscale_x == 2 && iscale_y == 2) dst[(size_t)y * dstep + x] = (uint8_t)((sum + 2) >> 2);
-                else {
-                    long v = lrintf((float)sum * scale);
-                    dst[(size_t)y * dstep + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+            for (int x = 0; x < dw; x++)
+                for (int c = 0; c < cn; c++) {
+                    int sum = 0;
+                    for (int j = 0; j < iscale_y; j++)
+                        for (int i = 0; i < iscale_x; i++)
+                            sum += src[(size_t)(y * iscale_y + j) * sstep + (size_t)(x * iscale_x + i) * cn + c];
+                    uint8_t* d = dst + (size_t)y * dstep + (size_t)x * cn + c;
+                    if (iscale_x == 2 && iscale_y == 2) *d = (uint8_t)((sum + 2) >> 2);
+                    else {
+                        long v = lrintf((float)sum * scale);
+                        *d = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+                    }
                 }
-            }
         return 0;
     }
     orc_area_run* xt = (orc_area_run*)malloc(sizeof(orc_area_run) * dw);
     orc_area_run* yt = (orc_area_run*)malloc(sizeof(orc_area_run) * dh);
     orc_area_table(sw, dw, xt);
     orc_area_table(sh, dh, yt);
-    float* buf = (float*)malloc(sizeof(float) * dw);
-    float* sum = (float*)malloc(sizeof(float) * dw);
+    float* buf = (float*)malloc(sizeof(float) * dw * cn);
+    float* sum = (float*)malloc(sizeof(float) * dw * cn);
     for (int dy = 0; dy < dh; dy++) {
         for (int j = 0; j < yt[dy].count; j++) {
             const uint8_t* S = src + (size_t)(yt[dy].first + j) * sstep;
             float beta = area_weight(&yt[dy], j);
-            for (int dx = 0; dx < dw; dx++) {
-                float acc = 0.f;
-                for (int k = 0; k < xt[dx].count; k++) {
-                    float term = (float)S[xt[dx].first + k] * area_weight(&xt[dx], k); /* no fused multiply-add */
-                    acc += term;
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    float acc = 0.f;
+                    for (int k = 0; k < xt[dx].count; k++) {
+                        float term = (float)S[(size_t)(xt[dx].first + k) * cn + c] * area_weight(&xt[dx], k); /* no fused multiply-add */
+                        acc += term;
+                    }
+                    buf[dx * cn + c] = acc;
                 }
-                buf[dx] = acc;
-            }
-            for (int dx = 0; dx < dw; dx++) {
-                float term = beta * buf[dx];
-                sum[dx] = j == 0 ? term : sum[dx] + term;
+            for (int i = 0; i < dw * cn; i++) {
+                float term = beta * buf[i];
+                sum[i] = j == 0 ? term : sum[i] + term;
             }
         }
-        for (int dx = 0; dx < dw; dx++) {
-            long v = lrintf(sum[dx]);
-            dst[(size_t)dy * dstep + dx] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        for (int i = 0; i < dw * cn; i++) {
+            long v = lrintf(sum[i]);
+            dst[(size_t)dy * dstep + i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
         }
     }
     free(xt); free(yt); free(buf); free(sum);
     return 0;
+}
+
+int orc_resize_area_u8(const uint8_t* src, size_t sstep, int sh, int sw, uint8_t* dst, size_t dstep, int dh, int dw)
+{
+    return orc_resize_area_u8_cn(src, sstep, sh, sw, 1, dst, dstep, dh, dw);
+}
+
+/* cv2.resize(INTER_NEAREST), 8-bit, cn channels (resize.cpp resizeNN): source index = min(floor(d * scale), size-1)
+ * with scale = 1 / (dst/src) in double. */
+void orc_resize_nearest_u8(const uint8_t* src, size_t sstep, int sh, int sw, int cn, uint8_t* dst, size_t dstep, int dh, int dw)
+{
+    double ifx = 1. / ((double)dw / sw), ify = 1. / ((double)dh / sh);
+    for (int y = 0; y < dh; y++) {
+        int sy = (int)floor(y * ify);
+        if (sy > sh - 1) sy = sh - 1;
+        for (int x = 0; x < dw; x++) {
+            int sx = (int)floor(x * ifx);
+            if (sx > sw - 1) sx = sw - 1;
+            for (int c = 0; c < cn; c++) dst[(size_t)y * dstep + (size_t)x * cn + c] = src[(size_t)sy * sstep + (size_t)sx * cn + c];
+        }
+    }
 }
 
 /* Orthonormal 2-D DCT-II of an n x n float32 block: out = C * in * C^T,

@@ -126,13 +126,16 @@ def resize(src, dsize, interpolation=INTER_LINEAR):
     sh, sw = src.shape[:2]
     cn = 1 if src.ndim == 2 else src.shape[2]
     dw, dh = int(dsize[0]), int(dsize[1])
-    if interpolation == INTER_AREA and cn == 1:
-        dst = np.empty((dh, dw), np.uint8)
-        if _orc.lib().orc_resize_area_u8(src.ctypes.data, sw, sh, sw, dst.ctypes.data, dw, dh, dw) != 0:
+    dst = np.empty((dh, dw) + (() if src.ndim == 2 else (cn,)), np.uint8)
+    if interpolation == INTER_AREA:
+        if _orc.lib().orc_resize_area_u8_cn(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw) != 0:
             raise NotImplementedError("cv2 shim: INTER_AREA only for decimation")
         return dst
+    if interpolation == INTER_NEAREST:
+        _orc.lib().orc_resize_nearest_u8(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw)
+        return dst
     if interpolation != INTER_LINEAR:
-        raise NotImplementedError("cv2 shim: only INTER_LINEAR (and single-channel INTER_AREA)")
+        raise NotImplementedError("cv2 shim: INTER_LINEAR, INTER_NEAREST and INTER_AREA only")
     dst = np.empty((dh, dw) + (() if src.ndim == 2 else (cn,)), np.uint8)
     _orc.lib().orc_resize_linear_u8(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw)
     return dst

@@ -66,13 +66,14 @@ class OracleEngine:
     Lets the host logic (detectors, SceneManager, sharding) be tested without a GPU.  Never used
     by the product."""
 
-    def score_host(self, frames, prev=None, flags=7, edge_kernel=0, downscale=1.0):
+    def score_host(self, frames, prev=None, flags=7, edge_kernel=0, downscale=1.0, interpolation=1):
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
         if downscale > 1.0:
             import cv2  # the shim
 
             def rs(f):
-                return cv2.resize(f, (max(1, round(f.shape[1] / downscale)), max(1, round(f.shape[0] / downscale))))
+                return cv2.resize(f, (max(1, round(f.shape[1] / downscale)), max(1, round(f.shape[0] / downscale))),
+                                  interpolation=interpolation)
 
             frames = np.stack([rs(f) for f in frames])
             prev = rs(prev) if prev is not None else None
@@ -84,13 +85,13 @@ class OracleEngine:
             rec["byte_sum"] = 0
         return rec
 
-    def hash_thumbs_host(self, frames, size, downscale=1.0):
+    def hash_thumbs_host(self, frames, size, downscale=1.0, interpolation=1):
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
         if downscale > 1.0:
             import cv2  # the shim
 
-            frames = np.stack([cv2.resize(f, (max(1, round(f.shape[1] / downscale)), max(1, round(f.shape[0] / downscale))))
-                               for f in frames])
+            frames = np.stack([cv2.resize(f, (max(1, round(f.shape[1] / downscale)), max(1, round(f.shape[0] / downscale))),
+                                          interpolation=interpolation) for f in frames])
         from oracle import lib as _lib
 
         return _lib.hash_thumbs(frames, size)

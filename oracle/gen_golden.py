@@ -124,10 +124,14 @@ def build_detector(cls_name, kwargs):
             "HashDetector": HashDetector}[cls_name](**kw)
 
 
-def run(frames, cls_name, kwargs, with_stats, auto_downscale, fps=25.0):
+def run(frames, cls_name, kwargs, with_stats, auto_downscale, fps=25.0, interpolation=None):
     stats = StatsManager() if with_stats else None
     sm = SceneManager(stats)
     sm.auto_downscale = auto_downscale
+    if interpolation is not None:
+        from scenedetect.common import Interpolation
+
+        sm.interpolation = Interpolation[interpolation]
     det = build_detector(cls_name, kwargs)
     sm.add_detector(det)
     video = MemoryStream(frames, fps)
@@ -260,6 +264,15 @@ def main():
         cls_name, kwargs, with_stats = CONFIGS[cname]
         entry["results"][cname] = run(fr, cls_name, kwargs, with_stats, False)
     golden["clips"]["uniform_u"] = entry
+    # the non-default downscale filters the device implements (scene_manager.py:265-272, common.py:148-160)
+    frames, _ = make_clip(*CLIPS["wide_d"][:4], **CLIPS["wide_d"][4])
+    golden["interp"] = {}
+    for mode in ("NEAREST", "AREA"):
+        golden["interp"][mode] = {}
+        for cname in ("content_stats", "hist_default", "hash_default"):
+            cls_name, kwargs, with_stats = CONFIGS[cname]
+            golden["interp"][mode][cname] = run(frames, cls_name, kwargs, with_stats, True, interpolation=mode)
+            print("wide_d", mode, cname, golden["interp"][mode][cname]["cuts"])
     golden["kats"] = kats()
     golden["scenarios"] = scenarios()
     path = os.path.join(OUT, "reference_runs.json")

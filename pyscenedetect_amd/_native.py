@@ -118,6 +118,7 @@ SYMBOLS = {
     "psd_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "psd_hsv_tables": (_i, [_vp, _vp]),
     "psd_edge_map_device": (_i, [_vp, _vp, _i, _i, _sz, _i, _vp]),
+    "psd_resize_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _sz, _i, _vp]),
     "psd_resize_linear_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _sz, _vp]),
     "psd_hash_thumbs_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp]),
     "psd_hash_thumbs": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp]),

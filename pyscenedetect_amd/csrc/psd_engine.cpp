@@ -43,6 +43,8 @@ int edges_map(psd_engine* e, const uint8_t* d_frame, int height, int width, size
 void edges_release(psd_engine* e);
 int resize_linear(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride,
                   uint8_t* d_dst, int dst_h, int dst_w, size_t dst_frame_stride, hipStream_t stream);
+int resize_other(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
+                 int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream);
 // psd_hash_kernels.hip
 struct AreaRun;
 int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
@@ -519,17 +521,26 @@ int psd_edge_map_device(psd_engine* e, const uint8_t* d_frame, int height, int w
     return psd::edges_map(e, d_frame, height, width, row_stride, edge_kernel, h_edges);
 }
 
+int psd_resize_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride,
+                      uint8_t* d_dst, int dst_h, int dst_w, size_t dst_frame_stride, int interpolation, void* stream)
+{
+    if (!e || n < 0 || (n > 0 && (!d_src || !d_dst)) || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) {
+        psd_set_error("psd_resize_device: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    if (interpolation == PSD_INTER_LINEAR)
+        return psd::resize_linear(d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, s);
+    return psd::resize_other(d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, interpolation, s);
+}
+
 int psd_resize_linear_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w,
                              size_t src_frame_stride, uint8_t* d_dst, int dst_h, int dst_w,
                              size_t dst_frame_stride, void* stream)
 {
-    if (!e || n < 0 || (n > 0 && (!d_src || !d_dst)) || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0) {
-        psd_set_error("psd_resize_linear_device: invalid argument");
-        return PSD_ERR_INVALID;
-    }
-    HIP_TRY(hipSetDevice(e->device));
-    return psd::resize_linear(d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride,
-                              stream ? (hipStream_t)stream : e->stream);
+    return psd_resize_device(e, d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride,
+                             PSD_INTER_LINEAR, stream);
 }
 
 }  // extern "C"

@@ -96,10 +96,10 @@ class ScoringEngine:
 
     # -- host frames -----------------------------------------------------------------------
     def score_host(self, frames: np.ndarray, prev: np.ndarray | None = None, flags: int = SCORE_ALL & ~SCORE_EDGES,
-                   edge_kernel: int = 0, downscale: float = 1.0) -> np.ndarray:
+                   edge_kernel: int = 0, downscale: float = 1.0, interpolation: int = 1) -> np.ndarray:
         """Score ``frames`` uint8[N,H,W,3] (BGR, any row/frame strides) held in host memory."""
         if downscale > 1.0:
-            return self._score_host_downscaled(frames, prev, flags, edge_kernel, downscale)
+            return self._score_host_downscaled(frames, prev, flags, edge_kernel, downscale, interpolation)
         frames = np.asarray(frames)
         if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[3] != 3:
             raise ValueError("frames must be uint8[N,H,W,3]")
@@ -125,7 +125,7 @@ class ScoringEngine:
         )
         return out
 
-    def _score_host_downscaled(self, frames, prev, flags, edge_kernel, factor):
+    def _score_host_downscaled(self, frames, prev, flags, edge_kernel, factor, interpolation=1):
         """Upload, ``cv2.resize(INTER_LINEAR)`` on the device to the reference's target size
         (``scene_manager.py:670-678``), then score the small frames.  ``prev`` is resized too."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
@@ -150,7 +150,7 @@ class ScoringEngine:
                 src.upload(last.reshape(-1), 0)
                 p = 1
             src.upload(frames[done:done + cnt].reshape(-1), p * sstride)
-            self.resize_device(src.ptr, cnt + p, h, w, dst.ptr, dh, dw, dst_frame_stride=dstride)
+            self.resize_device(src.ptr, cnt + p, h, w, dst.ptr, dh, dw, dst_frame_stride=dstride, interpolation=interpolation)
             out[done:done + cnt] = self.score_device(dst.ptr + p * dstride, cnt, dh, dw, dw * 3, dstride,
                                                      d_prev=dst.ptr if p else None, flags=flags, edge_kernel=edge_kernel)
             last = frames[done + cnt - 1]
@@ -158,13 +158,13 @@ class ScoringEngine:
         return out
 
     def score_frames(self, frames, prev=None, flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0,
-                     downscale: float = 1.0) -> np.ndarray:
+                     downscale: float = 1.0, interpolation: int = 1) -> np.ndarray:
         """Score a list of separately allocated host frames (what a decoder hands out) without first
         stacking them on the host: every frame is uploaded straight into one device batch."""
-        return self.analyze_frames(frames, prev, flags, edge_kernel, downscale)[0]
+        return self.analyze_frames(frames, prev, flags, edge_kernel, downscale, interpolation=interpolation)[0]
 
     def analyze_frames(self, frames, prev=None, flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0,
-                       downscale: float = 1.0, hash_size: int = 0):
+                       downscale: float = 1.0, hash_size: int = 0, interpolation: int = 1):
         """One upload of a list of host frames, then (records, thumbs): the score records for ``flags``
         (None if 0) and the grey ``hash_size`` x ``hash_size`` INTER_AREA thumbnails HashDetector needs (None if
         0), both computed from the (optionally downscaled) frames resident in HBM."""
@@ -190,7 +190,8 @@ class ScoringEngine:
             fw, fh = max(1, round(w / downscale)), max(1, round(h / downscale))
             stride = (fh * fw * 3 + 15) & ~15
             buf = self._scratch("fr_dst", (n + 1) * stride)
-            self.resize_device(src.ptr, n + p, h, w, buf.ptr, fh, fw, src_frame_stride=sstride, dst_frame_stride=stride)
+            self.resize_device(src.ptr, n + p, h, w, buf.ptr, fh, fw, src_frame_stride=sstride, dst_frame_stride=stride,
+                               interpolation=interpolation)
         records = thumbs = None
         if flags:
             records = self.score_device(buf.ptr + p * stride, n, fh, fw, fw * 3, stride, d_prev=buf.ptr if p else None,
@@ -210,13 +211,13 @@ class ScoringEngine:
                                                        frame_stride, int(size), out.ctypes.data if n else None))
         return out
 
-    def hash_thumbs_host(self, frames: np.ndarray, size: int, downscale: float = 1.0) -> np.ndarray:
+    def hash_thumbs_host(self, frames: np.ndarray, size: int, downscale: float = 1.0, interpolation: int = 1) -> np.ndarray:
         """Same for frames uint8[N,H,W,3] in host memory (staged in bounded chunks by the engine)."""
         frames = np.asarray(frames)
         if frames.dtype != np.uint8 or frames.ndim != 4 or frames.shape[3] != 3:
             raise ValueError("frames must be uint8[N,H,W,3]")
         if downscale > 1.0:
-            return self.analyze_frames(list(frames), None, 0, 0, downscale, size)[1]
+            return self.analyze_frames(list(frames), None, 0, 0, downscale, size, interpolation)[1]
         if frames.strides[3] != 1 or frames.strides[2] != 3:
             frames = np.ascontiguousarray(frames)
         n, h, w, _ = frames.shape
@@ -239,11 +240,14 @@ class ScoringEngine:
         return buf
 
     def resize_device(self, d_src: int, n: int, src_h: int, src_w: int, d_dst: int, dst_h: int, dst_w: int,
-                      src_frame_stride: int | None = None, dst_frame_stride: int | None = None, stream: int | None = None):
-        """``cv2.resize(frame, (dst_w, dst_h), interpolation=INTER_LINEAR)`` for n packed BGR frames in HBM."""
-        _native.check(self._lib.psd_resize_linear_device(
+                      src_frame_stride: int | None = None, dst_frame_stride: int | None = None, stream: int | None = None,
+                      interpolation: int = 1):
+        """``cv2.resize(frame, (dst_w, dst_h), interpolation=...)`` for n packed BGR frames in HBM; ``interpolation``
+        takes cv2's values (0 NEAREST, 1 LINEAR, 3 AREA)."""
+        _native.check(self._lib.psd_resize_device(
             self._h, d_src, int(n), int(src_h), int(src_w), src_h * src_w * 3 if src_frame_stride is None else src_frame_stride,
-            d_dst, int(dst_h), int(dst_w), dst_h * dst_w * 3 if dst_frame_stride is None else dst_frame_stride, stream))
+            d_dst, int(dst_h), int(dst_w), dst_h * dst_w * 3 if dst_frame_stride is None else dst_frame_stride,
+            int(interpolation), stream))
 
     # -- device frames ---------------------------------------------------------------------
     def score_device(self, d_frames: int, n: int, height: int, width: int, row_stride: int | None = None,

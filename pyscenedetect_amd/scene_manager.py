@@ -31,8 +31,8 @@ DEFAULT_BATCH_FRAMES: int = 64
 
 
 class Interpolation(Enum):
-    """Resize filters of the reference (``scenedetect/common.py:148-160``, values = OpenCV's
-    ``INTER_*``).  Only LINEAR -- the reference's default -- is implemented on the device."""
+    """Resize filters of the reference (``scenedetect/common.py:148-160``, values = OpenCV's ``INTER_*``).
+    LINEAR (the reference's default), NEAREST and AREA are implemented on the device."""
 
     NEAREST = 0
     LINEAR = 1
@@ -109,8 +109,8 @@ class SceneManager:
     @interpolation.setter
     def interpolation(self, value: Interpolation):
         value = Interpolation(value)
-        if value != Interpolation.LINEAR:
-            raise NotImplementedError(f"only Interpolation.LINEAR is implemented on the device, not {value.name}")
+        if value not in (Interpolation.LINEAR, Interpolation.NEAREST, Interpolation.AREA):
+            raise NotImplementedError(f"Interpolation.{value.name} is not implemented on the device")
         self._interpolation = value
 
     @property
@@ -270,6 +270,8 @@ class SceneManager:
                         # Same target size as the reference's cv2.resize call (:670-678).
                         scored_size = (max(1, round(shape[0] / factor)), max(1, round(shape[1] / factor)))
                     kwargs = {"downscale": factor} if factor > 1.0 else {}
+                    if factor > 1.0 and self._interpolation != Interpolation.LINEAR:
+                        kwargs["interpolation"] = self._interpolation.value
                     if hasattr(engine, "analyze_frames"):
                         # frames go to the device one by one: no host-side stacking copy
                         records, thumbs = engine.analyze_frames(frames, prev=last_frame, flags=flags, edge_kernel=edge_kernel,

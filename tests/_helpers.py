@@ -17,10 +17,13 @@ def build_detector(cls_name, kwargs, engine=None):
     return cls(engine=engine, **kw)
 
 
-def run_config(frames, cls_name, kwargs, with_stats, engine, auto_downscale=False, batch_frames=64, fps=25.0):
+def run_config(frames, cls_name, kwargs, with_stats, engine, auto_downscale=False, batch_frames=64, fps=25.0,
+               interpolation=None):
     stats = psd.StatsManager() if with_stats else None
     sm = psd.SceneManager(stats, engine=engine, batch_frames=batch_frames)
     sm.auto_downscale = auto_downscale
+    if interpolation is not None:
+        sm.interpolation = psd.Interpolation[interpolation]
     det = build_detector(cls_name, kwargs, engine)
     sm.add_detector(det)
     video = psd.ArrayVideoStream(frames, fps)

@@ -487,3 +487,45 @@ def test_hash_thumbs_randomised_shapes(hip_engine):
                                                 frame_stride=h * (w + pad) * 3)
         assert np.array_equal(got_dev, want), ("device", n, h, w, size, pad)
         buf.free()
+
+
+# ---- SceneManager.interpolation = NEAREST / AREA --------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [((180, 320), (144, 256)), ((200, 300), (100, 150)), ((97, 131), (41, 77)),
+                                   ((64, 96), (32, 32)), ((1080, 1920), (144, 256)), ((90, 120), (30, 40)),
+                                   ((50, 70), (50, 70))])
+@pytest.mark.parametrize("mode", ["NEAREST", "AREA"])
+def test_resize_nearest_and_area_match_oracle(hip_engine, shape, mode):
+    import cv2  # the oracle shim
+
+    (sh, sw), (dh, dw) = shape
+    inter = {"NEAREST": cv2.INTER_NEAREST, "AREA": cv2.INTER_AREA}[mode]
+    rng = np.random.default_rng(sh * 3 + dw)
+    src = rng.integers(0, 256, (2, sh, sw, 3), dtype=np.uint8)
+    src[1, : sh // 2] = 255
+    a = hip_engine.alloc(src.nbytes)
+    a.upload(src.reshape(-1))
+    b = hip_engine.alloc(2 * dh * dw * 3)
+    hip_engine.resize_device(a.ptr, 2, sh, sw, b.ptr, dh, dw, interpolation=inter)
+    got = b.download().reshape(2, dh, dw, 3)
+    for i in range(2):
+        want = cv2.resize(src[i], (dw, dh), interpolation=inter)
+        assert np.array_equal(got[i], want), f"{mode} {sh}x{sw}->{dh}x{dw}: {np.count_nonzero(got[i] != want)} bytes differ"
+
+
+def test_resize_unsupported_modes(hip_engine):
+    a = hip_engine.alloc(64 * 64 * 3)
+    b = hip_engine.alloc(128 * 128 * 3)
+    with pytest.raises(NotImplementedError):
+        hip_engine.resize_device(a.ptr, 1, 64, 64, b.ptr, 32, 32, interpolation=2)     # CUBIC
+    with pytest.raises(NotImplementedError):
+        hip_engine.resize_device(a.ptr, 1, 64, 64, b.ptr, 128, 128, interpolation=3)   # AREA is decimation only
+
+
+def test_downscale_interpolation_modes_golden_through_hip(golden, hip_engine):
+    frames = golden_clip(golden, "wide_d")
+    for mode, runs in golden["interp"].items():
+        for name, want in runs.items():
+            cls_name, kwargs, with_stats = golden["configs"][name]
+            got = run_config(frames, cls_name, kwargs, with_stats, hip_engine, auto_downscale=True, interpolation=mode)
+            assert_same_run(got, want, f"wide_d/{mode}/{name}")

@@ -190,6 +190,22 @@ def test_auto_downscale_matches_reference(golden, oracle_engine):
         assert_same_run(got, golden["clips"]["wide_d"]["results"][name], f"wide_d/{name}")
 
 
+def test_downscale_interpolation_modes_match_reference(golden, oracle_engine):
+    """SceneManager.interpolation = NEAREST / AREA (reference scene_manager.py:265-272): the downscale in front of the
+    detectors uses the requested cv2.resize filter."""
+    frames = golden_clip(golden, "wide_d")
+    for mode, runs in golden["interp"].items():
+        for name, want in runs.items():
+            cls_name, kwargs, with_stats = golden["configs"][name]
+            got = run_config(frames, cls_name, kwargs, with_stats, oracle_engine, auto_downscale=True, interpolation=mode)
+            assert_same_run(got, want, f"wide_d/{mode}/{name}")
+    sm = psd.SceneManager(engine=oracle_engine)
+    with pytest.raises(NotImplementedError):
+        sm.interpolation = psd.Interpolation.CUBIC
+    with pytest.raises(NotImplementedError):
+        sm.interpolation = psd.Interpolation.LANCZOS4
+
+
 # ---- plug-in surface: constructor validation, metric keys, look-behind (oracle/gen_api_golden.py) -------------------
 
 def _api_cases():
