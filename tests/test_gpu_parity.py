@@ -529,3 +529,14 @@ def test_downscale_interpolation_modes_golden_through_hip(golden, hip_engine):
             cls_name, kwargs, with_stats = golden["configs"][name]
             got = run_config(frames, cls_name, kwargs, with_stats, hip_engine, auto_downscale=True, interpolation=mode)
             assert_same_run(got, want, f"wide_d/{mode}/{name}")
+
+
+def test_hash_thumbs_host_batches_larger_than_one_staging_chunk(hip_engine):
+    """Host frames are staged in 256 MiB chunks; the thumbnails must not depend on where the chunks end."""
+    rng = np.random.default_rng(4)
+    n, h, w = 47, 1080, 1920                      # 292 MB: two chunks
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    got = hip_engine.hash_thumbs_host(frames, 16)
+    one_by_one = np.stack([hip_engine.hash_thumbs_host(frames[i : i + 1], 16)[0] for i in (0, 42, 43, 46)])
+    assert np.array_equal(got[[0, 42, 43, 46]], one_by_one)
+    assert np.array_equal(got[-1], orc.hash_thumbs(frames[-1:], 16)[0])
