@@ -254,3 +254,23 @@ def test_dct_matches_scipy_and_hash_bits_are_balanced():
     assert bits.shape == (5, 16, 16)
     assert all(b.sum() == 128 for b in bits[:4])  # strictly-above-median of 256 distinct values
     assert bits[4].sum() == 0
+
+
+def test_nearest_and_multichannel_area_resize():
+    import cv2  # the oracle shim
+
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    for (dh, dw) in ((41, 77), (97, 131), (10, 13), (48, 65)):
+        got = cv2.resize(img, (dw, dh), interpolation=cv2.INTER_NEAREST)
+        ys = np.minimum(np.floor(np.arange(dh) * (1.0 / (dh / 97))).astype(int), 96)
+        xs = np.minimum(np.floor(np.arange(dw) * (1.0 / (dw / 131))).astype(int), 130)
+        assert np.array_equal(got, img[ys][:, xs])
+        # INTER_AREA treats the interleaved channels independently
+        area = cv2.resize(img, (dw, dh), interpolation=cv2.INTER_AREA)
+        for c in range(3):
+            assert np.array_equal(area[..., c], cv2.resize(np.ascontiguousarray(img[..., c]), (dw, dh), interpolation=cv2.INTER_AREA))
+    with pytest.raises(NotImplementedError):
+        cv2.resize(img, (200, 200), interpolation=cv2.INTER_AREA)
+    with pytest.raises(NotImplementedError):
+        cv2.resize(img, (50, 50), interpolation=cv2.INTER_CUBIC)
