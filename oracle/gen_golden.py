@@ -26,6 +26,7 @@ sys.path[:0] = [os.path.join(HERE, "cv2_shim"), ROOT, "/root/reference"]
 import numpy as np  # noqa: E402
 import scenedetect  # noqa: E402  (the reference)
 from scenedetect import FrameTimecode  # noqa: E402
+from scenedetect.common import Timecode  # noqa: E402
 from scenedetect.detector import FlashFilter  # noqa: E402
 from scenedetect.detectors import (AdaptiveDetector, ContentDetector, HashDetector, HistogramDetector,  # noqa: E402
                                    ThresholdDetector)
@@ -71,6 +72,26 @@ class MemoryStream(VideoStream):
 
     def seek(self, target):
         self._next = int(target)
+
+
+class VfrMemoryStream(MemoryStream):
+    """Positions are presentation timestamps (what the reference's PyAV backend reports, backends/pyav.py): frame i
+    is shown at pts[i] ticks of `time_base`; the nominal frame rate is only an average."""
+
+    def __init__(self, frames, fps, pts, time_base):
+        super().__init__(frames, fps)
+        self._pts = pts
+        self._tb = time_base
+
+    position = property(lambda self: FrameTimecode(Timecode(self._pts[max(0, self._next - 1)], self._tb), self._fps))
+    duration = property(lambda self: FrameTimecode(Timecode(self._pts[-1], self._tb), self._fps))
+
+
+def vfr_pts(n, seed=5):
+    """Irregular frame durations: 40 ms nominal, with 20 / 60 / 80 ms outliers."""
+    rng = np.random.default_rng(seed)
+    steps = rng.choice([20, 40, 40, 40, 40, 60, 80], size=n - 1)
+    return [0] + [int(x) for x in np.cumsum(steps)]
 
 
 # name -> (seed, n_frames, height, width, make_clip kwargs)
@@ -273,6 +294,22 @@ def main():
             cls_name, kwargs, with_stats = CONFIGS[cname]
             golden["interp"][mode][cname] = run(frames, cls_name, kwargs, with_stats, True, interpolation=mode)
             print("wide_d", mode, cname, golden["interp"][mode][cname]["cuts"])
+    # variable frame rate: PTS-backed positions through the unmodified SceneManager / detectors
+    frames, _ = make_clip(*CLIPS["scenes_a"][:4], **CLIPS["scenes_a"][4])
+    pts = vfr_pts(len(frames))
+    golden["vfr"] = {"clip": "scenes_a", "pts_seed": 5, "time_base": [1, 1000], "fps": 25.0, "results": {}}
+    for cname in ("content_default", "content_kernel5_secs", "adaptive_w3", "hist_default", "threshold_final", "hash_8_lp4_secs"):
+        cls_name, kwargs, with_stats = CONFIGS[cname]
+        sm = SceneManager(StatsManager() if with_stats else None)
+        sm.auto_downscale = False
+        sm.add_detector(build_detector(cls_name, kwargs))
+        n = sm.detect_scenes(VfrMemoryStream(frames, 25.0, pts, Fraction(1, 1000)))
+        cuts = sm.get_cut_list(show_warning=False)
+        golden["vfr"]["results"][cname] = {
+            "frames_processed": n,
+            "cuts": [[c.frame_num, c.pts, c.seconds, c.get_timecode()] for c in cuts],
+            "scenes": [[a.pts, b.pts, a.get_timecode(), b.get_timecode()] for a, b in sm.get_scene_list()]}
+        print("vfr", cname, [c.pts for c in cuts])
     golden["kats"] = kats()
     golden["scenarios"] = scenarios()
     path = os.path.join(OUT, "reference_runs.json")

@@ -15,7 +15,7 @@ from fractions import Fraction
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(HERE, "cv2_shim"), os.path.dirname(HERE), "/root/reference"]
 
-from scenedetect.common import FrameTimecode, framerate_to_fraction  # noqa: E402
+from scenedetect.common import FrameTimecode, Timecode, framerate_to_fraction  # noqa: E402
 
 FPS = [1.0, 10.0, 23.976, 24.0, 25.0, 29.97, 30.0, 59.94, 60.0, 120.0, [24000, 1001], [30000, 1001], [60000, 1001]]
 VALUES = [0, 1, 10, 99, 1001, 86400, 0.0, 0.5, 1.0, 2.41, 10.0, 59.999, 3600.5, "0", "100", "00:00:01", "00:01:00.500",
@@ -93,6 +93,56 @@ def main():
         a, b = FrameTimecode(10, 25.0), FrameTimecode(10, 30.0)
         return {"eq": a == b} if op == "eq" else {"frame_num": (a + b).frame_num} if op == "add" else {"lt": a < b}
     out["cross_rate"] = [{"op": op, **outcome(lambda: cross(op))} for op in ("eq", "add", "lt")]
+    # ---- presentation-timestamp backed values (variable frame rate decoders) --------------------------------------
+    # operand encoding: ["pts", pts, [num, den]] = FrameTimecode(Timecode(pts, Fraction(num, den)), fps);
+    #                   ["bare", pts, [num, den]] = a bare Timecode; anything else is passed as is / wrapped as before
+    def mk(x, f):
+        if isinstance(x, list) and x[0] == "pts":
+            return FrameTimecode(Timecode(x[1], Fraction(*x[2])), fps_of(f))
+        if isinstance(x, list) and x[0] == "bare":
+            return Timecode(x[1], Fraction(*x[2]))
+        if isinstance(x, list) and x[0] == "tc":
+            return FrameTimecode(x[1], fps_of(f))
+        return x
+
+    PTS = [["pts", 0, [1, 1000]], ["pts", 1, [1, 1000]], ["pts", 40, [1, 1000]], ["pts", 1001, [1, 30000]],
+           ["pts", 2002, [1, 30000]], ["pts", 90000, [1, 90000]], ["pts", 93753, [1, 90000]], ["pts", 417, [1, 10000]],
+           ["pts", 12345678, [1, 1000000]], ["pts", 3, [1001, 30000]]]
+    OTHERS = PTS[:6] + [["bare", 40, [1, 1000]], ["bare", 3003, [1, 30000]], ["tc", 1], ["tc", 10], ["tc", 0.5],
+                        ["tc", "00:00:01.500"], 0, 1, 25, 0.04, 1.0, "00:00:00.040", "2", "0.5s"]
+    out["pts_describe"] = []
+    for f in (25.0, 29.97, [30000, 1001], 1000.0):
+        for a in PTS:
+            def d():
+                tc = mk(a, f)
+                r = describe(tc)
+                r.update({"pts": _field(lambda: tc.pts), "time_base": _field(lambda: [tc.time_base.numerator, tc.time_base.denominator]),
+                          "repr": _field(lambda: repr(tc)), "tc_exact": _field(lambda: tc.get_timecode(nearest_frame=False))})
+                return r
+            out["pts_describe"].append({"a": a, "fps": f, **outcome(d)})
+    out["pts_arith"], out["pts_compare"] = [], []
+    for f in (25.0, [30000, 1001]):
+        for a in PTS + [["tc", 5], ["tc", 0.2]]:
+            for b in OTHERS:
+                if not (isinstance(a, list) and a[0] == "pts") and not (isinstance(b, list) and b[0] in ("pts", "bare")):
+                    continue   # no PTS involved: covered above
+                for op in ("add", "sub"):
+                    def run():
+                        x, y = mk(a, f), mk(b, f)
+                        r = x + y if op == "add" else x - y
+                        return {"frame_num": r.frame_num, "seconds": r.seconds, "pts": r.pts,
+                                "time_base": [r.time_base.numerator, r.time_base.denominator], "repr": repr(r)}
+                    out["pts_arith"].append({"a": a, "b": b, "fps": f, "op": op, **outcome(run)})
+                def cmp():
+                    x, y = mk(a, f), mk(b, f)
+                    return {"eq": x == y, "ne": x != y, "lt": x < y, "le": x <= y, "gt": x > y, "ge": x >= y}
+                out["pts_compare"].append({"a": a, "b": b, "fps": f, **outcome(cmp)})
+    # two PTS-backed values of different nominal rates compare by frame number, not exactly
+    def cross_pts():
+        x = FrameTimecode(Timecode(1001, Fraction(1, 30000)), 25.0)
+        y = FrameTimecode(Timecode(1001, Fraction(1, 30000)), 30.0)
+        return {"eq": x == y, "lt": x < y, "hash_x": hash(x), "hash_y": hash(y)}
+    out["pts_cross_rate"] = outcome(cross_pts)
     path = os.path.join(os.path.dirname(HERE), "tests", "golden", "timecode_cases.json")
     with open(path, "w") as fh:
         json.dump(out, fh, separators=(",", ":"))

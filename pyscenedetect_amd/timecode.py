@@ -1,25 +1,42 @@
 """Frame-accurate time values for the host side of the scoring engine.
 
-Mirror of the subset of ``scenedetect.common.FrameTimecode`` (reference
-``scenedetect/common.py:191-810``) that the detector hot path touches: a position is either an
-exact frame number or a number of seconds, always paired with a rational frame rate.  Compare /
-subtract semantics follow the reference for those two representations:
+Mirror of ``scenedetect.common.FrameTimecode`` / ``Timecode`` (reference ``scenedetect/common.py:163-174,191-860``) as
+the detector hot path sees them.  A position is held in one of three forms, always next to a rational frame rate:
 
-* comparing with an ``int`` compares frame numbers; with a ``float``/``str`` the other side is
-  first converted to frames with ``round(seconds * fps)`` (``common.py:480-486,535-556``);
-* ``a - b`` clamps at zero (``common.py:700-755``);
+* ``"frames"``  an exact frame number (what constant-frame-rate decoders hand out);
+* ``"seconds"`` a float number of seconds (``float`` / ``"HH:MM:SS.nnn"`` / ``"1.5s"`` inputs);
+* ``"pts"``     a presentation timestamp ``pts * time_base`` (:class:`Timecode`; what PyAV-style decoders of variable
+  frame rate video hand out).
+
+Semantics follow the reference for every pair of forms:
+
+* comparing with an ``int`` compares frame numbers; two timecodes compare by frame number, except two PTS-backed ones
+  of the same nominal rate, which compare as exact rationals (``common.py:822-860``); a float/str operand is compared
+  in seconds when this side is seconds- or PTS-backed, else converted with ``round(seconds * fps)``;
+* ``a + b`` / ``a - b`` keep the form of the PTS-backed operand (finer time base when both are), else of ``a``; results
+  clamp at zero (``common.py:640-760``);
 * the hash is the frame number, so an ``int`` can index a stats dictionary (``common.py:783-791``).
-
-PTS-backed (variable frame rate) timecodes come from video decoders, which are outside this
-package's scope, and are not modelled.
 """
 
+from dataclasses import dataclass
 from fractions import Fraction
 
 MAX_FPS_DELTA = 1.0 / 1000000000.0
 _NTSC_TOLERANCE = 1e-3
 
 TimecodeLike = "int | float | str | FrameTimecode"
+
+
+@dataclass(frozen=True)
+class Timecode:
+    """Presentation timestamp of a frame: ``pts`` ticks of ``time_base`` seconds (reference ``common.py:163-174``)."""
+
+    pts: int
+    time_base: Fraction
+
+    @property
+    def seconds(self) -> float:
+        return float(self.time_base * self.pts)
 
 
 def framerate_to_fraction(fps) -> Fraction:
@@ -61,15 +78,15 @@ def parse_timecode_seconds(text: str, rate: Fraction) -> float:
 
 
 class FrameTimecode:
-    """A position in a constant-frame-rate video: frame number or seconds, plus the frame rate."""
+    """A position in a video: frame number, seconds, or presentation timestamp, plus the frame rate."""
 
-    __slots__ = ("_frames", "_secs", "_rate")
+    __slots__ = ("_frames", "_secs", "_pts", "_rate")
 
     def __init__(self, timecode, fps=None):
         if _is_foreign_timecode(timecode):
-            timecode = FrameTimecode(int(timecode.frame_num), framerate_to_fraction(timecode.frame_rate))
+            timecode = _adopt_foreign(timecode)
         if isinstance(timecode, FrameTimecode):
-            self._frames, self._secs = timecode._frames, timecode._secs
+            self._frames, self._secs, self._pts = timecode._frames, timecode._secs, timecode._pts
             self._rate = timecode._rate if fps is None else _as_rate(fps)
             return
         if fps is None:
@@ -77,6 +94,10 @@ class FrameTimecode:
         self._rate = _as_rate(fps)
         self._frames = None
         self._secs = None
+        self._pts = None
+        if isinstance(timecode, Timecode):
+            self._pts = timecode
+            return
         if isinstance(timecode, str) and timecode.isdigit():
             timecode = int(timecode)
         if isinstance(timecode, str):
@@ -99,19 +120,41 @@ class FrameTimecode:
 
     @property
     def frame_num(self) -> int:
+        """Frame number; for PTS-backed values an approximation from the nominal rate."""
+        if self._pts is not None:
+            return round(self._pts.seconds * float(self._rate))
         if self._frames is not None:
             return self._frames
         return round(self._secs * self._rate)
 
     @property
     def seconds(self) -> float:
+        if self._pts is not None:
+            return self._pts.seconds
         if self._secs is not None:
             return self._secs
         return float(self._frames / self._rate)
 
-    def get_timecode(self, precision: int = 3, use_rounding: bool = True) -> str:
-        """``HH:MM:SS.nnn`` snapped to the frame boundary (reference ``common.py:421-465``)."""
-        secs = self.frame_num / float(self._rate)
+    @property
+    def time_base(self) -> Fraction:
+        return self._pts.time_base if self._pts is not None else 1 / self._rate
+
+    @property
+    def pts(self) -> int:
+        return self._pts.pts if self._pts is not None else self.frame_num
+
+    def equal_frame_rate(self, other) -> bool:
+        if isinstance(other, FrameTimecode):
+            other = other._rate
+        return abs(float(self._rate) - float(other)) < MAX_FPS_DELTA
+
+    def get_timecode(self, precision: int = 3, use_rounding: bool = True, nearest_frame: bool = True) -> str:
+        """``HH:MM:SS.nnn``; frame- and seconds-backed values snap to the frame boundary, a PTS already is one
+        (reference ``common.py:421-465``)."""
+        if nearest_frame and self._pts is None:
+            secs = self.frame_num / float(self._rate)
+        else:
+            secs = self.seconds
         hrs = int(secs / 3600.0)
         secs -= hrs * 3600.0
         mins = int(secs / 60.0)
@@ -138,10 +181,12 @@ class FrameTimecode:
             return round(other * self._rate)
         if isinstance(other, str):
             return round(parse_timecode_seconds(other, self._rate) * self._rate)
+        if isinstance(other, Timecode):
+            return round(other.seconds * self._rate)
         if isinstance(other, FrameTimecode):
-            if other._rate != self._rate and abs(float(other._rate) - float(self._rate)) > MAX_FPS_DELTA:
+            if not self.equal_frame_rate(other._rate):
                 raise ValueError("FrameTimecode instances require equal frame rate for frame-based arithmetic.")
-            return other._frames if other._frames is not None else round(other._secs * self._rate)
+            return other._frames if other._frames is not None else round(other.seconds * self._rate)
         raise TypeError("Cannot obtain frame number for this timecode.")
 
     def _seconds_of(self, other) -> float:
@@ -153,7 +198,7 @@ class FrameTimecode:
             return other
         if isinstance(other, str):
             return parse_timecode_seconds(other, self._rate)
-        if isinstance(other, FrameTimecode):
+        if isinstance(other, (Timecode, FrameTimecode)):
             return other.seconds
         raise TypeError("Unsupported type for performing arithmetic with FrameTimecode.")
 
@@ -162,11 +207,13 @@ class FrameTimecode:
         if _is_foreign_timecode(other):
             other = FrameTimecode(other)
         if isinstance(other, FrameTimecode):
+            if self._pts is not None and other._pts is not None and self._rate == other._rate:
+                return self._pts.pts * self._pts.time_base, other._pts.pts * other._pts.time_base
             return self.frame_num, other.frame_num
         if isinstance(other, int):
             return self.frame_num, other
-        if self._secs is not None:
-            return self._secs, self._seconds_of(other)
+        if self._frames is None:
+            return self.seconds, self._seconds_of(other)
         return self._frames, self._frames_of(other)
 
     def __eq__(self, other):
@@ -199,8 +246,27 @@ class FrameTimecode:
 
     # -- arithmetic --------------------------------------------------------------------------------
     def _shifted(self, other, sign: int) -> "FrameTimecode":
+        if _is_foreign_timecode(other):
+            other = FrameTimecode(other)
         out = FrameTimecode(self)
-        if self._secs is not None:
+        theirs = other._pts if isinstance(other, FrameTimecode) else (other if isinstance(other, Timecode) else None)
+        mine = self._pts
+        if mine is not None and theirs is not None:
+            base = mine.time_base
+            a, b = mine.pts, theirs.pts
+            if theirs.time_base != base:   # keep the finer of the two time bases
+                base = min(mine.time_base, theirs.time_base)
+                a = round(Fraction(mine.pts) * mine.time_base / base)
+                b = round(Fraction(theirs.pts) * theirs.time_base / base)
+            out._pts = Timecode(max(0, a + sign * b), base)
+        elif mine is not None:
+            ticks = round(self._seconds_of(other) / mine.time_base)
+            out._pts = Timecode(max(0, mine.pts + sign * ticks), mine.time_base)
+        elif theirs is not None:
+            ticks = round(self.seconds / theirs.time_base)
+            out._frames = out._secs = None
+            out._pts = Timecode(max(0, theirs.pts + ticks if sign > 0 else ticks - theirs.pts), theirs.time_base)
+        elif self._secs is not None:
             if isinstance(other, FrameTimecode) and other._secs is not None:
                 delta = other._secs
             else:
@@ -226,6 +292,8 @@ class FrameTimecode:
         return self.get_timecode()
 
     def __repr__(self):
+        if self._pts is not None:
+            return f"{self.get_timecode()} [pts={self._pts.pts}, time_base={self._pts.time_base}]"
         if self._secs is not None:
             return f"{self.get_timecode()} [seconds={self._secs}, fps={self._rate}]"
         return f"{self.get_timecode()} [frame_num={self._frames}, fps={self._rate}]"
@@ -233,7 +301,16 @@ class FrameTimecode:
 
 def _is_foreign_timecode(obj) -> bool:
     """Another library's frame timecode (e.g. ``scenedetect.FrameTimecode``): duck-typed."""
-    return not isinstance(obj, FrameTimecode) and hasattr(obj, "frame_num") and hasattr(obj, "frame_rate")
+    return not isinstance(obj, (FrameTimecode, Timecode)) and hasattr(obj, "frame_num") and hasattr(obj, "frame_rate")
+
+
+def _adopt_foreign(obj) -> "FrameTimecode":
+    """Take over a foreign timecode, keeping its presentation timestamp when it has one."""
+    rate = framerate_to_fraction(obj.frame_rate)
+    inner = getattr(obj, "_time", None)
+    if inner is not None and hasattr(inner, "pts") and hasattr(inner, "time_base"):
+        return FrameTimecode(Timecode(int(inner.pts), Fraction(inner.time_base)), rate)
+    return FrameTimecode(int(obj.frame_num), rate)
 
 
 def _as_rate(fps) -> Fraction:

@@ -13,13 +13,21 @@ from fractions import Fraction
 
 import numpy as np
 
-from pyscenedetect_amd.timecode import FrameTimecode
+from pyscenedetect_amd.timecode import FrameTimecode, Timecode
 
 
 class ArrayVideoStream:
     """In-memory BGR frames ``uint8[N,H,W,3]`` (or any indexable of ``uint8[H,W,3]``)."""
 
-    def __init__(self, frames, fps: float | Fraction = 25.0, name: str = "array"):
+    def __init__(self, frames, fps: float | Fraction = 25.0, name: str = "array", pts=None, time_base: Fraction | None = None):
+        """``pts`` / ``time_base``: optional presentation timestamps (one per frame), for frames that came out of a
+        variable-frame-rate decoder; positions are then PTS-backed like those of the reference's PyAV backend."""
+        if (pts is None) != (time_base is None):
+            raise ValueError("pts and time_base go together")
+        if pts is not None and len(pts) != len(frames):
+            raise ValueError("one presentation timestamp per frame is required")
+        self._pts = pts
+        self._time_base = Fraction(time_base) if time_base is not None else None
         self._frames = frames
         self._n = len(frames)
         first = np.asarray(frames[0]) if self._n else np.zeros((0, 0, 3), np.uint8)
@@ -43,6 +51,8 @@ class ArrayVideoStream:
 
     @property
     def duration(self) -> FrameTimecode:
+        if self._pts is not None and self._n:
+            return FrameTimecode(Timecode(int(self._pts[-1]), self._time_base), self._base.frame_rate)
         return self._base + self._n
 
     @property
@@ -53,6 +63,8 @@ class ArrayVideoStream:
     @property
     def position(self) -> FrameTimecode:
         """Timecode of the last frame read (frame 0 before any read)."""
+        if self._pts is not None and self._n:
+            return FrameTimecode(Timecode(int(self._pts[max(0, self._next - 1)]), self._time_base), self._base.frame_rate)
         return self._base + max(0, self._next - 1)
 
     def read(self, decode: bool = True):

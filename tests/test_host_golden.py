@@ -252,3 +252,28 @@ def test_rejected_frames_and_manager_properties_match_reference(oracle_engine):
         sm.add_detector(getattr(psd, cls)(engine=oracle_engine, **kw))
         sizes.append(sm._frame_buffer_size)
     assert {"ok": sizes} == cases["frame_buffer_sizes"]
+
+
+def test_variable_frame_rate_positions_match_reference(golden, oracle_engine):
+    """PTS-backed positions (what the reference's PyAV backend reports for VFR video) through SceneManager and the
+    detectors: cuts and scene boundaries carry the same presentation timestamps as the reference's."""
+    from fractions import Fraction
+
+    from tests._helpers import build_detector
+
+    v = golden["vfr"]
+    frames = golden_clip(golden, v["clip"])
+    rng = np.random.default_rng(v["pts_seed"])
+    steps = rng.choice([20, 40, 40, 40, 40, 60, 80], size=len(frames) - 1)
+    pts = [0] + [int(x) for x in np.cumsum(steps)]
+    for name, want in v["results"].items():
+        cls_name, kwargs, with_stats = golden["configs"][name]
+        sm = psd.SceneManager(psd.StatsManager() if with_stats else None, engine=oracle_engine, batch_frames=48)
+        sm.auto_downscale = False
+        sm.add_detector(build_detector(cls_name, kwargs, oracle_engine))
+        n = sm.detect_scenes(psd.ArrayVideoStream(frames, v["fps"], pts=pts, time_base=Fraction(*v["time_base"])))
+        assert n == want["frames_processed"], name
+        cuts = [[c.frame_num, c.pts, c.seconds, c.get_timecode()] for c in sm.get_cut_list()]
+        assert cuts == want["cuts"], f"{name}: {cuts} vs {want['cuts']}"
+        scenes = [[a.pts, b.pts, a.get_timecode(), b.get_timecode()] for a, b in sm.get_scene_list()]
+        assert scenes == want["scenes"], name

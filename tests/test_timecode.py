@@ -156,3 +156,51 @@ def test_cross_rate_behaviour_matches_reference():
             op = c["op"]
             return {"eq": a == b} if op == "eq" else {"frame_num": (a + b).frame_num} if op == "add" else {"lt": a < b}
         _same(_outcome(run), {k: c[k] for k in ("ok", "raises") if k in c}, f"cross-rate {c['op']}")
+
+
+# ---- presentation-timestamp backed timecodes (same fixture file) ---------------------------------------------
+
+from pyscenedetect_amd.timecode import Timecode as _PTS
+
+
+def _mk(x, f):
+    if isinstance(x, list) and x[0] == "pts":
+        return _TC(_PTS(x[1], Fraction(*x[2])), _fps(f))
+    if isinstance(x, list) and x[0] == "bare":
+        return _PTS(x[1], Fraction(*x[2]))
+    if isinstance(x, list) and x[0] == "tc":
+        return _TC(x[1], _fps(f))
+    return x
+
+
+def test_pts_backed_views_match_reference():
+    for c in _CASES["pts_describe"]:
+        def d():
+            tc = _mk(c["a"], c["fps"])
+            r = _describe(tc)
+            r.update({"pts": _field(lambda: tc.pts),
+                      "time_base": _field(lambda: [tc.time_base.numerator, tc.time_base.denominator]),
+                      "repr": _field(lambda: repr(tc)), "tc_exact": _field(lambda: tc.get_timecode(nearest_frame=False))})
+            return r
+        _same(_outcome(d), {k: c[k] for k in ("ok", "raises") if k in c}, f"{c['a']} @ {c['fps']}")
+
+
+def test_pts_backed_arithmetic_matches_reference():
+    for c in _CASES["pts_arith"]:
+        def run():
+            x, y = _mk(c["a"], c["fps"]), _mk(c["b"], c["fps"])
+            r = x + y if c["op"] == "add" else x - y
+            return {"frame_num": r.frame_num, "seconds": r.seconds, "pts": r.pts,
+                    "time_base": [r.time_base.numerator, r.time_base.denominator], "repr": repr(r)}
+        _same(_outcome(run), {k: c[k] for k in ("ok", "raises") if k in c}, f"{c['a']} {c['op']} {c['b']} @ {c['fps']}")
+
+
+def test_pts_backed_comparisons_match_reference():
+    for c in _CASES["pts_compare"]:
+        def run():
+            x, y = _mk(c["a"], c["fps"]), _mk(c["b"], c["fps"])
+            return {"eq": x == y, "ne": x != y, "lt": x < y, "le": x <= y, "gt": x > y, "ge": x >= y}
+        _same(_outcome(run), {k: c[k] for k in ("ok", "raises") if k in c}, f"{c['a']} vs {c['b']} @ {c['fps']}")
+    x = _TC(_PTS(1001, Fraction(1, 30000)), 25.0)
+    y = _TC(_PTS(1001, Fraction(1, 30000)), 30.0)
+    assert {"ok": {"eq": x == y, "lt": x < y, "hash_x": hash(x), "hash_y": hash(y)}} == _CASES["pts_cross_rate"]
