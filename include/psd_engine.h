@@ -156,7 +156,8 @@ int psd_hash_thumbs(psd_engine* e, const uint8_t* h_frames, int n, int height, i
  * Frame positions are frame numbers first_frame .. first_frame+n-1 at a constant frame rate
  * fps_num/fps_den.  min_scene_len is given either in frames (min_len_frames >= 0 and
  * min_len_secs < 0) or in seconds (min_len_secs >= 0), like the reference's TimecodeLike.
- * Cut frame numbers are written to cuts[0..*n_cuts) (capacity n+1). */
+ * Cut frame numbers are written to cuts[0..*n_cuts) (capacity n+1).  Constant frame rate only: positions that are
+ * presentation timestamps (variable frame rate sources) are decided frame by frame by the host-language detectors. */
 
 typedef struct psd_content_params {
     double threshold;        /* ContentDetector(threshold=27.0) */
