@@ -117,6 +117,25 @@ def main():
             sizes.append(sm._frame_buffer_size)
         return sizes
     out["frame_buffer_sizes"] = outcome(buffer_sizes)
+    # FlashFilter driven directly with random above/below-threshold sequences: which cuts come out, and WHEN
+    # (merge mode emits late), for frame- and time-based lengths at several frame rates (detector.py:106-224)
+    rng = np.random.default_rng(77)
+    out["flash_filter"] = []
+    for case in range(48):
+        fps = [25.0, 29.97, 10.0, 60.0][case % 4]
+        length = [15, 0, 1, 7, 0.5, 1.2, "00:00:00.300", "20", 40, 0.0, "0.8s", 3][case % 12]
+        mode = "MERGE" if (case // 4) % 2 == 0 else "SUPPRESS"
+        n = 220
+        density = [0.02, 0.1, 0.3, 0.6][(case // 12) % 4]
+        above = (rng.random(n) < density).tolist()
+        def drive():
+            flt = FlashFilter(FlashFilter.Mode[mode], length)
+            emitted = []
+            for i, a in enumerate(above):
+                for c in flt.filter(FrameTimecode(i, fps), bool(a)):
+                    emitted.append([i, c.frame_num])
+            return {"emitted": emitted, "max_behind": int(flt.max_behind)}
+        out["flash_filter"].append({"fps": fps, "length": length, "mode": mode, "above": [int(a) for a in above], **outcome(drive)})
     path = os.path.join(os.path.dirname(HERE), "tests", "golden", "api_cases.json")
     with open(path, "w") as fh:
         json.dump(out, fh, separators=(",", ":"))

@@ -277,3 +277,16 @@ def test_variable_frame_rate_positions_match_reference(golden, oracle_engine):
         assert cuts == want["cuts"], f"{name}: {cuts} vs {want['cuts']}"
         scenes = [[a.pts, b.pts, a.get_timecode(), b.get_timecode()] for a, b in sm.get_scene_list()]
         assert scenes == want["scenes"], name
+
+
+def test_flash_filter_random_sequences_match_reference():
+    """FlashFilter fed with random above/below sequences: same cuts, emitted while processing the same frames."""
+    for c in _api_cases()["flash_filter"]:
+        def drive():
+            flt = FlashFilter(FlashFilter.Mode[c["mode"]], c["length"])
+            emitted = []
+            for i, a in enumerate(c["above"]):
+                for cut in flt.filter(FrameTimecode(i, c["fps"]), bool(a)):
+                    emitted.append([i, cut.frame_num])
+            return {"emitted": emitted, "max_behind": int(flt.max_behind)}
+        assert _outcome(drive) == {k: c[k] for k in ("ok", "raises") if k in c}, (c["fps"], c["length"], c["mode"])
