@@ -8,7 +8,8 @@ path): :class:`SceneManager`, :class:`ContentDetector`, :class:`AdaptiveDetector
 
 from pyscenedetect_amd.detector import FlashFilter, SceneDetector
 from pyscenedetect_amd.detectors import AdaptiveDetector, ContentDetector, HashDetector, HistogramDetector, ThresholdDetector
-from pyscenedetect_amd.scene_manager import Interpolation, SceneManager, compute_downscale_factor, get_scenes_from_cuts
+from pyscenedetect_amd.scene_manager import (Interpolation, SceneManager, compute_downscale_factor, expand_scenes_to_bounds,
+                                             get_scenes_from_cuts)
 from pyscenedetect_amd.stats_manager import StatsFileCorrupt, StatsManager
 from pyscenedetect_amd.timecode import FrameTimecode, Timecode
 from pyscenedetect_amd.video_stream import ArrayVideoStream
@@ -37,6 +38,6 @@ def detect(video, detector, stats_file_path=None, show_progress=False, start_tim
 
 __all__ = [
     "AdaptiveDetector", "ArrayVideoStream", "ContentDetector", "FlashFilter", "FrameTimecode", "HashDetector", "HistogramDetector", "Interpolation",
-    "SceneDetector", "SceneManager", "StatsFileCorrupt", "StatsManager", "Timecode", "ThresholdDetector", "compute_downscale_factor", "detect",
+    "SceneDetector", "SceneManager", "StatsFileCorrupt", "StatsManager", "Timecode", "ThresholdDetector", "compute_downscale_factor", "detect", "expand_scenes_to_bounds",
     "get_scenes_from_cuts",
 ]

@@ -49,6 +49,16 @@ def compute_downscale_factor(frame_width: int, effective_width: int = DEFAULT_MI
     return frame_width / float(effective_width)
 
 
+def expand_scenes_to_bounds(scenes, start, end):
+    """New scene list whose first scene starts at ``start`` and whose last scene ends at ``end`` (scenes detected
+    inside a sub-window of a video, reference ``scene_manager.py:143-168``).  The input is not modified."""
+    expanded = list(scenes)
+    if expanded:
+        expanded[0] = (start, expanded[0][1])
+        expanded[-1] = (expanded[-1][0], end)
+    return expanded
+
+
 def get_scenes_from_cuts(cut_list, start_pos, end_pos):
     """Contiguous (start, end) pairs from a sorted cut list; one scene if there are no cuts."""
     bounds = [start_pos, *cut_list, end_pos]

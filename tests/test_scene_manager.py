@@ -205,3 +205,26 @@ def test_stats_manager_csv_round_trip_and_corrupt_files(golden, oracle_engine, t
         bad.write_text(text)
         with pytest.raises(psd.StatsFileCorrupt):
             psd.StatsManager().load_from_csv(str(bad))
+
+
+def test_crop_setter_validation(oracle_engine):
+    """Same accept / reject behaviour as the reference's setter (scene_manager.py:298-321, tests/test_scene_manager.py:199)."""
+    sm = psd.SceneManager(engine=oracle_engine)
+    for ok in (None, (0, 0, 0, 0), (1, 1, 0, 0), (0, 0, 1, 1)):
+        sm.crop = ok
+    for bad in (1, (1, 1), (1, 1, 1)):
+        with pytest.raises(TypeError):
+            sm.crop = bad
+    with pytest.raises(ValueError):
+        sm.crop = (1, 1, 1, -1)
+
+
+def test_expand_scenes_to_bounds():
+    """Outer endpoints are replaced, inner boundaries kept, the input list untouched (reference scene_manager.py:143-168)."""
+    tc = lambda n: psd.FrameTimecode(n, 10.0)  # noqa: E731
+    scenes = [(tc(130), tc(150)), (tc(150), tc(170))]
+    before = list(scenes)
+    assert psd.expand_scenes_to_bounds(scenes, tc(0), tc(300)) == [(tc(0), tc(150)), (tc(150), tc(300))]
+    assert scenes == before
+    assert psd.expand_scenes_to_bounds([(tc(130), tc(170))], tc(0), tc(300)) == [(tc(0), tc(300))]
+    assert psd.expand_scenes_to_bounds([], tc(0), tc(100)) == []
