@@ -290,3 +290,18 @@ def test_flash_filter_random_sequences_match_reference():
                     emitted.append([i, cut.frame_num])
             return {"emitted": emitted, "max_behind": int(flt.max_behind)}
         assert _outcome(drive) == {k: c[k] for k in ("ok", "raises") if k in c}, (c["fps"], c["length"], c["mode"])
+
+
+@pytest.mark.parametrize("cls_name", ["ContentDetector", "AdaptiveDetector", "HistogramDetector", "HashDetector", "ThresholdDetector"])
+def test_min_scene_len_accepts_time_values(golden, oracle_engine, cls_name):
+    """int frames, float seconds and both string forms of the same duration give the same cut list
+    (the reference checks this on goldeneye.mp4, tests/test_detectors.py:236-262; here 15 frames at 25 fps)."""
+    frames = golden_clip(golden, "scenes_a")
+    results = []
+    for min_scene_len in (15, 0.6, "0.6s", "00:00:00.600"):
+        got = run_config(frames, cls_name, {"min_scene_len": min_scene_len}, False, oracle_engine)
+        results.append(got["cuts"])
+    assert results[0] == results[1] == results[2] == results[3], results
+    default_name = {"ContentDetector": "content_default", "AdaptiveDetector": "adaptive_default", "HistogramDetector": "hist_default",
+                    "HashDetector": "hash_default", "ThresholdDetector": "threshold_default"}[cls_name]
+    assert results[0] == golden["clips"]["scenes_a"]["results"][default_name]["cuts"]
