@@ -6,16 +6,18 @@
 //   hist[256] : histogram of BT.601 luma Y   histogram_detector.py:156-159
 //   byte_sum  : sum of all B,G,R bytes       threshold_detector.py:127
 //
-// Design (see DESIGN.md):
-//  * A workgroup owns a fixed spatial tile of the frame and WALKS THE TIME AXIS over a chunk of
-//    T frames, carrying the previous frame's H,S,V for its pixels in registers (packed 4 px per
-//    dword).  Every pixel of the batch is therefore read from HBM once (3 B/px algorithmic) and
-//    converted to HSV once; only the one halo frame in front of each chunk is read twice.
-//  * A lane handles groups of 16 pixels = 48 contiguous bytes = three dwordx4 loads.
-//  * The two fixed-point division tables of the 8-bit HSV conversion live in LDS, replicated 32x
-//    so that lane l always reads bank l%32 (conflict-free for any data; a wave64 ds_read_b32 is
-//    serviced in two 32-lane groups).  The luma histogram is replicated the same way, so the
-//    LDS atomics never collide -- flat frames (all pixels in one bin) cost the same as noise.
+// Design (see DESIGN.md 4.1):
+//  * HSV needs the previous frame, so a workgroup owns a fixed spatial tile of the frame and WALKS THE TIME AXIS over
+//    a chunk of T frames, carrying the previous frame's H,S,V for its pixels in registers (packed 4 px per dword).
+//    Every pixel of the batch is read from HBM once (3 B/px algorithmic) and converted to HSV once; only the one
+//    halo frame in front of each chunk is read twice.  The luma histogram / byte sum alone need no carry: that pass
+//    (luma_hist_kernel) takes one tile of one frame per workgroup.
+//  * A lane handles groups of 16 pixels = 48 contiguous bytes.  On the fast path the bytes travel HBM -> LDS with
+//    global_load_lds_dwordx4 into wave-private slots (score_frames_dma_kernel); score_frames_kernel is the
+//    register-load / byte-load form for strided, unaligned or ragged input.
+//  * The two fixed-point division tables of the 8-bit HSV conversion live in LDS, replicated so the lanes of a wave
+//    spread over the banks; the luma histogram is replicated the same way, so the LDS atomics never collide -- flat
+//    frames (all pixels in one bin) cost the same as noise.
 //  * Per-frame results leave the workgroup as one global atomic per non-empty bin / sum.
 //    Everything is integer, so the result is independent of scheduling order.
 #include <hip/hip_runtime.h>
