@@ -102,8 +102,9 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU batch")
     ap.add_argument("--dist", default="U", choices=["U", "K", "S"])
-    ap.add_argument("--detector", default="content", choices=["content", "hist", "all"],
-                    help="content = ContentDetector (headline); hist = Histogram+Threshold; all = all four fused")
+    ap.add_argument("--detector", default="content", choices=["content", "hist", "all", "hash"],
+                    help="content = ContentDetector (headline); hist = Histogram+Threshold; all = all four fused; "
+                         "hash = HashDetector (thumbnail kernel + DCT epilogue)")
     ap.add_argument("--res", default="1080p", choices=["1080p", "4k"])
     ap.add_argument("--cpu-sample", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -156,7 +157,7 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
 
     eng = engine_factory(local_rank) if engine_factory else E.ScoringEngine(local_rank)
     flags = {"content": E.SCORE_HSV_SAD, "hist": E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM,
-             "all": E.SCORE_HSV_SAD | E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM}[args.detector]
+             "all": E.SCORE_HSV_SAD | E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM, "hash": 0}[args.detector]
     n = args.frames
     batch = make_batch(n, args.dist, 20250921 + rank, device)
     ptr = batch.data_ptr()
@@ -202,7 +203,19 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
         if args.detector == "all":
             epilogue.adaptive_cuts(sc["content_val"], 25.0)
 
+    def run_hash(steps: int, timing: bool):
+        # HashDetector: grey INTER_AREA thumbnails on the device, DCT / median / Hamming distance / decision on the host
+        for _ in range(steps):
+            thumbs = eng.hash_thumbs_device(ptr, n, H, W, 16)
+            if timing:
+                kernel_ms.append(eng.last_kernel_ms()[0])
+            bits = epilogue.hash_bits(thumbs, 8)
+            state["cuts"] = epilogue.hash_cuts(bits, 25.0, threshold=0.35, min_scene_len=15)[0]
+            state["thumbs"] = thumbs
+
     def run(steps: int, timing: bool):
+        if args.detector == "hash":
+            return run_hash(steps, timing)
         eng.submit_device(ptr, n, H, W, flags=flags)
         for _ in range(steps - 1):
             eng.submit_device(ptr, n, H, W, flags=flags)
@@ -273,7 +286,7 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
                             f"distribution {args.dist}",
                 "frames_per_gpu": n, "height": H, "width": W, "distribution": args.dist,
                 "parallelism": f"clips sharded over {world} GPU(s), RCCL all-gather of score vectors" if use_dist else "1 GPU",
-                "pipeline_depth": 2,
+                "pipeline_depth": 1 if args.detector == "hash" else 2,
             },
             "roofline": {
                 "bound": "hbm",
@@ -282,13 +295,26 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "kernel": "psd::score_frames_dma_kernel",
+                "kernel": {"content": "psd::score_frames_dma_kernel", "all": "psd::score_frames_dma_kernel",
+                           "hist": "psd::luma_hist_kernel", "hash": "psd::gray_area_dma_kernel"}[args.detector],
                 "avg_launch_ms": round(avg_kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
             },
             "cuts_found": len(state["cuts"]),
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.detector == "hash":
+            from oracle import lib as orc
+
+            sample = batch[: min(64, n)].cpu().numpy()
+            t0 = time.perf_counter()
+            ref = orc.hash_thumbs(sample, 16)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(len(sample) / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": "%d frames of the same batch through oracle/cv2_restate.c (grey + INTER_AREA), "
+                                             "one thread; real OpenCV is not installed" % len(sample)}
+            out["parity_sample"] = ("thumbnails of the first %d frames identical to the oracle" % len(sample)
+                                    if np.array_equal(state["thumbs"][: len(sample)], ref) else "MISMATCH vs oracle")
+        elif not args.no_cpu_baseline and world == 1:
             sample = batch[: args.cpu_sample].cpu().numpy()
             cb = cpu_baseline(sample, flags & 7, os.cpu_count() or 1)
             ref = cb.pop("_records")
