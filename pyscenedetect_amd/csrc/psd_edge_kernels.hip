@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void value_plane_hist_dma_kernel(ChunkSrc src,
             for (int q = 0; q < 3; q++) {
                 const long off = gfirst * 48 + q * 1024 + lane * 16;
                 if (off + 16 <= limit)
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + off), (lds_ptr_t)(slot + q * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + off), (lds_ptr_t)(slot + q * 1024), 16, 0, PSD_DMA_AUX);
             }
         }
     };

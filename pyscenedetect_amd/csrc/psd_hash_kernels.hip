@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kHashWG) void gray_area_dma_kernel(const HashGeom g
             for (int j = 0; j < 3; j++) {
                 const long off = gfirst * 48 + j * 1024 + lane * 16;
                 if (off + 16 <= limit)
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + off), (lds_ptr_t)(slot + j * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + off), (lds_ptr_t)(slot + j * 1024), 16, 0, PSD_DMA_AUX);
             }
         }
         istep++;

@@ -8,6 +8,13 @@
 
 #include "psd_engine.h"
 
+// Cache policy of the LDS-DMA frame stream (aux operand of global_load_lds): 2 = nt.  Every frame byte is read once,
+// by one CU; a plain 16-byte-load microbenchmark streams 7.1 TB/s with nt and 6.1 TB/s with the default policy
+// (profiles/r01_k_ubench_stream_read.txt).
+#ifndef PSD_DMA_AUX
+#define PSD_DMA_AUX 2
+#endif
+
 namespace psd {
 
 constexpr int kScoreWG = 1024;  // threads per workgroup of the scoring kernels (16 waves) ...

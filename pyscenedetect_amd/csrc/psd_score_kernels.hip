@@ -518,7 +518,7 @@ constexpr int ACD_MAX = 16;  // accumulator replicas
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-template <int G, int NW>
+template <int G, int NW, int AUX>
 __device__ __forceinline__ void dma_issue(const ScoreParams& p, const uint8_t* frame, int wave_group0, int tile_end, int wave,
                                           int lane, uint8_t* stage)
 {
@@ -536,7 +536,7 @@ __device__ __forceinline__ void dma_issue(const ScoreParams& p, const uint8_t* f
         for (int j = 0; j < 3; j++) {
             const long off = gfirst * 48 + j * 1024 + lane * 16;
             if (off + 16 <= limit)
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + off), (lds_ptr_t)(slot + j * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + off), (lds_ptr_t)(slot + j * 1024), 16, 0, AUX);
         }
     }
 }
@@ -604,6 +604,8 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
     constexpr int NA = LUMA ? NACC : 4;       // accumulators per frame slot
     constexpr int F = LUMA ? (HSV ? PSD_FUSED_F : PSD_LUMA_F) : 8;   // frames per barrier
     constexpr int SLOTS = 2 * F;
+    // nt policy on the frame stream: +2 % for the HSV pass, +5 % for the luma pass, but -3 % for the fused one (A/B)
+    constexpr int DMA_AUX = (HSV && LUMA) ? 0 : PSD_DMA_AUX;
     __shared__ __attribute__((aligned(16))) u32 lut_s[HSV ? 256 * LCD : 4];
     __shared__ __attribute__((aligned(16))) u32 lut_h[HSV ? 256 * LCD : 4];
     __shared__ __attribute__((aligned(16))) u32 acc[SLOTS][NA * ACD];
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
         const uint8_t* halo = (t0 > 0) ? p.frames + (size_t)(t0 - 1) * p.frame_stride : p.prev;
         if (halo != nullptr) {
             have_prev = true;
-            dma_issue<G, NW>(p, halo, wave_group0, g1, wave, lane, stage);
+            dma_issue<G, NW, DMA_AUX>(p, halo, wave_group0, g1, wave, lane, stage);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stage_read<G, NW>(stage, wave, lane, cur);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
             }
         }
     }
-    if (t0 < t1) dma_issue<G, NW>(p, p.frames + (size_t)t0 * p.frame_stride, wave_group0, g1, wave, lane, stage);
+    if (t0 < t1) dma_issue<G, NW, DMA_AUX>(p, p.frames + (size_t)t0 * p.frame_stride, wave_group0, g1, wave, lane, stage);
 
     for (int t = t0; t < t1; t++) {
         const int slot = (t - t0) % SLOTS;
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stage_read<G, NW>(stage, wave, lane, cur);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (t + 1 < t1) dma_issue<G, NW>(p, p.frames + (size_t)(t + 1) * p.frame_stride, wave_group0, g1, wave, lane, stage);
+        if (t + 1 < t1) dma_issue<G, NW, DMA_AUX>(p, p.frames + (size_t)(t + 1) * p.frame_stride, wave_group0, g1, wave, lane, stage);
 #else
 #pragma unroll
         for (int k = 0; k < G; k++)
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(kLumaWG) void luma_hist_kernel(const ScoreParams p)
             for (int j = 0; j < 3; j++) {
                 const long off = gfirst * 48 + j * 1024 + lane * 16;
                 if (off + 16 <= limit)
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + off), (lds_ptr_t)(slot + j * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + off), (lds_ptr_t)(slot + j * 1024), 16, 0, PSD_DMA_AUX);
             }
         }
     };
