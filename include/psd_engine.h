@@ -203,6 +203,11 @@ int psd_epilogue_hist_cuts(const psd_frame_scores* recs, int n, const psd_frame_
                            int64_t first_frame, int64_t fps_num, int64_t fps_den,
                            const psd_hist_params* p, double* hist_diff, int64_t* cuts, int* n_cuts);
 
+/* The two per-frame steps of the above, for hosts that decide frame by frame (HistogramDetector.process_frame):
+ * cv2.calcHist(bins) + cv2.normalize (L2, float32) of one 256-bin luma histogram, and cv2.compareHist(CORREL). */
+int psd_epilogue_hist_normalize(const uint32_t hist256[256], int bins, float* out);
+int psd_epilogue_hist_correl(const float* h1, const float* h2, int bins, double* out);
+
 typedef struct psd_threshold_params {
     int threshold;       /* int(threshold), default 12 */
     int method;          /* 0 = FLOOR, 1 = CEILING */

@@ -126,6 +126,8 @@ SYMBOLS = {
     "psd_epilogue_content_cuts": (_i, [_vp, _i, _i64, _i64, _i64, _P(ContentParams), _vp, _P(_i)]),
     "psd_epilogue_adaptive_cuts": (_i, [_vp, _i, _i64, _i64, _i64, _P(AdaptiveParams), _vp, _vp, _P(_i)]),
     "psd_epilogue_hist_cuts": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _P(HistParams), _vp, _vp, _P(_i)]),
+    "psd_epilogue_hist_normalize": (_i, [_vp, _i, _vp]),
+    "psd_epilogue_hist_correl": (_i, [_vp, _vp, _i, _P(ctypes.c_double)]),
     "psd_epilogue_threshold_cuts": (_i, [_vp, _i, _i, _i, _i64, _i64, _i64, _P(ThresholdParams), _vp, _vp, _P(_i)]),
     "psd_epilogue_hash_bits": (_i, [_vp, _i, _i, _i, _vp]),
     "psd_epilogue_hash_cuts": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _P(HashParams), _vp, _vp, _P(_i)]),

@@ -177,10 +177,10 @@ int psd_epilogue_adaptive_cuts(const double* content_val, int n, int64_t first_f
 }
 
 // cv2.calcHist LUT + cv2.normalize(NORM_L2) of one record's luma histogram.
-static void normalized_hist(const psd_frame_scores& r, int bins, const int* lut, float* out)
+static void normalized_hist(const uint32_t* hist256, int bins, const int* lut, float* out)
 {
     std::vector<uint64_t> cnt((size_t)bins, 0);
-    for (int j = 0; j < 256; j++) cnt[(size_t)lut[j]] += r.hist[j];
+    for (int j = 0; j < 256; j++) cnt[(size_t)lut[j]] += hist256[j];
     double ss = 0.0;
     for (int i = 0; i < bins; i++) {
         out[i] = (float)cnt[(size_t)i];  // exact below 2^24, a single rounding above (as OpenCV's int->f32)
@@ -235,12 +235,12 @@ int psd_epilogue_hist_cuts(const psd_frame_scores* recs, int n, const psd_frame_
     float* last = a.data();
     float* cur = b.data();
     bool have_last = false;
-    if (prev_rec) { normalized_hist(*prev_rec, p->bins, lut, last); have_last = true; }
+    if (prev_rec) { normalized_hist(prev_rec->hist, p->bins, lut, last); have_last = true; }
     int nc = 0;
     int64_t last_cut = first_frame - (prev_rec ? 1 : 0);
     for (int t = 0; t < n; t++) {
         const int64_t tc = first_frame + t;
-        normalized_hist(recs[t], p->bins, lut, cur);
+        normalized_hist(recs[t].hist, p->bins, lut, cur);
         double d = NAN;
         if (have_last) {
             d = correl(last, cur, p->bins);
@@ -251,6 +251,31 @@ int psd_epilogue_hist_cuts(const psd_frame_scores* recs, int n, const psd_frame_
         have_last = true;
     }
     *n_cuts = nc;
+    return PSD_OK;
+}
+
+int psd_epilogue_hist_normalize(const uint32_t hist256[256], int bins, float* out)
+{
+    if (!hist256 || !out || bins < 1 || bins > 256) {
+        psd_set_error("psd_epilogue_hist_normalize: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    int lut[256];
+    for (int j = 0; j < 256; j++) {
+        int idx = (int)std::floor(j * (bins / 256.0));
+        lut[j] = idx < 0 ? 0 : (idx > bins - 1 ? bins - 1 : idx);
+    }
+    normalized_hist(hist256, bins, lut, out);
+    return PSD_OK;
+}
+
+int psd_epilogue_hist_correl(const float* h1, const float* h2, int bins, double* out)
+{
+    if (!h1 || !h2 || !out || bins < 1) {
+        psd_set_error("psd_epilogue_hist_correl: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    *out = correl(h1, h2, bins);
     return PSD_OK;
 }
 

@@ -6,6 +6,7 @@ The device returns the exact 256-bin histogram of BT.601 luma (what ``cv2.cvtCol
 ``cv2.compareHist(HISTCMP_CORREL)`` (float64) are restated here operation for operation.
 """
 
+import ctypes
 import math
 import sys
 import typing as ty
@@ -60,6 +61,21 @@ def compare_hist_correl(h1: np.ndarray, h2: np.ndarray) -> float:
     return num / math.sqrt(denom2) if abs(denom2) > sys.float_info.epsilon else 1.0
 
 
+def _native_normalized(hist256: np.ndarray, bins: int) -> np.ndarray:
+    """`normalized_histogram` through ``psd_epilogue_hist_normalize`` (same arithmetic, ~20x less Python)."""
+    h = np.ascontiguousarray(hist256, dtype=np.uint32)
+    out = np.empty(bins, np.float32)
+    _native.check(_native.load().psd_epilogue_hist_normalize(h.ctypes.data, int(bins), out.ctypes.data))
+    return out
+
+
+def _native_correl(h1: np.ndarray, h2: np.ndarray) -> float:
+    """`compare_hist_correl` through ``psd_epilogue_hist_correl``."""
+    out = ctypes.c_double(0.0)
+    _native.check(_native.load().psd_epilogue_hist_correl(h1.ctypes.data, h2.ctypes.data, int(h1.size), ctypes.byref(out)))
+    return out.value
+
+
 class HistogramDetector(SceneDetector):
     METRIC_KEYS: ty.ClassVar[list[str]] = ["hist_diff"]
 
@@ -94,9 +110,9 @@ class HistogramDetector(SceneDetector):
         cut_list = []
         if not self._last_cut:
             self._last_cut = timecode
-        hist = normalized_histogram(record["hist"], self._bins)
+        hist = _native_normalized(record["hist"], self._bins)
         if self._last_hist is not None:
-            hist_diff = compare_hist_correl(self._last_hist, hist)
+            hist_diff = _native_correl(self._last_hist, hist)
             if hist_diff <= self._threshold and ((timecode - self._last_cut) >= self._min_scene_len):
                 cut_list.append(timecode)
                 self._last_cut = timecode

@@ -100,3 +100,25 @@ def test_threshold_and_histogram(seed):
     key = det.get_metrics()[0]
     for i in range(1, n):
         assert det.stats_manager.get_metrics(i, [key])[0] == diff[i]
+
+
+def test_per_frame_histogram_steps_native_equals_numpy():
+    """HistogramDetector decides through psd_epilogue_hist_normalize / _correl; the numpy restatements next to them
+    (cv2.calcHist + normalize + compareHist, operation for operation) must stay bit-identical."""
+    import numpy as np
+
+    from pyscenedetect_amd.detectors import histogram_detector as hd
+
+    rng = np.random.default_rng(31)
+    for bins in (128, 256, 100, 16, 7, 1):
+        hists = [rng.integers(0, 5000, 256), np.zeros(256, np.int64), np.full(256, 8100), rng.integers(0, 3, 256) * 4_000_000,
+                 np.eye(256, dtype=np.int64)[17] * 2_073_600]
+        normed = []
+        for h in hists:
+            a, b = hd.normalized_histogram(h, bins), hd._native_normalized(h, bins)
+            assert a.dtype == b.dtype == np.float32 and np.array_equal(a, b), bins
+            normed.append(a)
+        for x in normed:
+            for y in normed:
+                p, q = hd.compare_hist_correl(x, y), hd._native_correl(x, y)
+                assert p == q or (p != p and q != q), (bins, p, q)
