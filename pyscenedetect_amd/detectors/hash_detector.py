@@ -54,12 +54,17 @@ class HashDetector(SceneDetector):
         thumb = _thumbs_of(engine, frame_img, hash_size * factor)
         return epilogue.hash_bits(thumb[None], hash_size)[0]
 
-    def process_thumb(self, timecode: FrameTimecode, thumb: np.ndarray) -> list[FrameTimecode]:
-        """Decide from the frame's grey ``size*lowpass`` square thumbnail."""
+    @property
+    def hash_size(self) -> int:
+        return self._size
+
+    def process_thumb(self, timecode: FrameTimecode, thumb: np.ndarray, bits: np.ndarray | None = None) -> list[FrameTimecode]:
+        """Decide from the frame's grey ``size*lowpass`` square thumbnail (or from its hash ``bits`` when the caller
+        already ran ``epilogue.hash_bits`` over a whole batch of thumbnails)."""
         cut_list = []
         if self._last_scene_cut is None:
             self._last_scene_cut = timecode
-        curr_hash = epilogue.hash_bits(np.asarray(thumb)[None], self._size)[0]
+        curr_hash = bits if bits is not None else epilogue.hash_bits(np.asarray(thumb)[None], self._size)[0]
         if self._last_hash is not None:
             hash_dist = int(np.count_nonzero(curr_hash.flatten() != self._last_hash.flatten()))
             hash_dist_norm = hash_dist / self._size_sq

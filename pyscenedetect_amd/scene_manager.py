@@ -190,7 +190,7 @@ class SceneManager:
             self._engine = default_engine()
         return self._engine
 
-    def _dispatch(self, position, frame_im, record, callback, scored_size=None, thumb=None) -> bool:
+    def _dispatch(self, position, frame_im, record, callback, scored_size=None, thumb=None, bits=None) -> bool:
         """One frame's worth of decisions for every detector (reference ``_process_frame`` :410-435)."""
         new_cuts = False
         self._frame_buffer.append((position, frame_im))
@@ -200,7 +200,10 @@ class SceneManager:
             if record is not None and detector.score_flags():
                 cuts = detector.process_record(position, record, h, w)
             elif thumb is not None and detector.hash_thumb_size():
-                cuts = detector.process_thumb(position, thumb)
+                if bits is not None and getattr(detector, "hash_size", None) in bits:
+                    cuts = detector.process_thumb(position, thumb, bits=bits[detector.hash_size])
+                else:
+                    cuts = detector.process_thumb(position, thumb)
             else:
                 cuts = detector.process_frame(position, frame_im)
             self._cutting_list += cuts
@@ -293,9 +296,19 @@ class SceneManager:
                         if hash_size:
                             thumbs = engine.hash_thumbs_host(stacked, hash_size, **kwargs)
                     last_frame = frames[-1]
+                batch_bits = {}
+                if thumbs is not None:
+                    # DCT / median for the whole batch at once (native, threaded) instead of once per frame
+                    from pyscenedetect_amd import epilogue
+
+                    for det in self._detector_list:
+                        hs = getattr(det, "hash_size", None)
+                        if det.hash_thumb_size() and hs is not None and hs not in batch_bits:
+                            batch_bits[hs] = epilogue.hash_bits(thumbs, hs)
                 for i, (frame_im, position) in enumerate(zip(frames, positions)):
                     self._dispatch(position, frame_im, records[i] if records is not None else None, callback, scored_size,
-                                   thumbs[i] if thumbs is not None else None)
+                                   thumbs[i] if thumbs is not None else None,
+                                   {hs: b[i] for hs, b in batch_bits.items()} if batch_bits else None)
         finally:
             self._stop.set()
             while worker.is_alive():
