@@ -59,3 +59,29 @@ def test_canny_dilate_hist_resize(seed):
         out = np.empty((dh, dw, 3), np.uint8)
         orc.lib().orc_resize_linear_u8(img.ctypes.data, img.shape[1] * 3, img.shape[0], img.shape[1], 3, out.ctypes.data, dw * 3, dh, dw)
         assert np.array_equal(out, cv2.resize(img, (dw, dh), interpolation=cv2.INTER_LINEAR))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hash_detector_primitives_and_other_resize_modes(seed):
+    """BGR2GRAY, INTER_AREA (fractional, integer, 2x2), INTER_NEAREST bit-exact; cv2.dct within float32 noise
+    (its operation order depends on the OpenCV build)."""
+    img = _img(seed, 108, 192)
+    gray = cv2.cvtColor(img, cv2.COLOR_BGR2GRAY)
+    mine = np.empty_like(gray)
+    orc.lib().orc_bgr2gray(img.ctypes.data, img.shape[1] * 3, mine.ctypes.data, img.shape[1], img.shape[0], img.shape[1])
+    assert np.array_equal(gray, mine)
+    for size in (16, 32, 27, 54, 96):
+        want = cv2.resize(gray, (size, size), interpolation=cv2.INTER_AREA)
+        got = np.empty((size, size), np.uint8)
+        assert orc.lib().orc_resize_area_u8(gray.ctypes.data, gray.shape[1], gray.shape[0], gray.shape[1], got.ctypes.data, size, size, size) == 0
+        assert np.array_equal(got, want), size
+    for dw, dh in ((96, 54), (64, 36), (100, 41), (192, 108)):
+        for inter, fn in ((cv2.INTER_AREA, "orc_resize_area_u8_cn"), (cv2.INTER_NEAREST, "orc_resize_nearest_u8")):
+            want = cv2.resize(img, (dw, dh), interpolation=inter)
+            got = np.empty((dh, dw, 3), np.uint8)
+            getattr(orc.lib(), fn)(img.ctypes.data, img.shape[1] * 3, img.shape[0], img.shape[1], 3, got.ctypes.data, dw * 3, dh, dw)
+            assert np.array_equal(got, want), (dw, dh, fn)
+    x = (np.float32(cv2.resize(gray, (32, 32), interpolation=cv2.INTER_AREA)) / 255).astype(np.float32)
+    low = np.empty((16, 16), np.float32)
+    orc.lib().orc_dct2d_f32(np.ascontiguousarray(x).ctypes.data, 32, 16, low.ctypes.data)
+    assert np.abs(cv2.dct(x)[:16, :16] - low).max() <= 1e-5

@@ -36,6 +36,15 @@ def main():
         out[f"hist128_{seed}"] = h
         out[f"hist128n_{seed}"] = cv2.normalize(h, h).flatten()
         out[f"resize_{seed}"] = cv2.resize(img, (64, 48), interpolation=cv2.INTER_LINEAR)
+        out[f"resize_nearest_{seed}"] = cv2.resize(img, (64, 48), interpolation=cv2.INTER_NEAREST)
+        out[f"resize_area_{seed}"] = cv2.resize(img, (64, 48), interpolation=cv2.INTER_AREA)
+        # HashDetector.hash_frame (hash_detector.py:117-151)
+        gray = cv2.cvtColor(img, cv2.COLOR_BGR2GRAY)
+        out[f"gray{seed}"] = gray
+        for size in (16, 32):
+            small = cv2.resize(gray, (size, size), interpolation=cv2.INTER_AREA)
+            out[f"gray_area{size}_{seed}"] = small
+            out[f"dct{size}_{seed}"] = cv2.dct(np.float32(small) / max(1, int(small.max())))
     path = os.path.join(ROOT, "tests", "golden", "cv2_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)
