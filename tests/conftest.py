@@ -30,6 +30,11 @@ def _gpu_available() -> bool:
 def pytest_collection_modifyitems(config, items):
     if _gpu_available():
         return
+    # `pytest -m gpu` asks for the GPU tests explicitly: without a usable GPU / libpsd_hip.so they must FAIL loudly
+    # (engine creation raises), not pass by being skipped.  Only an unfiltered run on a CPU box skips them.
+    markexpr = (config.getoption("markexpr", "") or "").strip()
+    if "gpu" in markexpr and "not gpu" not in markexpr:
+        return
     skip = pytest.mark.skip(reason="no AMD GPU visible")
     for item in items:
         if "gpu" in item.keywords:
