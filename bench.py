@@ -153,7 +153,6 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
 
     from pyscenedetect_amd import engine as E
     from pyscenedetect_amd import epilogue
-    from pyscenedetect_amd._native import RECORD_DTYPE
 
     eng = engine_factory(local_rank) if engine_factory else E.ScoringEngine(local_rank)
     flags = {"content": E.SCORE_HSV_SAD, "hist": E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM,
