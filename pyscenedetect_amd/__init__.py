@@ -2,10 +2,12 @@
 
 Drop-in surface (same names and semantics as the reference's ``scenedetect`` package for the hot
 path): :class:`SceneManager`, :class:`ContentDetector`, :class:`AdaptiveDetector`,
-:class:`HistogramDetector`, :class:`ThresholdDetector`, :class:`FrameTimecode`,
-:class:`StatsManager`, :class:`SceneDetector`, :class:`FlashFilter`.
+:class:`HistogramDetector`, :class:`ThresholdDetector`, :class:`HashDetector`, :class:`FrameTimecode`,
+:class:`StatsManager`, :class:`SceneDetector`, :class:`FlashFilter`; ``engine`` (the C-ABI binding) and ``epilogue``
+(whole-clip native decisions) are the batch face underneath.
 """
 
+from pyscenedetect_amd import engine, epilogue  # noqa: F401  (submodules of the public surface; the library loads on first use)
 from pyscenedetect_amd.detector import FlashFilter, SceneDetector
 from pyscenedetect_amd.detectors import AdaptiveDetector, ContentDetector, HashDetector, HistogramDetector, ThresholdDetector
 from pyscenedetect_amd.scene_manager import (Interpolation, SceneManager, compute_downscale_factor, expand_scenes_to_bounds,
