@@ -155,13 +155,21 @@ int psd_create(int device, psd_engine** out)
     int rc = PSD_OK;
     do {
         if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { rc = PSD_ERR_HIP; break; }
-        if (hipMalloc((void**)&e->d_lut, 512 * sizeof(uint32_t)) != hipSuccess) { rc = PSD_ERR_HIP; break; }
+        if (hipMalloc((void**)&e->d_lut, 1024 * sizeof(uint32_t)) != hipSuccess) { rc = PSD_ERR_HIP; break; }
         int32_t tab[512];
         fill_tables(tab, tab + 256);
         // The kernels keep both tables pre-shifted by 4 so that S and H land 16-bit aligned in the
         // products (see pixel<> in psd_score_kernels.hip).
+        // The HSV-only pass computes in float32 (psd_score_kernels.hip, PSD_HSV_FP32): sdiv / 4096 bumped by one ulp so
+        // that the exact .5 ties of diff * sdiv / 4096 round up like (x + 2048) >> 12, and hdiv180 / 4096 (both exact).
+        float tabf[512];
+        for (int i = 0; i < 256; i++) {
+            tabf[i] = tab[i] ? nextafterf((float)tab[i] / 4096.0f, INFINITY) : 0.0f;
+            tabf[256 + i] = (float)tab[256 + i] / 4096.0f;
+        }
         for (int i = 0; i < 512; i++) tab[i] <<= 4;
         if (hipMemcpy(e->d_lut, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) { rc = PSD_ERR_HIP; break; }
+        if (hipMemcpy(e->d_lut + 512, tabf, sizeof(tabf), hipMemcpyHostToDevice) != hipSuccess) { rc = PSD_ERR_HIP; break; }
         for (auto& s : e->slots) {
             if (hipEventCreate(&s.ev_start) != hipSuccess || hipEventCreate(&s.ev_stop) != hipSuccess ||
                 hipEventCreate(&s.ev_done) != hipSuccess) { rc = PSD_ERR_HIP; break; }
@@ -261,6 +269,7 @@ int psd_score_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int h
             p.prev = d_prev;
             p.out = s.d_recs;
             p.lut = e->d_lut;
+            p.lutf = e->d_lut + 512;
             p.frame_stride = frame_stride;
             p.row_stride = row_stride;
             p.npix = (long)height * width;

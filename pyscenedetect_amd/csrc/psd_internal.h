@@ -28,7 +28,8 @@ struct ScoreParams {
     const uint8_t* frames;   // device, frame t at frames + t*frame_stride
     const uint8_t* prev;     // device, frame preceding frame 0, or nullptr
     psd_frame_scores* out;   // device, n records, zero-initialised
-    const uint32_t* lut;     // device, [0..255] = sdiv, [256..511] = hdiv180
+    const uint32_t* lut;     // device, [0..255] = sdiv << 4, [256..511] = hdiv180 << 4
+    const uint32_t* lutf;    // device, float32 bit patterns: [0..255] = nextafter(sdiv / 4096), [256..511] = hdiv180 / 4096
     size_t frame_stride;
     size_t row_stride;
     long npix;               // height*width

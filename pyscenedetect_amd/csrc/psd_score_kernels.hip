@@ -237,20 +237,179 @@ __device__ __forceinline__ void pixel(const u32 (&d)[3], u32& hq, u32& sq, u32& 
 #endif
 }
 
-__device__ __forceinline__ u32 perm_b32(u32 s0, u32 s1, u32 sel)
+__device__ __forceinline__ u32 perm_b32(u32 s0, u32 s1, u32 sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+
+
+// ---- fp32-pipe formulation of the same integers (PSD_HSV_FP32) ---------------------------------
+//
+// On gfx950 the plain fp32 add / sub / fma forms (and 32-bit add, logic, right shifts, 16-bit shifts) issue at twice
+// the rate of everything else the integer formulation leans on (v_bfe, v_max3, 24-bit multiplies, v_lshl_add, compares
+// and selects, v_perm, SDWA): tools/ubench/valu_rate3.hip / valu_rate4.hip.  Every quantity of OpenCV's 8-bit HSV is an
+// integer far below 2^24 (or an integer / 4096 below 2^8), so float32 holds it exactly:
+//   * a channel byte becomes the float 2^23 + byte with ONE v_perm_b32 (the byte under the three upper bytes of
+//     0x4B000000); the bias cancels in every difference and leaves the integer in the low bits for the LDS address;
+//   * v == r / v == g become the 0/1 floats clamp(v - r), clamp(v - g) (the VOP3 clamp modifier is free) and the two
+//     selects become fused multiply-adds;
+//   * S = RNE(diff * sdiv'[v] + 2^23) with sdiv' = nextafter(sdiv / 4096): the bump breaks the exact .5 ties upwards
+//     like OpenCV's (x + 2048) >> 12 and moves nothing else (every other value is >= 2^-12 away from a tie);
+//   * H = RNE((hraw * hdiv[diff] / 4096 + 2^-13) + 1.5 * 2^23): the first fma is exact (a multiple of 2^-12 below 2^8
+//     plus 2^-13), the second rounds to floor(x + 0.5) for either sign and leaves h as a 16-bit two's complement in the
+//     low half, where the wrap min(h, h + 180) of the integer formulation applies unchanged.
+// tools/hsv_fp32_check.py replays this arithmetic in numpy float32 over all 2^24 triples; the -m gpu exhaustive test
+// runs it through the kernel.
+#ifndef PSD_HSV_FP32
+#define PSD_HSV_FP32 1
+#endif
+
+typedef const __attribute__((address_space(3))) float* lds_cf32_t;
+
+struct FpLane {          // per-lane constants of the fp32 formulation
+    u32 bias;            // 0x4B000000: float 2^23 with a zero low byte
+    u32 off_s, off_h;    // LDS byte address of this lane's replica of the two tables
+    float bias_h;        // LS == 4 only: 2^21 + off_h / 16 (see pixel_fp_front)
+};
+
+// (compiler builtins rather than inline asm wherever one exists: hipcc pads every use of an asm-defined register with
+//  an s_nop because it cannot rule out the gfx950 trans-op hazard for an instruction it does not see)
+template <int K>
+__device__ __forceinline__ float unpack_biased(u32 w, u32 bias)
 {
-    u32 d;
-    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(s0), "v"(s1), "s"(sel));
-    return d;
+    // byte K of w under the upper three bytes of `bias`
+    return __uint_as_float(__builtin_amdgcn_perm(w, bias, 0x03020104u + (u32)K));
+}
+// positive floats order like their bit patterns: integer max3 / min3 on the biased channels
+__device__ __forceinline__ float max3_f32(float a, float b, float c)
+{
+    return __uint_as_float(max(max(__float_as_uint(a), __float_as_uint(b)), __float_as_uint(c)));
+}
+__device__ __forceinline__ float min3_f32(float a, float b, float c)
+{
+    return __uint_as_float(min(min(__float_as_uint(a), __float_as_uint(b)), __float_as_uint(c)));
+}
+// clamp(a - b) to [0, 1]: med3 with the constants 0 and 1 folds into the subtraction's clamp modifier
+__device__ __forceinline__ float sub_clamp(float a, float b) { return __builtin_amdgcn_fmed3f(a - b, 0.0f, 1.0f); }
+// (low 16 bits of x) << S, upper half zero
+// (asm: written in C++ this becomes a 32-bit shift, which issues at half rate, plus an and)
+template <int S>
+__device__ __forceinline__ u32 lshl16(u32 x) { u32 d; asm("v_lshlrev_b16_e32 %0, %1, %2" : "=v"(d) : "n"(S), "v"(x)); return d; }
+// ((low 16 bits of x) << S) + y
+template <int S>
+__device__ __forceinline__ u32 lshl16_add(u32 x, u32 y) { u32 d; asm("v_lshlrev_b16_e32 %0, %1, %2\n\tv_add_u32_e32 %0, %0, %3" : "=&v"(d) : "n"(S), "v"(x), "v"(y)); return d; }
+template <int K>
+__device__ __forceinline__ u32 min_lo16_to_byte(u32 a, u32 b, u32 packed)
+{
+    if (K == 0) {
+        u32 d;
+        asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(d) : "v"(a), "v"(b));
+        return d;
+    }
+    if (K == 1) asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(packed) : "v"(a), "v"(b));
+    if (K == 2) asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(packed) : "v"(a), "v"(b));
+    if (K == 3) asm("v_min_u16_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(packed) : "v"(a), "v"(b));
+    return packed;
+}
+
+// The quad is written in three phases so that the eight table reads of its four pixels are in flight while the
+// table-free hue arithmetic runs (the scheduler keeps this source order).  LS = log2(bytes per table entry across
+// the replicas).
+struct PxFp {
+    float B, G, R, V, diff, sdiv, hdiv;
+};
+
+template <int K>
+__device__ __forceinline__ float channel_fp(const u32 (&d)[3], int c, u32 bias)
+{
+    const int i = 3 * K + c;
+    const u32 w = d[i >> 2];
+    return (i & 3) == 0 ? unpack_biased<0>(w, bias) : (i & 3) == 1 ? unpack_biased<1>(w, bias)
+         : (i & 3) == 2 ? unpack_biased<2>(w, bias) : unpack_biased<3>(w, bias);
+}
+
+// phase 1: unpack, V, diff, table addresses, table reads issued
+template <int LS, int K>
+__device__ __forceinline__ void pixel_fp_front(const u32 (&d)[3], const FpLane& fl, PxFp& x)
+{
+    x.B = channel_fp<K>(d, 0, fl.bias);
+    x.G = channel_fp<K>(d, 1, fl.bias);
+    x.R = channel_fp<K>(d, 2, fl.bias);
+    x.V = max3_f32(x.B, x.G, x.R);                     // 2^23 + v
+    x.diff = x.V - min3_f32(x.B, x.G, x.R);            // exact, 0..255
+    const u32 a_s = lshl16_add<LS>(__float_as_uint(x.V), fl.off_s);
+    u32 a_h;
+    if constexpr (LS == 4) {
+        // floats in [2^21, 2^22) step by 1/4: the low bits of diff + (2^21 + off_h / 16) are 4 diff + off_h / 4, and a
+        // 16-bit shift by 2 turns them into 16 diff + off_h (< 2^16: the HSV-only pass has 24 KiB of LDS)
+        a_h = lshl16<2>(__float_as_uint(x.diff + fl.bias_h));
+    } else {
+        a_h = lshl16_add<LS>(__float_as_uint(x.diff + 8388608.0f), fl.off_h);
+    }
+    x.sdiv = *(lds_cf32_t)a_s;
+    x.hdiv = *(lds_cf32_t)a_h;
+}
+
+// phase 2: hraw = v == r ? g - b : v == g ? b - r + 2 diff : r - g + 4 diff (the biases cancel)
+__device__ __forceinline__ float pixel_fp_hraw(const PxFp& x)
+{
+    const float c_r = x.G - x.B;
+    const float c_g = __builtin_fmaf(x.diff, 2.0f, x.B - x.R);
+    const float c_b = __builtin_fmaf(x.diff, 4.0f, x.R - x.G);
+    const float nm_r = sub_clamp(x.V, x.R), nm_g = sub_clamp(x.V, x.G);   // 0 where the channel IS the maximum
+    const float y = __builtin_fmaf(nm_g, c_b - c_g, c_g);                  // v == g ? c_g : c_b
+    return __builtin_fmaf(nm_r, y - c_r, c_r);                             // v == r ? c_r : y
+}
+
+// phase 3: the two table products; hue into byte K of hq, S in the low byte of the return value
+template <int K>
+__device__ __forceinline__ u32 pixel_fp_back(const PxFp& x, float hraw, u32& hq)
+{
+    const float t = __builtin_fmaf(hraw, x.hdiv, 0.0001220703125f);       // exact: a multiple of 2^-13 below 2^8
+    const u32 hb = __float_as_uint(t + 12582912.0f);                       // low half = floor(. + .5), two's complement
+    hq = min_lo16_to_byte<K>(hb, hb + 180u, hq);
+    return __float_as_uint(__builtin_fmaf(x.diff, x.sdiv, 8388608.0f));    // low byte = S
 }
 
 // 8-bit BGR -> HSV exactly as OpenCV's RGB2HSV_b (hsv_shift = 12, hue range 180), plus luma
 // histogram and byte sum.  lut_s/lut_h/hist are already offset by the lane's replica index.
-template <bool HSV, bool LUMA, int LC = COPIES, int AC = COPIES>
+template <bool HSV, bool LUMA, int LC = COPIES, int AC = COPIES, bool FP = false>
 __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __restrict__ lut_s,
                                               const u32* __restrict__ lut_h, u32* __restrict__ hist,
                                               u32& byte_sum, u32 inc = 1u)
 {
+    if constexpr (FP) {
+        static_assert(HSV && !LUMA, "the fp32 formulation serves the HSV-only pass");
+        constexpr int LS = LC == 4 ? 4 : LC == 8 ? 5 : LC == 16 ? 6 : LC == 32 ? 7 : LC == 2 ? 3 : -1;
+        static_assert(LS > 0, "");
+        FpLane fl;
+        fl.bias = 0x4B000000u;
+        fl.off_s = (u32)(uintptr_t)lut_s;   // low half of a flat LDS address = the LDS byte address
+        fl.off_h = (u32)(uintptr_t)lut_h;
+        fl.bias_h = 2097152.0f + (float)fl.off_h * 0.0625f;   // exact: off_h is a multiple of 4 below 2^16
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (q > 0)
+                asm volatile("" : "+v"(g.w[3 * q]), "+v"(g.w[3 * q + 1]), "+v"(g.w[3 * q + 2]) : "v"(o.h[q - 1]), "v"(o.s[q - 1]), "v"(o.v[q - 1]));
+            const u32 d[3] = {g.w[3 * q], g.w[3 * q + 1], g.w[3 * q + 2]};
+#if PSD_ABLATE & 8
+            o.h[q] = d[0]; o.s[q] = d[1]; o.v[q] = d[2];
+            continue;
+#endif
+            PxFp x0, x1, x2, x3;
+            pixel_fp_front<LS, 0>(d, fl, x0);
+            pixel_fp_front<LS, 1>(d, fl, x1);
+            pixel_fp_front<LS, 2>(d, fl, x2);
+            pixel_fp_front<LS, 3>(d, fl, x3);
+            const float r0 = pixel_fp_hraw(x0), r1 = pixel_fp_hraw(x1), r2 = pixel_fp_hraw(x2), r3 = pixel_fp_hraw(x3);
+            u32 hq = 0;
+            const u32 s0 = pixel_fp_back<0>(x0, r0, hq), s1 = pixel_fp_back<1>(x1, r1, hq);
+            const u32 s2 = pixel_fp_back<2>(x2, r2, hq), s3 = pixel_fp_back<3>(x3, r3, hq);
+            const u32 s01 = perm_b32(s1, s0, 0x0c0c0400u), v01 = perm_b32(__float_as_uint(x1.V), __float_as_uint(x0.V), 0x0c0c0400u);
+            const u32 s23 = perm_b32(s3, s2, 0x0c0c0400u), v23 = perm_b32(__float_as_uint(x3.V), __float_as_uint(x2.V), 0x0c0c0400u);
+            o.h[q] = hq;
+            o.s[q] = perm_b32(s23, s01, 0x05040100u);
+            o.v[q] = perm_b32(v23, v01, 0x05040100u);
+        }
+        return;
+    }
     if (LUMA) {
         u32 local = 0;
 #pragma unroll
@@ -357,12 +516,14 @@ __global__ __launch_bounds__(WG) void score_frames_kernel(const ScoreParams p)
     const int l32 = tid & 31;
     const int tile = blockIdx.x % p.n_tiles;
     const int chunk = blockIdx.x / p.n_tiles;
+    constexpr bool FPK = HSV && !LUMA && PSD_HSV_FP32;   // HSV-only: the fp32 formulation and its float tables
 
     // Fill the replicated LUTs and clear the accumulators.
     if (HSV) {
+        const uint32_t* tab = FPK ? p.lutf : p.lut;
         for (int i = tid; i < 256 * COPIES; i += WG) {
-            lut_s[i] = p.lut[i / COPIES];
-            lut_h[i] = p.lut[256 + i / COPIES];
+            lut_s[i] = tab[i / COPIES];
+            lut_h[i] = tab[256 + i / COPIES];
         }
     }
     for (int i = tid; i < 2 * NACC * COPIES; i += WG) (&acc[0][0])[i] = 0;
@@ -396,7 +557,7 @@ __global__ __launch_bounds__(WG) void score_frames_kernel(const ScoreParams p)
                     Group g;
                     load_group<FAST>(p, halo, grp[k], g);
                     u32 dummy = 0;
-                    convert_group<true, false>(g, prev[k], my_lut_s, my_lut_h, nullptr, dummy);
+                    convert_group<true, false, COPIES, COPIES, FPK>(g, prev[k], my_lut_s, my_lut_h, nullptr, dummy);
                 }
             }
         }
@@ -439,7 +600,7 @@ __global__ __launch_bounds__(WG) void score_frames_kernel(const ScoreParams p)
         for (int k = 0; k < G; k++) {
             if (live[k]) {
                 Hsv16 c;
-                convert_group<HSV, LUMA>(cur[k], c, my_lut_s, my_lut_h, my_hist, bs);
+                convert_group<HSV, LUMA, COPIES, COPIES, FPK>(cur[k], c, my_lut_s, my_lut_h, my_hist, bs);
                 if (HSV) {
                     if (have_prev) sad_group(c, prev[k], sh, ss, sv);
                     prev[k] = c;
@@ -619,10 +780,12 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
     const int tile = blockIdx.x % p.n_tiles;
     const int chunk = blockIdx.x / p.n_tiles;
 
+    constexpr bool FPK = HSV && !LUMA && PSD_HSV_FP32;   // HSV-only: the fp32 formulation and its float tables
     if (HSV) {
+        const uint32_t* tab = FPK ? p.lutf : p.lut;
         for (int i = tid; i < 256 * LCD; i += WG) {
-            lut_s[i] = p.lut[i / LCD];
-            lut_h[i] = p.lut[256 + i / LCD];
+            lut_s[i] = tab[i / LCD];
+            lut_h[i] = tab[256 + i / LCD];
         }
     }
     for (int i = tid; i < SLOTS * NA * ACD; i += WG) (&acc[0][0])[i] = 0;
@@ -655,7 +818,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
 #pragma unroll
             for (int k = 0; k < G; k++) {
                 u32 dummy = 0;
-                convert_group<true, false, LCD, ACD>(cur[k], prev[k], my_lut_s, my_lut_h, nullptr, dummy);
+                convert_group<true, false, LCD, ACD, FPK>(cur[k], prev[k], my_lut_s, my_lut_h, nullptr, dummy);
             }
         }
     }
@@ -682,7 +845,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
         for (int k = 0; k < G; k++) {
             if (HSV || live[k]) {
                 Hsv16 c;
-                convert_group<HSV, LUMA, LCD, ACD>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs, live[k] ? 1u : 0u);
+                convert_group<HSV, LUMA, LCD, ACD, FPK>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs, live[k] ? 1u : 0u);
                 if (HSV) {
                     if (have_prev) sad_group(c, prev[k], sh, ss, sv);
                     prev[k] = c;
