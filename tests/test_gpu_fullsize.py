@@ -1,0 +1,177 @@
+"""GPU: the configurations BASELINE.json names, at their full sizes, against the CPU oracle.
+
+Round-1 review: the edge term had only met the oracle on frames up to 131x257 with k <= 9, and the fused
+HSV + luma + byte-sum variant on three 1080p frames.  Here: the reference's automatic dilation kernel at 1080p
+(k = 13) and 4K (k = 19) (``content_detector.py:39-46, 213-239``), kernels whose windows straddle 32-bit words of
+the bit rows (k = 31, 33, 63), a weak-edge chain that needs dozens of hysteresis relaunches, and the fused variant
+on 64 uniform and on constant frames at 1080p.  Everything bit-exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import lib as orc
+from oracle.detectors_np import edge_map, estimated_kernel_size
+from oracle.detectors_np import score_batch as oracle_score
+from pyscenedetect_amd import engine as E
+from pyscenedetect_amd.synth import make_clip
+
+pytestmark = pytest.mark.gpu
+NOEDGE = E.SCORE_HSV_SAD | E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM
+FIELDS = ("sad_h", "sad_s", "sad_v", "byte_sum", "hist")
+
+
+def same(a, b, fields=FIELDS):
+    for f in fields:
+        assert np.array_equal(a[f], b[f]), f"field {f} differs at {np.argwhere(a[f] != b[f])[:4].tolist()}"
+
+
+def device_copy(engine, frames):
+    buf = engine.alloc(frames.nbytes)
+    buf.upload(frames.reshape(-1))
+    return buf
+
+
+def shots_with_objects(seed, n, h, w, noise=3.0):
+    """Shot-like frames that actually contain edges: the smooth synthetic shots plus, per frame, a few flat
+    rectangles and a diagonal band that move a little from frame to frame."""
+    frames, _ = make_clip(seed, n, h, w, shot_len=(2, 3), noise=noise, fade_every=0)
+    rng = np.random.default_rng(seed + 1)
+    rects = [(int(rng.integers(0, h - h // 4)), int(rng.integers(0, w - w // 4)), int(rng.integers(h // 16, h // 4)),
+              int(rng.integers(w // 16, w // 4)), rng.integers(0, 256, 3)) for _ in range(6)]
+    yy, xx = np.mgrid[0:h, 0:w]
+    for t in range(n):
+        for (y, x, rh, rw, col) in rects:
+            y2, x2 = min(h - rh, y + 3 * t), min(w - rw, x + 5 * t)
+            frames[t, y2:y2 + rh, x2:x2 + rw] = col
+        band = np.abs(yy - xx * h // w - 7 * t) < max(2, h // 90)
+        frames[t][band] = (frames[t][band].astype(np.int32) + 80).clip(0, 255).astype(np.uint8)
+    return frames
+
+
+def check_edge_maps(engine, frames, k, which):
+    n, h, w, _ = frames.shape
+    buf = device_copy(engine, frames)
+    for i in which:
+        got = engine.edge_map(buf.ptr + i * h * w * 3, h, w, edge_kernel=k)
+        want = edge_map(frames[i], k)
+        assert np.array_equal(got, want), f"{w}x{h} k={k} frame {i}: {np.count_nonzero(got != want)} px differ"
+    buf.free()
+
+
+def test_edges_1080p_auto_kernel_shot_like_and_uniform(hip_engine):
+    """BASELINE config 2, second run: weights (1,1,1,1) at 1920x1080, where the reference picks k = 13."""
+    assert estimated_kernel_size(1920, 1080) == 13
+    shots = shots_with_objects(41, 8, 1080, 1920)
+    rng = np.random.default_rng(42)
+    noise = rng.integers(0, 256, (3, 1080, 1920, 3), dtype=np.uint8)
+    for frames, which in ((shots, (0, 5)), (noise, (1,))):
+        want = oracle_score(frames, edges=True)
+        buf = device_copy(hip_engine, frames)
+        got = hip_engine.score_device(buf.ptr, len(frames), 1080, 1920, flags=E.SCORE_ALL)
+        buf.free()
+        same(got, want, FIELDS + ("edge_xor",))
+        if frames is shots:      # (uniform noise dilated by 13x13 is all edge in every frame: its XOR counts are 0)
+            assert want["edge_xor"][1:].all()
+        check_edge_maps(hip_engine, frames, 0, which)
+
+
+def test_edges_4k_auto_kernel(hip_engine):
+    """3840x2160: k = 19."""
+    assert estimated_kernel_size(3840, 2160) == 19
+    shots = shots_with_objects(43, 2, 2160, 3840)
+    rng = np.random.default_rng(44)
+    frames = np.concatenate([shots, rng.integers(0, 256, (1, 2160, 3840, 3), dtype=np.uint8)])
+    want = oracle_score(frames, edges=True)
+    buf = device_copy(hip_engine, frames)
+    got = hip_engine.score_device(buf.ptr, 3, 2160, 3840, flags=E.SCORE_ALL)
+    buf.free()
+    same(got, want, FIELDS + ("edge_xor",))
+    check_edge_maps(hip_engine, frames, 0, (0, 2))
+
+
+@pytest.mark.parametrize("k", [13, 19, 31, 33, 63])
+def test_dilation_windows_across_word_boundaries(hip_engine, k):
+    """Horizontal windows wider than a 32-bit word of the bit rows, vertical windows taller than the frame edge."""
+    shots = shots_with_objects(50 + k, 3, 150, 260, noise=5.0)
+    rng = np.random.default_rng(k)
+    sparse = np.full((2, 97, 131, 3), 60, np.uint8)          # odd width: the last word of a bit row is partial
+    sparse[0, 40:44, 60:64] = 250
+    sparse[1, 3:5, 125:131] = 250                            # touches the right border
+    sparse[1, 90:97, 0:3] = 250                              # and the bottom-left corner
+    noise = rng.integers(0, 256, (2, 70, 100, 3), dtype=np.uint8)
+    for frames in (shots, sparse, noise):
+        n, h, w, _ = frames.shape
+        check_edge_maps(hip_engine, frames, k, range(n))
+        got = hip_engine.score_host(frames, flags=E.SCORE_EDGES, edge_kernel=k)
+        want = oracle_score(frames, edges=True, kernel_size=k)
+        assert np.array_equal(got["edge_xor"], want["edge_xor"])
+
+
+def serpentine(h, w, seed=True, m=90, s=20, strong=70, pitch=16, width=8):
+    """A corridor 20 grey levels above the background that snakes across the frame: its outline is ONE connected chain
+    of weak Canny pixels (4 * 20 = 80 between the thresholds 60 and 120 that the median 90 gives); a small bright
+    patch at the start of the corridor supplies the only strong pixels."""
+    img = np.full((h, w), m, np.uint8)
+    runs = list(range(8, w - 8 - width, pitch))
+    for i, x0 in enumerate(runs):
+        img[8:h - 8, x0:x0 + width] = m + s
+        if i + 1 < len(runs):
+            x1 = runs[i + 1]
+            if i % 2 == 0:
+                img[h - 8 - width:h - 8, x0:x1 + width] = m + s
+            else:
+                img[8:8 + width, x0:x1 + width] = m + s
+    if seed:
+        img[20:26, runs[0]:runs[0] + 4] = m + s + strong
+    return np.repeat(img[:, :, None], 3, axis=2), runs
+
+
+@pytest.mark.parametrize("shape", [(512, 512), (300, 700), (1080, 1920)])
+def test_hysteresis_chain_far_longer_than_one_round_of_launches(hip_engine, shape):
+    """The chain crosses hundreds of 64x64 hysteresis tiles one after the other, so the device has to relaunch
+    the hysteresis kernel dozens of times; without the bright patch there is no edge at all."""
+    h, w = shape
+    frame, runs = serpentine(h, w)
+    want = edge_map(frame, 3)
+    assert not edge_map(serpentine(h, w, seed=False)[0], 3).any()
+    assert want[:, runs[-1] - 4:runs[-1] + 12].any(), "the chain must reach the far end of the corridor"
+    buf = device_copy(hip_engine, frame[None])
+    got = hip_engine.edge_map(buf.ptr, h, w, edge_kernel=3)
+    buf.free()
+    assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} px differ"
+    # as the second frame of a batch: the XOR count against the seedless frame is the whole chain
+    pair = np.stack([serpentine(h, w, seed=False)[0], frame])
+    rec = hip_engine.score_host(pair, flags=E.SCORE_EDGES, edge_kernel=3)
+    assert rec["edge_xor"][1] == np.count_nonzero(want)
+
+
+def test_fused_all_terms_1080p_64_uniform_frames(hip_engine):
+    """BASELINE config 5's kernel (HSV + luma histogram + byte sum in one pass) on 64 full-size frames."""
+    rng = np.random.default_rng(64)
+    frames = rng.integers(0, 256, (64, 1080, 1920, 3), dtype=np.uint8)
+    prev = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    want = orc.score_batch(frames, prev)
+    buf = device_copy(hip_engine, np.concatenate([prev[None], frames]))
+    stride = 1080 * 1920 * 3
+    got = hip_engine.score_device(buf.ptr + stride, 64, 1080, 1920, d_prev=buf.ptr, flags=NOEDGE)
+    same(got, want)
+    same(hip_engine.score_device(buf.ptr + stride, 64, 1080, 1920, d_prev=buf.ptr, flags=E.SCORE_HSV_SAD), want,
+         ("sad_h", "sad_s", "sad_v"))
+    same(hip_engine.score_device(buf.ptr + stride, 64, 1080, 1920, flags=E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM), want,
+         ("hist", "byte_sum"))
+    buf.free()
+
+
+def test_fused_all_terms_1080p_constant_frames(hip_engine):
+    """The K distribution (every pixel of a frame in ONE histogram bin) at full size, fused and separate passes."""
+    vals = [(0, 0, 0), (255, 255, 255), (128, 128, 128), (255, 0, 0), (0, 255, 0), (0, 0, 255), (17, 200, 99), (1, 1, 2),
+            (254, 255, 254), (128, 128, 128), (128, 128, 128), (90, 10, 200)]
+    frames = np.empty((len(vals), 1080, 1920, 3), np.uint8)
+    for i, v in enumerate(vals):
+        frames[i] = v
+    want = orc.score_batch(frames)
+    buf = device_copy(hip_engine, frames)
+    same(hip_engine.score_device(buf.ptr, len(vals), 1080, 1920, flags=NOEDGE), want)
+    same(hip_engine.score_device(buf.ptr, len(vals), 1080, 1920, flags=E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM), want, ("hist", "byte_sum"))
+    same(hip_engine.score_device(buf.ptr, len(vals), 1080, 1920, flags=E.SCORE_HSV_SAD), want, ("sad_h", "sad_s", "sad_v"))
+    buf.free()
