@@ -14,8 +14,8 @@
  *                         scenedetect/detectors/threshold_detector.py:127
  *     PSD_SCORE_EDGES     numpy.median + cv2.Canny + cv2.dilate + _mean_pixel_distance(edges)
  *                         scenedetect/detectors/content_detector.py:170-174,213-239
- *   psd_resize_linear_device                   cv2.resize(..., INTER_LINEAR)
- *                         scenedetect/scene_manager.py:666-678
+ *   psd_resize_device / psd_score_downscaled_device   cv2.resize(..., interpolation) in front of the detectors
+ *                         scenedetect/scene_manager.py:110,123-140,666-678
  *   psd_epilogue_*                             the O(1)-per-frame decisions that follow the pixel work
  *                         content_detector.py:177-180,192-211 + detector.py:106-224 (FlashFilter)
  *                         adaptive_detector.py:100-143
@@ -137,6 +137,22 @@ enum psd_interpolation { PSD_INTER_NEAREST = 0, PSD_INTER_LINEAR = 1, PSD_INTER_
 int psd_resize_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w,
                       size_t src_frame_stride, uint8_t* d_dst, int dst_h, int dst_w,
                       size_t dst_frame_stride, int interpolation, void* stream);
+/* The reference's default pipeline in one call (scene_manager.py:110,123-140,666-678 followed by the detectors'
+ * process_frame): cv2.resize(frame, (dst_w, dst_h), interpolation) and then the terms of `flags` on the RESIZED frames.
+ * Source frames: packed rows (row stride 3*src_w), frame t at d_frames + t*frame_stride; d_prev is the SOURCE-size
+ * frame preceding frame 0 or NULL.  Records are those psd_score_batch_device would return for the resized frames.
+ * With INTER_LINEAR and flags == PSD_SCORE_HSV_SAD (ContentDetector / AdaptiveDetector, the reference's default
+ * detectors) on 16-byte aligned frames the resized frame never exists in memory: one kernel reads the 2*dst_h source
+ * rows that carry taps, interpolates and scores.  Every other combination resizes into an engine-owned buffer first.
+ * The submit form pairs with psd_score_collect() like psd_score_submit_device(). */
+int psd_score_downscaled_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w,
+                                size_t frame_stride, const uint8_t* d_prev, int dst_h, int dst_w,
+                                int interpolation, uint32_t flags, int edge_kernel, psd_frame_scores* out,
+                                void* stream);
+int psd_score_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w,
+                                       size_t frame_stride, const uint8_t* d_prev, int dst_h, int dst_w,
+                                       int interpolation, uint32_t flags, int edge_kernel, void* stream);
+
 /* psd_resize_device(..., PSD_INTER_LINEAR, ...) */
 int psd_resize_linear_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w,
                              size_t src_frame_stride, uint8_t* d_dst, int dst_h, int dst_w,

@@ -119,6 +119,8 @@ SYMBOLS = {
     "psd_hsv_tables": (_i, [_vp, _vp]),
     "psd_edge_map_device": (_i, [_vp, _vp, _i, _i, _sz, _i, _vp]),
     "psd_resize_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _sz, _i, _vp]),
+    "psd_score_downscaled_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _i, _u32, _i, _vp, _vp]),
+    "psd_score_downscaled_submit_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _i, _u32, _i, _vp]),
     "psd_resize_linear_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _sz, _vp]),
     "psd_hash_thumbs_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp]),
     "psd_hash_thumbs": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp]),

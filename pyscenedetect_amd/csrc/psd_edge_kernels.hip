@@ -1,4 +1,4 @@
-// psd_edge_kernels.hip -- the edge term of ContentDetector and the bilinear downscale, for gfx950.
+// psd_edge_kernels.hip -- the edge term of ContentDetector and the NEAREST / AREA downscale modes, for gfx950.
 //
 // Edge term (reference scenedetect/detectors/content_detector.py:170-174,213-239):
 //     edges_t   = cv2.dilate(cv2.Canny(V_t, low, high), ones(k,k))   with low/high from numpy.median(V_t)
@@ -15,9 +15,6 @@
 //                         popcount -> edge_xor; the dilated bits stay resident for the next frame
 // Algorithmic traffic is 5 B/px (3 read + edge map write + previous edge map read);
 // the intermediate planes are implementation overhead.
-//
-// Downscale (reference scenedetect/scene_manager.py:666-678): cv2.resize(..., INTER_LINEAR) with
-// OpenCV's 11-bit fixed-point coefficients; exact 2x decimation takes OpenCV's INTER_AREA shortcut.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -755,114 +752,10 @@ void edges_release(psd_engine* e)
     *engine_edge_ws_bytes(e) = 0;
 }
 
-// ---- cv2.resize(INTER_LINEAR), 8-bit, 3 channels --------------------------------------------------
-
-struct ResizeTabs {
-    const int* xofs; const short* ialpha; const int* yofs; const short* ibeta;
-};
-
-// grid = (ceil(dst_w/64), dst_h, frames), block 64: one destination pixel (3 channels) per thread.
-__global__ __launch_bounds__(64) void resize_linear_kernel(const uint8_t* src, int sh, int sw, size_t sstride, uint8_t* dst, int dh,
-                                                           int dw, size_t dstride, ResizeTabs t)
-{
-    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y;
-    if (dx >= dw) return;
-    const uint8_t* S = src + (size_t)blockIdx.z * sstride;
-    uint8_t* D = dst + (size_t)blockIdx.z * dstride + ((size_t)dy * dw + dx) * 3;
-    const int sy0 = min(max(t.yofs[dy], 0), sh - 1), sy1 = min(max(t.yofs[dy] + 1, 0), sh - 1);
-    const int sx = t.xofs[dx], sx1 = min(sx + 1, sw - 1);
-    const int a0 = t.ialpha[2 * dx], a1 = t.ialpha[2 * dx + 1], b0 = t.ibeta[2 * dy], b1 = t.ibeta[2 * dy + 1];
-    const uint8_t* r0 = S + (size_t)sy0 * sw * 3;
-    const uint8_t* r1 = S + (size_t)sy1 * sw * 3;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const int h0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
-        const int h1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
-        D[c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
-    }
-}
-
-// exact 2x2 decimation: OpenCV routes INTER_LINEAR to INTER_AREA, i.e. the rounded box mean
-__global__ __launch_bounds__(64) void resize_area2_kernel(const uint8_t* src, int sw, size_t sstride, uint8_t* dst, int dh, int dw,
-                                                          size_t dstride)
-{
-    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y;
-    if (dx >= dw) return;
-    const uint8_t* p = src + (size_t)blockIdx.z * sstride + ((size_t)(2 * dy) * sw + 2 * dx) * 3;
-    uint8_t* D = dst + (size_t)blockIdx.z * dstride + ((size_t)dy * dw + dx) * 3;
-    const size_t row = (size_t)sw * 3;
-#pragma unroll
-    for (int c = 0; c < 3; c++) D[c] = (uint8_t)((p[c] + p[3 + c] + p[row + c] + p[row + 3 + c] + 2) >> 2);
-}
-
-static short sat_s16_round(float v)
-{
-    long r = lrintf(v);
-    return (short)(r > 32767 ? 32767 : (r < -32768 ? -32768 : r));
-}
-
-int resize_linear(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
-                  int dst_w, size_t dst_frame_stride, hipStream_t stream)
-{
-    if (n == 0) return PSD_OK;
-    const double scale_x = 1. / ((double)dst_w / src_w), scale_y = 1. / ((double)dst_h / src_h);
-    const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
-    const bool area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
-    const dim3 grid((dst_w + 63) / 64, dst_h, n);
-    if (area_fast && iscale_x == 2 && iscale_y == 2) {
-        hipLaunchKernelGGL(resize_area2_kernel, grid, dim3(64), 0, stream, d_src, src_w, src_frame_stride, d_dst, dst_h, dst_w,
-                           dst_frame_stride);
-        HIP_TRY(hipGetLastError());
-        return PSD_OK;
-    }
-    // OpenCV's coefficient tables (resize.cpp, INTER_LINEAR, 11-bit fixed point), built on the host
-    // in the same float arithmetic.
-    std::vector<int> xofs(dst_w), yofs(dst_h);
-    std::vector<short> ialpha(2 * (size_t)dst_w), ibeta(2 * (size_t)dst_h);
-    for (int dx = 0; dx < dst_w; dx++) {
-        float fx = (float)((dx + 0.5) * scale_x - 0.5);
-        int sx = (int)floorf(fx);
-        fx -= sx;
-        if (sx < 0) { fx = 0; sx = 0; }
-        if (sx >= src_w - 1) { fx = 0; sx = src_w - 1; }
-        xofs[dx] = sx;
-        ialpha[2 * dx] = sat_s16_round((1.f - fx) * 2048);
-        ialpha[2 * dx + 1] = sat_s16_round(fx * 2048);
-    }
-    for (int dy = 0; dy < dst_h; dy++) {
-        float fy = (float)((dy + 0.5) * scale_y - 0.5);
-        int sy = (int)floorf(fy);
-        fy -= sy;
-        yofs[dy] = sy;
-        ibeta[2 * dy] = sat_s16_round((1.f - fy) * 2048);
-        ibeta[2 * dy + 1] = sat_s16_round(fy * 2048);
-    }
-    const size_t bx = align_up(dst_w * sizeof(int)), ba = align_up(2 * (size_t)dst_w * sizeof(short));
-    const size_t by = align_up(dst_h * sizeof(int)), bb = align_up(2 * (size_t)dst_h * sizeof(short));
-    uint8_t* tabs = nullptr;
-    HIP_TRY(hipMalloc((void**)&tabs, bx + ba + by + bb));
-    ResizeTabs t;
-    t.xofs = (const int*)tabs; t.ialpha = (const short*)(tabs + bx);
-    t.yofs = (const int*)(tabs + bx + ba); t.ibeta = (const short*)(tabs + bx + ba + by);
-    hipError_t err = hipMemcpyAsync((void*)t.xofs, xofs.data(), dst_w * sizeof(int), hipMemcpyHostToDevice, stream);
-    if (err == hipSuccess) err = hipMemcpyAsync((void*)t.ialpha, ialpha.data(), 2 * (size_t)dst_w * sizeof(short), hipMemcpyHostToDevice, stream);
-    if (err == hipSuccess) err = hipMemcpyAsync((void*)t.yofs, yofs.data(), dst_h * sizeof(int), hipMemcpyHostToDevice, stream);
-    if (err == hipSuccess) err = hipMemcpyAsync((void*)t.ibeta, ibeta.data(), 2 * (size_t)dst_h * sizeof(short), hipMemcpyHostToDevice, stream);
-    if (err == hipSuccess) {
-        hipLaunchKernelGGL(resize_linear_kernel, grid, dim3(64), 0, stream, d_src, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w,
-                           dst_frame_stride, t);
-        err = hipGetLastError();
-    }
-    if (err == hipSuccess) err = hipStreamSynchronize(stream);  // the tables are freed below
-    (void)hipFree(tabs);
-    if (err != hipSuccess) { psd_set_error("resize failed: %s", hipGetErrorString(err)); return PSD_ERR_HIP; }
-    return PSD_OK;
-}
-
 // ---- cv2.resize(INTER_NEAREST) and cv2.resize(INTER_AREA), 8-bit, 3 channels ---------------------------
 // The other two `Interpolation` modes SceneManager can be asked to downscale with (reference common.py:148-160,
-// scene_manager.py:670-678).  One destination pixel per thread, like resize_linear_kernel: correctness paths, not
-// tuned (the default is INTER_LINEAR).
+// scene_manager.py:670-678).  One destination pixel per thread: correctness paths, not tuned (the default,
+// INTER_LINEAR, lives in psd_resize_kernels.hip).
 
 __global__ __launch_bounds__(64) void resize_nearest_kernel(const uint8_t* src, int sh, int sw, size_t sstride, uint8_t* dst, int dh,
                                                             int dw, size_t dstride, const int* xofs, const int* yofs)

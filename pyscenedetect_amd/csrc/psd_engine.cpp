@@ -41,8 +41,11 @@ int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
 int edges_map(psd_engine* e, const uint8_t* d_frame, int height, int width, size_t row_stride,
               int edge_kernel, uint8_t* h_edges);
 void edges_release(psd_engine* e);
-int resize_linear(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride,
-                  uint8_t* d_dst, int dst_h, int dst_w, size_t dst_frame_stride, hipStream_t stream);
+// psd_resize_kernels.hip
+int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_row_stride,
+                        size_t src_frame_stride, const uint8_t* d_prev, uint8_t* d_dst, int dst_h, int dst_w,
+                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches);
+void resize_release(psd_engine* e);
 int resize_other(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
                  int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream);
 // psd_hash_kernels.hip
@@ -80,6 +83,9 @@ struct psd_engine {
     uint8_t* d_hash = nullptr;  // thumbnails + run tables of psd_hash_thumbs*
     size_t hash_bytes = 0;
     hipEvent_t ev_hash[2] = {nullptr, nullptr};
+    void* resize_cache = nullptr;   // coefficient tables per (src, dst) shape, owned by psd_resize_kernels.hip
+    uint8_t* d_small = nullptr;     // resized frames of psd_score_downscaled_* when the terms need them in memory
+    size_t small_bytes = 0;
 };
 
 static void fill_tables(int32_t* sdiv, int32_t* hdiv)
@@ -190,6 +196,8 @@ void psd_destroy(psd_engine* e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     psd::edges_release(e);
+    psd::resize_release(e);
+    if (e->d_small) (void)hipFree(e->d_small);
     for (auto& s : e->slots) {
         if (s.d_recs) (void)hipFree(s.d_recs);
         if (s.h_recs) (void)hipHostFree(s.h_recs);
@@ -240,6 +248,71 @@ static int validate(const void* frames, int n, int height, int width, size_t row
     return PSD_OK;
 }
 
+// One submission = a record slot of the ring: zeroed records, timing events around the kernels, the copy of the
+// records into the pinned mirror.  submit_begin / submit_end bracket whatever fills the records.
+static int submit_begin(psd_engine* e, int n, hipStream_t stream, psd_slot** out)
+{
+    if (e->pending >= PSD_MAX_INFLIGHT) {
+        psd_set_error("too many submissions in flight (max %d); call psd_score_collect", PSD_MAX_INFLIGHT);
+        return PSD_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    psd_slot& s = e->slots[e->head];
+    int rc = ensure_slot(e, s, n);
+    if (rc != PSD_OK) return rc;
+    s.n = n;
+    s.launches = 0;
+    if (n > 0) {
+        HIP_TRY(hipMemsetAsync(s.d_recs, 0, (size_t)n * sizeof(psd_frame_scores), stream));
+        HIP_TRY(hipEventRecord(s.ev_start, stream));
+    }
+    *out = &s;
+    return PSD_OK;
+}
+
+static int submit_end(psd_engine* e, psd_slot& s, hipStream_t stream)
+{
+    if (s.n > 0) {
+        HIP_TRY(hipEventRecord(s.ev_stop, stream));
+        HIP_TRY(hipMemcpyAsync(s.h_recs, s.d_recs, (size_t)s.n * sizeof(psd_frame_scores), hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipEventRecord(s.ev_done, stream));
+    s.pending = true;
+    e->head = (e->head + 1) % PSD_MAX_INFLIGHT;
+    e->pending++;
+    return PSD_OK;
+}
+
+// the scoring terms of `flags` for n resident frames, added into the slot's records
+static int score_terms(psd_engine* e, psd_slot& s, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
+                       size_t frame_stride, const uint8_t* d_prev, uint32_t flags, int edge_kernel, hipStream_t stream)
+{
+    const bool hsv = flags & PSD_SCORE_HSV_SAD;
+    const bool luma = flags & (PSD_SCORE_LUMA_HIST | PSD_SCORE_BYTE_SUM);
+    if (hsv || luma) {
+        psd::ScoreParams p{};
+        p.frames = d_frames;
+        p.prev = d_prev;
+        p.out = s.d_recs;
+        p.lut = e->d_lut;
+        p.lutf = e->d_lut + 512;
+        p.frame_stride = frame_stride;
+        p.row_stride = row_stride;
+        p.npix = (long)height * width;
+        p.width = width;
+        p.n = n;
+        const bool fast = row_stride == (size_t)width * 3 && ((uintptr_t)d_frames % 16 == 0) &&
+                          (frame_stride % 16 == 0 || n == 1) && (!d_prev || (uintptr_t)d_prev % 16 == 0);
+        // ~8 workgroups per CU over the launch keeps the tail short (one 1024-thread WG per CU).
+        HIP_TRY(psd::launch_score_frames(p, hsv, luma, fast, e->num_cus * 8, stream, &s.launches));
+    }
+    if (flags & PSD_SCORE_EDGES) {
+        int rc = psd::edges_score(e, d_frames, n, height, width, row_stride, frame_stride, d_prev, edge_kernel, s.d_recs, stream);
+        if (rc != PSD_OK) return rc;
+    }
+    return PSD_OK;
+}
+
 int psd_score_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width,
                             size_t row_stride, size_t frame_stride, const uint8_t* d_prev,
                             uint32_t flags, int edge_kernel, void* stream_)
@@ -247,52 +320,90 @@ int psd_score_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int h
     if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
     int rc = validate(d_frames, n, height, width, row_stride, frame_stride, flags, edge_kernel);
     if (rc != PSD_OK) return rc;
-    if (e->pending >= PSD_MAX_INFLIGHT) {
-        psd_set_error("too many submissions in flight (max %d); call psd_score_collect", PSD_MAX_INFLIGHT);
-        return PSD_ERR_INVALID;
-    }
-    HIP_TRY(hipSetDevice(e->device));
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : e->stream;
-    psd_slot& s = e->slots[e->head];
-    rc = ensure_slot(e, s, n);
+    psd_slot* s = nullptr;
+    rc = submit_begin(e, n, stream, &s);
     if (rc != PSD_OK) return rc;
-    s.n = n;
-    s.launches = 0;
     if (n > 0) {
-        HIP_TRY(hipMemsetAsync(s.d_recs, 0, (size_t)n * sizeof(psd_frame_scores), stream));
-        HIP_TRY(hipEventRecord(s.ev_start, stream));
-        const bool hsv = flags & PSD_SCORE_HSV_SAD;
-        const bool luma = flags & (PSD_SCORE_LUMA_HIST | PSD_SCORE_BYTE_SUM);
-        if (hsv || luma) {
-            psd::ScoreParams p{};
-            p.frames = d_frames;
-            p.prev = d_prev;
-            p.out = s.d_recs;
-            p.lut = e->d_lut;
-            p.lutf = e->d_lut + 512;
-            p.frame_stride = frame_stride;
-            p.row_stride = row_stride;
-            p.npix = (long)height * width;
-            p.width = width;
-            p.n = n;
-            const bool fast = row_stride == (size_t)width * 3 && ((uintptr_t)d_frames % 16 == 0) &&
-                              (frame_stride % 16 == 0 || n == 1) && (!d_prev || (uintptr_t)d_prev % 16 == 0);
-            // ~8 workgroups per CU over the launch keeps the tail short (one 1024-thread WG per CU).
-            HIP_TRY(psd::launch_score_frames(p, hsv, luma, fast, e->num_cus * 8, stream, &s.launches));
+        rc = score_terms(e, *s, d_frames, n, height, width, row_stride, frame_stride, d_prev, flags, edge_kernel, stream);
+        if (rc != PSD_OK) return rc;
+    }
+    return submit_end(e, *s, stream);
+}
+
+static int resize_any(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst,
+                      int dst_h, int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream)
+{
+    if (interpolation == PSD_INTER_LINEAR)
+        return psd::resize_linear_score(e, d_src, n, src_h, src_w, (size_t)src_w * 3, src_frame_stride, nullptr, d_dst, dst_h, dst_w,
+                                        dst_frame_stride, nullptr, stream, nullptr);
+    return psd::resize_other(d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, interpolation, stream);
+}
+
+int psd_score_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w, size_t frame_stride,
+                                       const uint8_t* d_prev, int dst_h, int dst_w, int interpolation, uint32_t flags,
+                                       int edge_kernel, void* stream_)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    int rc = validate(d_frames, n, src_h, src_w, (size_t)src_w * 3, frame_stride, flags, edge_kernel);
+    if (rc != PSD_OK) return rc;
+    if (dst_h <= 0 || dst_w <= 0) { psd_set_error("invalid target size %dx%d", dst_w, dst_h); return PSD_ERR_INVALID; }
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : e->stream;
+    psd_slot* s = nullptr;
+    rc = submit_begin(e, n, stream, &s);
+    if (rc != PSD_OK) return rc;
+    if (n > 0) {
+        bool done = false;
+        if (interpolation == PSD_INTER_LINEAR && flags == PSD_SCORE_HSV_SAD) {
+            // ContentDetector / AdaptiveDetector behind the default downscale: the resized frame never leaves the CU
+            rc = psd::resize_linear_score(e, d_frames, n, src_h, src_w, (size_t)src_w * 3, frame_stride, d_prev, nullptr, dst_h, dst_w, 0,
+                                          s->d_recs, stream, &s->launches);
+            if (rc == PSD_OK) done = true;
+            else if (rc != PSD_ERR_UNSUPPORTED) return rc;
         }
-        if (flags & PSD_SCORE_EDGES) {
-            rc = psd::edges_score(e, d_frames, n, height, width, row_stride, frame_stride, d_prev, edge_kernel,
-                                  s.d_recs, stream);
+        if (!done) {
+            // resize [prev,] frames into the engine's small-frame buffer, then score them there
+            const size_t sstride = (((size_t)dst_h * dst_w * 3) + 15) & ~(size_t)15;
+            const size_t need = sstride * ((size_t)n + 1);
+            if (e->small_bytes < need) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(hipStreamSynchronize(e->stream));
+                if (e->d_small) HIP_TRY(hipFree(e->d_small));
+                e->d_small = nullptr; e->small_bytes = 0;
+                hipError_t err = hipMalloc((void**)&e->d_small, need);
+                if (err != hipSuccess) {
+                    psd_set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(err));
+                    return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
+                }
+                e->small_bytes = need;
+            }
+            if (d_prev) {
+                rc = resize_any(e, d_prev, 1, src_h, src_w, frame_stride, e->d_small, dst_h, dst_w, sstride, interpolation, stream);
+                if (rc != PSD_OK) return rc;
+            }
+            rc = resize_any(e, d_frames, n, src_h, src_w, frame_stride, e->d_small + sstride, dst_h, dst_w, sstride, interpolation, stream);
+            if (rc != PSD_OK) return rc;
+            s->launches += 1;
+            rc = score_terms(e, *s, e->d_small + sstride, n, dst_h, dst_w, (size_t)dst_w * 3, sstride, d_prev ? e->d_small : nullptr, flags,
+                             edge_kernel, stream);
             if (rc != PSD_OK) return rc;
         }
-        HIP_TRY(hipEventRecord(s.ev_stop, stream));
-        HIP_TRY(hipMemcpyAsync(s.h_recs, s.d_recs, (size_t)n * sizeof(psd_frame_scores), hipMemcpyDeviceToHost, stream));
     }
-    HIP_TRY(hipEventRecord(s.ev_done, stream));
-    s.pending = true;
-    e->head = (e->head + 1) % PSD_MAX_INFLIGHT;
-    e->pending++;
-    return PSD_OK;
+    return submit_end(e, *s, stream);
+}
+
+int psd_score_downscaled_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w, size_t frame_stride,
+                                const uint8_t* d_prev, int dst_h, int dst_w, int interpolation, uint32_t flags, int edge_kernel,
+                                psd_frame_scores* out, void* stream)
+{
+    if (e && e->pending != 0) {
+        psd_set_error("psd_score_downscaled_device: asynchronous submissions are still pending");
+        return PSD_ERR_INVALID;
+    }
+    int rc = psd_score_downscaled_submit_device(e, d_frames, n, src_h, src_w, frame_stride, d_prev, dst_h, dst_w, interpolation, flags,
+                                                edge_kernel, stream);
+    if (rc != PSD_OK) return rc;
+    return psd_score_collect(e, out, n);
 }
 
 int psd_score_collect(psd_engine* e, psd_frame_scores* out, int n)
@@ -539,9 +650,7 @@ int psd_resize_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int
     }
     HIP_TRY(hipSetDevice(e->device));
     hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    if (interpolation == PSD_INTER_LINEAR)
-        return psd::resize_linear(d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, s);
-    return psd::resize_other(d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, interpolation, s);
+    return resize_any(e, d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, interpolation, s);
 }
 
 int psd_resize_linear_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w,
@@ -560,4 +669,6 @@ void** engine_edge_ws(psd_engine* e) { return &e->edge_ws; }
 size_t* engine_edge_ws_bytes(psd_engine* e) { return &e->edge_ws_bytes; }
 int engine_num_cus(psd_engine* e) { return e->num_cus; }
 hipStream_t engine_stream(psd_engine* e) { return e->stream; }
+void** engine_resize_cache(psd_engine* e) { return &e->resize_cache; }
+const uint32_t* engine_lut(psd_engine* e) { return e->d_lut; }
 }  // namespace psd

@@ -1,0 +1,412 @@
+// psd_resize_kernels.hip -- the reference's default pipeline for gfx950: cv2.resize(INTER_LINEAR) in front of the detectors.
+//
+// SceneManager scores frames of about 256 pixels width unless told otherwise (reference scenedetect/scene_manager.py:110,
+// 123-140, 666-678): every frame goes through cv2.resize(frame, (round(w / f), round(h / f)), INTER_LINEAR) first.
+// For a decimation by f only TWO of every f source rows carry taps (and two of every f pixels inside them), so the
+// algorithmic traffic of "downscale, then ContentDetector" is 2 * dst_h source rows per frame -- 1,658,880 B of the
+// 6,220,800 B of a 1080p frame at the default 256 x 144 -- and nothing of the small frame has to exist in HBM.
+//
+//   resize_walk_kernel<STORE, HSV>
+//     A workgroup owns R destination rows and walks a chunk of consecutive frames (like the scoring kernels).  Per frame
+//     it streams the 2 R source rows it needs HBM -> LDS with global_load_lds_dwordx4 one frame ahead (double buffered,
+//     one barrier per frame), every thread gathers the four taps of its destination pixels from LDS, interpolates in
+//     OpenCV's 11-bit fixed point (resize.cpp HResizeLinear / VResizeLinear: ((b0 * (h0 >> 4)) >> 16) + ... + 2) >> 2),
+//     and then either stores the BGR pixel (STORE: the plain cv2.resize) and / or converts it to HSV and adds
+//     |HSV_t - HSV_{t-1}| to the frame's record (HSV: content_detector.py:155,166-169 on the resized frame), carrying the
+//     previous frame's HSV of its pixels in registers.  Everything integer, so records and pixels equal the oracle's.
+//   resize_linear_generic_kernel
+//     any alignment / odd row strides: one destination pixel per thread straight from global memory.
+//
+// Coefficient tables (xofs / ialpha / yofs / ibeta in OpenCV's float arithmetic) are built once per (src, dst) shape and
+// stay cached in the engine; no allocation or synchronisation on the call path.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <tuple>
+#include <vector>
+
+#include "psd_internal.h"
+
+extern "C" void psd_set_error(const char* fmt, ...);
+
+namespace psd {
+
+void** engine_resize_cache(psd_engine* e);
+int engine_num_cus(psd_engine* e);
+const uint32_t* engine_lut(psd_engine* e);
+
+typedef uint32_t u32;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+#define HIP_TRY(expr)                                                                                \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            psd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PSD_ERR_HIP;                                                                      \
+        }                                                                                            \
+    } while (0)
+
+struct XTap { int o0, o1; int a; };   // byte offsets 3*sx, 3*min(sx+1, sw-1); a0 | a1 << 16
+struct YTap { int s0, s1; int b; };   // clamped source rows; b0 | b1 << 16
+
+struct ResizeTabs {
+    XTap* x = nullptr;   // device, [dst_w]
+    YTap* y = nullptr;   // device, [dst_h]
+    bool area2 = false;  // exact 2x2 decimation: OpenCV routes INTER_LINEAR to INTER_AREA (rounded box mean)
+};
+
+typedef std::map<std::tuple<int, int, int, int>, ResizeTabs> ResizeCache;
+
+static short sat_s16_round(float v)
+{
+    long r = lrintf(v);
+    return (short)(r > 32767 ? 32767 : (r < -32768 ? -32768 : r));
+}
+
+// OpenCV's coefficient tables (resize.cpp, INTER_LINEAR, 11-bit fixed point), in the same float arithmetic.
+static int get_tabs(psd_engine* e, int sh, int sw, int dh, int dw, hipStream_t stream, ResizeTabs* out)
+{
+    void** slot = engine_resize_cache(e);
+    if (!*slot) *slot = new ResizeCache();
+    ResizeCache& cache = *static_cast<ResizeCache*>(*slot);
+    const auto key = std::make_tuple(sh, sw, dh, dw);
+    auto it = cache.find(key);
+    if (it != cache.end()) { *out = it->second; return PSD_OK; }
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
+    ResizeTabs t;
+    t.area2 = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16 &&
+              iscale_x == 2 && iscale_y == 2;
+    std::vector<XTap> xt(dw);
+    std::vector<YTap> yt(dh);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
+        const short a0 = sat_s16_round((1.f - fx) * 2048), a1 = sat_s16_round(fx * 2048);
+        xt[dx].o0 = 3 * sx; xt[dx].o1 = 3 * sx1;
+        xt[dx].a = (int)((u32)(uint16_t)a0 | ((u32)(uint16_t)a1 << 16));
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        const short b0 = sat_s16_round((1.f - fy) * 2048), b1 = sat_s16_round(fy * 2048);
+        yt[dy].s0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+        yt[dy].s1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
+        yt[dy].b = (int)((u32)(uint16_t)b0 | ((u32)(uint16_t)b1 << 16));
+    }
+    uint8_t* d = nullptr;
+    const size_t xb = (sizeof(XTap) * dw + 255) & ~(size_t)255;
+    HIP_TRY(hipMalloc((void**)&d, xb + sizeof(YTap) * dh));
+    t.x = reinterpret_cast<XTap*>(d);
+    t.y = reinterpret_cast<YTap*>(d + xb);
+    // once per shape: a synchronous copy (the host vectors die with this call)
+    HIP_TRY(hipMemcpy(t.x, xt.data(), sizeof(XTap) * dw, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t.y, yt.data(), sizeof(YTap) * dh, hipMemcpyHostToDevice));
+    (void)stream;
+    cache[key] = t;
+    *out = t;
+    return PSD_OK;
+}
+
+void resize_release(psd_engine* e)
+{
+    void** slot = engine_resize_cache(e);
+    if (!*slot) return;
+    ResizeCache* cache = static_cast<ResizeCache*>(*slot);
+    for (auto& kv : *cache)
+        if (kv.second.x) (void)hipFree(kv.second.x);
+    delete cache;
+    *slot = nullptr;
+}
+
+struct RsParams {
+    const uint8_t* src;      // frame t at src + t * sstride, rows at srow
+    const uint8_t* prev;     // source-size frame preceding frame 0, or null
+    size_t sstride, srow;
+    int sh, sw, row_bytes;   // row_bytes = 3 * sw
+    uint8_t* dst;            // STORE: frame t at dst + t * dstride, packed rows
+    size_t dstride;
+    int dh, dw;
+    psd_frame_scores* out;   // HSV: n records, zero-initialised
+    const uint32_t* lut;     // [0..255] = sdiv << 4, [256..511] = hdiv180 << 4
+    const XTap* xt;
+    const YTap* yt;
+    int n, rows_per_tile, n_tiles, frames_per_chunk, row_pad;
+    int area2;
+};
+
+__device__ __forceinline__ u32 interp(u32 p00, u32 p01, u32 p10, u32 p11, int a0, int a1, int b0, int b1)
+{
+    const int h0 = (int)p00 * a0 + (int)p01 * a1;
+    const int h1 = (int)p10 * a0 + (int)p11 * a1;
+    return (u32)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+}
+
+// OpenCV's 8-bit BGR -> HSV (RGB2HSV_b, hue range 180) for one pixel, tables pre-shifted by 4 (psd_score_kernels.hip)
+__device__ __forceinline__ void hsv_px(u32 b, u32 g, u32 r, const u32* lut_s, const u32* lut_h, u32& h, u32& s, u32& v)
+{
+    v = max(max(b, g), r);
+    const u32 vmin = min(min(b, g), r);
+    const u32 diff = v - vmin;
+    s = ((diff * lut_s[v] + (2048u << 4)) >> 16) & 0xffu;
+    const int d = (int)diff;
+    const int hraw = v == r ? (int)g - (int)b : v == g ? (int)b - (int)r + 2 * d : (int)r - (int)g + 4 * d;
+    int hh = (hraw * (int)lut_h[diff] + (2048 << 4)) >> 16;
+    if (hh < 0) hh += 180;
+    h = (u32)hh;
+}
+
+constexpr int RS_WG = 256, RS_NW = 4, RS_SLOTS = 16;
+
+// grid.x = n_tiles * n_chunks.  Dynamic LDS: 2 buffers x (2 R rows x row_pad bytes).
+template <bool STORE, bool HSV, int G>
+__global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t rs_stage[];
+    __shared__ u32 lut_s[256], lut_h[256];
+    __shared__ u32 sums[RS_SLOTS][4];
+    __shared__ int srows[64];           // clamped source rows of this tile: slot 2 * lr + k
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x % p.n_tiles, chunk = blockIdx.x / p.n_tiles;
+    const int r0 = tile * p.rows_per_tile;
+    const int nrows = min(p.rows_per_tile, p.dh - r0);
+    const int t0 = chunk * p.frames_per_chunk, t1 = min(p.n, t0 + p.frames_per_chunk);
+    if (HSV) {
+        for (int i = tid; i < 256; i += RS_WG) { lut_s[i] = p.lut[i]; lut_h[i] = p.lut[256 + i]; }
+        for (int i = tid; i < RS_SLOTS * 4; i += RS_WG) (&sums[0][0])[i] = 0;
+    }
+    if (tid < 2 * nrows) {
+        const YTap y = p.yt[r0 + (tid >> 1)];
+        srows[tid] = p.area2 ? 2 * (r0 + (tid >> 1)) + (tid & 1) : ((tid & 1) ? y.s1 : y.s0);
+    }
+    // this thread's destination pixels: p = g * 256 + tid over the tile's nrows * dw pixels
+    int lrow[G], o0[G], o1[G], a01[G], b01[G];
+    bool live[G];
+    const int npx = nrows * p.dw;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const int px = g * RS_WG + tid;
+        live[g] = px < npx;
+        const int lr = live[g] ? px / p.dw : 0, col = live[g] ? px - lr * p.dw : 0;
+        lrow[g] = lr;
+        if (p.area2) {
+            o0[g] = 6 * col; o1[g] = 6 * col + 3; a01[g] = 0; b01[g] = 0;
+        } else {
+            const XTap x = p.xt[col];
+            o0[g] = x.o0; o1[g] = x.o1; a01[g] = x.a;
+            b01[g] = p.yt[r0 + lr].b;
+        }
+    }
+    __syncthreads();
+    const int pieces = (p.row_bytes + 1023) >> 10;                // 1 KiB wave-instructions per source row
+    const size_t buf_bytes = (size_t)2 * p.rows_per_tile * p.row_pad;
+    auto issue = [&](const uint8_t* frame, int buf) {
+        uint8_t* base = rs_stage + (size_t)buf * buf_bytes;
+        for (int q = wave; q < pieces * 2 * nrows; q += RS_NW) {
+            const int slot = q / pieces, piece = q - slot * pieces;
+            const int off = piece * 1024 + lane * 16;
+            if (off + 16 <= p.row_bytes)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + (size_t)srows[slot] * p.srow + off),
+                                                 (lds_ptr_t)(base + (size_t)slot * p.row_pad + piece * 1024), 16, 0, PSD_DMA_AUX);
+        }
+    };
+    auto frame_ptr = [&](int t) { return t < 0 ? p.prev : p.src + (size_t)t * p.sstride; };
+    // the frame in front of the chunk only feeds the HSV carry
+    const bool halo = HSV && (t0 > 0 || p.prev != nullptr);
+    const int tb = halo ? t0 - 1 : t0;
+    u32 prev_hsv[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) prev_hsv[g] = 0;
+    bool have_prev = false;
+    if (tb < t1) issue(frame_ptr(tb), 0);
+    for (int t = tb; t < t1; t++) {
+        const int buf = (t - tb) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // every wave's rows of frame t have landed; frame t-1 is fully consumed
+        if (t + 1 < t1) issue(frame_ptr(t + 1), buf ^ 1);
+        const int rel = t - t0;                // chunk-relative frame index (-1 for the halo frame)
+        if (HSV && rel >= 8 && (rel & 7) == 0 && tid < 24) {
+            // frames rel-8 .. rel-1 are complete (all waves added them before this frame's barrier)
+            const int f = rel - 8 + tid / 3, q = tid % 3;
+            const u32 v = sums[f & (RS_SLOTS - 1)][q];
+            sums[f & (RS_SLOTS - 1)][q] = 0;
+            psd_frame_scores* rec = p.out + t0 + f;
+            if (v) atomicAdd(q == 0 ? (unsigned long long*)&rec->sad_h : q == 1 ? (unsigned long long*)&rec->sad_s
+                                                                            : (unsigned long long*)&rec->sad_v, (unsigned long long)v);
+        }
+        const uint8_t* base = rs_stage + (size_t)buf * buf_bytes;
+        u32 sh = 0, ss = 0, sv = 0;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (!live[g]) continue;
+            const uint8_t* ra = base + (size_t)(2 * lrow[g]) * p.row_pad;
+            const uint8_t* rb = ra + p.row_pad;
+            u32 c[3];
+            if (p.area2) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) c[k] = ((u32)ra[o0[g] + k] + ra[o1[g] + k] + rb[o0[g] + k] + rb[o1[g] + k] + 2) >> 2;
+            } else {
+                const int a0 = (short)(a01[g] & 0xffff), a1 = a01[g] >> 16, b0 = (short)(b01[g] & 0xffff), b1 = b01[g] >> 16;
+#pragma unroll
+                for (int k = 0; k < 3; k++) c[k] = interp(ra[o0[g] + k], ra[o1[g] + k], rb[o0[g] + k], rb[o1[g] + k], a0, a1, b0, b1);
+            }
+            if (STORE && t >= t0) {
+                uint8_t* d = p.dst + (size_t)t * p.dstride + ((size_t)(r0 + lrow[g]) * p.dw + (g * RS_WG + tid - lrow[g] * p.dw)) * 3;
+                d[0] = (uint8_t)c[0]; d[1] = (uint8_t)c[1]; d[2] = (uint8_t)c[2];
+            }
+            if (HSV) {
+                u32 h, s, v;
+                hsv_px(c[0], c[1], c[2], lut_s, lut_h, h, s, v);
+                const u32 cur = h | (s << 8) | (v << 16);
+                if (have_prev) {
+                    const u32 pv = prev_hsv[g];
+                    sh += (u32)abs((int)h - (int)(pv & 0xffu));
+                    ss += (u32)abs((int)s - (int)((pv >> 8) & 0xffu));
+                    sv += (u32)abs((int)v - (int)(pv >> 16));
+                }
+                prev_hsv[g] = cur;
+            }
+        }
+        if (HSV) {
+            if (have_prev) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    sh += __shfl_xor(sh, o); ss += __shfl_xor(ss, o); sv += __shfl_xor(sv, o);
+                }
+                if (lane == 0) {
+                    u32* s4 = sums[rel & (RS_SLOTS - 1)];
+                    atomicAdd(&s4[0], sh); atomicAdd(&s4[1], ss); atomicAdd(&s4[2], sv);
+                }
+            }
+            have_prev = true;
+        }
+    }
+    if (HSV) {
+        __syncthreads();
+        // the periodic flush took frames [0, 8 * floor((done - 1) / 8)); at most 8 are left
+        const int done = t1 - t0;
+        const int f = (done > 0 ? ((done - 1) & ~7) : 0) + tid / 3, q = tid % 3;
+        if (tid < 24 && f < done) {
+            const u32 v = sums[f & (RS_SLOTS - 1)][q];
+            psd_frame_scores* rec = p.out + t0 + f;
+            if (v) atomicAdd(q == 0 ? (unsigned long long*)&rec->sad_h : q == 1 ? (unsigned long long*)&rec->sad_s
+                                                                            : (unsigned long long*)&rec->sad_v, (unsigned long long)v);
+        }
+    }
+}
+
+// Generic cv2.resize(INTER_LINEAR): any alignment / row stride.  grid = (ceil(dw/256), dh, n)
+__global__ __launch_bounds__(256) void resize_linear_generic_kernel(const uint8_t* src, int sh, int sw, size_t srow, size_t sstride,
+                                                                    uint8_t* dst, int dh, int dw, size_t dstride, const XTap* xt,
+                                                                    const YTap* yt, int area2)
+{
+    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+    if (dx >= dw) return;
+    const uint8_t* S = src + (size_t)blockIdx.z * sstride;
+    uint8_t* D = dst + (size_t)blockIdx.z * dstride + ((size_t)dy * dw + dx) * 3;
+    if (area2) {
+        const uint8_t* q = S + (size_t)(2 * dy) * srow + (size_t)(2 * dx) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) D[c] = (uint8_t)((q[c] + q[3 + c] + q[srow + c] + q[srow + 3 + c] + 2) >> 2);
+        return;
+    }
+    const XTap x = xt[dx];
+    const YTap y = yt[dy];
+    const uint8_t* ra = S + (size_t)y.s0 * srow;
+    const uint8_t* rb = S + (size_t)y.s1 * srow;
+    const int a0 = (short)(x.a & 0xffff), a1 = x.a >> 16, b0 = (short)(y.b & 0xffff), b1 = y.b >> 16;
+#pragma unroll
+    for (int c = 0; c < 3; c++) D[c] = (uint8_t)interp(ra[x.o0 + c], ra[x.o1 + c], rb[x.o0 + c], rb[x.o1 + c], a0, a1, b0, b1);
+}
+
+template <bool STORE, bool HSV>
+static void launch_walk(const RsParams& p, int g, int grid, size_t lds, hipStream_t stream)
+{
+    switch (g) {
+    case 1: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 1>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    case 2: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 2>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    case 4: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 4>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    default: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 8>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    }
+}
+
+// cv2.resize(INTER_LINEAR) of n frames and / or the HSV term of the resized frames.
+//   d_dst   resized frames out (packed rows, dst_frame_stride apart) or null
+//   d_out   zero-initialised records to add sad_h / sad_s / sad_v of the resized frames into, or null
+//   d_prev  source-size frame preceding frame 0 (HSV carry), or null
+int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_row_stride,
+                        size_t src_frame_stride, const uint8_t* d_prev, uint8_t* d_dst, int dst_h, int dst_w,
+                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches)
+{
+    if (n == 0 || (!d_dst && !d_out)) return PSD_OK;
+    ResizeTabs tabs;
+    int rc = get_tabs(e, src_h, src_w, dst_h, dst_w, stream, &tabs);
+    if (rc != PSD_OK) return rc;
+    const int row_bytes = src_w * 3;
+    const bool fast = (row_bytes % 16 == 0) && (src_row_stride % 16 == 0) && ((uintptr_t)d_src % 16 == 0) &&
+                      (src_frame_stride % 16 == 0 || n == 1) && (!d_prev || (uintptr_t)d_prev % 16 == 0) && row_bytes <= 16384;
+    if (!fast) {
+        if (d_out) {
+            psd_set_error("fused downscale + score needs 16-byte aligned packed source rows");
+            return PSD_ERR_UNSUPPORTED;   // the caller resizes first and scores the small frames
+        }
+        hipLaunchKernelGGL(resize_linear_generic_kernel, dim3((dst_w + 255) / 256, dst_h, n), dim3(256), 0, stream, d_src, src_h, src_w,
+                           src_row_stride, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, tabs.x, tabs.y, tabs.area2 ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        if (launches) *launches += 1;
+        return PSD_OK;
+    }
+    RsParams p{};
+    p.src = d_src; p.prev = d_prev; p.sstride = src_frame_stride; p.srow = src_row_stride;
+    p.sh = src_h; p.sw = src_w; p.row_bytes = row_bytes;
+    p.dst = d_dst; p.dstride = dst_frame_stride; p.dh = dst_h; p.dw = dst_w;
+    p.out = d_out; p.lut = engine_lut(e); p.xt = tabs.x; p.yt = tabs.y; p.n = n; p.area2 = tabs.area2 ? 1 : 0;
+    p.row_pad = (row_bytes + 1023) & ~1023;            // whole 1 KiB pieces (the tail lanes of the last piece stay idle)
+    // rows per tile: two staging buffers of 2 R padded rows within ~48 KiB (three workgroups per CU), at most 8 pixels per thread
+    int R = (int)((48u << 10) / (4u * (unsigned)p.row_pad));
+    if (R < 1) R = 1;
+    if (R > 16) R = 16;
+    while (R > 1 && (R * dst_w + RS_WG - 1) / RS_WG > 8) R--;
+    if (R > dst_h) R = dst_h;
+    const int per_thread = (R * dst_w + RS_WG - 1) / RS_WG;
+    if (per_thread > 8) {   // destination rows wider than 2048 pixels: not a downscale for scoring; plain kernel
+        if (d_out) { psd_set_error("destination rows of %d pixels are too wide for the fused downscale + score", dst_w); return PSD_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL(resize_linear_generic_kernel, dim3((dst_w + 255) / 256, dst_h, n), dim3(256), 0, stream, d_src, src_h, src_w,
+                           src_row_stride, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, tabs.x, tabs.y, tabs.area2 ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        if (launches) *launches += 1;
+        return PSD_OK;
+    }
+    const int g = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : per_thread <= 4 ? 4 : 8;
+    p.rows_per_tile = R;
+    p.n_tiles = (dst_h + R - 1) / R;
+    // time chunks: enough workgroups for every CU several times over, walks long enough that the halo frame stays small
+    const int target = engine_num_cus(e) * 12;
+    int chunks = (target + p.n_tiles - 1) / p.n_tiles;
+    if (d_out) { const int by_walk = (n + 31) / 32; if (chunks > by_walk) chunks = by_walk; }
+    if (chunks > n) chunks = n;
+    if (chunks < 1) chunks = 1;
+    p.frames_per_chunk = (n + chunks - 1) / chunks;
+    chunks = (n + p.frames_per_chunk - 1) / p.frames_per_chunk;
+    const size_t lds = (size_t)2 * 2 * R * p.row_pad;
+    const int grid = p.n_tiles * chunks;
+    if (d_dst && d_out) launch_walk<true, true>(p, g, grid, lds, stream);
+    else if (d_out) launch_walk<false, true>(p, g, grid, lds, stream);
+    else launch_walk<true, false>(p, g, grid, lds, stream);
+    HIP_TRY(hipGetLastError());
+    if (launches) *launches += 1;
+    return PSD_OK;
+}
+
+}  // namespace psd

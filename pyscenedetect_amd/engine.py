@@ -267,6 +267,25 @@ class ScoringEngine:
                                               d_prev, int(flags), int(edge_kernel), stream)
         )
 
+    def submit_device_downscaled(self, d_frames: int, n: int, src_h: int, src_w: int, dst_h: int, dst_w: int,
+                                 frame_stride: int | None = None, d_prev: int | None = None,
+                                 flags: int = SCORE_HSV_SAD, edge_kernel: int = 0, interpolation: int = 1,
+                                 stream: int | None = None) -> None:
+        """``cv2.resize(frame, (dst_w, dst_h), interpolation)`` followed by the terms of ``flags`` on the resized frames
+        (the reference's default pipeline, ``scene_manager.py:666-678``); ``d_prev`` is a SOURCE-size frame.  Pair with
+        :meth:`collect`."""
+        frame_stride = src_h * src_w * 3 if frame_stride is None else frame_stride
+        _native.check(self._lib.psd_score_downscaled_submit_device(
+            self._h, d_frames, int(n), int(src_h), int(src_w), frame_stride, d_prev, int(dst_h), int(dst_w), int(interpolation),
+            int(flags), int(edge_kernel), stream))
+
+    def score_device_downscaled(self, d_frames: int, n: int, src_h: int, src_w: int, dst_h: int, dst_w: int,
+                                frame_stride: int | None = None, d_prev: int | None = None, flags: int = SCORE_HSV_SAD,
+                                edge_kernel: int = 0, interpolation: int = 1, stream: int | None = None) -> np.ndarray:
+        self.submit_device_downscaled(d_frames, n, src_h, src_w, dst_h, dst_w, frame_stride, d_prev, flags, edge_kernel,
+                                      interpolation, stream)
+        return self.collect(n)
+
     def collect(self, n: int) -> np.ndarray:
         out = np.zeros(n, RECORD_DTYPE)
         _native.check(self._lib.psd_score_collect(self._h, out.ctypes.data if n else None, int(n)))

@@ -175,3 +175,77 @@ def test_fused_all_terms_1080p_constant_frames(hip_engine):
     same(hip_engine.score_device(buf.ptr, len(vals), 1080, 1920, flags=E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM), want, ("hist", "byte_sum"))
     same(hip_engine.score_device(buf.ptr, len(vals), 1080, 1920, flags=E.SCORE_HSV_SAD), want, ("sad_h", "sad_s", "sad_v"))
     buf.free()
+
+
+# ---- the reference's default pipeline: downscale, then score (scene_manager.py:666-678) ---------------------------
+
+def oracle_downscaled(frames, prev, dh, dw, interpolation=1):
+    import cv2  # the oracle shim
+
+    small = np.stack([cv2.resize(f, (dw, dh), interpolation=interpolation) for f in frames])
+    sprev = cv2.resize(prev, (dw, dh), interpolation=interpolation) if prev is not None else None
+    return small, orc.score_batch(small, sprev)
+
+
+@pytest.mark.parametrize("case", [
+    (70, 180, 320, 144, 256),      # scale 1.25: neighbouring destination rows share source rows; 3 time chunks
+    (9, 1080, 1920, 144, 256),     # the default target of a 1080p source (factor 7.5)
+    (5, 2160, 3840, 144, 256),     # 4K source: one destination row per workgroup
+    (40, 720, 1280, 144, 256),
+    (12, 200, 304, 100, 152),      # exact 2x2 decimation: OpenCV's INTER_AREA shortcut
+    (6, 97, 131, 41, 77),          # odd sizes: rows not 16-byte aligned -> resize, then score
+    (33, 360, 640, 203, 361),      # wide destination rows (several pixels per thread)
+])
+def test_downscale_then_score_matches_oracle(hip_engine, case):
+    n, sh, sw, dh, dw = case
+    rng = np.random.default_rng(n * sh)
+    frames = rng.integers(0, 256, (n, sh, sw, 3), dtype=np.uint8)
+    if n > 8:   # shot-like stretches so that consecutive frames are close (small SADs) as well as far apart
+        frames[3:8] = frames[3]
+        frames[5, sh // 3: sh // 2] ^= 7
+    prev = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+    stride = (sh * sw * 3 + 15) & ~15
+    buf = hip_engine.alloc(stride * (n + 1))
+    buf.upload(prev.reshape(-1), 0)
+    for i in range(n):
+        buf.upload(frames[i].reshape(-1), (i + 1) * stride)
+    for with_prev in (False, True):
+        _, want = oracle_downscaled(frames, prev if with_prev else None, dh, dw)
+        for flags, fields in ((E.SCORE_HSV_SAD, ("sad_h", "sad_s", "sad_v")), (NOEDGE, FIELDS)):
+            got = hip_engine.score_device_downscaled(buf.ptr + stride, n, sh, sw, dh, dw, frame_stride=stride,
+                                                     d_prev=buf.ptr if with_prev else None, flags=flags)
+            same(got, want, fields)
+    buf.free()
+
+
+def test_downscale_then_score_other_terms_and_modes(hip_engine):
+    """Edges and the NEAREST / AREA modes go through the resize-then-score path of the same entry point."""
+    import cv2  # the oracle shim
+
+    n, sh, sw, dh, dw = 5, 360, 640, 144, 256
+    frames = shots_with_objects(77, n, sh, sw)
+    buf = device_copy(hip_engine, frames)
+    for interpolation in (1, 0, 3):
+        small = np.stack([cv2.resize(f, (dw, dh), interpolation=interpolation) for f in frames])
+        want = oracle_score(small, edges=True)
+        got = hip_engine.score_device_downscaled(buf.ptr, n, sh, sw, dh, dw, flags=E.SCORE_ALL, interpolation=interpolation)
+        same(got, want, FIELDS + ("edge_xor",))
+    with pytest.raises(NotImplementedError):
+        hip_engine.score_device_downscaled(buf.ptr, n, sh, sw, dh, dw, interpolation=2)
+    buf.free()
+
+
+def test_downscaled_submissions_pipeline(hip_engine):
+    import torch
+
+    n, sh, sw, dh, dw = 64, 1080, 1920, 144, 256
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    x = torch.randint(0, 256, (n, sh, sw, 3), dtype=torch.uint8, device="cuda", generator=g)
+    torch.cuda.synchronize()
+    hip_engine.submit_device_downscaled(x.data_ptr(), n, sh, sw, dh, dw)
+    hip_engine.submit_device_downscaled(x.data_ptr(), n, sh, sw, dh, dw)
+    a, b = hip_engine.collect(n), hip_engine.collect(n)
+    same(a, b, ("sad_h", "sad_s", "sad_v"))
+    _, want = oracle_downscaled(x[:6].cpu().numpy(), None, dh, dw)
+    same(a[:6], want, ("sad_h", "sad_s", "sad_v"))
