@@ -110,6 +110,12 @@ int psd_score_batch(psd_engine* e, const uint8_t* h_frames, int n, int height, i
                     size_t row_stride, size_t frame_stride, const uint8_t* h_prev, uint32_t flags,
                     int edge_kernel, psd_frame_scores* out);
 
+/* The records of the most recently COLLECTED submission where they were computed, in device memory (n of them):
+ * the per-frame score vectors can go straight into a collective (RCCL all-gather over xGMI) or
+ * another kernel without the round trip through the host.  The buffer belongs to the engine's ring of
+ * PSD_MAX_INFLIGHT record slots: it is overwritten by the PSD_MAX_INFLIGHT-th submission after the one it belongs to. */
+int psd_last_records_device(psd_engine* e, const psd_frame_scores** d_recs, int* n);
+
 /* Device time (ms, HIP events on the launch stream) spent in the scoring kernels of the most
  * recently *collected* submission, and the number of kernel launches it took. */
 int psd_last_kernel_ms(psd_engine* e, float* ms, int* launches);

@@ -73,6 +73,7 @@ struct psd_engine {
     psd_slot slots[PSD_MAX_INFLIGHT];
     int head = 0;   // next slot to submit into
     int tail = 0;   // next slot to collect
+    int last_slot = -1;   // most recently collected slot (psd_last_records_device)
     int pending = 0;
     float last_ms = 0.f;
     int last_launches = 0;
@@ -418,6 +419,7 @@ int psd_score_collect(psd_engine* e, psd_frame_scores* out, int n)
     HIP_TRY(hipSetDevice(e->device));
     hipError_t err = hipEventSynchronize(s.ev_done);
     s.pending = false;
+    e->last_slot = e->tail;
     e->tail = (e->tail + 1) % PSD_MAX_INFLIGHT;
     e->pending--;
     if (err != hipSuccess) {
@@ -448,6 +450,15 @@ int psd_score_batch_device(psd_engine* e, const uint8_t* d_frames, int n, int he
                                      edge_kernel, stream);
     if (rc != PSD_OK) return rc;
     return psd_score_collect(e, out, n);
+}
+
+int psd_last_records_device(psd_engine* e, const psd_frame_scores** d_recs, int* n)
+{
+    if (!e || !d_recs) { psd_set_error("psd_last_records_device: null argument"); return PSD_ERR_INVALID; }
+    if (e->last_slot < 0) { psd_set_error("psd_last_records_device: nothing collected yet"); return PSD_ERR_INVALID; }
+    *d_recs = e->slots[e->last_slot].d_recs;
+    if (n) *n = e->slots[e->last_slot].n;
+    return PSD_OK;
 }
 
 int psd_last_kernel_ms(psd_engine* e, float* ms, int* launches)

@@ -343,8 +343,8 @@ __device__ __forceinline__ void pixel_fp_front(const u32 (&d)[3], const FpLane& 
     } else {
         a_h = lshl16_add<LS>(__float_as_uint(x.diff + 8388608.0f), fl.off_h);
     }
-    x.sdiv = *(lds_cf32_t)a_s;
-    x.hdiv = *(lds_cf32_t)a_h;
+    x.sdiv = *(lds_cf32_t)(uintptr_t)a_s;
+    x.hdiv = *(lds_cf32_t)(uintptr_t)a_h;
 }
 
 // phase 2: hraw = v == r ? g - b : v == g ? b - r + 2 diff : r - g + 4 diff (the biases cancel)

@@ -34,12 +34,25 @@ def assign_clips(costs: list[int], world_size: int) -> list[list[int]]:
     return out
 
 
-def all_gather_records(local: np.ndarray, group=None) -> list[np.ndarray]:
+def device_records_tensor(ptr: int, n: int, device):
+    """Zero-copy ``uint8[n, 1064]`` torch view of ``n`` records sitting in HBM at ``ptr`` (``psd_last_records_device``)."""
+    import torch
+
+    class _View:
+        __cuda_array_interface__ = {"shape": (n, RECORD_DTYPE.itemsize), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    return torch.as_tensor(_View(), device=device)
+
+
+def all_gather_records(local: np.ndarray, group=None, device_records: tuple[int, int] | None = None) -> list[np.ndarray]:
     """All-gather ragged per-rank record arrays; returns one array per rank, in rank order.
 
     Two collectives: the counts (tiny) and one padded byte tensor.  With the ``nccl`` backend the
     payload travels GPU-to-GPU (RCCL); the records are KBs-MBs, so this is latency-bound and a
     single fused all-gather is the cheapest pattern on the point-to-point xGMI mesh.
+    ``device_records = engine.last_records_device()`` hands over the records where the kernels left them, so the
+    send buffer is filled by one device-to-device copy instead of a host -> device upload (SURVEY.md 8b / 8e);
+    ``local`` (the host copy the engine returned anyway) is then only used for its length.
     """
     import torch
     import torch.distributed as dist
@@ -54,10 +67,14 @@ def all_gather_records(local: np.ndarray, group=None) -> list[np.ndarray]:
     dist.all_gather_into_tensor(counts, mine, group=group)
     counts = counts.cpu().tolist()
     cap = max(max(counts), 1) * RECORD_DTYPE.itemsize
-    send = torch.zeros(cap, dtype=torch.uint8)
-    if len(local):
-        send[: local.nbytes] = torch.from_numpy(local.view(np.uint8).reshape(-1))
-    send = send.to(dev)
+    if on_gpu and device_records is not None and device_records[1] == len(local) and len(local):
+        send = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        send[: local.nbytes] = device_records_tensor(device_records[0], len(local), dev).reshape(-1)
+    else:
+        send = torch.zeros(cap, dtype=torch.uint8)
+        if len(local):
+            send[: local.nbytes] = torch.from_numpy(local.view(np.uint8).reshape(-1))
+        send = send.to(dev)
     recv = torch.empty(world * cap, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.cpu().numpy().reshape(world, cap)
@@ -77,7 +94,7 @@ def score_clip_sharded(engine, get_frames, n_frames: int, flags: int, edge_kerne
     if stop > start:
         halo = get_frames(start - 1, start)[0] if start > 0 else None
         local = engine.score_host(get_frames(start, stop), prev=halo, flags=flags, edge_kernel=edge_kernel)
-    parts = all_gather_records(local, group)
+    parts = all_gather_records(local, group)   # (host frames are scored in staging chunks: no single device record buffer)
     return np.concatenate(parts) if parts else np.zeros(0, RECORD_DTYPE)
 
 

@@ -291,6 +291,13 @@ class ScoringEngine:
         _native.check(self._lib.psd_score_collect(self._h, out.ctypes.data if n else None, int(n)))
         return out
 
+    def last_records_device(self) -> tuple[int, int]:
+        """``(device pointer, n)`` of the most recently collected submission's records, still in HBM (they feed the
+        RCCL all-gather of ``pyscenedetect_amd.distributed`` without a host bounce)."""
+        p, n = ctypes.c_void_p(), ctypes.c_int(0)
+        _native.check(self._lib.psd_last_records_device(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
     def last_kernel_ms(self) -> tuple[float, int]:
         ms, launches = ctypes.c_float(0), ctypes.c_int(0)
         _native.check(self._lib.psd_last_kernel_ms(self._h, ctypes.byref(ms), ctypes.byref(launches)))
