@@ -103,6 +103,20 @@ int psd_score_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int h
                             uint32_t flags, int edge_kernel, void* stream);
 int psd_score_collect(psd_engine* e, psd_frame_scores* out, int n);
 
+/* MANY clips of one resolution packed into ONE batch (north_star: "frames from many videos are packed into one device
+ * batch"; the reference scores one video per SceneManager, scene_manager.py:578-597, and benchmark/sweep.py:142-187 runs
+ * them one after the other): seg_first[0..n_seg) are the batch indices of the first frame of every clip, ascending.
+ * Such a frame has no predecessor -- its sad_* / edge_xor stay 0 exactly as for frame 0 of a separate call
+ * (content_detector.py:161-164) -- so the records equal those of n_seg separate psd_score_batch_device calls, from one
+ * launch per term instead of n_seg.  Frame 0 never has a predecessor here (list it or not).  The submit form pairs with
+ * psd_score_collect(). */
+int psd_score_segments_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width,
+                              size_t row_stride, size_t frame_stride, const int32_t* seg_first, int n_seg,
+                              uint32_t flags, int edge_kernel, psd_frame_scores* out, void* stream);
+int psd_score_segments_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width,
+                                     size_t row_stride, size_t frame_stride, const int32_t* seg_first, int n_seg,
+                                     uint32_t flags, int edge_kernel, void* stream);
+
 /* Same for frames in host memory: the engine stages them through its own pinned/device
  * buffers in bounded chunks (H2D overlapped with scoring) and carries the one-frame halo
  * between chunks itself.  h_prev may be NULL. */

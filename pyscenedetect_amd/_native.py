@@ -109,6 +109,8 @@ SYMBOLS = {
     "psd_destroy": (None, [_vp]),
     "psd_score_batch_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _u32, _i, _vp, _vp]),
     "psd_score_submit_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _u32, _i, _vp]),
+    "psd_score_segments_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _i, _u32, _i, _vp, _vp]),
+    "psd_score_segments_submit_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _i, _u32, _i, _vp]),
     "psd_score_collect": (_i, [_vp, _vp, _i]),
     "psd_score_batch": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _u32, _i, _vp]),
     "psd_last_records_device": (_i, [_vp, _P(_vp), _P(_i)]),

@@ -67,6 +67,14 @@ def score_clip(engine, clip, flags: int, edge_kernel: int = 0) -> np.ndarray:
     return engine.score_host(clip[0:len(clip)], flags=flags, edge_kernel=edge_kernel)
 
 
+def score_clips(engine, clips, flags: int, edge_kernel: int = 0) -> list[np.ndarray]:
+    """Records of every clip; engines that can pack clips of one resolution into shared batches (``ScoringEngine.score_clips``:
+    one launch per term per batch, SAD chain broken at clip starts) do so, others score clip by clip."""
+    if hasattr(engine, "score_clips"):
+        return engine.score_clips(clips, flags=flags, edge_kernel=edge_kernel)
+    return [score_clip(engine, c, flags, edge_kernel) for c in clips]
+
+
 def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: int = 0) -> list[dict]:
     """Detect cuts in every clip of ``clips`` (each ``uint8[n,H,W,3]``, sizes may differ).
 
@@ -85,6 +93,6 @@ def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: 
 
         records = score_clips_distributed(engine, clips, flags, edge_kernel, group)
     else:
-        records = [score_clip(engine, c, flags, edge_kernel) for c in clips]
+        records = score_clips(engine, clips, flags, edge_kernel)
     fps_list = fps if isinstance(fps, (list, tuple)) else [fps] * len(clips)
     return [decide(r, c.shape[1], c.shape[2], f, detectors) for r, c, f in zip(records, clips, fps_list)]

@@ -528,12 +528,13 @@ __global__ __launch_bounds__(256) void xor_count_kernel(const u32* dil, long wor
 
 // Copy the chunk's XOR counts into the batch records (virtual frame j -> batch frame first_t + j).
 __global__ void store_xor_kernel(const unsigned long long* xr, int count, int skip_first, int first_has_pred,
-                                 int first_t, psd_frame_scores* out)
+                                 int first_t, psd_frame_scores* out, const uint8_t* seg)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     if (skip_first && j == 0) return;          // virtual frame 0 is `prev`, not part of the batch
     if (j == 0 && !first_has_pred) return;     // no predecessor: edge_xor stays 0
+    if (seg && seg[first_t + j - skip_first]) return;   // first frame of a packed clip: no predecessor either
     out[first_t + j - skip_first].edge_xor = xr[j];
 }
 
@@ -681,7 +682,7 @@ static EdgeGeom make_geom(int height, int width, size_t row_stride, size_t frame
 
 int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
                 size_t frame_stride, const uint8_t* d_prev, int edge_kernel, psd_frame_scores* d_out,
-                hipStream_t stream)
+                hipStream_t stream, const uint8_t* d_seg)
 {
     const EdgeGeom g = make_geom(height, width, row_stride, frame_stride);
     const int k = edge_kernel ? edge_kernel : estimated_kernel_size(width, height);
@@ -709,7 +710,7 @@ int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
         hipLaunchKernelGGL(xor_count_kernel, dim3((unsigned)((words + 255) / 256), count), dim3(256), 0, stream, b.dil, (long)words,
                            b.carry, have_carry ? 1 : 0, b.xr);
         hipLaunchKernelGGL(store_xor_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, b.xr, count, src.first_is_prev,
-                           have_carry ? 1 : 0, src.start, d_out);
+                           have_carry ? 1 : 0, src.start, d_out, d_seg);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(b.carry, b.dil + (size_t)(count - 1) * words, words * 4, hipMemcpyDeviceToDevice, stream));
         have_carry = true;

@@ -37,14 +37,14 @@ namespace psd {
 // psd_edge_kernels.hip
 int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
                 size_t frame_stride, const uint8_t* d_prev, int edge_kernel, psd_frame_scores* d_out,
-                hipStream_t stream);
+                hipStream_t stream, const uint8_t* d_seg);
 int edges_map(psd_engine* e, const uint8_t* d_frame, int height, int width, size_t row_stride,
               int edge_kernel, uint8_t* h_edges);
 void edges_release(psd_engine* e);
 // psd_resize_kernels.hip
 int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_row_stride,
                         size_t src_frame_stride, const uint8_t* d_prev, uint8_t* d_dst, int dst_h, int dst_w,
-                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches);
+                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg);
 void resize_release(psd_engine* e);
 int resize_other(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
                  int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream);
@@ -63,6 +63,9 @@ struct psd_slot {
     bool pending = false;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_done = nullptr;
     int launches = 0;
+    uint8_t* d_seg = nullptr;   // clip-start flags of a segmented submission (device + pinned mirror)
+    uint8_t* h_seg = nullptr;
+    int seg_cap = 0;
 };
 
 struct psd_engine {
@@ -205,6 +208,8 @@ void psd_destroy(psd_engine* e)
         if (s.ev_start) (void)hipEventDestroy(s.ev_start);
         if (s.ev_stop) (void)hipEventDestroy(s.ev_stop);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        if (s.d_seg) (void)hipFree(s.d_seg);
+        if (s.h_seg) (void)hipHostFree(s.h_seg);
     }
     for (auto& d : e->d_stage) if (d) (void)hipFree(d);
     if (e->d_hash) (void)hipFree(e->d_hash);
@@ -286,7 +291,8 @@ static int submit_end(psd_engine* e, psd_slot& s, hipStream_t stream)
 
 // the scoring terms of `flags` for n resident frames, added into the slot's records
 static int score_terms(psd_engine* e, psd_slot& s, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
-                       size_t frame_stride, const uint8_t* d_prev, uint32_t flags, int edge_kernel, hipStream_t stream)
+                       size_t frame_stride, const uint8_t* d_prev, uint32_t flags, int edge_kernel, hipStream_t stream,
+                       const uint8_t* d_seg = nullptr)
 {
     const bool hsv = flags & PSD_SCORE_HSV_SAD;
     const bool luma = flags & (PSD_SCORE_LUMA_HIST | PSD_SCORE_BYTE_SUM);
@@ -294,6 +300,7 @@ static int score_terms(psd_engine* e, psd_slot& s, const uint8_t* d_frames, int 
         psd::ScoreParams p{};
         p.frames = d_frames;
         p.prev = d_prev;
+        p.seg = d_seg;
         p.out = s.d_recs;
         p.lut = e->d_lut;
         p.lutf = e->d_lut + 512;
@@ -308,7 +315,7 @@ static int score_terms(psd_engine* e, psd_slot& s, const uint8_t* d_frames, int 
         HIP_TRY(psd::launch_score_frames(p, hsv, luma, fast, e->num_cus * 8, stream, &s.launches));
     }
     if (flags & PSD_SCORE_EDGES) {
-        int rc = psd::edges_score(e, d_frames, n, height, width, row_stride, frame_stride, d_prev, edge_kernel, s.d_recs, stream);
+        int rc = psd::edges_score(e, d_frames, n, height, width, row_stride, frame_stride, d_prev, edge_kernel, s.d_recs, stream, d_seg);
         if (rc != PSD_OK) return rc;
     }
     return PSD_OK;
@@ -332,12 +339,71 @@ int psd_score_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int h
     return submit_end(e, *s, stream);
 }
 
+// clip-start flags of a packed batch -> the slot's device array (through its pinned mirror, on the launch stream)
+static int upload_segments(psd_slot& s, int n, const int32_t* seg_first, int n_seg, hipStream_t stream)
+{
+    if (s.seg_cap < n) {
+        const int cap = n < 64 ? 64 : n;
+        if (s.d_seg) HIP_TRY(hipFree(s.d_seg));
+        if (s.h_seg) HIP_TRY(hipHostFree(s.h_seg));
+        s.d_seg = nullptr; s.h_seg = nullptr; s.seg_cap = 0;
+        HIP_TRY(hipMalloc((void**)&s.d_seg, (size_t)cap));
+        HIP_TRY(hipHostMalloc((void**)&s.h_seg, (size_t)cap, hipHostMallocDefault));
+        s.seg_cap = cap;
+    }
+    memset(s.h_seg, 0, (size_t)n);
+    for (int i = 0; i < n_seg; i++) s.h_seg[seg_first[i]] = 1;
+    HIP_TRY(hipMemcpyAsync(s.d_seg, s.h_seg, (size_t)n, hipMemcpyHostToDevice, stream));
+    return PSD_OK;
+}
+
+int psd_score_segments_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
+                                     size_t frame_stride, const int32_t* seg_first, int n_seg, uint32_t flags, int edge_kernel,
+                                     void* stream_)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    int rc = validate(d_frames, n, height, width, row_stride, frame_stride, flags, edge_kernel);
+    if (rc != PSD_OK) return rc;
+    if (n_seg < 0 || (n_seg > 0 && !seg_first)) { psd_set_error("invalid segment table"); return PSD_ERR_INVALID; }
+    for (int i = 0; i < n_seg; i++) {
+        if (seg_first[i] < 0 || seg_first[i] >= n || (i > 0 && seg_first[i] <= seg_first[i - 1])) {
+            psd_set_error("segment table must hold ascending frame indices inside the batch (entry %d = %d, n = %d)", i, seg_first[i], n);
+            return PSD_ERR_INVALID;
+        }
+    }
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : e->stream;
+    psd_slot* s = nullptr;
+    rc = submit_begin(e, n, stream, &s);
+    if (rc != PSD_OK) return rc;
+    if (n > 0) {
+        rc = upload_segments(*s, n, seg_first, n_seg, stream);
+        if (rc != PSD_OK) return rc;
+        rc = score_terms(e, *s, d_frames, n, height, width, row_stride, frame_stride, nullptr, flags, edge_kernel, stream, s->d_seg);
+        if (rc != PSD_OK) return rc;
+    }
+    return submit_end(e, *s, stream);
+}
+
+int psd_score_segments_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
+                              size_t frame_stride, const int32_t* seg_first, int n_seg, uint32_t flags, int edge_kernel,
+                              psd_frame_scores* out, void* stream)
+{
+    if (e && e->pending != 0) {
+        psd_set_error("psd_score_segments_device: asynchronous submissions are still pending");
+        return PSD_ERR_INVALID;
+    }
+    int rc = psd_score_segments_submit_device(e, d_frames, n, height, width, row_stride, frame_stride, seg_first, n_seg, flags,
+                                              edge_kernel, stream);
+    if (rc != PSD_OK) return rc;
+    return psd_score_collect(e, out, n);
+}
+
 static int resize_any(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst,
                       int dst_h, int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream)
 {
     if (interpolation == PSD_INTER_LINEAR)
         return psd::resize_linear_score(e, d_src, n, src_h, src_w, (size_t)src_w * 3, src_frame_stride, nullptr, d_dst, dst_h, dst_w,
-                                        dst_frame_stride, nullptr, stream, nullptr);
+                                        dst_frame_stride, nullptr, stream, nullptr, nullptr);
     return psd::resize_other(d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, interpolation, stream);
 }
 
@@ -358,7 +424,7 @@ int psd_score_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, i
         if (interpolation == PSD_INTER_LINEAR && flags == PSD_SCORE_HSV_SAD) {
             // ContentDetector / AdaptiveDetector behind the default downscale: the resized frame never leaves the CU
             rc = psd::resize_linear_score(e, d_frames, n, src_h, src_w, (size_t)src_w * 3, frame_stride, d_prev, nullptr, dst_h, dst_w, 0,
-                                          s->d_recs, stream, &s->launches);
+                                          s->d_recs, stream, &s->launches, nullptr);
             if (rc == PSD_OK) done = true;
             else if (rc != PSD_ERR_UNSUPPORTED) return rc;
         }

@@ -30,6 +30,7 @@ struct ScoreParams {
     psd_frame_scores* out;   // device, n records, zero-initialised
     const uint32_t* lut;     // device, [0..255] = sdiv << 4, [256..511] = hdiv180 << 4
     const uint32_t* lutf;    // device, float32 bit patterns: [0..255] = nextafter(sdiv / 4096), [256..511] = hdiv180 / 4096
+    const uint8_t* seg;      // device, n flags: frame t starts a clip (no predecessor), or nullptr
     size_t frame_stride;
     size_t row_stride;
     long npix;               // height*width

@@ -133,6 +133,7 @@ void resize_release(psd_engine* e)
 struct RsParams {
     const uint8_t* src;      // frame t at src + t * sstride, rows at srow
     const uint8_t* prev;     // source-size frame preceding frame 0, or null
+    const uint8_t* seg;      // n flags: frame t starts a clip (no predecessor), or null
     size_t sstride, srow;
     int sh, sw, row_bytes;   // row_bytes = 3 * sw
     uint8_t* dst;            // STORE: frame t at dst + t * dstride, packed rows
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         }
         const uint8_t* base = rs_stage + (size_t)buf * buf_bytes;
         u32 sh = 0, ss = 0, sv = 0;
+        const bool chain = have_prev && !(HSV && t >= 0 && p.seg != nullptr && p.seg[t] != 0);
 #pragma unroll
         for (int g = 0; g < G; g++) {
             if (!live[g]) continue;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
                 u32 h, s, v;
                 hsv_px(c[0], c[1], c[2], lut_s, lut_h, h, s, v);
                 const u32 cur = h | (s << 8) | (v << 16);
-                if (have_prev) {
+                if (chain) {
                     const u32 pv = prev_hsv[g];
                     sh += (u32)abs((int)h - (int)(pv & 0xffu));
                     ss += (u32)abs((int)s - (int)((pv >> 8) & 0xffu));
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             }
         }
         if (HSV) {
-            if (have_prev) {
+            if (chain) {
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
                     sh += __shfl_xor(sh, o); ss += __shfl_xor(ss, o); sv += __shfl_xor(sv, o);
@@ -347,7 +349,7 @@ static void launch_walk(const RsParams& p, int g, int grid, size_t lds, hipStrea
 //   d_prev  source-size frame preceding frame 0 (HSV carry), or null
 int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_row_stride,
                         size_t src_frame_stride, const uint8_t* d_prev, uint8_t* d_dst, int dst_h, int dst_w,
-                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches)
+                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg)
 {
     if (n == 0 || (!d_dst && !d_out)) return PSD_OK;
     ResizeTabs tabs;
@@ -368,7 +370,7 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
         return PSD_OK;
     }
     RsParams p{};
-    p.src = d_src; p.prev = d_prev; p.sstride = src_frame_stride; p.srow = src_row_stride;
+    p.src = d_src; p.prev = d_prev; p.seg = d_seg; p.sstride = src_frame_stride; p.srow = src_row_stride;
     p.sh = src_h; p.sw = src_w; p.row_bytes = row_bytes;
     p.dst = d_dst; p.dstride = dst_frame_stride; p.dh = dst_h; p.dw = dst_w;
     p.out = d_out; p.lut = engine_lut(e); p.xt = tabs.x; p.yt = tabs.y; p.n = n; p.area2 = tabs.area2 ? 1 : 0;

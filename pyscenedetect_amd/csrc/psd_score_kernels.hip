@@ -596,13 +596,15 @@ __global__ __launch_bounds__(WG) void score_frames_kernel(const ScoreParams p)
         }
 #endif
         u32 sh = 0, ss = 0, sv = 0, bs = 0;
+        // the first frame of a clip packed into the batch has no predecessor (p.seg, psd_score_segments_device)
+        const bool chain = have_prev && !(p.seg != nullptr && p.seg[t] != 0);
 #pragma unroll
         for (int k = 0; k < G; k++) {
             if (live[k]) {
                 Hsv16 c;
                 convert_group<HSV, LUMA, COPIES, COPIES, FPK>(cur[k], c, my_lut_s, my_lut_h, my_hist, bs);
                 if (HSV) {
-                    if (have_prev) sad_group(c, prev[k], sh, ss, sv);
+                    if (chain) sad_group(c, prev[k], sh, ss, sv);
                     prev[k] = c;
                 }
                 if (!FAST && LUMA && pad_px && grp[k] == last_group)
@@ -841,13 +843,15 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
             for (int i = 0; i < 12; i++) asm volatile("" : "+v"(cur[k].w[i]));
 #endif
         u32 sh = 0, ss = 0, sv = 0, bs = 0;
+        // the first frame of a clip packed into the batch has no predecessor (p.seg, psd_score_segments_device)
+        const bool chain = have_prev && !(p.seg != nullptr && p.seg[t] != 0);
 #pragma unroll
         for (int k = 0; k < G; k++) {
             if (HSV || live[k]) {
                 Hsv16 c;
                 convert_group<HSV, LUMA, LCD, ACD, FPK>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs, live[k] ? 1u : 0u);
                 if (HSV) {
-                    if (have_prev) sad_group(c, prev[k], sh, ss, sv);
+                    if (chain) sad_group(c, prev[k], sh, ss, sv);
                     prev[k] = c;
                 }
             }

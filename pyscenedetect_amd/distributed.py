@@ -109,9 +109,10 @@ def score_clips_distributed(engine, clips, flags: int, edge_kernel: int = 0, gro
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     costs = [int(c.shape[0]) * int(c.shape[1]) * int(c.shape[2]) for c in clips]
     plan = assign_clips(costs, world)
-    from pyscenedetect_amd.corpus import score_clip
+    from pyscenedetect_amd.corpus import score_clips
 
-    mine = [score_clip(engine, clips[i], flags, edge_kernel) for i in plan[rank]]
+    # this rank's clips, packed by resolution into shared device batches where the engine can (one launch per batch)
+    mine = score_clips(engine, [clips[i] for i in plan[rank]], flags, edge_kernel)
     local = np.concatenate(mine) if mine else np.zeros(0, RECORD_DTYPE)
     parts = all_gather_records(local, group)
     out: list = [None] * len(clips)

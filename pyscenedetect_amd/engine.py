@@ -267,6 +267,74 @@ class ScoringEngine:
                                               d_prev, int(flags), int(edge_kernel), stream)
         )
 
+    def score_device_segments(self, d_frames: int, n: int, height: int, width: int, seg_first, row_stride: int | None = None,
+                              frame_stride: int | None = None, flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0,
+                              stream: int | None = None) -> np.ndarray:
+        """Score ``n`` resident frames that are SEVERAL clips packed back to back: ``seg_first`` holds the batch index of
+        every clip's first frame (such a frame has no predecessor).  One launch per term for all clips."""
+        row_stride = width * 3 if row_stride is None else row_stride
+        frame_stride = height * row_stride if frame_stride is None else frame_stride
+        seg = np.ascontiguousarray(seg_first, dtype=np.int32)
+        _native.check(self._lib.psd_score_segments_submit_device(self._h, d_frames, int(n), int(height), int(width), row_stride,
+                                                                 frame_stride, seg.ctypes.data if len(seg) else None, len(seg),
+                                                                 int(flags), int(edge_kernel), stream))
+        return self.collect(n)
+
+    def score_clips(self, clips, flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0,
+                    max_batch_bytes: int = 4 << 30) -> list[np.ndarray]:
+        """Records of many clips (host ``uint8[n,H,W,3]`` arrays, or device tensors with ``data_ptr()``): clips of one
+        resolution share device batches of up to ``max_batch_bytes``, scored with ONE launch per term per batch
+        (``psd_score_segments_device``) instead of one per clip -- thousands of short clips are launch-bound otherwise.
+        The result equals ``[score_host(c) for c in clips]``."""
+        out: list = [None] * len(clips)
+        groups: dict[tuple[int, int], list[int]] = {}
+        for i, c in enumerate(clips):
+            if len(c.shape) != 4 or c.shape[3] != 3:
+                raise ValueError("clips must be uint8[n,H,W,3]")
+            if c.shape[0] == 0:
+                out[i] = np.zeros(0, RECORD_DTYPE)
+                continue
+            groups.setdefault((int(c.shape[1]), int(c.shape[2])), []).append(i)
+        for (h, w), idxs in groups.items():
+            stride = h * w * 3
+            per_batch = max(1, max_batch_bytes // stride)
+            # device clips that already sit back to back in HBM are scored in place
+            dev = [i for i in idxs if hasattr(clips[i], "data_ptr")]
+            run: list[int] = []
+            for i in dev + [None]:
+                if i is not None and run and clips[run[-1]].data_ptr() + clips[run[-1]].shape[0] * stride == clips[i].data_ptr():
+                    run.append(i)
+                    continue
+                if run:
+                    first = np.cumsum([0] + [clips[j].shape[0] for j in run[:-1]])
+                    total = int(sum(clips[j].shape[0] for j in run))
+                    recs = self.score_device_segments(clips[run[0]].data_ptr(), total, h, w, first, flags=flags, edge_kernel=edge_kernel)
+                    for j, f0 in zip(run, first):
+                        out[j] = recs[f0:f0 + clips[j].shape[0]]
+                run = [i] if i is not None else []
+            host = [i for i in idxs if not hasattr(clips[i], "data_ptr")]
+            k = 0
+            while k < len(host):
+                batch, frames = [], 0
+                while k < len(host) and (not batch or frames + clips[host[k]].shape[0] <= per_batch):
+                    batch.append(host[k])
+                    frames += clips[host[k]].shape[0]
+                    k += 1
+                if len(batch) == 1 and frames > per_batch:      # one clip larger than a batch: the chunked host path
+                    out[batch[0]] = self.score_host(np.asarray(clips[batch[0]]), flags=flags, edge_kernel=edge_kernel)
+                    continue
+                buf = self._scratch("clips", frames * stride)
+                first, off = [], 0
+                for j in batch:
+                    c = np.ascontiguousarray(clips[j], dtype=np.uint8)
+                    buf.upload(c.reshape(-1), off * stride)
+                    first.append(off)
+                    off += c.shape[0]
+                recs = self.score_device_segments(buf.ptr, frames, h, w, first, flags=flags, edge_kernel=edge_kernel)
+                for j, f0 in zip(batch, first):
+                    out[j] = recs[f0:f0 + clips[j].shape[0]].copy()
+        return out
+
     def submit_device_downscaled(self, d_frames: int, n: int, src_h: int, src_w: int, dst_h: int, dst_w: int,
                                  frame_stride: int | None = None, d_prev: int | None = None,
                                  flags: int = SCORE_HSV_SAD, edge_kernel: int = 0, interpolation: int = 1,

@@ -249,3 +249,48 @@ def test_downscaled_submissions_pipeline(hip_engine):
     same(a, b, ("sad_h", "sad_s", "sad_v"))
     _, want = oracle_downscaled(x[:6].cpu().numpy(), None, dh, dw)
     same(a[:6], want, ("sad_h", "sad_s", "sad_v"))
+
+
+# ---- many clips packed into one batch (north_star; psd_score_segments_device) ----------------------------------------
+
+def test_packed_clips_equal_per_clip_records(hip_engine):
+    rng = np.random.default_rng(99)
+    shapes = [(7, 72, 128), (1, 72, 128), (33, 72, 128), (5, 90, 160), (2, 72, 128), (12, 90, 160), (70, 72, 128), (3, 37, 53)]
+    clips = [rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8) for n, h, w in shapes]
+    for flags, fields in ((NOEDGE, FIELDS), (E.SCORE_HSV_SAD, ("sad_h", "sad_s", "sad_v")), (E.SCORE_ALL, FIELDS + ("edge_xor",))):
+        want = [oracle_score(c, edges=bool(flags & E.SCORE_EDGES)) for c in clips]
+        got = hip_engine.score_clips(clips, flags=flags)
+        for g, wv, shp in zip(got, want, shapes):
+            assert len(g) == shp[0]
+            same(g, wv, fields)
+        # tiny batches: clips spill over several launches
+        got = hip_engine.score_clips(clips, flags=flags, max_batch_bytes=40 * 72 * 128 * 3)
+        for g, wv in zip(got, want):
+            same(g, wv, fields)
+
+
+def test_packed_device_clips_and_segment_validation(hip_engine):
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(8)
+    big = torch.randint(0, 256, (96, 180, 320, 3), dtype=torch.uint8, device="cuda", generator=g)
+    torch.cuda.synchronize()
+    lens = [10, 1, 40, 45]
+    clips, off = [], 0
+    for n in lens:
+        clips.append(big[off:off + n])
+        off += n
+    got = hip_engine.score_clips(clips, flags=NOEDGE)
+    host = big.cpu().numpy()
+    off = 0
+    for gr, n in zip(got, lens):
+        same(gr, orc.score_batch(host[off:off + n]))
+        off += n
+    # one launch over the whole tensor with the segment table == the per-clip results
+    recs = hip_engine.score_device_segments(big.data_ptr(), 96, 180, 320, [0, 10, 11, 51], flags=NOEDGE)
+    same(recs, np.concatenate(got))
+    with pytest.raises(ValueError):
+        hip_engine.score_device_segments(big.data_ptr(), 96, 180, 320, [0, 11, 10], flags=NOEDGE)
+    with pytest.raises(ValueError):
+        hip_engine.score_device_segments(big.data_ptr(), 96, 180, 320, [0, 96], flags=NOEDGE)
