@@ -1,0 +1,131 @@
+"""The binding a PySceneDetect maintainer would add, as a module that can be executed.
+
+``install()`` patches the three seams of the UNMODIFIED reference package so that its own detectors, driven by its own
+``SceneManager.detect_scenes``, take their pixel arithmetic from ``psd_score_batch`` (``include/psd_engine.h``):
+
+  * ``ContentDetector._calculate_frame_score``  (``scenedetect/detectors/content_detector.py:147-190``; AdaptiveDetector
+    inherits it): cv2.cvtColor + cv2.split + 3x ``_mean_pixel_distance`` + ``_detect_edges``  ->  PSD_SCORE_HSV_SAD | EDGES
+  * ``HistogramDetector.calculate_histogram``     (``histogram_detector.py:122-165``): cv2.cvtColor(BGR2YUV) + cv2.split +
+    cv2.calcHist -> PSD_SCORE_LUMA_HIST (cv2.normalize and cv2.compareHist stay the reference's calls)
+  * ``numpy.mean(frame_img)`` in ``ThresholdDetector.process_frame`` (``threshold_detector.py:127``) -> PSD_SCORE_BYTE_SUM
+
+Everything else -- weights, FlashFilter, the adaptive window, the fade state machine, StatsManager, timecodes --
+stays the reference's code.  Only the C-ABI is touched: ``psd_create``, ``psd_score_batch``, ``psd_last_error``,
+``psd_destroy`` on whatever shared library ``lib_path`` names (``pyscenedetect_amd/libpsd_hip.so`` on a machine with
+an MI355X).  Nothing of ``pyscenedetect_amd`` is imported.
+"""
+
+import ctypes
+
+import numpy as np
+
+HSV_SAD, LUMA_HIST, BYTE_SUM, EDGES = 1, 2, 4, 8
+
+
+class FrameScores(ctypes.Structure):            # psd_frame_scores, 1064 bytes
+    _fields_ = [("sad_h", ctypes.c_uint64), ("sad_s", ctypes.c_uint64), ("sad_v", ctypes.c_uint64),
+                ("edge_xor", ctypes.c_uint64), ("byte_sum", ctypes.c_uint64), ("hist", ctypes.c_uint32 * 256)]
+
+
+class Binding:
+    """One engine behind the C-ABI."""
+
+    def __init__(self, lib_path: str, device: int = 0):
+        lib = ctypes.CDLL(lib_path)
+        lib.psd_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        lib.psd_destroy.argtypes = [ctypes.c_void_p]
+        lib.psd_destroy.restype = None
+        lib.psd_score_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
+                                        ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+        lib.psd_last_error.restype = ctypes.c_char_p
+        self._lib = lib
+        self._engine = ctypes.c_void_p()
+        if lib.psd_create(device, ctypes.byref(self._engine)) != 0:
+            raise RuntimeError(lib.psd_last_error().decode())
+
+    def close(self):
+        if self._engine:
+            self._lib.psd_destroy(self._engine)
+            self._engine = ctypes.c_void_p()
+
+    def score(self, frame: np.ndarray, prev: np.ndarray | None, flags: int, kernel: int = 0) -> FrameScores:
+        if frame.dtype != np.uint8 or frame.ndim != 3 or frame.shape[2] != 3:
+            raise ValueError("Image must be 8-bit BGR")
+        frame = np.ascontiguousarray(frame)
+        if prev is not None:
+            prev = np.ascontiguousarray(prev)
+        rec = FrameScores()
+        h, w, _ = frame.shape
+        rc = self._lib.psd_score_batch(self._engine, frame.ctypes.data, 1, h, w, frame.strides[0], frame.nbytes,
+                                       prev.ctypes.data if prev is not None else None, flags, kernel, ctypes.byref(rec))
+        if rc != 0:
+            raise (ValueError if rc == -1 else RuntimeError)(self._lib.psd_last_error().decode())
+        return rec
+
+
+class _NumpyWithDeviceMean:
+    """Stands in for the ``numpy`` name inside threshold_detector.py: ``mean`` of a BGR frame comes from the device."""
+
+    def __init__(self, binding: Binding):
+        self._b = binding
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    def mean(self, a, *args, **kwargs):
+        if not args and not kwargs and isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3:
+            rec = self._b.score(a, None, BYTE_SUM)
+            return np.float64(rec.byte_sum) / np.float64(a.size)        # integer-exact sum, one float64 divide
+        return np.mean(a, *args, **kwargs)
+
+
+def install(binding: Binding):
+    """Patch the reference package (must be importable as ``scenedetect``).  Returns a function that undoes it."""
+    import cv2
+    from scenedetect.detectors import content_detector, histogram_detector, threshold_detector
+    from scenedetect.detectors.content_detector import ContentDetector
+    from scenedetect.detectors.histogram_detector import HistogramDetector
+
+    saved = (ContentDetector._calculate_frame_score, HistogramDetector.calculate_histogram, threshold_detector.numpy)
+
+    def _calculate_frame_score(self, timecode, frame_img):
+        calculate_edges = (self._weights.delta_edges > 0.0) or self.stats_manager is not None
+        last = getattr(self, "_amd_last_img", None)
+        kernel = int(self._kernel.shape[0]) if self._kernel is not None else 0
+        rec = binding.score(frame_img, last, HSV_SAD | (EDGES if calculate_edges else 0), kernel)
+        self._amd_last_img = np.array(frame_img, copy=True)
+        if last is None:
+            return 0.0
+        n = float(frame_img.shape[0] * frame_img.shape[1])
+        score_components = ContentDetector.Components(
+            delta_hue=rec.sad_h / n, delta_sat=rec.sad_s / n, delta_lum=rec.sad_v / n,
+            delta_edges=(255 * rec.edge_xor) / n if calculate_edges else 0.0)
+        frame_score = sum(c * w for (c, w) in zip(score_components, self._weights, strict=True)) / sum(abs(w) for w in self._weights)
+        if self.stats_manager is not None:
+            metrics = {self.FRAME_SCORE_KEY: frame_score}
+            metrics.update(score_components._asdict())
+            self.stats_manager.set_metrics(timecode, metrics)
+        return frame_score
+
+    def calculate_histogram(frame_img, bins: int = 256, normalize: bool = True):
+        rec = binding.score(frame_img, None, LUMA_HIST)
+        counts = np.frombuffer(rec.hist, dtype=np.uint32)
+        # cv2.calcHist with `bins` uniform bins over [0, 256): value v falls into bin floor(v * bins / 256)
+        lut = np.floor(np.arange(256) * (bins / 256.0)).astype(np.int64)
+        hist = np.zeros((bins, 1), np.float32)
+        np.add.at(hist[:, 0], lut, counts.astype(np.float32))      # exact: counts < 2^24
+        if normalize:
+            hist = cv2.normalize(hist, hist).flatten()
+        return hist
+
+    ContentDetector._calculate_frame_score = _calculate_frame_score
+    HistogramDetector.calculate_histogram = staticmethod(calculate_histogram)
+    threshold_detector.numpy = _NumpyWithDeviceMean(binding)
+
+    def uninstall():
+        ContentDetector._calculate_frame_score = saved[0]
+        HistogramDetector.calculate_histogram = staticmethod(saved[1])
+        threshold_detector.numpy = saved[2]
+        _ = content_detector, histogram_detector
+
+    return uninstall

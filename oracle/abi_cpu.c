@@ -1,0 +1,113 @@
+/*
+ * abi_cpu.c -- the entry points of include/psd_engine.h that a per-frame binding touches (psd_create, psd_destroy,
+ * psd_score_batch, psd_last_error, psd_abi_version), implemented on the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY, like everything under oracle/.  It exists so that the reference-side binding of
+ * INTEGRATION.md B (integration/scenedetect_amd.py) can be EXECUTED against the unmodified reference in the build
+ * container, where /root/reference is present but no GPU is: tests/test_reference_binding.py loads this library
+ * instead of libpsd_hip.so.  The product never loads it and has no CPU fallback.
+ * Edge term: numpy.median + cv2.Canny + cv2.dilate + _mean_pixel_distance(edges) as
+ * scenedetect/detectors/content_detector.py:170-174,213-239 composes them.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/psd_engine.h"
+
+typedef struct {
+    uint64_t sad_h, sad_s, sad_v, edge_xor, byte_sum;
+    uint32_t hist[256];
+} orc_frame_scores;
+void orc_score_batch_flags(const uint8_t* frames, int n, int h, int w, size_t row_stride, size_t frame_stride,
+                           const uint8_t* prev, orc_frame_scores* out, unsigned flags);
+void orc_bgr2hsv_planes(const uint8_t* src, size_t src_step, uint8_t* hp, uint8_t* sp, uint8_t* vp, int h, int w);
+void orc_canny(const uint8_t* src, size_t step, int h, int w, double low_thresh, double high_thresh, uint8_t* dst);
+void orc_dilate_rect(const uint8_t* src, size_t step, int h, int w, int kh, int kw, uint8_t* dst);
+
+struct psd_engine { int unused; };
+static __thread char g_err[256];
+
+int psd_abi_version(void) { return PSD_ABI_VERSION; }
+const char* psd_last_error(void) { return g_err; }
+
+int psd_create(int device, psd_engine** out)
+{
+    (void)device;
+    if (!out) { snprintf(g_err, sizeof g_err, "psd_create: null out"); return PSD_ERR_INVALID; }
+    *out = (psd_engine*)calloc(1, sizeof(psd_engine));
+    return *out ? PSD_OK : PSD_ERR_NOMEM;
+}
+
+void psd_destroy(psd_engine* e) { free(e); }
+
+static int estimated_kernel_size(int width, int height)
+{
+    int size = 4 + (int)nearbyint(sqrt((double)width * (double)height) / 192.0);   /* Python round: half to even */
+    return size % 2 == 0 ? size + 1 : size;
+}
+
+/* dilated Canny edge map of one frame (0 / 255 per pixel) */
+static void edge_map(const uint8_t* frame, int h, int w, size_t row_stride, int k, uint8_t* out)
+{
+    const size_t np = (size_t)h * w;
+    uint8_t* planes = (uint8_t*)malloc(np * 3);
+    uint8_t* lum = planes + 2 * np;
+    orc_bgr2hsv_planes(frame, row_stride, planes, planes + np, lum, h, w);
+    /* numpy.median of the V plane: mean of the two middle order statistics */
+    size_t hist[256] = {0};
+    for (size_t i = 0; i < np; i++) hist[lum[i]]++;
+    const size_t ka = (np - 1) / 2, kb = np / 2;
+    size_t run = 0;
+    int a = -1, b = -1;
+    for (int v = 0; v < 256 && b < 0; v++) {
+        run += hist[v];
+        if (a < 0 && run > ka) a = v;
+        if (run > kb) b = v;
+    }
+    const double median = (a + b) / 2.0, sigma = 1.0 / 3.0;
+    const double lo = (1.0 - sigma) * median, hi = (1.0 + sigma) * median;
+    const int low = (int)(lo > 0 ? lo : 0), high = (int)(hi < 255 ? hi : 255);
+    uint8_t* edges = (uint8_t*)malloc(np);
+    orc_canny(lum, (size_t)w, h, w, (double)low, (double)high, edges);
+    orc_dilate_rect(edges, (size_t)w, h, w, k, k, out);
+    free(edges);
+    free(planes);
+}
+
+int psd_score_batch(psd_engine* e, const uint8_t* h_frames, int n, int height, int width, size_t row_stride,
+                    size_t frame_stride, const uint8_t* h_prev, uint32_t flags, int edge_kernel, psd_frame_scores* out)
+{
+    if (!e || n < 0 || height <= 0 || width <= 0 || (n > 0 && (!h_frames || !out)) || row_stride < (size_t)width * 3 ||
+        flags == 0 || (flags & ~(uint32_t)PSD_SCORE_ALL)) {
+        snprintf(g_err, sizeof g_err, "invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    if ((flags & PSD_SCORE_EDGES) && edge_kernel != 0 && (edge_kernel < 3 || edge_kernel % 2 == 0)) {
+        snprintf(g_err, sizeof g_err, "kernel_size must be odd integer >= 3");
+        return PSD_ERR_INVALID;
+    }
+    if (n == 0) return PSD_OK;
+    orc_score_batch_flags(h_frames, n, height, width, row_stride, frame_stride, h_prev, (orc_frame_scores*)out, flags & 7u);
+    if (flags & PSD_SCORE_EDGES) {
+        const size_t np = (size_t)height * width;
+        const int k = edge_kernel ? edge_kernel : estimated_kernel_size(width, height);
+        uint8_t* cur = (uint8_t*)malloc(np);
+        uint8_t* last = (uint8_t*)malloc(np);
+        int have_last = 0;
+        if (h_prev) { edge_map(h_prev, height, width, row_stride, k, last); have_last = 1; }
+        for (int t = 0; t < n; t++) {
+            edge_map(h_frames + (size_t)t * frame_stride, height, width, row_stride, k, cur);
+            uint64_t x = 0;
+            if (have_last)
+                for (size_t i = 0; i < np; i++) x += cur[i] != last[i];
+            out[t].edge_xor = x;
+            uint8_t* sw = cur; cur = last; last = sw;
+            have_last = 1;
+        }
+        free(cur); free(last);
+    }
+    return PSD_OK;
+}

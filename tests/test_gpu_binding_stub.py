@@ -1,0 +1,39 @@
+"""GPU box: the reference-side binding (integration/scenedetect_amd.py) gets the same records from libpsd_hip.so as from
+the oracle-backed build of the same entry points -- the library the reference-side test (tests/test_reference_binding.py)
+runs against in the build container, where the reference is available and this GPU is not."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_same_records_through_the_same_binding():
+    sys.path.insert(0, os.path.join(ROOT, "integration"))
+    import scenedetect_amd as B
+    from pyscenedetect_amd.synth import make_clip
+
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "libpsd_oracle_abi.so"])
+    gpu = B.Binding(os.path.join(ROOT, "pyscenedetect_amd", "libpsd_hip.so"))
+    cpu = B.Binding(os.path.join(ROOT, "oracle", "libpsd_oracle_abi.so"))
+    frames, _ = make_clip(7, 8, 90, 160, shot_len=(3, 4), noise=4.0)
+    frames[2, 20:50, 30:90] = (250, 20, 20)
+    frames[3, 22:52, 34:94] = (250, 20, 20)
+    for flags, kernel in ((B.HSV_SAD, 0), (B.HSV_SAD | B.EDGES, 0), (B.HSV_SAD | B.EDGES, 5), (B.LUMA_HIST, 0), (B.BYTE_SUM, 0),
+                          (B.HSV_SAD | B.LUMA_HIST | B.BYTE_SUM | B.EDGES, 7)):
+        for t in range(len(frames)):
+            prev = frames[t - 1] if t else None
+            a, b = gpu.score(frames[t], prev, flags, kernel), cpu.score(frames[t], prev, flags, kernel)
+            assert bytes(a) == bytes(b), f"flags {flags} kernel {kernel} frame {t}"
+    with pytest.raises(ValueError):
+        gpu.score(frames[0], None, B.EDGES, 4)
+    with pytest.raises(ValueError):
+        cpu.score(frames[0], None, B.EDGES, 4)
+    gpu.close()
+    cpu.close()
+    assert ctypes.sizeof(B.FrameScores) == 1064

@@ -1,0 +1,77 @@
+"""INTEGRATION.md B, executed: the UNMODIFIED reference package, its seams patched by integration/scenedetect_amd.py,
+driven by its own SceneManager, reproduces the golden runs.
+
+Where this runs: the build container (the reference lives at /root/reference there and nowhere else); without a GPU the
+binding loads oracle/libpsd_oracle_abi.so -- the same five C-ABI entry points on the CPU oracle (test infrastructure).
+With a GPU visible (and the reference present) the very same test loads pyscenedetect_amd/libpsd_hip.so instead.
+tests/test_gpu_binding_stub.py covers the GPU box, where the reference is absent: identical records from both
+libraries through the identical binding.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "scenedetect")),
+                                reason="the reference checkout is only present in the build container")
+
+
+def _lib_path():
+    from tests.conftest import _gpu_available
+
+    if _gpu_available():
+        return os.path.join(ROOT, "pyscenedetect_amd", "libpsd_hip.so")
+    import subprocess
+
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "libpsd_oracle_abi.so"])
+    return os.path.join(ROOT, "oracle", "libpsd_oracle_abi.so")
+
+
+@pytest.fixture(scope="module")
+def patched_reference():
+    shim = os.path.join(ROOT, "oracle", "cv2_shim")
+    added = [p for p in (shim, REFERENCE) if p not in sys.path]
+    sys.path[:0] = added
+    sys.path.insert(0, os.path.join(ROOT, "integration"))
+    import scenedetect  # noqa: F401  (the reference, unmodified)
+    import scenedetect_amd
+
+    assert os.path.realpath(scenedetect.__file__).startswith(REFERENCE)
+    binding = scenedetect_amd.Binding(_lib_path())
+    undo = scenedetect_amd.install(binding)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gen_golden  # the reference-side MemoryStream / run() that produced the goldens
+
+    yield gen_golden
+    undo()
+    binding.close()
+
+
+CASES = [(clip, cfg) for clip in ("scenes_a", "fades_b", "ragged_c", "wide_d", "uniform_u")
+         for cfg in ("content_default", "content_stats", "content_edges", "content_luma_suppress", "content_kernel5_secs",
+                     "adaptive_default", "adaptive_w3", "hist_default", "hist_256", "hist_100", "threshold_default",
+                     "threshold_final", "threshold_ceiling")]
+
+
+@pytest.mark.parametrize("clip,cfg", CASES)
+def test_reference_with_bound_seams_reproduces_the_goldens(patched_reference, golden, clip, cfg):
+    from tests._helpers import assert_same_run
+    from tests.conftest import golden_clip
+
+    want = golden["clips"][clip]["results"].get(cfg)
+    if want is None:
+        pytest.skip("not part of this clip's golden set")
+    cls_name, kwargs, with_stats = golden["configs"][cfg]
+    frames = golden_clip(golden, clip)
+    got = patched_reference.run(frames, cls_name, kwargs, with_stats, clip == "wide_d")
+    assert_same_run(got, want, f"{clip}/{cfg}")
+
+
+def test_binding_only_touches_the_c_abi():
+    src = open(os.path.join(ROOT, "integration", "scenedetect_amd.py")).read()
+    assert "import pyscenedetect_amd" not in src and "from pyscenedetect_amd" not in src
+    assert "import ctypes" in src and "psd_score_batch" in src
