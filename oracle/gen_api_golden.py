@@ -136,6 +136,30 @@ def main():
                     emitted.append([i, c.frame_num])
             return {"emitted": emitted, "max_behind": int(flt.max_behind)}
         out["flash_filter"].append({"fps": fps, "length": length, "mode": mode, "above": [int(a) for a in above], **outcome(drive)})
+    # the same with presentation-timestamp positions (variable frame rate: 20 / 40 / 60 / 80 ms steps at a nominal 25 fps),
+    # where the filter's gaps are time differences, not frame counts
+    from fractions import Fraction
+
+    from scenedetect.common import Timecode
+
+    out["flash_filter_pts"] = []
+    for case in range(36):
+        length = [15, 1, 7, 0.5, 1.2, "00:00:00.300", "20", 40, "0.8s", 3, 0.25, 25][case % 12]
+        mode = "MERGE" if (case // 3) % 2 == 0 else "SUPPRESS"
+        n = 200
+        density = [0.05, 0.2, 0.5][case % 3]
+        above = (rng.random(n) < density).tolist()
+        steps = rng.choice([20, 40, 40, 40, 60, 80], size=n - 1)
+        pts = [0] + [int(x) for x in np.cumsum(steps)]
+        def drive_pts():
+            flt = FlashFilter(FlashFilter.Mode[mode], length)
+            emitted = []
+            for i, a in enumerate(above):
+                tc = FrameTimecode(Timecode(pts[i], Fraction(1, 1000)), 25.0)
+                for c in flt.filter(tc, bool(a)):
+                    emitted.append([i, c.pts])
+            return {"emitted": emitted, "max_behind": int(flt.max_behind)}
+        out["flash_filter_pts"].append({"length": length, "mode": mode, "above": [int(a) for a in above], "pts": pts, **outcome(drive_pts)})
     path = os.path.join(os.path.dirname(HERE), "tests", "golden", "api_cases.json")
     with open(path, "w") as fh:
         json.dump(out, fh, separators=(",", ":"))

@@ -125,9 +125,44 @@ class FlashFilter:
             self._threshold_frames = round(secs * rate)
         return self._threshold_frames
 
+    def _filter_by_time(self, timecode: FrameTimecode, above_threshold: bool) -> list[FrameTimecode]:
+        """Positions that are presentation timestamps (variable frame rate): the reference's own comparisons,
+        ``(timecode - last_above) >= seconds`` on timecode arithmetic (``detector.py:171-224``) -- frame numbers derived
+        from an average rate would misplace the gaps."""
+        if self._length_secs is None:
+            self._length_secs = self._length_frames / float(timecode.frame_rate)
+        if self._last_above is None:
+            self._last_above = timecode
+        min_length_met = (timecode - self._last_above) >= self._length_secs
+        if self._mode == FlashFilter.Mode.SUPPRESS:
+            if not (above_threshold and min_length_met):
+                return []
+            self._last_above = timecode
+            return [timecode]
+        if self._mode != FlashFilter.Mode.MERGE:
+            raise RuntimeError("Unhandled FlashFilter mode.")
+        if above_threshold:
+            self._last_above = timecode
+        if self._merging:
+            if min_length_met and not above_threshold and (self._last_above - self._merge_start) >= self._length_secs:
+                self._merging = False
+                return [self._last_above]
+            return []
+        if not above_threshold:
+            return []
+        if min_length_met:
+            self._armed = True
+            return [timecode]
+        if self._armed:
+            self._merging = True
+            self._merge_start = timecode
+        return []
+
     def filter(self, timecode: FrameTimecode, above_threshold: bool) -> list[FrameTimecode]:
         if self._disabled:
             return [timecode] if above_threshold else []
+        if getattr(timecode, "_pts", None) is not None:
+            return self._filter_by_time(timecode, above_threshold)
         need = self._resolve(timecode)
         now = timecode.frame_num
         if self._last_above is None:

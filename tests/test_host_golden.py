@@ -292,6 +292,26 @@ def test_flash_filter_random_sequences_match_reference():
         assert _outcome(drive) == {k: c[k] for k in ("ok", "raises") if k in c}, (c["fps"], c["length"], c["mode"])
 
 
+def test_flash_filter_random_pts_sequences_match_reference():
+    """The same on presentation-timestamp positions (variable frame rate): gaps are time differences."""
+    from fractions import Fraction
+
+    from pyscenedetect_amd.timecode import Timecode
+
+    cases = _api_cases()["flash_filter_pts"]
+    assert len(cases) >= 36
+    for c in cases:
+        def drive():
+            flt = FlashFilter(FlashFilter.Mode[c["mode"]], c["length"])
+            emitted = []
+            for i, a in enumerate(c["above"]):
+                tc = FrameTimecode(Timecode(c["pts"][i], Fraction(1, 1000)), 25.0)
+                for cut in flt.filter(tc, bool(a)):
+                    emitted.append([i, cut.pts])
+            return {"emitted": emitted, "max_behind": int(flt.max_behind)}
+        assert _outcome(drive) == {k: c[k] for k in ("ok", "raises") if k in c}, (c["length"], c["mode"])
+
+
 @pytest.mark.parametrize("cls_name", ["ContentDetector", "AdaptiveDetector", "HistogramDetector", "HashDetector", "ThresholdDetector"])
 def test_min_scene_len_accepts_time_values(golden, oracle_engine, cls_name):
     """int frames, float seconds and both string forms of the same duration give the same cut list
