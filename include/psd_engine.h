@@ -118,8 +118,9 @@ int psd_score_segments_submit_device(psd_engine* e, const uint8_t* d_frames, int
                                      uint32_t flags, int edge_kernel, void* stream);
 
 /* Same for frames in host memory: the engine stages them through its own pinned/device
- * buffers in bounded chunks (H2D overlapped with scoring) and carries the one-frame halo
- * between chunks itself.  h_prev may be NULL. */
+ * buffers in bounded chunks and carries the one-frame halo between chunks itself (copy and kernels share the
+ * engine's stream; hosts that want the copy of batch k+1 to overlap the scoring of batch k use psd_upload* below).
+ * h_prev may be NULL. */
 int psd_score_batch(psd_engine* e, const uint8_t* h_frames, int n, int height, int width,
                     size_t row_stride, size_t frame_stride, const uint8_t* h_prev, uint32_t flags,
                     int edge_kernel, psd_frame_scores* out);
@@ -140,6 +141,25 @@ int psd_device_alloc(psd_engine* e, size_t bytes, void** d_ptr);
 int psd_device_free(psd_engine* e, void* d_ptr);
 int psd_memcpy_h2d(psd_engine* e, void* d_dst, const void* h_src, size_t bytes);
 int psd_memcpy_d2h(psd_engine* e, void* h_dst, const void* d_src, size_t bytes);
+
+/* Feeding frames from the host (the decoder side of scene_manager.py:625-710, backends/pyav.py:322-363):
+ *   psd_host_alloc / psd_host_free   page-locked host memory: frames decoded INTO it cross PCIe by DMA at full rate and
+ *                                    asynchronously;
+ *   psd_upload        blocking host -> device copy that neither touches engine state nor waits for the engine's stream:
+ *                     safe from a decode thread while another thread scores (the destination must not be in use);
+ *   psd_upload_async  enqueue the copy on the engine's copy stream (page-locked source: truly asynchronous);
+ *   psd_upload_fence  wait_on_host = 0: later work on the engine's stream waits for every copy enqueued so far;
+ *                     wait_on_host = 1: the calling thread waits for them;
+ *   psd_memcpy_d2d    device -> device copy in the order of the engine's stream (e.g. keeping a batch's last frame as the
+ *                     next batch's predecessor);
+ *   psd_synchronize   the calling thread waits until the engine's stream is idle. */
+int psd_host_alloc(psd_engine* e, size_t bytes, void** h_ptr);
+int psd_host_free(psd_engine* e, void* h_ptr);
+int psd_upload(psd_engine* e, void* d_dst, const void* h_src, size_t bytes);
+int psd_upload_async(psd_engine* e, void* d_dst, const void* h_src, size_t bytes);
+int psd_upload_fence(psd_engine* e, int wait_on_host);
+int psd_memcpy_d2d(psd_engine* e, void* d_dst, const void* d_src, size_t bytes);
+int psd_synchronize(psd_engine* e);
 
 /* The device's fixed-point HSV tables (for validation against the oracle). */
 int psd_hsv_tables(int32_t sdiv[256], int32_t hdiv180[256]);

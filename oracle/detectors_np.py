@@ -85,6 +85,13 @@ class OracleEngine:
             rec["byte_sum"] = 0
         return rec
 
+    def downscale_host(self, frames, downscale, interpolation=1):
+        """The frames as the reference's detectors / callbacks receive them (scene_manager.py:666-678)."""
+        import cv2  # the shim
+
+        return np.stack([cv2.resize(f, (max(1, round(f.shape[1] / downscale)), max(1, round(f.shape[0] / downscale))),
+                                    interpolation=interpolation) for f in np.ascontiguousarray(frames, dtype=np.uint8)])
+
     def hash_thumbs_host(self, frames, size, downscale=1.0, interpolation=1):
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
         if downscale > 1.0:

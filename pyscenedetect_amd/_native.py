@@ -118,6 +118,13 @@ SYMBOLS = {
     "psd_device_alloc": (_i, [_vp, _sz, _P(_vp)]),
     "psd_device_free": (_i, [_vp, _vp]),
     "psd_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "psd_host_alloc": (_i, [_vp, _sz, _P(_vp)]),
+    "psd_host_free": (_i, [_vp, _vp]),
+    "psd_upload": (_i, [_vp, _vp, _vp, _sz]),
+    "psd_upload_async": (_i, [_vp, _vp, _vp, _sz]),
+    "psd_upload_fence": (_i, [_vp, _i]),
+    "psd_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
+    "psd_synchronize": (_i, [_vp]),
     "psd_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "psd_hsv_tables": (_i, [_vp, _vp]),
     "psd_edge_map_device": (_i, [_vp, _vp, _i, _i, _sz, _i, _vp]),

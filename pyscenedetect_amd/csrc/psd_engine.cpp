@@ -90,6 +90,8 @@ struct psd_engine {
     void* resize_cache = nullptr;   // coefficient tables per (src, dst) shape, owned by psd_resize_kernels.hip
     uint8_t* d_small = nullptr;     // resized frames of psd_score_downscaled_* when the terms need them in memory
     size_t small_bytes = 0;
+    hipStream_t copy_stream = nullptr;   // psd_upload_async: host -> device copies that overlap the scoring stream
+    hipEvent_t ev_copy = nullptr;
 };
 
 static void fill_tables(int32_t* sdiv, int32_t* hdiv)
@@ -215,6 +217,8 @@ void psd_destroy(psd_engine* e)
     if (e->d_hash) (void)hipFree(e->d_hash);
     for (auto& ev : e->ev_hash) if (ev) (void)hipEventDestroy(ev);
     if (e->d_lut) (void)hipFree(e->d_lut);
+    if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
+    if (e->ev_copy) (void)hipEventDestroy(e->ev_copy);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -696,6 +700,79 @@ int psd_memcpy_h2d(psd_engine* e, void* d_dst, const void* h_src, size_t bytes)
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));  // order against work queued on the engine's (non-blocking) stream
     HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return PSD_OK;
+}
+
+int psd_host_alloc(psd_engine* e, size_t bytes, void** h_ptr)
+{
+    if (!e || !h_ptr) { psd_set_error("psd_host_alloc: null argument"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(e->device));
+    *h_ptr = nullptr;
+    hipError_t err = hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (err != hipSuccess) {
+        psd_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+        return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
+    }
+    return PSD_OK;
+}
+
+int psd_host_free(psd_engine* e, void* h_ptr)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(e->device));
+    if (h_ptr) HIP_TRY(hipHostFree(h_ptr));
+    return PSD_OK;
+}
+
+int psd_upload(psd_engine* e, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!e || (bytes && (!d_dst || !h_src))) { psd_set_error("psd_upload: null argument"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(e->device));
+    // blocking for the CALLER only: no engine state is touched and the engine's stream is not waited for, so a decode
+    // thread can fill one device batch while the engine scores another
+    HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return PSD_OK;
+}
+
+int psd_upload_async(psd_engine* e, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!e || (bytes && (!d_dst || !h_src))) { psd_set_error("psd_upload_async: null argument"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_copy, hipEventDisableTiming));
+    }
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, e->copy_stream));
+    return PSD_OK;
+}
+
+int psd_upload_fence(psd_engine* e, int wait_on_host)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    if (!e->copy_stream) return PSD_OK;   // nothing was ever uploaded asynchronously
+    HIP_TRY(hipSetDevice(e->device));
+    if (wait_on_host) {
+        HIP_TRY(hipStreamSynchronize(e->copy_stream));
+    } else {
+        HIP_TRY(hipEventRecord(e->ev_copy, e->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_copy, 0));
+    }
+    return PSD_OK;
+}
+
+int psd_synchronize(psd_engine* e)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return PSD_OK;
+}
+
+int psd_memcpy_d2d(psd_engine* e, void* d_dst, const void* d_src, size_t bytes)
+{
+    if (!e || (bytes && (!d_dst || !d_src))) { psd_set_error("psd_memcpy_d2d: null argument"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, e->stream));
     return PSD_OK;
 }
 

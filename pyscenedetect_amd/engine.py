@@ -42,6 +42,14 @@ class DeviceBuffer:
             raise ValueError("upload out of range")
         _native.check(self._engine._lib.psd_memcpy_h2d(self._engine._h, self.ptr + offset, host.ctypes.data, host.nbytes))
 
+    def upload_unordered(self, host: np.ndarray, offset: int = 0) -> None:
+        """Blocking copy that does not wait for the engine's stream (``psd_upload``): for a decode thread filling a batch
+        buffer that no queued kernel reads."""
+        host = np.ascontiguousarray(host)
+        if offset + host.nbytes > self.nbytes:
+            raise ValueError("upload out of range")
+        _native.check(self._engine._lib.psd_upload(self._engine._h, self.ptr + offset, host.ctypes.data, host.nbytes))
+
     def download(self, nbytes: int | None = None, offset: int = 0) -> np.ndarray:
         nbytes = self.nbytes - offset if nbytes is None else nbytes
         out = np.empty(nbytes, np.uint8)
@@ -74,11 +82,17 @@ class ScoringEngine:
         _native.check(rc)
         self._h = h
         self.device = int(device)
+        # the composite calls below (upload + resize + score + collect) keep engine state between their steps; the lock
+        # makes an engine that ends up shared between threads safe, one at a time (distinct engines run concurrently)
+        self._lock = threading.RLock()
+        self._pinned: list[int] = []
 
     def close(self) -> None:
         for buf in self.__dict__.pop("_scratch_bufs", {}).values():
             buf.free()
         if getattr(self, "_h", None):
+            for p in self.__dict__.pop("_pinned", []):
+                self._lib.psd_host_free(self._h, p)
             self._lib.psd_destroy(self._h)
             self._h = None
 
@@ -199,6 +213,78 @@ class ScoringEngine:
         if hash_size:
             thumbs = self.hash_thumbs_device(buf.ptr + p * stride, n, fh, fw, hash_size, fw * 3, stride)
         return records, thumbs
+
+    # -- feeding frames from the host -------------------------------------------------------------
+    def pinned_array(self, shape, dtype=np.uint8) -> np.ndarray:
+        """A numpy array in page-locked host memory (``psd_host_alloc``): frames decoded into it cross PCIe by DMA at
+        full rate, and ``upload_async`` from it does not block.  Freed when the engine is closed."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        _native.check(self._lib.psd_host_alloc(self._h, nbytes, ctypes.byref(p)))
+        self._pinned.append(p.value)
+        buf = (ctypes.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def upload_async(self, d_dst: int, host: np.ndarray) -> None:
+        """Enqueue a host -> device copy on the engine's copy stream (asynchronous for ``pinned_array`` memory)."""
+        host = np.ascontiguousarray(host)
+        _native.check(self._lib.psd_upload_async(self._h, d_dst, host.ctypes.data, host.nbytes))
+
+    def upload_fence(self, wait_on_host: bool = False) -> None:
+        """Order the engine's stream (or the calling thread) after every ``upload_async`` issued so far."""
+        _native.check(self._lib.psd_upload_fence(self._h, 1 if wait_on_host else 0))
+
+    def copy_d2d(self, d_dst: int, d_src: int, nbytes: int) -> None:
+        _native.check(self._lib.psd_memcpy_d2d(self._h, d_dst, d_src, int(nbytes)))
+
+    def synchronize(self) -> None:
+        """Wait until the engine's stream is idle."""
+        _native.check(self._lib.psd_synchronize(self._h))
+
+    def analyze_device(self, d_frames: int, n: int, height: int, width: int, frame_stride: int, d_prev: int | None = None,
+                       flags: int = 0, edge_kernels=(0,), downscale: float = 1.0, hash_sizes=(), interpolation: int = 1,
+                       want_frames: bool = False) -> dict:
+        """Everything a batch of resident frames has to yield for a set of detectors, from ONE copy of the batch in HBM:
+        ``records`` (score records for ``flags``; ``edge_xor`` for the first entry of ``edge_kernels``), ``edge_xor``
+        ({kernel: array} when detectors use different dilation sizes), ``thumbs`` ({size: uint8[n,size,size]}) and, if
+        ``want_frames``, ``frames``: the frames exactly as the reference's detectors and callbacks would see them
+        (downscaled like ``scene_manager.py:666-678``).  ``size`` is that (height, width)."""
+        with self._lock:
+            kernels = list(dict.fromkeys(edge_kernels)) or [0]
+            fh, fw = height, width
+            ptr, stride, prev = d_frames, frame_stride, d_prev
+            out = {"records": None, "edge_xor": {}, "thumbs": {}, "frames": None}
+            small = None
+            if downscale > 1.0:
+                fw, fh = max(1, round(width / downscale)), max(1, round(height / downscale))
+                if flags and not hash_sizes and not want_frames and len(kernels) == 1:
+                    # resize + score inside the engine (one fused kernel for the HSV term behind INTER_LINEAR)
+                    out["records"] = self.score_device_downscaled(d_frames, n, height, width, fh, fw, frame_stride, d_prev, flags,
+                                                                  kernels[0], interpolation)
+                    out["size"] = (fh, fw)
+                    return out
+                stride = (fh * fw * 3 + 15) & ~15
+                small = self._scratch("an_small", (n + 1) * stride)
+                if d_prev:
+                    self.resize_device(d_prev, 1, height, width, small.ptr, fh, fw, src_frame_stride=frame_stride,
+                                       dst_frame_stride=stride, interpolation=interpolation)
+                self.resize_device(d_frames, n, height, width, small.ptr + stride, fh, fw, src_frame_stride=frame_stride,
+                                   dst_frame_stride=stride, interpolation=interpolation)
+                ptr, prev = small.ptr + stride, (small.ptr if d_prev else None)
+            out["size"] = (fh, fw)
+            if flags:
+                out["records"] = self.score_device(ptr, n, fh, fw, fw * 3, stride, d_prev=prev, flags=flags, edge_kernel=kernels[0])
+                if flags & SCORE_EDGES:
+                    out["edge_xor"][kernels[0]] = out["records"]["edge_xor"]
+                    for k in kernels[1:]:
+                        out["edge_xor"][k] = self.score_device(ptr, n, fh, fw, fw * 3, stride, d_prev=prev, flags=SCORE_EDGES,
+                                                               edge_kernel=k)["edge_xor"]
+            for size in hash_sizes:
+                out["thumbs"][size] = self.hash_thumbs_device(ptr, n, fh, fw, size, fw * 3, stride)
+            if want_frames and small is not None:
+                raw = small.download(n * stride, offset=stride).reshape(n, stride)
+                out["frames"] = raw[:, : fh * fw * 3].reshape(n, fh, fw, 3)
+            return out
 
     # -- HashDetector thumbnails ---------------------------------------------------------------
     def hash_thumbs_device(self, d_frames: int, n: int, height: int, width: int, size: int,
@@ -381,23 +467,48 @@ class ScoringEngine:
         return out
 
 
+def _locked(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        with self._lock:
+            return fn(self, *args, **kwargs)
+
+    return wrapper
+
+
+# the synchronous calls hold the engine's lock from their first step to their last (the submit_* / collect pairs of the
+# pipelined API stay the caller's to serialise)
+for _name in ("score_host", "_score_host_downscaled", "analyze_frames", "hash_thumbs_device", "hash_thumbs_host", "score_device",
+              "score_device_downscaled", "score_device_segments", "score_clips", "edge_map", "resize_device"):
+    setattr(ScoringEngine, _name, _locked(getattr(ScoringEngine, _name)))
+
 _default_lock = threading.Lock()
-_default_engines: dict[int, ScoringEngine] = {}
+_default_engines: dict[tuple[int, int], ScoringEngine] = {}
 
 
 def default_engine(device: int | None = None) -> ScoringEngine:
-    """Process-wide engine for ``device`` (default: ``LOCAL_RANK`` or 0).  Raises without a GPU."""
+    """The calling THREAD's engine for ``device`` (default: ``LOCAL_RANK`` or 0).  An engine keeps state between the
+    steps of a call (record slots, staging buffers), so threads do not share one: two SceneManagers or detectors running
+    on different threads each get their own stream and buffers (the reference runs one detector set per thread,
+    ``benchmark/sweep.py:160-180``).  Raises without a GPU."""
     import os
 
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
         if device >= max(device_count(), 1):
             device = 0
+    key = (threading.get_ident(), device)
     with _default_lock:
-        eng = _default_engines.get(device)
+        eng = _default_engines.get(key)
         if eng is None:
+            # drop engines of threads that are gone
+            alive = {t.ident for t in threading.enumerate()}
+            for k in [k for k in _default_engines if k[0] not in alive]:
+                _default_engines.pop(k).close()
             eng = ScoringEngine(device)
-            _default_engines[device] = eng
+            _default_engines[key] = eng
         return eng
 
 

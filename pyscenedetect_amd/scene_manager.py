@@ -190,20 +190,25 @@ class SceneManager:
             self._engine = default_engine()
         return self._engine
 
-    def _dispatch(self, position, frame_im, record, callback, scored_size=None, thumb=None, bits=None) -> bool:
-        """One frame's worth of decisions for every detector (reference ``_process_frame`` :410-435)."""
+    def _dispatch(self, position, frame_im, result, i: int, callback) -> bool:
+        """One frame's worth of decisions for every detector (reference ``_process_frame`` :410-435).  ``result`` is the
+        batch's device output (``_score_batch``), ``i`` the frame's index in it."""
         new_cuts = False
         self._frame_buffer.append((position, frame_im))
         self._frame_buffer = self._frame_buffer[-(self._frame_buffer_size + 1):]
-        h, w = scored_size if scored_size is not None else (frame_im.shape[0], frame_im.shape[1])
+        h, w = result["size"] if result is not None else (frame_im.shape[0], frame_im.shape[1])
         for detector in self._detector_list:
-            if record is not None and detector.score_flags():
+            if result is not None and result["records"] is not None and detector.score_flags():
+                record = result["records"][i]
+                k = detector.edge_kernel_size()
+                if len(result["edge_xor"]) > 1 and (detector.score_flags() & 8):
+                    record = record.copy()      # this detector's own dilation size (content_detector.py:135-137)
+                    record["edge_xor"] = result["edge_xor"][k][i]
                 cuts = detector.process_record(position, record, h, w)
-            elif thumb is not None and detector.hash_thumb_size():
-                if bits is not None and getattr(detector, "hash_size", None) in bits:
-                    cuts = detector.process_thumb(position, thumb, bits=bits[detector.hash_size])
-                else:
-                    cuts = detector.process_thumb(position, thumb)
+            elif result is not None and detector.hash_thumb_size() and detector.hash_thumb_size() in result["thumbs"]:
+                size = detector.hash_thumb_size()
+                bits = result["bits"].get((size, getattr(detector, "hash_size", None)))
+                cuts = detector.process_thumb(position, result["thumbs"][size][i], bits=None if bits is None else bits[i])
             else:
                 cuts = detector.process_frame(position, frame_im)
             self._cutting_list += cuts
@@ -214,6 +219,61 @@ class SceneManager:
                         if cut == buffered_pos:
                             callback(buffered, buffered_pos)
         return new_cuts
+
+    def _plan(self, callback, factor: float) -> dict:
+        """What one pass over a batch has to produce for the registered detectors."""
+        flags, kernels, thumb_sizes, fallback = 0, [], [], False
+        for det in self._detector_list:
+            f = det.score_flags()
+            flags |= f
+            if f & 8 and det.edge_kernel_size() not in kernels:
+                kernels.append(det.edge_kernel_size())
+            if det.hash_thumb_size() and det.hash_thumb_size() not in thumb_sizes:
+                thumb_sizes.append(det.hash_thumb_size())
+            if not f and not det.hash_thumb_size():
+                fallback = True      # a plug-in detector without a device path: process_frame(frame) like the reference
+        # detectors on process_frame() and callbacks get the frame the reference would hand them: the DOWNSCALED one
+        # (its decode thread resizes before queueing, scene_manager.py:666-678)
+        want_frames = factor > 1.0 and (fallback or callback is not None)
+        return {"flags": flags, "kernels": kernels or [0], "thumb_sizes": thumb_sizes, "want_frames": want_frames,
+                "device": bool(flags or thumb_sizes), "fallback": fallback}
+
+    def _score_batch(self, engine, plan, frames, factor, last_frame, slot=None):
+        """Device results for one batch: records, per-kernel edge counts, thumbnails (+ hash bits), the frames as the
+        detectors see them."""
+        from pyscenedetect_amd import epilogue
+
+        interp = self._interpolation.value
+        if slot is not None:
+            res = engine.analyze_device(slot["ptr"], len(frames), slot["h"], slot["w"], slot["stride"], d_prev=slot["prev"],
+                                        flags=plan["flags"], edge_kernels=plan["kernels"], downscale=factor,
+                                        hash_sizes=plan["thumb_sizes"], interpolation=interp, want_frames=plan["want_frames"])
+        else:
+            # engines without device batches (the CPU stand-in of the tests): same results through score_host
+            kwargs = {"downscale": factor} if factor > 1.0 else {}
+            if factor > 1.0 and interp != 1:
+                kwargs["interpolation"] = interp
+            stacked = np.stack(frames)
+            res = {"records": None, "edge_xor": {}, "thumbs": {}, "frames": None}
+            shape = frames[0].shape
+            res["size"] = ((max(1, round(shape[0] / factor)), max(1, round(shape[1] / factor))) if factor > 1.0 else shape[:2])
+            if plan["flags"]:
+                res["records"] = engine.score_host(stacked, prev=last_frame, flags=plan["flags"], edge_kernel=plan["kernels"][0], **kwargs)
+                if plan["flags"] & 8:
+                    res["edge_xor"][plan["kernels"][0]] = res["records"]["edge_xor"]
+                    for k in plan["kernels"][1:]:
+                        res["edge_xor"][k] = engine.score_host(stacked, prev=last_frame, flags=8, edge_kernel=k, **kwargs)["edge_xor"]
+            for size in plan["thumb_sizes"]:
+                res["thumbs"][size] = engine.hash_thumbs_host(stacked, size, **kwargs)
+            if plan["want_frames"]:
+                res["frames"] = engine.downscale_host(stacked, factor, interp)
+        # DCT / median for the whole batch at once (native, threaded) instead of once per frame
+        res["bits"] = {}
+        for det in self._detector_list:
+            size, hs = det.hash_thumb_size(), getattr(det, "hash_size", None)
+            if size and hs is not None and size in res["thumbs"] and (size, hs) not in res["bits"]:
+                res["bits"][(size, hs)] = epilogue.hash_bits(res["thumbs"][size], hs)
+        return res
 
     def detect_scenes(self, video=None, duration=None, end_time=None, frame_skip: int = 0,
                       show_progress: bool = False,
@@ -249,22 +309,16 @@ class SceneManager:
         elif duration is not None:
             end_time = (self._base_timecode + duration) + start_frame_num
 
-        flags = 0
-        edge_kernel = 0
-        thumb_sizes = set()
-        for det in self._detector_list:
-            flags |= det.score_flags()
-            edge_kernel = edge_kernel or det.edge_kernel_size()
-            if det.hash_thumb_size():
-                thumb_sizes.add(det.hash_thumb_size())
-        # one thumbnail size per pass; detectors with another size score their own frames in process_frame
-        hash_size = thumb_sizes.pop() if len(thumb_sizes) == 1 else 0
-        engine = self._engine_or_default() if (flags or hash_size) else None
+        plan = self._plan(callback, factor)
+        engine = self._engine_or_default() if plan["device"] else None
+        # Engines with device batches: the decode thread uploads every frame straight into one of three device batch
+        # buffers while this thread scores and decides the previous batch (host -> device copies overlap everything else).
+        feeder = _DeviceFeeder(engine, self._batch_frames) if engine is not None and hasattr(engine, "analyze_device") else None
 
-        batches: queue.Queue = queue.Queue(2)
+        batches: queue.Queue = queue.Queue(1 if feeder else 2)
         self._stop.clear()
         self._exception_info = None
-        worker = threading.Thread(target=self._decode_thread, args=(video, frame_skip, end_time, batches), daemon=True)
+        worker = threading.Thread(target=self._decode_thread, args=(video, frame_skip, end_time, batches, feeder), daemon=True)
         worker.start()
         last_frame = None
         try:
@@ -272,49 +326,32 @@ class SceneManager:
                 batch = batches.get()
                 if batch is None:
                     break
-                frames, positions = batch
-                records = thumbs = None
-                scored_size = None
+                frames, positions, slot = batch
+                result = None
                 if engine is not None:
-                    shape = frames[0].shape
-                    if last_frame is not None and last_frame.shape != shape:
+                    if last_frame is not None and last_frame.shape != frames[0].shape:
                         last_frame = None
-                    if factor > 1.0:
-                        # Same target size as the reference's cv2.resize call (:670-678).
-                        scored_size = (max(1, round(shape[0] / factor)), max(1, round(shape[1] / factor)))
-                    kwargs = {"downscale": factor} if factor > 1.0 else {}
-                    if factor > 1.0 and self._interpolation != Interpolation.LINEAR:
-                        kwargs["interpolation"] = self._interpolation.value
-                    if hasattr(engine, "analyze_frames"):
-                        # frames go to the device one by one: no host-side stacking copy
-                        records, thumbs = engine.analyze_frames(frames, prev=last_frame, flags=flags, edge_kernel=edge_kernel,
-                                                                hash_size=hash_size, **kwargs)
-                    else:
-                        stacked = np.stack(frames)
-                        if flags:
-                            records = engine.score_host(stacked, prev=last_frame, flags=flags, edge_kernel=edge_kernel, **kwargs)
-                        if hash_size:
-                            thumbs = engine.hash_thumbs_host(stacked, hash_size, **kwargs)
+                        if feeder:
+                            feeder.forget_halo()
+                    if slot is not None:
+                        slot["prev"] = feeder.halo_ptr(slot)
+                    result = self._score_batch(engine, plan, frames, factor, last_frame, slot)
+                    if slot is not None:
+                        feeder.release(slot, keep_last=len(frames))
                     last_frame = frames[-1]
-                batch_bits = {}
-                if thumbs is not None:
-                    # DCT / median for the whole batch at once (native, threaded) instead of once per frame
-                    from pyscenedetect_amd import epilogue
-
-                    for det in self._detector_list:
-                        hs = getattr(det, "hash_size", None)
-                        if det.hash_thumb_size() and hs is not None and hs not in batch_bits:
-                            batch_bits[hs] = epilogue.hash_bits(thumbs, hs)
-                for i, (frame_im, position) in enumerate(zip(frames, positions)):
-                    self._dispatch(position, frame_im, records[i] if records is not None else None, callback, scored_size,
-                                   thumbs[i] if thumbs is not None else None,
-                                   {hs: b[i] for hs, b in batch_bits.items()} if batch_bits else None)
+                shown = result["frames"] if result is not None and result.get("frames") is not None else frames
+                for i, position in enumerate(positions):
+                    self._dispatch(position, shown[i], result, i, callback)
         finally:
             self._stop.set()
+            if feeder:
+                feeder.abort()
             while worker.is_alive():
                 while not batches.empty():
                     batches.get_nowait()
                 worker.join(timeout=0.1)
+            if feeder:
+                feeder.close()
         if self._exception_info is not None:
             exc = self._exception_info[1]
             raise exc.with_traceback(self._exception_info[2])
@@ -323,17 +360,19 @@ class SceneManager:
             self._cutting_list += detector.post_process(video.position)
         return video.frame_number - start_frame_num
 
-    def _decode_thread(self, video, frame_skip: int, end_time, out_queue: queue.Queue) -> None:
+    def _decode_thread(self, video, frame_skip: int, end_time, out_queue: queue.Queue, feeder=None) -> None:
         """Reads, size-checks and crops frames and hands them over in batches
-        (reference ``_decode_thread`` :625-710; the downscale of :670-678 runs on the device)."""
+        (reference ``_decode_thread`` :625-710; the downscale of :670-678 runs on the device).  With a device feeder
+        every frame is copied into the current device batch as soon as it is read."""
         frames: list[np.ndarray] = []
         positions: list[FrameTimecode] = []
+        slot = None
 
         def flush():
-            nonlocal frames, positions
+            nonlocal frames, positions, slot
             if frames:
-                out_queue.put((frames, positions))
-                frames, positions = [], []
+                out_queue.put((frames, positions, slot))
+                frames, positions, slot = [], [], None
 
         try:
             while not self._stop.is_set():
@@ -358,6 +397,14 @@ class SceneManager:
                     frame_im = frame_im[y0:y1, x0:x1]
                 if self._start_pos is None:
                     self._start_pos = video.position
+                if feeder is not None:
+                    if slot is not None and slot["shape"] != frame_im.shape:
+                        flush()              # a batch holds frames of one size
+                    if slot is None:
+                        slot = feeder.acquire(frame_im.shape)
+                        if slot is None:     # stopped while waiting for a free buffer
+                            break
+                    feeder.put(slot, len(frames), frame_im)
                 frames.append(frame_im)
                 positions.append(FrameTimecode(video.position))  # also accepts the reference's FrameTimecode
                 if len(frames) >= self._batch_frames:
@@ -379,3 +426,87 @@ class SceneManager:
             if self._start_pos is None:
                 self._start_pos = video.position
             out_queue.put(None)
+
+
+class _DeviceFeeder:
+    """Three device batch buffers cycling between the decode thread (fills one, frame by frame, with ``psd_upload``) and
+    the scoring thread (``SceneManager.detect_scenes``).  Slot 0 of every buffer is the place of the frame preceding
+    the batch: the last frame of batch k is copied there for batch k + 1 on the engine's stream before buffer k is
+    handed back (the model is the bounded prefetch of the reference's ``_fan_out.py:39-154`` / ``Queue(4)`` of
+    ``scene_manager.py:565-572``, with HBM as the queue's storage)."""
+
+    N_SLOTS = 3
+
+    def __init__(self, engine, batch_frames: int):
+        self._engine = engine
+        self._batch = batch_frames
+        self._free: queue.Queue = queue.Queue()
+        self._slots: list[dict] = []
+        self._halo = None          # (DeviceBuffer, shape): the last frame of the most recent batch
+        self._have_halo = False
+        self._stopped = False
+        for i in range(self.N_SLOTS):
+            self._free.put({"id": i, "buf": None, "shape": None})
+
+    def acquire(self, shape):
+        """A free buffer shaped for frames of ``shape`` (decode thread; waits for the scoring thread if all are busy)."""
+        while not self._stopped:
+            try:
+                slot = self._free.get(timeout=0.1)
+            except queue.Empty:
+                continue
+            h, w, _ = shape
+            stride = (h * w * 3 + 15) & ~15
+            need = stride * (self._batch + 1)
+            if slot["buf"] is None or slot["buf"].nbytes < need:
+                if slot["buf"] is not None:
+                    slot["buf"].free()
+                slot["buf"] = self._engine.alloc(need)
+            slot.update(shape=tuple(shape), h=h, w=w, stride=stride, ptr=slot["buf"].ptr + stride, prev=None)
+            return slot
+        return None
+
+    def put(self, slot, index: int, frame: np.ndarray) -> None:
+        slot["buf"].upload_unordered(np.ascontiguousarray(frame).reshape(-1), (index + 1) * slot["stride"])
+
+    def halo_ptr(self, slot):
+        """Device address of the frame preceding this batch (None for the first batch or after a size change)."""
+        if not self._have_halo or self._halo[1] != slot["shape"]:
+            return None
+        return self._halo[0].ptr
+
+    def forget_halo(self) -> None:
+        self._have_halo = False
+
+    def release(self, slot, keep_last: int) -> None:
+        """The batch is scored: keep its last frame for the next batch, hand the buffer back to the decode thread."""
+        nbytes = slot["stride"]
+        if self._halo is None or self._halo[0].nbytes < nbytes:
+            if self._halo is not None:
+                self._halo[0].free()
+            self._halo = (self._engine.alloc(nbytes), slot["shape"])
+        self._halo = (self._halo[0], slot["shape"])
+        self._engine.copy_d2d(self._halo[0].ptr, slot["buf"].ptr + keep_last * slot["stride"], nbytes)
+        # the batch's results were collected before we got here, so this copy is the only work left on the stream that
+        # reads the buffer: wait for it, then the decode thread may overwrite the buffer
+        self._engine.synchronize()
+        self._have_halo = True
+        self._slots.append(slot)
+        self._free.put(slot)
+
+    def abort(self) -> None:
+        self._stopped = True
+
+    def close(self) -> None:
+        seen = set()
+        while True:
+            try:
+                slot = self._free.get_nowait()
+            except queue.Empty:
+                break
+            if slot["buf"] is not None and id(slot["buf"]) not in seen:
+                seen.add(id(slot["buf"]))
+                slot["buf"].free()
+        if self._halo is not None:
+            self._halo[0].free()
+            self._halo = None

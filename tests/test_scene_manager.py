@@ -228,3 +228,93 @@ def test_expand_scenes_to_bounds():
     assert scenes == before
     assert psd.expand_scenes_to_bounds([(tc(130), tc(170))], tc(0), tc(300)) == [(tc(0), tc(300))]
     assert psd.expand_scenes_to_bounds([], tc(0), tc(100)) == []
+
+
+# ---- several detectors in one manager: nobody's results depend on who else is registered -------------------------------
+
+class _ProbeDetector(psd.SceneDetector):
+    """A plug-in detector without a device path: records what process_frame is handed."""
+
+    def __init__(self):
+        super().__init__()
+        self.shapes = []
+        self.sums = []
+
+    def get_metrics(self):
+        return []
+
+    def process_frame(self, timecode, frame_img):
+        self.shapes.append(frame_img.shape)
+        self.sums.append(int(frame_img.sum()))
+        return []
+
+
+def _independence_checks(golden, engine):
+    import cv2  # the oracle shim
+
+    frames = golden_clip(golden, "wide_d")                       # 320 x 180: auto-downscale to 256 x 144
+
+    def run(dets, callback=None, stats=True):
+        sm = psd.SceneManager(psd.StatsManager() if stats else None, engine=engine, batch_frames=16)
+        for d in dets:
+            sm.add_detector(d)
+        sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), callback=callback)
+        return sm
+
+    def metric(sm, key):
+        return [sm.stats_manager.get_metrics(i, [key])[0] if sm.stats_manager.metrics_exist(i, [key]) else None for i in range(len(frames))]
+
+    # plug-in detectors and callbacks see the DOWNSCALED frame, like the reference (its decode thread resizes first)
+    probe = _ProbeDetector()
+    seen = []
+    sm = run([psd.ContentDetector(engine=engine), probe], callback=lambda img, pos: seen.append((pos.frame_num, img.shape, int(img.sum()))))
+    small = [cv2.resize(f, (256, 144)) for f in frames]
+    assert set(probe.shapes) == {(144, 256, 3)} and probe.sums == [int(s.sum()) for s in small]
+    assert seen and all(shape == (144, 256, 3) and total == int(small[n].sum()) for n, shape, total in seen)
+    assert [c.frame_num for c in sm.get_cut_list()] == golden["clips"]["wide_d"]["results"]["content_default"]["cuts"]
+
+    # two thumbnail sizes in one pass: each HashDetector's metrics equal its solo run (and the reference's)
+    key8, key16 = "hash_dist [size=8 lowpass=2]", "hash_dist [size=16 lowpass=2]"
+    solo8 = metric(run([psd.HashDetector(engine=engine)]), key8)
+    solo16 = metric(run([psd.HashDetector(size=16, lowpass=2, threshold=0.3, min_scene_len=5, engine=engine)]), key16)
+    both = run([psd.HashDetector(engine=engine), psd.HashDetector(size=16, lowpass=2, threshold=0.3, min_scene_len=5, engine=engine),
+                _ProbeDetector()])
+    assert metric(both, key8) == solo8 == golden["clips"]["wide_d"]["results"]["hash_default"]["metrics"][key8]
+    assert metric(both, key16) == solo16 == golden["clips"]["wide_d"]["results"]["hash_16_lp2"]["metrics"][key16]
+
+    # two edge-dilation sizes in one pass: each detector is scored with its own kernel (content_detector.py:135-137)
+    class Scored(psd.ContentDetector):
+        def __init__(self, **kw):
+            super().__init__(**kw)
+            self.scores = []
+
+        def process_record(self, timecode, record, height, width):
+            cuts = super().process_record(timecode, record, height, width)
+            self.scores.append(self._frame_score)
+            return cuts
+
+    frames = frames.copy()
+    for t in range(len(frames)):                                   # something with edges that moves
+        frames[t, 40 + t:90 + t, 60 + 2 * t:140 + 2 * t] = (230, 40, 200)
+    w = psd.ContentDetector.Components(0.0, 0.0, 0.0, 1.0)
+    mk = lambda k: Scored(weights=w, kernel_size=k, engine=engine)  # noqa: E731
+    solo = []
+    for k in (3, 9, None):
+        d = mk(k)
+        run([d], stats=False)
+        solo.append(d.scores)
+    assert solo[0] != solo[1] and solo[1] != solo[2] and any(solo[0])
+    for order in ((0, 1, 2), (2, 1, 0)):
+        dets = [mk((3, 9, None)[i]) for i in order]
+        run(dets, stats=False)
+        for i, d in zip(order, dets):
+            assert d.scores == solo[i], f"kernel {(3, 9, None)[i]} scored differently next to other detectors"
+
+
+def test_detectors_do_not_depend_on_co_registered_detectors(golden, oracle_engine):
+    _independence_checks(golden, oracle_engine)
+
+
+@pytest.mark.gpu
+def test_detectors_do_not_depend_on_co_registered_detectors_gpu(golden, hip_engine):
+    _independence_checks(golden, hip_engine)

@@ -1,0 +1,54 @@
+"""End-to-end rates of the host-fed paths (PCIe inclusive; never the headline `value`): SceneManager.detect_scenes from
+host frames (pageable and page-locked), psd_score_batch, and the pinned async upload on its own.  One JSON object."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import pyscenedetect_amd as psd  # noqa: E402
+from pyscenedetect_amd import engine as E  # noqa: E402
+
+eng = E.ScoringEngine(0)
+out = {}
+H, W, N = 1080, 1920, 384
+rng = np.random.default_rng(0)
+hf = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+pinned = eng.pinned_array((N, H, W, 3))
+pinned[:] = hf
+
+
+def best_of(fn, reps=3):
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+out["psd_score_batch_pageable_fps"] = round(N / best_of(lambda: eng.score_host(hf, flags=E.SCORE_HSV_SAD)), 1)
+out["psd_score_batch_pinned_fps"] = round(N / best_of(lambda: eng.score_host(pinned, flags=E.SCORE_HSV_SAD)), 1)
+buf = eng.alloc(hf.nbytes)
+
+
+def up_async():
+    eng.upload_async(buf.ptr, pinned)
+    eng.upload_fence(wait_on_host=True)
+
+
+dt = best_of(up_async)
+out["upload_async_pinned_GBps"] = round(hf.nbytes / dt / 1e9, 2)
+dt = best_of(lambda: buf.upload_unordered(hf.reshape(-1)))
+out["upload_blocking_pageable_GBps"] = round(hf.nbytes / dt / 1e9, 2)
+for src_name, src in (("pageable", hf), ("pinned", pinned)):
+    for name, auto in (("full_res", False), ("auto_downscale", True)):
+        def run():
+            sm = psd.SceneManager(engine=eng)
+            sm.auto_downscale = auto
+            sm.add_detector(psd.ContentDetector(engine=eng))
+            sm.detect_scenes(psd.ArrayVideoStream(src, 25.0))
+        out[f"scene_manager_1080p_{name}_{src_name}_fps"] = round(N / best_of(run, 2), 1)
+print(json.dumps(out))
