@@ -318,3 +318,40 @@ def test_detectors_do_not_depend_on_co_registered_detectors(golden, oracle_engin
 @pytest.mark.gpu
 def test_detectors_do_not_depend_on_co_registered_detectors_gpu(golden, hip_engine):
     _independence_checks(golden, hip_engine)
+
+
+def test_benchmark_harness_predictions_and_reference_evaluator(tmp_path, golden, oracle_engine):
+    """tools/bbc_harness.py runs the reference's benchmark loop on this package; tools/bbc_evaluate.py scores the
+    predictions with the reference's own evaluator (only where the reference checkout exists)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bbc_harness as H
+
+    frames = golden_clip(golden, "scenes_a")
+    os.makedirs(tmp_path / "videos")
+    os.makedirs(tmp_path / "fixed")
+    truth = golden["clips"]["scenes_a"]["true_cuts"]
+    for vid in ("01", "02"):
+        np.save(tmp_path / "videos" / f"bbc_{vid}.npy", frames)
+        bounds = [0, *truth, len(frames)]
+        with open(tmp_path / "fixed" / f"{vid}-scenes.txt", "w") as f:
+            for a, b in zip(bounds[:-1], bounds[1:]):
+                f.write(f"{a}\t{b - 1}\n")          # start, last frame of the scene (0-based), as in the BBC files
+    samples = H.bbc_samples(str(tmp_path))
+    assert [s["hard_cuts"] for s in samples] == [[*truth, len(frames)]] * 2
+    recs = H.run_predictions(samples, "detect-content", engine=oracle_engine)
+    want = golden["clips"]["scenes_a"]["results"]["content_default"]["cuts"]
+    assert [r["predicted_cuts"] for r in recs] == [[*want, len(frames)]] * 2
+    H.dump(recs, str(tmp_path / "pred.json"), detector="detect-content")
+    if not os.path.isdir("/root/reference/benchmark"):
+        pytest.skip("the reference checkout (benchmark/evaluator.py) is only present in the build container")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "bbc_evaluate.py"), str(tmp_path / "pred.json"), "--tolerances", "0,2"],
+                         capture_output=True, text=True, check=True)
+    res = json.loads(out.stdout)["results"]
+    assert res[0]["tolerance"] == 0 and res[0]["videos"] == 2 and 0.0 < res[0]["f1"] <= res[1]["f1"] <= 1.0
+    assert res[0]["matched"] + res[0]["missed"] == 2 * (len(truth) + 1)

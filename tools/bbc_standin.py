@@ -4,10 +4,12 @@ synthetic "broadcast" clips with known cut positions, sharded by clip over the G
 The BBC Planet Earth set (11 videos, reference benchmark/README.md:58-68) is not available offline and
 there is no decoder in this image, so the clips are generated on the device: 640x360 shots of random
 length built from a smooth random image plus noise and slow drift, hard cuts between shots, some shots
-fading out and in through black.  Reports frames/s and precision/recall/F1 (tolerance 0, like the
-reference's evaluator) against the generator's ground truth.
+fading out and in through black.  Reports frames/s and a quick precision/recall/F1 against the generator's ground
+truth; ``--dump FILE`` writes the predictions in the format of tools/bbc_harness.py (the reference's convention:
+predicted cuts = the end of every scene, the last one included) for tools/bbc_evaluate.py, which scores them with the
+reference's own benchmark/evaluator.py.
 
-    python tools/bbc_standin.py [--clips 11] [--frames 6000]
+    python tools/bbc_standin.py [--clips 11] [--frames 6000] [--dump predictions.json]
     python -m torch.distributed.run --nproc-per-node 8 tools/bbc_standin.py   # sharded by clip
 """
 import argparse, json, os, sys, time
@@ -55,6 +57,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=11)
     ap.add_argument("--frames", type=int, default=6000)
+    ap.add_argument("--dump", default=None, help="write predictions + ground truth for tools/bbc_evaluate.py")
     args = ap.parse_args()
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
     if world > 1:
@@ -98,6 +101,16 @@ def main():
         pred = [r["adaptive"] for r in res]
         P = [prf(p, t) for p, t in zip(pred, truth)]
         allp = prf([(i, c) for i, p in enumerate(pred) for c in p], [(i, c) for i, t in enumerate(truth) for c in t])
+        if args.dump:
+            # scene ends as `detect()` reports them: every cut, then the end of the video (the annotations of the BBC
+            # set list every scene, the last one too, benchmark/dataset.py:66-74)
+            vids = [{"video_file": "standin_%02d" % i, "predicted_cuts": [int(c) for c in p] + ([lengths[i]] if p else []),
+                     "hard_cuts": [int(c) for c in t] + [lengths[i]], "elapsed": dt * lengths[i] / sum(lengths)}
+                    for i, (p, t) in enumerate(zip(pred, truth))]
+            with open(args.dump, "w") as f:
+                json.dump({"format": "psd-benchmark-predictions/1", "detector": "detect-adaptive", "n_gpus": world,
+                           "dataset": "synthetic stand-in for BBC Planet Earth (%d clips of 640x360, %d frames)" % (args.clips, sum(lengths)),
+                           "videos": vids}, f)
         print(json.dumps({"config": "AdaptiveDetector(w=2, min_content_val=15) on %d synthetic 640x360 clips, %d frames, sharded by clip"
                           % (args.clips, sum(lengths)), "n_gpus": world, "frames_per_s": round(sum(lengths) / dt, 1),
                           "seconds": round(dt, 4), "precision": round(allp[0], 4), "recall": round(allp[1], 4), "f1": round(allp[2], 4),
