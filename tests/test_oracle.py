@@ -274,3 +274,16 @@ def test_nearest_and_multichannel_area_resize():
         cv2.resize(img, (200, 200), interpolation=cv2.INTER_AREA)
     with pytest.raises(NotImplementedError):
         cv2.resize(img, (50, 50), interpolation=cv2.INTER_CUBIC)
+
+
+def test_fp32_formulation_of_the_hsv_pass_is_exact_on_all_triples():
+    """The float32 arithmetic the HSV-only kernel uses (psd_score_kernels.hip, pixel_fp_*), replayed on the host over all
+    2^24 BGR triples against the oracle (tools/hsv_fp32_check.py); the -m gpu twin runs the kernel itself."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "hsv_fp32_check.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all 2^24 triples: 0" in out.stdout

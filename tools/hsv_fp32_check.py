@@ -1,8 +1,17 @@
-"""Exhaustive check (all 2^24 BGR triples, numpy float32) of the fp32-pipe formulation of OpenCV's 8-bit HSV that
-DESIGN.md section 7 lists as the next candidate for the HSV pass: B, G, R as floats, max / min / differences / the
-2*diff and 4*diff terms as float adds and fused multiply-adds, S = trunc(fma(diff, sdiv[v] * 2^-12, 0.5)); only the
-hue product (more than 24 bits) stays integer.  Every float intermediate is an integer (or an integer / 4096) below
-2^24, so float32 holds it exactly -- this script confirms it against the oracle's tables and formulas.
+"""Exhaustive host replay (all 2^24 BGR triples, numpy float32 / float64) of the fp32-pipe formulation of OpenCV's 8-bit
+HSV that the HSV-only scoring pass runs (pixel_fp_* in pyscenedetect_amd/csrc/psd_score_kernels.hip):
+
+  channel   -> float 2^23 + byte (the kernel builds it with one v_perm_b32; the bias cancels in every difference)
+  v, vmin   -> max / min of the biased floats; diff = v - vmin (exact)
+  S         -> low byte of RNE(diff * sdiv' + 2^23), sdiv' = nextafter(sdiv / 4096): the one-ulp bump sends the exact .5
+               ties of diff * sdiv / 4096 upwards like OpenCV's (x + 2048) >> 12 and moves nothing else
+  v==r, v==g-> the 0/1 floats clamp(v - r), clamp(v - g); the two selects are fused multiply-adds
+  H         -> t = fma(hraw, hdiv / 4096, 2^-13) (exact), low 16 bits of RNE(t + 1.5 * 2^23) = floor(x + .5) as a two's
+               complement, then min(h, h + 180) on unsigned 16-bit values
+
+Every fused multiply-add is evaluated in float64 and rounded once to float32 (exact products: 8 x 24 and 11 x 17 bits),
+which is what the hardware fma does.  The -m gpu test test_exhaustive_hsv_through_the_kernel runs the same triples
+through the kernel itself.
     python tools/hsv_fp32_check.py
 """
 import os
@@ -13,30 +22,43 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import lib as orc  # noqa: E402
 
+f32, f64 = np.float32, np.float64
 sdiv, hdiv = orc.hsv_tables()
-sdiv_f = (sdiv.astype(np.float64) / 4096.0).astype(np.float32)
-assert np.array_equal(sdiv_f.astype(np.float64) * 4096.0, sdiv.astype(np.float64)), "sdiv * 2^-12 must be exact in float32"
+sdivf = (sdiv.astype(f64) / 4096.0).astype(f32)
+assert np.array_equal(sdivf.astype(f64) * 4096.0, sdiv.astype(f64)), "sdiv / 4096 must be exact in float32"
+sdivf = np.where(sdiv != 0, np.nextafter(sdivf, f32(np.inf)), f32(0))
+hdivf = (hdiv.astype(f64) / 4096.0).astype(f32)
+assert np.array_equal(hdivf.astype(f64) * 4096.0, hdiv.astype(f64)), "hdiv / 4096 must be exact in float32"
+
+
+def fma(a, b, c):
+    """float32 fused multiply-add: exact in float64 for these operand widths, one rounding to float32."""
+    return (a.astype(f64) * b.astype(f64) + f64(c) if np.isscalar(c) else a.astype(f64) * b.astype(f64) + c.astype(f64)).astype(f32)
+
+
 g8 = np.arange(256, dtype=np.uint8)
 bad = 0
+BIAS = f32(8388608.0)
 for b0 in range(0, 256, 32):
     bb, gg, rr = np.meshgrid(g8[b0:b0 + 32], g8, g8, indexing="ij")
     img = np.ascontiguousarray(np.stack([bb, gg, rr], axis=-1).reshape(32 * 256, 256, 3))
     want = np.empty_like(img)
     orc.lib().orc_bgr2hsv(img.ctypes.data, 256 * 3, want.ctypes.data, 256 * 3, img.shape[0], 256)
-    b, g, r = (img[..., c].astype(np.float32) for c in range(3))
-    v = np.maximum(np.maximum(b, g), r)
-    vmin = np.minimum(np.minimum(b, g), r)
-    diff = v - vmin
-    vi, di = v.astype(np.int64), diff.astype(np.int64)
-    s = np.trunc(diff * sdiv_f[vi] + np.float32(0.5))            # product and sum are exact, so fma == mul + add
-    assert s.dtype == np.float32
-    c_r = g - b
-    c_g = (b - r) + np.float32(2.0) * diff
-    c_b = (r - g) + np.float32(4.0) * diff
-    hraw = np.where(v == r, c_r, np.where(v == g, c_g, c_b)).astype(np.int64)
-    hh = (hraw * hdiv[di].astype(np.int64) + 2048) >> 12
-    hh = np.where(hh < 0, hh + 180, hh)
-    got = np.stack([hh, s.astype(np.int64), vi], axis=-1)
+    B, G, R = (img[..., c].astype(f32) + BIAS for c in range(3))
+    V = np.maximum(np.maximum(B, G), R)
+    diff = V - np.minimum(np.minimum(B, G), R)
+    vi, di = (V - BIAS).astype(np.int64), diff.astype(np.int64)
+    s_bits = fma(diff, sdivf[vi], BIAS).view(np.uint32) & 0xFF
+    c_r = G - B
+    c_g = fma(diff, np.full_like(diff, 2.0), B - R)
+    c_b = fma(diff, np.full_like(diff, 4.0), R - G)
+    nm_r, nm_g = np.clip(V - R, 0, 1).astype(f32), np.clip(V - G, 0, 1).astype(f32)
+    y = fma(nm_g, c_b - c_g, c_g)
+    hraw = fma(nm_r, y - c_r, c_r)
+    t = fma(hraw, hdivf[di], f32(2.0 ** -13))
+    hb = (t + f32(12582912.0)).view(np.uint32) & 0xFFFF
+    h = np.minimum(hb, (hb + 180) & 0xFFFF)
+    got = np.stack([h, s_bits, vi], axis=-1)
     bad += int(np.count_nonzero(got != want.astype(np.int64)))
 print("fp32-pipe HSV formulation: mismatching channel values over all 2^24 triples:", bad)
 sys.exit(1 if bad else 0)
