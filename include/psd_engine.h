@@ -131,6 +131,23 @@ int psd_score_batch(psd_engine* e, const uint8_t* h_frames, int n, int height, i
  * PSD_MAX_INFLIGHT record slots: it is overwritten by the PSD_MAX_INFLIGHT-th submission after the one it belongs to. */
 int psd_last_records_device(psd_engine* e, const psd_frame_scores** d_recs, int* n);
 
+/* ---- multi-GPU: the exchange step ------------------------------------------------------------------------------------
+ * One process per GPU; the pixel work needs no collective (clips are independent, a frame range plus a one-frame halo is
+ * self-contained).  What is exchanged is the per-frame score records, so that every rank can run the deterministic
+ * epilogues for every clip: one RCCL all-gather over xGMI.  RCCL is loaded at run time
+ * (librccl.so; a copy already in the process, e.g. PyTorch's, is reused); PSD_ERR_UNSUPPORTED if there is none.
+ *   psd_comm_unique_id   rank 0 makes the 128-byte id and hands it to the other ranks by the host's own means;
+ *   psd_comm_create      collective over all ranks of the node (ncclCommInitRank) on the engine's device;
+ *   psd_allgather_scores every rank contributes n_local records that sit in device memory (psd_last_records_device) and
+ *                        receives everybody's in rank order: counts[r] records of rank r (counts must be the same array
+ *                        on every rank, counts[rank] == n_local), h_all = host array of sum(counts) records. */
+typedef struct psd_comm psd_comm;
+int psd_comm_unique_id(void* id128);
+int psd_comm_create(psd_engine* e, int n_ranks, int rank, const void* id128, psd_comm** out);
+void psd_comm_destroy(psd_comm* c);
+int psd_allgather_scores(psd_comm* c, const psd_frame_scores* d_local, int n_local, const int* counts,
+                         psd_frame_scores* h_all);
+
 /* Device time (ms, HIP events on the launch stream) spent in the scoring kernels of the most
  * recently *collected* submission, and the number of kernel launches it took. */
 int psd_last_kernel_ms(psd_engine* e, float* ms, int* launches);

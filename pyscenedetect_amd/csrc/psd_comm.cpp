@@ -1,0 +1,187 @@
+// psd_comm.cpp -- the one exchange step of the multi-GPU path behind the C-ABI: an RCCL all-gather of per-frame score
+// records.  The pixel work shards with no data-path collective (clips are independent; a frame range
+// plus a one-frame halo is self-contained); what every rank needs afterwards is every clip's records (<= 1064 B per
+// frame) to run the deterministic epilogues, so cut lists do not depend on the GPU count.  Records are KBs to a few MBs:
+// the exchange is latency-bound, one fused ncclAllGather of padded per-rank blocks over the xGMI mesh.
+//
+// RCCL is loaded at run time (dlopen): a host that already carries one (PyTorch bundles its own librccl.so) keeps
+// exactly one copy in the process; the library itself does not link against RCCL, so single-GPU hosts need none.
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "psd_internal.h"
+
+extern "C" void psd_set_error(const char* fmt, ...);
+
+namespace psd {
+int engine_device(psd_engine* e);
+hipStream_t engine_stream(psd_engine* e);
+}  // namespace psd
+
+namespace {
+
+struct NcclUniqueId { char internal[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+typedef void* NcclComm;
+typedef int (*fn_get_unique_id)(NcclUniqueId*);
+typedef int (*fn_comm_init_rank)(NcclComm*, int, NcclUniqueId, int);
+typedef int (*fn_all_gather)(const void*, void*, size_t, int /*ncclDataType_t*/, NcclComm, hipStream_t);
+typedef int (*fn_comm_destroy)(NcclComm);
+typedef const char* (*fn_error_string)(int);
+
+struct Rccl {
+    void* handle = nullptr;
+    fn_get_unique_id get_unique_id = nullptr;
+    fn_comm_init_rank comm_init_rank = nullptr;
+    fn_all_gather all_gather = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_error_string error_string = nullptr;
+};
+
+Rccl* rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.handle ? &r : nullptr;
+    tried = true;
+    // a copy that is already in the process first (RTLD_NOLOAD), then the system's
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    for (const char* n : names)
+        if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    const char* paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* p : paths)
+        if (!r.handle) r.handle = dlopen(p, RTLD_NOW | RTLD_GLOBAL);
+    if (!r.handle) return nullptr;
+    r.get_unique_id = (fn_get_unique_id)dlsym(r.handle, "ncclGetUniqueId");
+    r.comm_init_rank = (fn_comm_init_rank)dlsym(r.handle, "ncclCommInitRank");
+    r.all_gather = (fn_all_gather)dlsym(r.handle, "ncclAllGather");
+    r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
+    r.error_string = (fn_error_string)dlsym(r.handle, "ncclGetErrorString");
+    if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy) { r.handle = nullptr; return nullptr; }
+    return &r;
+}
+
+int rccl_fail(Rccl* r, const char* what, int rc)
+{
+    psd_set_error("%s failed: %s", what, r && r->error_string ? r->error_string(rc) : "RCCL error");
+    return PSD_ERR_HIP;
+}
+
+}  // namespace
+
+struct psd_comm {
+    psd_engine* engine = nullptr;
+    NcclComm comm = nullptr;
+    int n_ranks = 0, rank = 0;
+    uint8_t* d_send = nullptr;   // cap records
+    uint8_t* d_recv = nullptr;   // n_ranks * cap records
+    uint8_t* h_recv = nullptr;   // pinned mirror of d_recv
+    size_t cap = 0;
+};
+
+#define HIP_TRY(expr)                                                                                \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            psd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PSD_ERR_HIP;                                                                      \
+        }                                                                                            \
+    } while (0)
+
+extern "C" {
+
+int psd_comm_unique_id(void* id128)
+{
+    if (!id128) { psd_set_error("psd_comm_unique_id: null argument"); return PSD_ERR_INVALID; }
+    Rccl* r = rccl();
+    if (!r) { psd_set_error("RCCL (librccl.so) is not available: %s", dlerror() ? dlerror() : "not found"); return PSD_ERR_UNSUPPORTED; }
+    NcclUniqueId id;
+    const int rc = r->get_unique_id(&id);
+    if (rc != 0) return rccl_fail(r, "ncclGetUniqueId", rc);
+    memcpy(id128, &id, sizeof id);
+    return PSD_OK;
+}
+
+int psd_comm_create(psd_engine* e, int n_ranks, int rank, const void* id128, psd_comm** out)
+{
+    if (!e || !id128 || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) {
+        psd_set_error("psd_comm_create: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    *out = nullptr;
+    Rccl* r = rccl();
+    if (!r) { psd_set_error("RCCL (librccl.so) is not available"); return PSD_ERR_UNSUPPORTED; }
+    HIP_TRY(hipSetDevice(psd::engine_device(e)));
+    psd_comm* c = new (std::nothrow) psd_comm();
+    if (!c) { psd_set_error("out of memory"); return PSD_ERR_NOMEM; }
+    c->engine = e; c->n_ranks = n_ranks; c->rank = rank;
+    NcclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    const int rc = r->comm_init_rank(&c->comm, n_ranks, id, rank);
+    if (rc != 0) { delete c; return rccl_fail(r, "ncclCommInitRank", rc); }
+    *out = c;
+    return PSD_OK;
+}
+
+void psd_comm_destroy(psd_comm* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(psd::engine_device(c->engine));
+    (void)hipStreamSynchronize(psd::engine_stream(c->engine));
+    Rccl* r = rccl();
+    if (r && c->comm) (void)r->comm_destroy(c->comm);
+    if (c->d_send) (void)hipFree(c->d_send);
+    if (c->d_recv) (void)hipFree(c->d_recv);
+    if (c->h_recv) (void)hipHostFree(c->h_recv);
+    delete c;
+}
+
+int psd_allgather_scores(psd_comm* c, const psd_frame_scores* d_local, int n_local, const int* counts, psd_frame_scores* h_all)
+{
+    if (!c || !counts || n_local < 0 || (n_local > 0 && !d_local)) { psd_set_error("psd_allgather_scores: invalid argument"); return PSD_ERR_INVALID; }
+    if (counts[c->rank] != n_local) {
+        psd_set_error("psd_allgather_scores: counts[%d] = %d but this rank contributes %d records", c->rank, counts[c->rank], n_local);
+        return PSD_ERR_INVALID;
+    }
+    Rccl* r = rccl();
+    if (!r) { psd_set_error("RCCL (librccl.so) is not available"); return PSD_ERR_UNSUPPORTED; }
+    size_t cap = 1, total = 0;
+    for (int i = 0; i < c->n_ranks; i++) {
+        if (counts[i] < 0) { psd_set_error("psd_allgather_scores: negative count"); return PSD_ERR_INVALID; }
+        if ((size_t)counts[i] > cap) cap = (size_t)counts[i];
+        total += (size_t)counts[i];
+    }
+    if (total > 0 && !h_all) { psd_set_error("psd_allgather_scores: null output"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(psd::engine_device(c->engine)));
+    hipStream_t stream = psd::engine_stream(c->engine);
+    const size_t rec = sizeof(psd_frame_scores);
+    if (c->cap < cap) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c->d_send) HIP_TRY(hipFree(c->d_send));
+        if (c->d_recv) HIP_TRY(hipFree(c->d_recv));
+        if (c->h_recv) HIP_TRY(hipHostFree(c->h_recv));
+        c->d_send = c->d_recv = c->h_recv = nullptr; c->cap = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_send, cap * rec));
+        HIP_TRY(hipMalloc((void**)&c->d_recv, cap * rec * c->n_ranks));
+        HIP_TRY(hipHostMalloc((void**)&c->h_recv, cap * rec * c->n_ranks, hipHostMallocDefault));
+        c->cap = cap;
+    }
+    // ragged blocks padded to the largest: one fused collective (the point-to-point xGMI mesh makes a ring pay a hop per
+    // rank; at these sizes latency is everything)
+    if (n_local > 0) HIP_TRY(hipMemcpyAsync(c->d_send, d_local, (size_t)n_local * rec, hipMemcpyDeviceToDevice, stream));
+    const int rc = r->all_gather(c->d_send, c->d_recv, c->cap * rec, 0 /* ncclChar */, c->comm, stream);
+    if (rc != 0) return rccl_fail(r, "ncclAllGather", rc);
+    HIP_TRY(hipMemcpyAsync(c->h_recv, c->d_recv, c->cap * rec * c->n_ranks, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    size_t off = 0;
+    for (int i = 0; i < c->n_ranks; i++) {
+        memcpy(h_all + off, c->h_recv + (size_t)i * c->cap * rec, (size_t)counts[i] * rec);
+        off += (size_t)counts[i];
+    }
+    return PSD_OK;
+}
+
+}  // extern "C"

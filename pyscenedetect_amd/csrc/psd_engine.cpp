@@ -823,6 +823,7 @@ void** engine_edge_ws(psd_engine* e) { return &e->edge_ws; }
 size_t* engine_edge_ws_bytes(psd_engine* e) { return &e->edge_ws_bytes; }
 int engine_num_cus(psd_engine* e) { return e->num_cus; }
 hipStream_t engine_stream(psd_engine* e) { return e->stream; }
+int engine_device(psd_engine* e) { return e->device; }
 void** engine_resize_cache(psd_engine* e) { return &e->resize_cache; }
 const uint32_t* engine_lut(psd_engine* e) { return e->d_lut; }
 }  // namespace psd

@@ -122,3 +122,73 @@ def score_clips_distributed(engine, clips, flags: int, edge_kernel: int = 0, gro
             out[i] = parts[r][off: off + len(clips[i])]
             off += len(clips[i])
     return out
+
+
+class NativeComm:
+    """The exchange step through the C-ABI itself (``psd_comm_*`` / ``psd_allgather_scores``): RCCL loaded by
+    ``libpsd_hip.so``, no torch in the data path.  ``unique_id`` (128 bytes from :meth:`make_unique_id` on rank 0) reaches
+    the other ranks by whatever means the host has; :meth:`from_process_group` uses an existing ``torch.distributed``
+    group (any backend) just for that hand-over."""
+
+    def __init__(self, engine, n_ranks: int, rank: int, unique_id: bytes):
+        import ctypes
+
+        from pyscenedetect_amd import _native
+
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of psd_comm_unique_id")
+        self._engine, self._lib, self.n_ranks, self.rank = engine, _native.load(), int(n_ranks), int(rank)
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(unique_id, 128)
+        _native.check(self._lib.psd_comm_create(engine._h, self.n_ranks, self.rank, buf, ctypes.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def make_unique_id() -> bytes:
+        import ctypes
+
+        from pyscenedetect_amd import _native
+
+        buf = ctypes.create_string_buffer(128)
+        _native.check(_native.load().psd_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, engine, group=None) -> "NativeComm":
+        import torch.distributed as dist
+
+        box = [cls.make_unique_id() if dist.get_rank(group) == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(engine, dist.get_world_size(group), dist.get_rank(group), box[0])
+
+    def all_gather_records(self, counts, local: np.ndarray | None = None, device_records: tuple[int, int] | None = None) -> list[np.ndarray]:
+        """Every rank's records, in rank order.  ``counts[r]`` = number of records of rank r (the same list on every
+        rank); this rank's come from ``device_records`` (default: the engine's last collected submission, still in HBM)."""
+        import ctypes
+
+        from pyscenedetect_amd import _native
+
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        ptr, n = device_records if device_records is not None else self._engine.last_records_device()
+        if local is not None and len(local) != n:
+            raise ValueError("local records and device records disagree")
+        out = np.zeros(int(counts.sum()), RECORD_DTYPE)
+        _native.check(self._lib.psd_allgather_scores(self._h, ptr if n else None, int(n), counts.ctypes.data,
+                                                     out.ctypes.data if len(out) else None))
+        parts, off = [], 0
+        for c in counts:
+            parts.append(out[off:off + int(c)])
+            off += int(c)
+        _ = ctypes
+        return parts
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.psd_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -294,3 +294,28 @@ def test_packed_device_clips_and_segment_validation(hip_engine):
         hip_engine.score_device_segments(big.data_ptr(), 96, 180, 320, [0, 11, 10], flags=NOEDGE)
     with pytest.raises(ValueError):
         hip_engine.score_device_segments(big.data_ptr(), 96, 180, 320, [0, 96], flags=NOEDGE)
+
+
+# ---- the exchange step through the C-ABI (psd_allgather_scores, RCCL loaded by libpsd_hip.so) -----------------------------
+
+def test_native_rccl_all_gather_of_device_records_one_rank(hip_engine):
+    """One GPU per box here, so one rank: the communicator comes up, the records travel device -> RCCL -> host and come
+    back identical; a count that disagrees with the contribution is refused.  (N > 1 runs on the driver's 8-GPU node
+    through the same code; the gloo tests cover the host logic around it.)"""
+    from pyscenedetect_amd.distributed import NativeComm
+
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (37, 72, 128, 3), dtype=np.uint8)
+    want = hip_engine.score_host(frames, flags=NOEDGE)
+    buf = device_copy(hip_engine, frames)
+    recs = hip_engine.score_device(buf.ptr, 37, 72, 128, flags=NOEDGE)
+    same(recs, want)
+    comm = NativeComm(hip_engine, 1, 0, NativeComm.make_unique_id())
+    parts = comm.all_gather_records([37])
+    assert len(parts) == 1 and parts[0].tobytes() == recs.tobytes()
+    recs2 = hip_engine.score_device(buf.ptr, 5, 72, 128, flags=E.SCORE_HSV_SAD)
+    assert comm.all_gather_records([5], local=recs2)[0].tobytes() == recs2.tobytes()      # smaller than the buffers: reuse
+    with pytest.raises(ValueError):
+        comm.all_gather_records([6])
+    comm.close()
+    buf.free()
