@@ -96,7 +96,8 @@ int psd_score_batch_device(psd_engine* e, const uint8_t* d_frames, int n, int he
 
 /* Asynchronous form: enqueue the work and the device->pinned-host copy of the records on
  * `stream` and return.  psd_score_collect() waits for it and copies the records to `out`.
- * At most PSD_MAX_INFLIGHT submissions may be pending; they complete in submission order. */
+ * At most PSD_MAX_INFLIGHT submissions may be pending; they complete in submission order.  The frames (and d_prev) must
+ * stay valid and unchanged until the submission has been collected. */
 #define PSD_MAX_INFLIGHT 4
 int psd_score_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width,
                             size_t row_stride, size_t frame_stride, const uint8_t* d_prev,

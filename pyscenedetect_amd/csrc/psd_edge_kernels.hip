@@ -617,8 +617,21 @@ static void threshold_table(int2* tab)
     }
 }
 
+// after the fixed rounds of the speculative path: did the last launch still pass something on?
+__global__ void note_unconverged_kernel(const int* last_flag, int* unconverged)
+{
+    if (*last_flag) atomicOr(unconverged, 1);
+}
+
+constexpr int HYST_SPEC_LAUNCHES = 6;   // hysteresis launches of the speculative path: chains that cross up to 5 tile borders
+
 // Runs K1..K6a for `count` virtual frames; on return (stream-ordered) b.dil holds their dilated bits.
-static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, const EdgeBuffers& b, hipStream_t stream)
+// d_unconverged == nullptr: the hysteresis is relaunched until a launch changes nothing, the host reading the flags
+// after every round (exact, blocks the calling thread).  Otherwise: HYST_SPEC_LAUNCHES launches are enqueued without
+// any host round trip and *d_unconverged is set if the last one still promoted pixels on a tile border -- the caller
+// then repeats the work on the exact path (weak-edge chains that long are rare: tests/test_gpu_fullsize.py builds one).
+static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, const EdgeBuffers& b, hipStream_t stream,
+                      int* d_unconverged = nullptr)
 {
     const size_t words = (size_t)g.height * g.words_per_row;
     HIP_TRY(hipMemsetAsync(b.hist, 0, (size_t)count * 256 * 4, stream));
@@ -646,23 +659,33 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
     const size_t dirty_bytes = b.tiles_per_frame * (size_t)count;
     HIP_TRY(hipMemsetAsync(b.dirty[0], 1, dirty_bytes, stream));
     int launch = 0;
-    bool converged = false;
-    for (int round = 0; round < 4096 && !converged; round++) {
-        constexpr int R = 3;
-        HIP_TRY(hipMemsetAsync(b.flags, 0, R * sizeof(int), stream));
-        for (int i = 0; i < R; i++, launch++) {
+    if (d_unconverged) {
+        HIP_TRY(hipMemsetAsync(b.flags, 0, HYST_SPEC_LAUNCHES * sizeof(int), stream));
+        for (; launch < HYST_SPEC_LAUNCHES; launch++) {
             HIP_TRY(hipMemsetAsync(b.dirty[(launch + 1) & 1], 0, dirty_bytes, stream));
             hipLaunchKernelGGL(hysteresis_kernel, hgrid, dim3(256), 0, stream, b.map, g, b.dirty[launch & 1], b.dirty[(launch + 1) & 1],
-                               b.flags + i);
+                               b.flags + launch);
         }
-        int flags[R];
-        HIP_TRY(hipMemcpyAsync(flags, b.flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        for (int i = 0; i < R; i++) converged = converged || !flags[i];   // a launch with nothing to pass on ends it
-    }
-    if (!converged) {
-        psd_set_error("edge hysteresis did not converge within %d launches", launch);
-        return PSD_ERR_HIP;
+        hipLaunchKernelGGL(note_unconverged_kernel, dim3(1), dim3(1), 0, stream, b.flags + HYST_SPEC_LAUNCHES - 1, d_unconverged);
+    } else {
+        bool converged = false;
+        for (int round = 0; round < 4096 && !converged; round++) {
+            constexpr int R = 3;
+            HIP_TRY(hipMemsetAsync(b.flags, 0, R * sizeof(int), stream));
+            for (int i = 0; i < R; i++, launch++) {
+                HIP_TRY(hipMemsetAsync(b.dirty[(launch + 1) & 1], 0, dirty_bytes, stream));
+                hipLaunchKernelGGL(hysteresis_kernel, hgrid, dim3(256), 0, stream, b.map, g, b.dirty[launch & 1], b.dirty[(launch + 1) & 1],
+                                   b.flags + i);
+            }
+            int flags[R];
+            HIP_TRY(hipMemcpyAsync(flags, b.flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            for (int i = 0; i < R; i++) converged = converged || !flags[i];   // a launch with nothing to pass on ends it
+        }
+        if (!converged) {
+            psd_set_error("edge hysteresis did not converge within %d launches", launch);
+            return PSD_ERR_HIP;
+        }
     }
     hipLaunchKernelGGL(pack_hdilate_kernel, dim3(g.height, count), dim3(256), (g.words_per_row + 2) * sizeof(u32), stream, b.map, g,
                        k, b.hbits);
@@ -682,7 +705,7 @@ static EdgeGeom make_geom(int height, int width, size_t row_stride, size_t frame
 
 int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
                 size_t frame_stride, const uint8_t* d_prev, int edge_kernel, psd_frame_scores* d_out,
-                hipStream_t stream, const uint8_t* d_seg)
+                hipStream_t stream, const uint8_t* d_seg, int* d_unconverged)
 {
     const EdgeGeom g = make_geom(height, width, row_stride, frame_stride);
     const int k = edge_kernel ? edge_kernel : estimated_kernel_size(width, height);
@@ -690,10 +713,10 @@ int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
     EdgeBuffers b;
     int rc = edge_buffers(e, g, total, &b);
     if (rc != PSD_OK) return rc;
-    int2 tab[511];
-    threshold_table(tab);
-    HIP_TRY(hipMemcpyAsync(b.thr_tab, tab, sizeof(tab), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));  // `tab` lives on this stack frame
+    // the 511 threshold pairs never change: built once, kept for the life of the process (no stack buffer behind an
+    // asynchronous copy, no synchronisation on the call path)
+    static const int2* tab = [] { int2* t = new int2[511]; threshold_table(t); return t; }();
+    HIP_TRY(hipMemcpyAsync(b.thr_tab, tab, 511 * sizeof(int2), hipMemcpyHostToDevice, stream));
     const size_t words = (size_t)g.height * g.words_per_row;
     int done = 0;          // virtual frames processed
     bool have_carry = false;
@@ -704,7 +727,7 @@ int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
         src.prev = d_prev;
         src.first_is_prev = (done == 0 && d_prev) ? 1 : 0;
         src.start = done - (d_prev ? 1 : 0) + src.first_is_prev;  // batch index of the first non-prev virtual frame
-        rc = edge_chunk(g, src, count, k, b, stream);
+        rc = edge_chunk(g, src, count, k, b, stream, d_unconverged);
         if (rc != PSD_OK) return rc;
         HIP_TRY(hipMemsetAsync(b.xr, 0, (size_t)count * 8, stream));
         hipLaunchKernelGGL(xor_count_kernel, dim3((unsigned)((words + 255) / 256), count), dim3(256), 0, stream, b.dil, (long)words,
