@@ -1,7 +1,7 @@
 #!/bin/bash
 # pJ per byte of the frame stream by access path: tools/ubench/stream_power <mode> while rocm-smi samples power and clocks
 O=gpurun_out/${1:-r02e}; mkdir -p $O
-for m in x4 x3 dma; do
+for m in ${MODES:-x4 x3 dma}; do
   ./tools/ubench/stream_power $m 7 > $O/sp_$m.txt 2>&1 &
   BP=$!
   sleep 4

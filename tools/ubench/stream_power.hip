@@ -53,7 +53,9 @@ __global__ __launch_bounds__(256) void k_x3(const uint8_t* __restrict__ src, siz
     if (r == 0x12345678u) sink[0] = r;
 }
 
-// 4 waves; each wave streams 3 KiB pieces through its own LDS slot, one piece ahead
+// 4 waves; each wave streams 3 KiB pieces through its own LDS slot, one piece ahead.  AUX = cache policy bits of the
+// LDS-DMA load (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX>
 __global__ __launch_bounds__(256) void k_dma(const uint8_t* __restrict__ src, size_t n_pieces, u32* sink)
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage[2][4][3072];
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void k_dma(const uint8_t* __restrict__ src, si
         const uint8_t* p = src + piece * 3072;
 #pragma unroll
         for (int j = 0; j < 3; j++)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p + j * 1024 + lane * 16), (lds_ptr_t)(&stage[buf][wave][j * 1024]), 16, 0, 2);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p + j * 1024 + lane * 16), (lds_ptr_t)(&stage[buf][wave][j * 1024]), 16, 0, AUX);
     };
     size_t piece = wave_id;
     int buf = 0;
@@ -106,7 +108,15 @@ int main(int argc, char** argv)
         for (int r = 0; r < 8; r++) {
             if (!strcmp(mode, "x4")) hipLaunchKernelGGL(k_x4, dim3(grid), dim3(256), 0, 0, (const u32x4*)d, bytes / 16, sink);
             else if (!strcmp(mode, "x3")) hipLaunchKernelGGL(k_x3, dim3(grid), dim3(256), 0, 0, d, bytes / 12, sink);
-            else hipLaunchKernelGGL(k_dma, dim3(grid), dim3(256), 0, 0, d, bytes / 3072, sink);
+            else if (!strcmp(mode, "dma")) hipLaunchKernelGGL(k_dma<2>, dim3(grid), dim3(256), 0, 0, d, bytes / 3072, sink);
+            else if (!strcmp(mode, "dma0")) hipLaunchKernelGGL(k_dma<0>, dim3(grid), dim3(256), 0, 0, d, bytes / 3072, sink);
+            else if (!strcmp(mode, "dma1")) hipLaunchKernelGGL(k_dma<1>, dim3(grid), dim3(256), 0, 0, d, bytes / 3072, sink);
+            else if (!strcmp(mode, "dma3")) hipLaunchKernelGGL(k_dma<3>, dim3(grid), dim3(256), 0, 0, d, bytes / 3072, sink);
+            else if (!strcmp(mode, "dma16")) hipLaunchKernelGGL(k_dma<16>, dim3(grid), dim3(256), 0, 0, d, bytes / 3072, sink);
+            else if (!strcmp(mode, "dma17")) hipLaunchKernelGGL(k_dma<17>, dim3(grid), dim3(256), 0, 0, d, bytes / 3072, sink);
+            else if (!strcmp(mode, "dma18")) hipLaunchKernelGGL(k_dma<18>, dim3(grid), dim3(256), 0, 0, d, bytes / 3072, sink);
+            else if (!strcmp(mode, "dma19")) hipLaunchKernelGGL(k_dma<19>, dim3(grid), dim3(256), 0, 0, d, bytes / 3072, sink);
+            else { printf("unknown mode %s\n", mode); return 1; }
         }
         hipEventRecord(b);
         hipEventSynchronize(b);
