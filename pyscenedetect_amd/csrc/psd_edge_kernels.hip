@@ -338,6 +338,126 @@ __global__ __launch_bounds__(256) void sobel_nms_kernel(const uint8_t* vplane, E
     }
 }
 
+// K3, dword form (frames whose width and pixel count are multiples of 4: 1080p, 4K, 720p, 256x144 ...).
+// 128 x 32 tiles.  Phase 1 computes only the magnitude |dx| + |dy| of the tile plus a 1-px ring, four pixels of a row
+// per work item as two packed 16-bit pairs (even / odd columns), rolling down the rows of a 5-row segment: per row three
+// dword reads of V, two v_perm + two masks to get the four column pairs, packed adds / multiply-adds for the separable
+// Sobel sums.  Phase 2 suppresses non-maxima: a pixel whose magnitude is not above `low` is done after one read (almost
+// all of a natural frame); the others recompute dx, dy from the 3x3 V neighbourhood, classify the direction with OpenCV's
+// TG22 fixed point and compare with the two neighbours along it.  Results leave as dwords.  Same integers as
+// sobel_nms_kernel, a quarter of its instructions.
+constexpr int N2_W = 128, N2_H = 32, N2_SVW = N2_W + 8, N2_SEG = 5, N2_NSEG = 7, N2_NCG = N2_SVW / 4;
+static_assert(N2_NCG * N2_NSEG <= 256 && N2_SEG * N2_NSEG >= N2_H + 2, "one pass of 256 threads covers the ring");
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { u32 d; asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ u32 pk_sub(u32 a, u32 b) { u32 d; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { u32 d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// a + 2 b on both halves
+__device__ __forceinline__ u32 pk_add2(u32 a, u32 b) { return pk_add(a, pk_add(b, b)); }
+__device__ __forceinline__ u32 pk_abs(u32 a) { return pk_max(a, pk_sub(0u, a)); }
+
+// grid = (tiles_x, tiles_y, frames)
+__global__ __launch_bounds__(256) void sobel_nms_dword_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, uint8_t* map)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sv[N2_H + 4][N2_SVW];          // rows y0-2 .. y0+33, cols x0-4 .. x0+131
+    __shared__ __attribute__((aligned(16))) unsigned short smag[N2_H + 2][N2_SVW]; // rows y0-1 .. y0+32, same columns
+    const int j = blockIdx.z, tid = threadIdx.x;
+    const uint8_t* V = vplane + (size_t)j * g.npix;
+    const int x0 = blockIdx.x * N2_W, y0 = blockIdx.y * N2_H, H = g.height, W = g.width;
+    const bool inner = x0 >= 4 && x0 + N2_W + 4 <= W && y0 >= 2 && y0 + N2_H + 2 <= H;
+    if (inner) {
+        for (int i = tid; i < (N2_H + 4) * N2_NCG; i += 256) {
+            const int ly = i / N2_NCG, lw = i - ly * N2_NCG;
+            *reinterpret_cast<u32*>(&sv[ly][lw * 4]) = *reinterpret_cast<const u32*>(V + (size_t)(y0 + ly - 2) * W + x0 - 4 + lw * 4);
+        }
+    } else {   // border tiles: replicate (BORDER_REPLICATE of cv2.Sobel inside Canny)
+        for (int i = tid; i < (N2_H + 4) * N2_SVW; i += 256) {
+            const int ly = i / N2_SVW, lx = i - ly * N2_SVW;
+            const int y = min(max(y0 + ly - 2, 0), H - 1), x = min(max(x0 + lx - 4, 0), W - 1);
+            sv[ly][lx] = V[(size_t)y * W + x];
+        }
+    }
+    __syncthreads();
+    // ---- phase 1: magnitudes of smag rows [5 seg, 5 seg + 5), columns 4 cg .. 4 cg + 3
+    if (tid < N2_NCG * N2_NSEG) {
+        const int cg = tid % N2_NCG, seg = tid / N2_NCG;
+        const int m0 = seg * N2_SEG, m1 = min(m0 + N2_SEG, N2_H + 2);
+        const int cl = max(cg - 1, 0) * 4, cm = cg * 4, cr = min(cg + 1, N2_NCG - 1) * 4;   // clamped neighbours only feed unused columns
+        // columns of the four outputs in the image, for the "magnitude outside the image is 0" rule
+        const int xb = x0 - 4 + cm;
+        const u32 keepE = ((xb >= 0 && xb < W) ? 0xffffu : 0u) | ((xb + 2 >= 0 && xb + 2 < W) ? 0xffff0000u : 0u);
+        const u32 keepO = ((xb + 1 >= 0 && xb + 1 < W) ? 0xffffu : 0u) | ((xb + 3 >= 0 && xb + 3 < W) ? 0xffff0000u : 0u);
+        u32 h1E[3], h1O[3], h2E[3], h2O[3];
+        auto horiz = [&](int r, int slot) {
+            const u32 wl = *reinterpret_cast<const u32*>(&sv[r][cl]), wm = *reinterpret_cast<const u32*>(&sv[r][cm]),
+                      wr = *reinterpret_cast<const u32*>(&sv[r][cr]);
+            // pixels a0 = wl.b3, a1..a4 = wm, a5 = wr.b0; pairs P0 = (a0,a2) P1 = (a1,a3) P2 = (a2,a4) P3 = (a3,a5)
+            const u32 P1 = wm & 0x00ff00ffu, P2 = (wm >> 8) & 0x00ff00ffu;
+            const u32 P0 = __builtin_amdgcn_perm(wm, wl, 0x0c050c03u);   // [wl.b3, 0, wm.b1, 0]
+            const u32 P3 = __builtin_amdgcn_perm(wr, wm, 0x0c040c02u);   // [wm.b2, 0, wr.b0, 0]
+            h1E[slot] = pk_sub(P2, P0); h1O[slot] = pk_sub(P3, P1);      // right - left
+            h2E[slot] = pk_add(pk_add2(P0, P1), P2); h2O[slot] = pk_add(pk_add2(P1, P2), P3);   // left + 2 mid + right
+        };
+        horiz(m0, 0);
+        horiz(m0 + 1, 1);
+#pragma unroll
+        for (int k = 0; k < N2_SEG; k++) {
+            const int my = m0 + k;
+            if (my < m1) {
+                const int a = k % 3, b = (k + 1) % 3, c = (k + 2) % 3;
+                horiz(my + 2, c);
+                const u32 dxE = pk_add(pk_add2(h1E[a], h1E[b]), h1E[c]), dxO = pk_add(pk_add2(h1O[a], h1O[b]), h1O[c]);
+                const u32 dyE = pk_sub(h2E[c], h2E[a]), dyO = pk_sub(h2O[c], h2O[a]);
+                u32 mE = pk_add(pk_abs(dxE), pk_abs(dyE)), mO = pk_add(pk_abs(dxO), pk_abs(dyO));
+                const int y = y0 - 1 + my;
+                if (y < 0 || y >= H) { mE = 0; mO = 0; }
+                mE &= keepE; mO &= keepO;
+                uint2 out;
+                out.x = __builtin_amdgcn_perm(mO, mE, 0x05040100u);    // mag[c], mag[c+1]
+                out.y = __builtin_amdgcn_perm(mO, mE, 0x07060302u);    // mag[c+2], mag[c+3]
+                *reinterpret_cast<uint2*>(&smag[my][cm]) = out;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: non-maximum suppression, four pixels of a row per thread and step
+    const int low = thr[j].x, high = thr[j].y;
+    for (int i = tid; i < N2_H * (N2_W / 4); i += 256) {
+        const int ly = i / (N2_W / 4), q = i - ly * (N2_W / 4);
+        const int y = y0 + ly, xq = x0 + 4 * q;
+        if (y >= H || xq >= W) continue;
+        const uint2 m4 = *reinterpret_cast<const uint2*>(&smag[ly + 1][4 + 4 * q]);
+        const int mm[4] = {(int)(m4.x & 0xffffu), (int)(m4.x >> 16), (int)(m4.y & 0xffffu), (int)(m4.y >> 16)};
+        u32 packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int m = mm[k];
+            if (m > low) {
+                const int r = ly + 2, c = 4 + 4 * q + k;       // centre in sv; magnitude at smag[ly + 1][c]
+                const int tl = sv[r - 1][c - 1], tc = sv[r - 1][c], tr = sv[r - 1][c + 1], ml = sv[r][c - 1], mr = sv[r][c + 1],
+                          bl = sv[r + 1][c - 1], bc = sv[r + 1][c], br = sv[r + 1][c + 1];
+                const int xs = (tr + 2 * mr + br) - (tl + 2 * ml + bl), ys = (bl + 2 * bc + br) - (tl + 2 * tc + tr);
+                const int ax = abs(xs), ay = abs(ys) << 15;
+                const int tg22x = ax * 13573;  // TG22 = round(tan(22.5 deg) * 2^15)
+                bool is_max;
+                if (ay < tg22x) {
+                    is_max = m > smag[ly + 1][c - 1] && m >= smag[ly + 1][c + 1];
+                } else if (ay > tg22x + (ax << 16)) {
+                    is_max = m > smag[ly][c] && m >= smag[ly + 2][c];
+                } else {
+                    const int sgn = (xs ^ ys) < 0 ? -1 : 1;
+                    is_max = m > smag[ly][c - sgn] && m > smag[ly + 2][c + sgn];
+                }
+                if (is_max) packed |= (m > high ? 2u : 1u) << (8 * k);
+            }
+        }
+        *reinterpret_cast<u32*>(map + (size_t)j * g.npix + (size_t)y * W + xq) = packed;
+    }
+}
+
 // ---- K4: hysteresis -----------------------------------------------------------------------------
 
 constexpr int HT = 64;  // hysteresis tile edge
@@ -650,8 +770,13 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
                            b.vplane, b.hist);
     }
     hipLaunchKernelGGL(median_thresholds_kernel, dim3(count), dim3(256), 0, stream, b.hist, g.npix, b.thr_tab, b.thr);
-    hipLaunchKernelGGL(sobel_nms_kernel, dim3((g.width + NT_W - 1) / NT_W, (g.height + NT_H - 1) / NT_H, count), dim3(256), 0,
-                       stream, b.vplane, g, b.thr, b.map);
+    static const bool nms_bytes = [] { const char* e = getenv("PSD_EDGE_NMS_BYTES"); return e && atoi(e) != 0; }();
+    if ((g.width & 3) == 0 && (g.npix & 3) == 0 && !nms_bytes)
+        hipLaunchKernelGGL(sobel_nms_dword_kernel, dim3((g.width + N2_W - 1) / N2_W, (g.height + N2_H - 1) / N2_H, count), dim3(256), 0,
+                           stream, b.vplane, g, b.thr, b.map);
+    else
+        hipLaunchKernelGGL(sobel_nms_kernel, dim3((g.width + NT_W - 1) / NT_W, (g.height + NT_H - 1) / NT_H, count), dim3(256), 0,
+                           stream, b.vplane, g, b.thr, b.map);
     HIP_TRY(hipGetLastError());
     // hysteresis to the fix point: rounds of R launches (ping-pong dirty-tile lists, one flag per
     // launch); done when a launch promoted nothing on any tile border.
