@@ -346,6 +346,7 @@ __global__ __launch_bounds__(256) void sobel_nms_kernel(const uint8_t* vplane, E
 // all of a natural frame); the others recompute dx, dy from the 3x3 V neighbourhood, classify the direction with OpenCV's
 // TG22 fixed point and compare with the two neighbours along it.  Results leave as dwords.  Same integers as
 // sobel_nms_kernel, a quarter of its instructions.
+constexpr int HT_TILE = 64;   // = HT, the hysteresis tile edge (defined below)
 constexpr int N2_W = 128, N2_H = 32, N2_SVW = N2_W + 8, N2_SEG = 5, N2_NSEG = 7, N2_NCG = N2_SVW / 4;
 static_assert(N2_NCG * N2_NSEG <= 256 && N2_SEG * N2_NSEG >= N2_H + 2, "one pass of 256 threads covers the ring");
 
@@ -360,7 +361,10 @@ __device__ __forceinline__ u32 pk_add2(u32 a, u32 b) { return pk_add(a, pk_add(b
 __device__ __forceinline__ u32 pk_abs(u32 a) { return pk_max(a, pk_sub(0u, a)); }
 
 // grid = (tiles_x, tiles_y, frames)
-__global__ __launch_bounds__(256) void sobel_nms_dword_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, uint8_t* map)
+// `dirty` (zeroed by the caller): one flag per 64x64 hysteresis tile of the frame, set where this tile leaves a weak pixel --
+// the first hysteresis launch then only looks at tiles that can change at all (a natural frame has few of them).
+__global__ __launch_bounds__(256) void sobel_nms_dword_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, uint8_t* map,
+                                                              uint8_t* dirty, int htiles_x, int htiles_per_frame)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sv[N2_H + 4][N2_SVW];          // rows y0-2 .. y0+33, cols x0-4 .. x0+131
     __shared__ __attribute__((aligned(16))) unsigned short smag[N2_H + 2][N2_SVW]; // rows y0-1 .. y0+32, same columns
@@ -455,12 +459,16 @@ __global__ __launch_bounds__(256) void sobel_nms_dword_kernel(const uint8_t* vpl
             }
         }
         *reinterpret_cast<u32*>(map + (size_t)j * g.npix + (size_t)y * W + xq) = packed;
+        // a byte equal to 1 (weak): (packed ^ 0x01010101) has a zero byte there
+        const u32 z = packed ^ 0x01010101u;
+        if ((z - 0x01010101u) & ~z & 0x80808080u) dirty[(size_t)j * htiles_per_frame + (size_t)(y / HT_TILE) * htiles_x + xq / HT_TILE] = 1;
     }
 }
 
 // ---- K4: hysteresis -----------------------------------------------------------------------------
 
 constexpr int HT = 64;  // hysteresis tile edge
+static_assert(HT == HT_TILE, "");
 
 // grid = (tiles_x, tiles_y, frames).  Grows strong (2) into 8-connected weak (1) pixels inside the
 // tile until nothing changes, using the neighbouring tiles' current state as a read-only halo.
@@ -771,18 +779,21 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
     }
     hipLaunchKernelGGL(median_thresholds_kernel, dim3(count), dim3(256), 0, stream, b.hist, g.npix, b.thr_tab, b.thr);
     static const bool nms_bytes = [] { const char* e = getenv("PSD_EDGE_NMS_BYTES"); return e && atoi(e) != 0; }();
-    if ((g.width & 3) == 0 && (g.npix & 3) == 0 && !nms_bytes)
+    const dim3 hgrid((g.width + HT - 1) / HT, (g.height + HT - 1) / HT, count);
+    const size_t dirty_bytes = b.tiles_per_frame * (size_t)count;
+    if ((g.width & 3) == 0 && (g.npix & 3) == 0 && !nms_bytes) {
+        // the dword kernel reports which hysteresis tiles hold weak pixels: only those are looked at
+        HIP_TRY(hipMemsetAsync(b.dirty[0], 0, dirty_bytes, stream));
         hipLaunchKernelGGL(sobel_nms_dword_kernel, dim3((g.width + N2_W - 1) / N2_W, (g.height + N2_H - 1) / N2_H, count), dim3(256), 0,
-                           stream, b.vplane, g, b.thr, b.map);
-    else
+                           stream, b.vplane, g, b.thr, b.map, b.dirty[0], (int)hgrid.x, (int)b.tiles_per_frame);
+    } else {
+        HIP_TRY(hipMemsetAsync(b.dirty[0], 1, dirty_bytes, stream));
         hipLaunchKernelGGL(sobel_nms_kernel, dim3((g.width + NT_W - 1) / NT_W, (g.height + NT_H - 1) / NT_H, count), dim3(256), 0,
                            stream, b.vplane, g, b.thr, b.map);
+    }
     HIP_TRY(hipGetLastError());
     // hysteresis to the fix point: rounds of R launches (ping-pong dirty-tile lists, one flag per
     // launch); done when a launch promoted nothing on any tile border.
-    const dim3 hgrid((g.width + HT - 1) / HT, (g.height + HT - 1) / HT, count);
-    const size_t dirty_bytes = b.tiles_per_frame * (size_t)count;
-    HIP_TRY(hipMemsetAsync(b.dirty[0], 1, dirty_bytes, stream));
     int launch = 0;
     if (d_unconverged) {
         HIP_TRY(hipMemsetAsync(b.flags, 0, HYST_SPEC_LAUNCHES * sizeof(int), stream));
