@@ -631,6 +631,65 @@ __global__ __launch_bounds__(256) void vdilate_kernel(const u32* hbits, EdgeGeom
     dil[(size_t)j * words + i] = v;
 }
 
+// K5 + K6 in one kernel: a workgroup takes a band of `band` image rows, packs the strong pixels of the rows it needs
+// (band + the k/2 rows above and below) into bit rows in LDS, dilates them horizontally (second LDS array), then ORs
+// the k-window vertically and writes the band's dilated bit rows.  The bit rows never travel through HBM and a frame is
+// ~17-34 workgroups instead of one per image row.  grid = (bands, frames); dynamic LDS = 2 * (band + k - 1) * (nw + 2) words.
+__global__ __launch_bounds__(256) void pack_dilate_kernel(const uint8_t* map, EdgeGeom g, int k, int band, u32* dil)
+{
+    extern __shared__ u32 pd_lds[];
+    const int j = blockIdx.y, W = g.width, H = g.height, nw = g.words_per_row, pitch = nw + 2;
+    const int y0 = blockIdx.x * band, y1 = min(H, y0 + band);
+    const int up = k / 2, dn = k - 1 - k / 2;
+    const int r0 = max(0, y0 - up), r1 = min(H, y1 + dn);          // rows [r0, r1) are needed
+    const int nrows = r1 - r0;
+    u32* raw = pd_lds;                                             // [nrows][pitch], one zero word on each side
+    u32* hd = pd_lds + (size_t)(band + k - 1) * pitch;             // [nrows][pitch] horizontally dilated
+    const uint8_t* M = map + (size_t)j * g.npix;
+    for (int i = threadIdx.x; i < nrows * pitch; i += 256) {
+        const int rr = i / pitch, w = i - rr * pitch;
+        u32 bits = 0;
+        if (w >= 1 && w <= nw) {
+            const int xb = (w - 1) * 32;
+            const uint8_t* row = M + (size_t)(r0 + rr) * W;
+            if (xb + 32 <= W && ((((uintptr_t)row) + xb) & 15) == 0) {
+                // 32 map bytes (values 0,1,2): bit 1 marks "strong"; gather one bit per byte with a multiply
+                const uint4 a = *reinterpret_cast<const uint4*>(row + xb), c = *reinterpret_cast<const uint4*>(row + xb + 16);
+                const u32 q[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int t = 0; t < 8; t++) bits |= ((((q[t] >> 1) & 0x01010101u) * 0x01020408u) >> 24) << (4 * t);
+            } else {
+                for (int b = 0; b < 32; b++) {
+                    const int x = xb + b;
+                    if (x < W && row[x] == 2) bits |= 1u << b;
+                }
+            }
+        }
+        raw[i] = bits;
+    }
+    __syncthreads();
+    const int left = k / 2, right = k - 1 - k / 2;  // output x is set if any input in [x-left, x+right] is set
+    for (int i = threadIdx.x; i < nrows * nw; i += 256) {
+        const int rr = i / nw, w = i - rr * nw;
+        const u32 lo = raw[rr * pitch + w], mid = raw[rr * pitch + w + 1], hi = raw[rr * pitch + w + 2];
+        u32 out = mid;
+        for (int sft = 1; sft <= right; sft++) out |= sft < 32 ? (u32)((((u64)hi << 32) | mid) >> sft) : (hi >> (sft - 32));
+        for (int sft = 1; sft <= left; sft++) out |= sft < 32 ? (u32)(((((u64)mid << 32) | lo) << sft) >> 32) : (lo << (sft - 32));
+        const int xb = w * 32;
+        if (xb + 32 > W) out &= (1u << (W - xb)) - 1u;
+        hd[rr * pitch + w] = out;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (y1 - y0) * nw; i += 256) {
+        const int ly = i / nw, w = i - ly * nw;
+        const int y = y0 + ly;
+        const int ytop = max(y - up, 0), ybot = min(y + dn, H - 1);
+        u32 v = 0;
+        for (int yy = ytop; yy <= ybot; yy++) v |= hd[(yy - r0) * pitch + w];
+        dil[((size_t)j * H + y) * nw + w] = v;
+    }
+}
+
 // Number of pixels whose dilated edge bit differs between virtual frame j and its predecessor
 // (dil[j-1], or `carry` = last frame of the previous chunk for j == 0).
 __global__ __launch_bounds__(256) void xor_count_kernel(const u32* dil, long words, const u32* carry, int have_carry,
@@ -823,9 +882,20 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
             return PSD_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL(pack_hdilate_kernel, dim3(g.height, count), dim3(256), (g.words_per_row + 2) * sizeof(u32), stream, b.map, g,
-                       k, b.hbits);
-    hipLaunchKernelGGL(vdilate_kernel, dim3((unsigned)((words + 255) / 256), count), dim3(256), 0, stream, b.hbits, g, k, b.dil);
+    // band height of the fused pack + dilate kernel: as tall as two LDS arrays of (band + k - 1) bit rows allow within ~56 KiB
+    const size_t pitch = (size_t)g.words_per_row + 2;
+    int band = (int)((56u << 10) / (2 * pitch * sizeof(u32))) - (k - 1);
+    static const bool split_dilate = [] { const char* e = getenv("PSD_EDGE_SPLIT_DILATE"); return e && atoi(e) != 0; }();
+    if (band >= 8 && !split_dilate) {
+        if (band > 64) band = 64;
+        if (band > g.height) band = g.height;
+        hipLaunchKernelGGL(pack_dilate_kernel, dim3((g.height + band - 1) / band, count), dim3(256),
+                           2 * (size_t)(band + k - 1) * pitch * sizeof(u32), stream, b.map, g, k, band, b.dil);
+    } else {
+        hipLaunchKernelGGL(pack_hdilate_kernel, dim3(g.height, count), dim3(256), (g.words_per_row + 2) * sizeof(u32), stream, b.map, g,
+                           k, b.hbits);
+        hipLaunchKernelGGL(vdilate_kernel, dim3((unsigned)((words + 255) / 256), count), dim3(256), 0, stream, b.hbits, g, k, b.dil);
+    }
     HIP_TRY(hipGetLastError());
     return PSD_OK;
 }
