@@ -353,9 +353,11 @@ static_assert(N2_NCG * N2_NSEG <= 256 && N2_SEG * N2_NSEG >= N2_H + 2, "one pass
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { u32 d; asm("v_pk_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ u32 pk_sub(u32 a, u32 b) { u32 d; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { u32 d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// packed 16-bit arithmetic through clang's vector types (v_pk_add_u16 / v_pk_sub_i16 / v_pk_max_i16 without inline asm,
+// which hipcc would pad with s_nop and could not schedule across)
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { return __builtin_bit_cast(u32, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ u32 pk_sub(u32 a, u32 b) { return __builtin_bit_cast(u32, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
 // a + 2 b on both halves
 __device__ __forceinline__ u32 pk_add2(u32 a, u32 b) { return pk_add(a, pk_add(b, b)); }
 __device__ __forceinline__ u32 pk_abs(u32 a) { return pk_max(a, pk_sub(0u, a)); }
