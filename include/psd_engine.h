@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PSD_ABI_VERSION 1
+#define PSD_ABI_VERSION 2 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records) */
 
 typedef enum psd_status {
     PSD_OK = 0,

@@ -206,8 +206,8 @@ def load() -> ctypes.CDLL:
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from ex
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.psd_abi_version() != 1:
-        raise NativeLibraryError(f"ABI version mismatch: library has {lib.psd_abi_version()}, binding wants 1")
+    if lib.psd_abi_version() != 2:
+        raise NativeLibraryError(f"ABI version mismatch: library has {lib.psd_abi_version()}, binding wants 2")
     _lib = lib
     return lib
 
