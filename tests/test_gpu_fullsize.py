@@ -319,3 +319,68 @@ def test_native_rccl_all_gather_of_device_records_one_rank(hip_engine):
         comm.all_gather_records([6])
     comm.close()
     buf.free()
+
+
+# ---- threads: every thread gets its own default engine; SceneManagers in parallel -------------------------------------------
+
+def test_scene_managers_on_two_threads_use_their_own_default_engines(golden):
+    import threading
+
+    import pyscenedetect_amd as psd
+    from pyscenedetect_amd.engine import default_engine
+    from tests.conftest import golden_clip
+
+    jobs = [("wide_d", "content_default", psd.ContentDetector, True), ("scenes_a", "hist_default", psd.HistogramDetector, False)]
+    engines, errors = {}, []
+
+    def work(i):
+        clip, cfg, cls, auto = jobs[i]
+        try:
+            engines[i] = default_engine()
+            frames = golden_clip(golden, clip)
+            for _ in range(3):
+                sm = psd.SceneManager(batch_frames=16)          # no engine given: the thread's default engine
+                sm.auto_downscale = auto
+                sm.add_detector(cls())
+                sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+                assert [c.frame_num for c in sm.get_cut_list()] == golden["clips"][clip]["results"][cfg]["cuts"]
+        except Exception as ex:  # noqa: BLE001
+            errors.append((i, ex))
+
+    for name in ("wide_d", "scenes_a"):
+        golden_clip(golden, name)      # build the shared cache on this thread first
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert engines[0] is not engines[1] and default_engine() is not engines[0]
+
+
+def test_downscaled_scoring_properties_at_the_headline_size(hip_engine):
+    """4096 x 1080p behind the default downscale: chunking invariance (one call == four calls with a predecessor frame),
+    idempotence, and an oracle sample at a chunk boundary of the kernel's time walk."""
+    import torch
+
+    n, sh, sw, dh, dw = 4096, 1080, 1920, 144, 256
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    x = torch.empty((n, sh, sw, 3), dtype=torch.uint8, device="cuda")
+    for i in range(0, n, 64):
+        x[i:i + 64] = torch.randint(0, 256, (64, sh, sw, 3), dtype=torch.uint8, device="cuda", generator=g)
+    x[100:140] = x[100]                      # a run of identical frames: zero SADs
+    torch.cuda.synchronize()
+    stride = sh * sw * 3
+    whole = hip_engine.score_device_downscaled(x.data_ptr(), n, sh, sw, dh, dw)
+    again = hip_engine.score_device_downscaled(x.data_ptr(), n, sh, sw, dh, dw)
+    same(whole, again, ("sad_h", "sad_s", "sad_v"))
+    assert not whole["sad_v"][101:140].any() and whole["sad_v"][100] > 0 and whole["sad_v"][140] > 0 and whole["sad_h"][0] == 0
+    parts = []
+    for a in range(0, n, 1024):
+        parts.append(hip_engine.score_device_downscaled(x.data_ptr() + a * stride, 1024, sh, sw, dh, dw,
+                                                        d_prev=x.data_ptr() + (a - 1) * stride if a else None))
+    same(np.concatenate(parts), whole, ("sad_h", "sad_s", "sad_v"))
+    for a in (30, 63, 2047):                 # around the ends of 32-frame walks
+        _, want = oracle_downscaled(x[a:a + 3].cpu().numpy(), x[a - 1].cpu().numpy(), dh, dw)
+        same(whole[a:a + 3], want, ("sad_h", "sad_s", "sad_v"))
