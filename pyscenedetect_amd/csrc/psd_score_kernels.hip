@@ -35,6 +35,9 @@
 #ifndef PSD_PACK3
 #define PSD_PACK3 1
 #endif
+#ifndef PSD_FUSED_PHASED
+#define PSD_FUSED_PHASED 1   // the fused HSV + luma quad in phases (quad_fused); 0 = pixel by pixel as in round 1
+#endif
 // (Instruction-selection experiments that did NOT pay, measured on the HSV variant, N=1024 1080p:
 //  0xff/180 from SGPRs instead of literals -1.7 %, shift+and instead of v_bfe -1.5 %, 2d/4d by
 //  additions instead of v_lshl_add -4 %; the 16-bit v_min_u16 for the hue wrap +1.3 % is kept.)
@@ -368,6 +371,76 @@ __device__ __forceinline__ u32 pixel_fp_back(const PxFp& x, float hraw, u32& hq)
     return __float_as_uint(__builtin_fmaf(x.diff, x.sdiv, 8388608.0f));    // low byte = S
 }
 
+// ---- the fused HSV + luma quad (integer formulation), written in phases -------------------------------------------------
+// LDS operations of a wave complete in order, and the histogram increment is an (unreturned) LDS atomic: issued per pixel
+// in front of that pixel's two table reads -- what pixel<true, true> does -- every pixel waits for its own atomic, slowed by
+// bank conflicts, before its table values arrive, 16 times per group with four waves per SIMD to hide it (round 1: 47 % of
+// the wave cycles parked in s_waitcnt, VALU 70 % busy at the full 2.4 GHz).  Here a quad first issues its eight table reads,
+// computes the four luma values and the hue candidates while they are in flight, consumes them, and only then issues its
+// four histogram atomics, which drain under the next quad's arithmetic.
+template <int K>
+__device__ __forceinline__ void extract_bgr(const u32 (&d)[3], u32& b, u32& g, u32& r)
+{
+    constexpr int ib = 3 * K, ig = 3 * K + 1, ir = 3 * K + 2;
+    b = (d[ib >> 2] >> ((ib & 3) * 8)) & 0xffu;
+    g = (d[ig >> 2] >> ((ig & 3) * 8)) & 0xffu;
+    r = (d[ir >> 2] >> ((ir & 3) * 8)) & 0xffu;
+}
+
+template <int LC, int AC>
+__device__ __forceinline__ void quad_fused(const u32 (&d)[3], u32& hq_out, u32& sq_out, u32& vq_out, const u32* __restrict__ lut_s,
+                                           const u32* __restrict__ lut_h, u32* __restrict__ hist, u32 inc)
+{
+    u32 b[4], g[4], r[4], v[4], diff[4], sdiv16[4], y[4];
+    int hdiv16[4], hraw[4];
+    extract_bgr<0>(d, b[0], g[0], r[0]);
+    extract_bgr<1>(d, b[1], g[1], r[1]);
+    extract_bgr<2>(d, b[2], g[2], r[2]);
+    extract_bgr<3>(d, b[3], g[3], r[3]);
+    // phase A: the eight table reads
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v[k] = max(max(b[k], g[k]), r[k]);
+        diff[k] = v[k] - min(min(b[k], g[k]), r[k]);
+        sdiv16[k] = lut_s[v[k] * LC];
+        hdiv16[k] = (int)lut_h[diff[k] * LC];
+    }
+    // (scheduling fences: left alone, hipcc sinks the reads below phase B and waits for them right after issuing them)
+    __builtin_amdgcn_sched_barrier(0);
+    // phase B: everything that needs no table value
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        y[k] = mad_u24_vsv(r[k], kR2Y, mad_u24_vsv(g[k], kG2Y, mad_u24_vvs(b[k], vgpr_b2y(), 8192u))) >> 14;
+        const int dd = (int)diff[k];
+        const int c_r = (int)g[k] - (int)b[k];
+        const int c_g = (int)b[k] - (int)r[k] + 2 * dd;
+        const int c_b = (int)r[k] - (int)g[k] + 4 * dd;
+        hraw[k] = sel_eq(v[k], r[k], c_r, sel_eq(v[k], g[k], c_g, c_b));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // phase C: the two products per pixel, packing
+    u32 hq = 0, s16[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) s16[k] = mad_u24(diff[k], sdiv16[k], 2048u << 4);
+    {
+        const int h0 = mad_i24(hraw[0], hdiv16[0], 2048 << 4), h1 = mad_i24(hraw[1], hdiv16[1], 2048 << 4);
+        const int h2 = mad_i24(hraw[2], hdiv16[2], 2048 << 4), h3 = mad_i24(hraw[3], hdiv16[3], 2048 << 4);
+        hq = min_hi16_to_byte<0>((u32)h0, (u32)h0 + (180u << 16), hq);
+        hq = min_hi16_to_byte<1>((u32)h1, (u32)h1 + (180u << 16), hq);
+        hq = min_hi16_to_byte<2>((u32)h2, (u32)h2 + (180u << 16), hq);
+        hq = min_hi16_to_byte<3>((u32)h3, (u32)h3 + (180u << 16), hq);
+    }
+    const u32 s01 = perm_b32(s16[1], s16[0], 0x0c0c0602u), v01 = perm_b32(v[1], v[0], 0x0c0c0400u);
+    const u32 s23 = perm_b32(s16[3], s16[2], 0x0c0c0602u), v23 = perm_b32(v[3], v[2], 0x0c0c0400u);
+    hq_out = hq;
+    sq_out = perm_b32(s23, s01, 0x05040100u);
+    vq_out = perm_b32(v23, v01, 0x05040100u);
+    // phase D: the histogram increments, behind the reads in the LDS queue
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        __hip_atomic_fetch_add(&hist[y[k] * AC], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // 8-bit BGR -> HSV exactly as OpenCV's RGB2HSV_b (hsv_shift = 12, hue range 180), plus luma
 // histogram and byte sum.  lut_s/lut_h/hist are already offset by the lane's replica index.
 template <bool HSV, bool LUMA, int LC = COPIES, int AC = COPIES, bool FP = false>
@@ -428,6 +501,12 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
         if (HSV && q > 0)
             asm volatile("" : "+v"(g.w[3 * q]), "+v"(g.w[3 * q + 1]), "+v"(g.w[3 * q + 2]) : "v"(o.h[q - 1]), "v"(o.s[q - 1]), "v"(o.v[q - 1]));
         const u32 d[3] = {g.w[3 * q], g.w[3 * q + 1], g.w[3 * q + 2]};
+#if PSD_FUSED_PHASED && PSD_PACK3 && !(PSD_ABLATE & 8)
+        if constexpr (HSV && LUMA) {
+            quad_fused<LC, AC>(d, o.h[q], o.s[q], o.v[q], lut_s, lut_h, hist, inc);
+            continue;
+        }
+#endif
 #if PSD_PACK3 && !(PSD_ABLATE & 8)
         if (HSV) {
             u32 s0, s1, s2, s3, v0, v1, v2, v3;
