@@ -145,6 +145,7 @@ struct RsParams {
     const YTap* yt;
     int n, rows_per_tile, n_tiles, frames_per_chunk, row_pad;
     int area2;
+    int depth;               // staging buffers: 2 = one frame ahead, 3 = two frames ahead
 };
 
 __device__ __forceinline__ u32 interp(u32 p00, u32 p01, u32 p10, u32 p11, int a0, int a1, int b0, int b1)
@@ -230,12 +231,30 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
 #pragma unroll
     for (int g = 0; g < G; g++) prev_hsv[g] = 0;
     bool have_prev = false;
+    // this wave's LDS-DMA instructions per frame (the same every frame): with three buffers the rows of frame t+1 may
+    // still be in flight when frame t is taken (DMA completes in order, so "at most that many outstanding" means
+    // frame t has landed)
+    const int mine = (pieces * 2 * nrows - wave + RS_NW - 1) / RS_NW;
+    const int ahead = p.depth - 1;             // frames in flight beyond the current one
     if (tb < t1) issue(frame_ptr(tb), 0);
+    if (ahead > 1 && tb + 1 < t1) issue(frame_ptr(tb + 1), 1);
     for (int t = tb; t < t1; t++) {
-        const int buf = (t - tb) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int step = t - tb;
+        const int buf = ahead > 1 ? step % 3 : (step & 1);
+        if (ahead > 1 && t + 1 < t1) {
+            if (mine >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (mine >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (mine >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (mine >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (mine >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (mine >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (mine >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();                       // every wave's rows of frame t have landed; frame t-1 is fully consumed
-        if (t + 1 < t1) issue(frame_ptr(t + 1), buf ^ 1);
+        if (t + ahead < t1) issue(frame_ptr(t + ahead), ahead > 1 ? (step + 2) % 3 : (buf ^ 1));
         const int rel = t - t0;                // chunk-relative frame index (-1 for the halo frame)
         if (HSV && rel >= 8 && (rel & 7) == 0 && tid < 24) {
             // frames rel-8 .. rel-1 are complete (all waves added them before this frame's barrier)
@@ -375,8 +394,15 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     p.dst = d_dst; p.dstride = dst_frame_stride; p.dh = dst_h; p.dw = dst_w;
     p.out = d_out; p.lut = engine_lut(e); p.xt = tabs.x; p.yt = tabs.y; p.n = n; p.area2 = tabs.area2 ? 1 : 0;
     p.row_pad = (row_bytes + 1023) & ~1023;            // whole 1 KiB pieces (the tail lanes of the last piece stay idle)
-    // rows per tile: two staging buffers of 2 R padded rows within ~48 KiB (three workgroups per CU), at most 8 pixels per thread
-    int R = (int)((48u << 10) / (4u * (unsigned)p.row_pad));
+    // staging depth: 2 buffers (one frame ahead).  PSD_RESIZE_DEPTH=3 keeps two frames in flight per workgroup; measured on
+    // 4096 x 1080p -> 256x144 (kernel ms; rows per tile / depth): 2/2 1.29, 1/2 1.36, 3/2 1.44, 1/3 1.57, 2/3 1.75 -- the
+    // extra LDS costs more residency than the deeper prefetch buys
+    static const int depth_env = [] { const char* v = getenv("PSD_RESIZE_DEPTH"); return v ? atoi(v) : 0; }();
+    p.depth = depth_env == 3 ? 3 : 2;
+    // rows per tile: `depth` staging buffers of 2 R padded rows within ~24 KiB each, at most 8 pixels per thread
+    int R = (int)((24u << 10) / (2u * (unsigned)p.row_pad));
+    static const int rows_env = [] { const char* v = getenv("PSD_RESIZE_ROWS"); return v ? atoi(v) : 0; }();
+    if (rows_env > 0) R = rows_env;   // experiments
     if (R < 1) R = 1;
     if (R > 16) R = 16;
     while (R > 1 && (R * dst_w + RS_WG - 1) / RS_WG > 8) R--;
@@ -401,7 +427,7 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     if (chunks < 1) chunks = 1;
     p.frames_per_chunk = (n + chunks - 1) / chunks;
     chunks = (n + p.frames_per_chunk - 1) / p.frames_per_chunk;
-    const size_t lds = (size_t)2 * 2 * R * p.row_pad;
+    const size_t lds = (size_t)p.depth * 2 * R * p.row_pad;
     const int grid = p.n_tiles * chunks;
     if (d_dst && d_out) launch_walk<true, true>(p, g, grid, lds, stream);
     else if (d_out) launch_walk<false, true>(p, g, grid, lds, stream);
