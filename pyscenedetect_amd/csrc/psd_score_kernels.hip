@@ -350,15 +350,19 @@ __device__ __forceinline__ void pixel_fp_front(const u32 (&d)[3], const FpLane& 
     x.hdiv = *(lds_cf32_t)(uintptr_t)a_h;
 }
 
-// phase 2: hraw = v == r ? g - b : v == g ? b - r + 2 diff : r - g + 4 diff (the biases cancel)
+// phase 2: hraw = v == r ? g - b : v == g ? b - r + 2 diff : r - g + 4 diff (the biases cancel).
+// With p = g - b, q = b - r and the 0/1 floats nr = (v != r), ng = (v != g):
+//   hraw = p + nr * ((q - p + 2 diff) + ng * (2 diff - p - 2 q))
+// (sector r: p; sector g: p + q - p + 2 diff = b - r + 2 diff; sector b: that + 2 diff - p - 2 q = r - g + 4 diff).
+// Nine full-rate instructions: 2 differences, w = 2 diff - p, two more sums, two clamps, two fused multiply-adds.
 __device__ __forceinline__ float pixel_fp_hraw(const PxFp& x)
 {
-    const float c_r = x.G - x.B;
-    const float c_g = __builtin_fmaf(x.diff, 2.0f, x.B - x.R);
-    const float c_b = __builtin_fmaf(x.diff, 4.0f, x.R - x.G);
-    const float nm_r = sub_clamp(x.V, x.R), nm_g = sub_clamp(x.V, x.G);   // 0 where the channel IS the maximum
-    const float y = __builtin_fmaf(nm_g, c_b - c_g, c_g);                  // v == g ? c_g : c_b
-    return __builtin_fmaf(nm_r, y - c_r, c_r);                             // v == r ? c_r : y
+    const float p = x.G - x.B, q = x.B - x.R;
+    const float w = __builtin_fmaf(x.diff, 2.0f, -p);                     // 2 diff - p
+    const float a = w + q;                                                 // c_g - c_r
+    const float b = __builtin_fmaf(q, -2.0f, w);                           // c_b - c_g
+    const float nr = sub_clamp(x.V, x.R), ng = sub_clamp(x.V, x.G);       // 0 where the channel IS the maximum
+    return __builtin_fmaf(nr, __builtin_fmaf(ng, b, a), p);
 }
 
 // phase 3: the two table products; hue into byte K of hq, S in the low byte of the return value

@@ -5,7 +5,8 @@ HSV that the HSV-only scoring pass runs (pixel_fp_* in pyscenedetect_amd/csrc/ps
   v, vmin   -> max / min of the biased floats; diff = v - vmin (exact)
   S         -> low byte of RNE(diff * sdiv' + 2^23), sdiv' = nextafter(sdiv / 4096): the one-ulp bump sends the exact .5
                ties of diff * sdiv / 4096 upwards like OpenCV's (x + 2048) >> 12 and moves nothing else
-  v==r, v==g-> the 0/1 floats clamp(v - r), clamp(v - g); the two selects are fused multiply-adds
+  v==r, v==g-> the 0/1 floats nr = clamp(v - r), ng = clamp(v - g); hraw = p + nr * ((q - p + 2 diff) + ng * (2 diff - p - 2 q))
+               with p = g - b, q = b - r: nine full-rate instructions
   H         -> t = fma(hraw, hdiv / 4096, 2^-13) (exact), low 16 bits of RNE(t + 1.5 * 2^23) = floor(x + .5) as a two's
                complement, then min(h, h + 180) on unsigned 16-bit values
 
@@ -49,12 +50,11 @@ for b0 in range(0, 256, 32):
     diff = V - np.minimum(np.minimum(B, G), R)
     vi, di = (V - BIAS).astype(np.int64), diff.astype(np.int64)
     s_bits = fma(diff, sdivf[vi], BIAS).view(np.uint32) & 0xFF
-    c_r = G - B
-    c_g = fma(diff, np.full_like(diff, 2.0), B - R)
-    c_b = fma(diff, np.full_like(diff, 4.0), R - G)
+    p, q = G - B, B - R
+    w = fma(diff, np.full_like(diff, 2.0), -p)
+    a, b = w + q, fma(q, np.full_like(q, -2.0), w)
     nm_r, nm_g = np.clip(V - R, 0, 1).astype(f32), np.clip(V - G, 0, 1).astype(f32)
-    y = fma(nm_g, c_b - c_g, c_g)
-    hraw = fma(nm_r, y - c_r, c_r)
+    hraw = fma(nm_r, fma(nm_g, b, a), p)
     t = fma(hraw, hdivf[di], f32(2.0 ** -13))
     hb = (t + f32(12582912.0)).view(np.uint32) & 0xFFFF
     h = np.minimum(hb, (hb + 180) & 0xFFFF)
