@@ -263,6 +263,9 @@ __device__ __forceinline__ u32 perm_b32(u32 s0, u32 s1, u32 sel) { return __buil
 #ifndef PSD_HSV_FP32
 #define PSD_HSV_FP32 1
 #endif
+#ifndef PSD_HSV_SINGLE_S
+#define PSD_HSV_SINGLE_S 1   // staged HSV-only pass: one copy of the sdiv table, its address is a single 16-bit shift (pixel_fp_front)
+#endif
 
 typedef const __attribute__((address_space(3))) float* lds_cf32_t;
 
@@ -329,7 +332,7 @@ __device__ __forceinline__ float channel_fp(const u32 (&d)[3], int c, u32 bias)
 }
 
 // phase 1: unpack, V, diff, table addresses, table reads issued
-template <int LS, int K>
+template <int LS, int K, bool S1>
 __device__ __forceinline__ void pixel_fp_front(const u32 (&d)[3], const FpLane& fl, PxFp& x)
 {
     x.B = channel_fp<K>(d, 0, fl.bias);
@@ -337,7 +340,10 @@ __device__ __forceinline__ void pixel_fp_front(const u32 (&d)[3], const FpLane& 
     x.R = channel_fp<K>(d, 2, fl.bias);
     x.V = max3_f32(x.B, x.G, x.R);                     // 2^23 + v
     x.diff = x.V - min3_f32(x.B, x.G, x.R);            // exact, 0..255
-    const u32 a_s = lshl16_add<LS>(__float_as_uint(x.V), fl.off_s);
+    // S1: ONE copy of the sdiv table at a 1 KiB-aligned LDS address whose number (address >> 10) sits in byte 1 of the
+    // bias, i.e. in bits 8..15 of every channel float: a 16-bit shift of V's bits by 2 IS the table address, no addition.
+    // (The copies only spread bank conflicts; the LDS pipe has headroom, the VALU and the power budget do not.)
+    const u32 a_s = S1 ? lshl16<2>(__float_as_uint(x.V)) : lshl16_add<LS>(__float_as_uint(x.V), fl.off_s);
     u32 a_h;
     if constexpr (LS == 4) {
         // floats in [2^21, 2^22) step by 1/4: the low bits of diff + (2^21 + off_h / 16) are 4 diff + off_h / 4, and a
@@ -447,7 +453,7 @@ __device__ __forceinline__ void quad_fused(const u32 (&d)[3], u32& hq_out, u32& 
 
 // 8-bit BGR -> HSV exactly as OpenCV's RGB2HSV_b (hsv_shift = 12, hue range 180), plus luma
 // histogram and byte sum.  lut_s/lut_h/hist are already offset by the lane's replica index.
-template <bool HSV, bool LUMA, int LC = COPIES, int AC = COPIES, bool FP = false>
+template <bool HSV, bool LUMA, int LC = COPIES, int AC = COPIES, bool FP = false, bool S1 = false>
 __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __restrict__ lut_s,
                                               const u32* __restrict__ lut_h, u32* __restrict__ hist,
                                               u32& byte_sum, u32 inc = 1u)
@@ -457,8 +463,8 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
         constexpr int LS = LC == 4 ? 4 : LC == 8 ? 5 : LC == 16 ? 6 : LC == 32 ? 7 : LC == 2 ? 3 : -1;
         static_assert(LS > 0, "");
         FpLane fl;
-        fl.bias = 0x4B000000u;
         fl.off_s = (u32)(uintptr_t)lut_s;   // low half of a flat LDS address = the LDS byte address
+        fl.bias = S1 ? (0x4B000000u | ((fl.off_s >> 10) << 8)) : 0x4B000000u;
         fl.off_h = (u32)(uintptr_t)lut_h;
         fl.bias_h = 2097152.0f + (float)fl.off_h * 0.0625f;   // exact: off_h is a multiple of 4 below 2^16
 #pragma unroll
@@ -471,10 +477,10 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
             continue;
 #endif
             PxFp x0, x1, x2, x3;
-            pixel_fp_front<LS, 0>(d, fl, x0);
-            pixel_fp_front<LS, 1>(d, fl, x1);
-            pixel_fp_front<LS, 2>(d, fl, x2);
-            pixel_fp_front<LS, 3>(d, fl, x3);
+            pixel_fp_front<LS, 0, S1>(d, fl, x0);
+            pixel_fp_front<LS, 1, S1>(d, fl, x1);
+            pixel_fp_front<LS, 2, S1>(d, fl, x2);
+            pixel_fp_front<LS, 3, S1>(d, fl, x3);
             const float r0 = pixel_fp_hraw(x0), r1 = pixel_fp_hraw(x1), r2 = pixel_fp_hraw(x2), r3 = pixel_fp_hraw(x3);
             u32 hq = 0;
             const u32 s0 = pixel_fp_back<0>(x0, r0, hq), s1 = pixel_fp_back<1>(x1, r1, hq);
@@ -852,7 +858,9 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
     constexpr int SLOTS = 2 * F;
     // nt policy on the frame stream: +2 % for the HSV pass, +5 % for the luma pass, but -3 % for the fused one (A/B)
     constexpr int DMA_AUX = (HSV && LUMA) ? 0 : PSD_DMA_AUX;
-    __shared__ __attribute__((aligned(16))) u32 lut_s[HSV ? 256 * LCD : 4];
+    constexpr bool FPK = HSV && !LUMA && PSD_HSV_FP32;   // HSV-only: the fp32 formulation and its float tables
+    constexpr bool S1 = FPK && PSD_HSV_SINGLE_S && LCD == 4;   // one copy of the sdiv table, addressed without an addition
+    __shared__ __attribute__((aligned(1024))) u32 lut_s[HSV ? (S1 ? 256 : 256 * LCD) : 4];
     __shared__ __attribute__((aligned(16))) u32 lut_h[HSV ? 256 * LCD : 4];
     __shared__ __attribute__((aligned(16))) u32 acc[SLOTS][NA * ACD];
     __shared__ __attribute__((aligned(16))) uint8_t stage[G * NW * 3072];
@@ -865,11 +873,11 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
     const int tile = blockIdx.x % p.n_tiles;
     const int chunk = blockIdx.x / p.n_tiles;
 
-    constexpr bool FPK = HSV && !LUMA && PSD_HSV_FP32;   // HSV-only: the fp32 formulation and its float tables
     if (HSV) {
         const uint32_t* tab = FPK ? p.lutf : p.lut;
         for (int i = tid; i < 256 * LCD; i += WG) {
-            lut_s[i] = tab[i / LCD];
+            if (!S1) lut_s[i] = tab[i / LCD];
+            else if (i < 256) lut_s[i] = tab[i];
             lut_h[i] = tab[256 + i / LCD];
         }
     }
@@ -886,7 +894,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
 #pragma unroll
     for (int k = 0; k < G; k++) live[k] = (wave_group0 + k * NW * 64 + lane) < g1;
 
-    const u32* my_lut_s = lut_s + l16;
+    const u32* my_lut_s = S1 ? lut_s : lut_s + l16;
     const u32* my_lut_h = lut_h + l16;
 
     Hsv16 prev[G];
@@ -903,7 +911,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
 #pragma unroll
             for (int k = 0; k < G; k++) {
                 u32 dummy = 0;
-                convert_group<true, false, LCD, ACD, FPK>(cur[k], prev[k], my_lut_s, my_lut_h, nullptr, dummy);
+                convert_group<true, false, LCD, ACD, FPK, S1>(cur[k], prev[k], my_lut_s, my_lut_h, nullptr, dummy);
             }
         }
     }
@@ -932,7 +940,7 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
         for (int k = 0; k < G; k++) {
             if (HSV || live[k]) {
                 Hsv16 c;
-                convert_group<HSV, LUMA, LCD, ACD, FPK>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs, live[k] ? 1u : 0u);
+                convert_group<HSV, LUMA, LCD, ACD, FPK, S1>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs, live[k] ? 1u : 0u);
                 if (HSV) {
                     if (chain) sad_group(c, prev[k], sh, ss, sv);
                     prev[k] = c;
