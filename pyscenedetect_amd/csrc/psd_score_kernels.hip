@@ -28,7 +28,7 @@
 
 // PSD_ABLATE (build-time, experiments only -- results are WRONG when non-zero):
 //   1 = no LDS table reads, 2 = no per-frame barrier/flush, 4 = no global loads inside the time loop,
-//   8 = no HSV arithmetic (loads + byte SAD only).  tools/ablate.sh builds and times the variants.
+//   8 = no HSV arithmetic (loads + byte SAD only), 16 = no histogram increments in the fused fp32 quad.  tools/ablate.sh builds and times the variants.
 #ifndef PSD_ABLATE
 #define PSD_ABLATE 0
 #endif
@@ -263,6 +263,9 @@ __device__ __forceinline__ u32 perm_b32(u32 s0, u32 s1, u32 sel) { return __buil
 #ifndef PSD_HSV_FP32
 #define PSD_HSV_FP32 1
 #endif
+#ifndef PSD_FUSED_FP32
+#define PSD_FUSED_FP32 1    // the fused HSV + luma pass in the fp32 formulation too (luma from the hue differences, pixel_fp_luma_bits)
+#endif
 #ifndef PSD_HSV_SINGLE_S
 #define PSD_HSV_SINGLE_S 1   // staged HSV-only pass: one copy of the sdiv table, its address is a single 16-bit shift (pixel_fp_front)
 #endif
@@ -381,6 +384,21 @@ __device__ __forceinline__ u32 pixel_fp_back(const PxFp& x, float hraw, u32& hq)
     return __float_as_uint(__builtin_fmaf(x.diff, x.sdiv, 8388608.0f));    // low byte = S
 }
 
+// luma of the fused pass from the hue differences: the coefficients of OpenCV's fixed-point BGR -> Y sum to 2^14, so
+//   (1868 b + 9617 g + 4899 r + 8192) >> 14 = g + floor((-6767 p - 4899 q) / 16384 + 1/2),  p = g - b, q = b - r
+// and in float32 (every product and sum below is exact: multiples of 2^-15 under 2^8; the 2^-15 pushes the exact ties up
+// like the integer + 8192, nothing else is nearer than 2^-14 to a tie; g + u > 0 because it IS the weighted sum / 2^14)
+//   u = p * (-6767 / 16384) + (q * (-4899 / 16384) + 2^-15),  2^23 + y = RNE((2^23 + g) + u)
+// three full-rate instructions per pixel on values the hue already has, against three 24-bit multiplies and a shift.
+__device__ __forceinline__ u32 pixel_fp_luma_bits(const PxFp& x)
+{
+    const float p = x.G - x.B, q = x.B - x.R;
+    const float u = __builtin_fmaf(p, -6767.0f / 16384.0f, __builtin_fmaf(q, -4899.0f / 16384.0f, 0.000030517578125f));
+    return __float_as_uint(x.G + u);   // low byte = y
+}
+
+typedef __attribute__((address_space(3))) u32* lds_u32_t;
+
 // ---- the fused HSV + luma quad (integer formulation), written in phases -------------------------------------------------
 // LDS operations of a wave complete in order, and the histogram increment is an (unreturned) LDS atomic: issued per pixel
 // in front of that pixel's two table reads -- what pixel<true, true> does -- every pixel waits for its own atomic, slowed by
@@ -459,7 +477,16 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
                                               u32& byte_sum, u32 inc = 1u)
 {
     if constexpr (FP) {
-        static_assert(HSV && !LUMA, "the fp32 formulation serves the HSV-only pass");
+        static_assert(HSV && !(LUMA && S1), "");
+        constexpr int LA = AC == 4 ? 4 : AC == 8 ? 5 : AC == 16 ? 6 : AC == 32 ? 7 : AC == 2 ? 3 : AC == 1 ? 2 : -1;   // log2(bytes per bin)
+        static_assert(!LUMA || LA > 0, "");
+        const u32 off_a = LUMA ? (u32)(uintptr_t)hist : 0u;
+        if constexpr (LUMA) {
+            u32 local = 0;
+#pragma unroll
+            for (int i = 0; i < 12; i++) local = __builtin_amdgcn_sad_u8(g.w[i], 0u, local);
+            byte_sum += local * inc;
+        }
         constexpr int LS = LC == 4 ? 4 : LC == 8 ? 5 : LC == 16 ? 6 : LC == 32 ? 7 : LC == 2 ? 3 : -1;
         static_assert(LS > 0, "");
         FpLane fl;
@@ -481,7 +508,16 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
             pixel_fp_front<LS, 1, S1>(d, fl, x1);
             pixel_fp_front<LS, 2, S1>(d, fl, x2);
             pixel_fp_front<LS, 3, S1>(d, fl, x3);
+            if constexpr (LUMA) __builtin_amdgcn_sched_barrier(0);   // the eight table reads stay in front (see quad_fused)
             const float r0 = pixel_fp_hraw(x0), r1 = pixel_fp_hraw(x1), r2 = pixel_fp_hraw(x2), r3 = pixel_fp_hraw(x3);
+            u32 ya[4];
+            if constexpr (LUMA) {
+                ya[0] = lshl16_add<LA>(pixel_fp_luma_bits(x0), off_a);
+                ya[1] = lshl16_add<LA>(pixel_fp_luma_bits(x1), off_a);
+                ya[2] = lshl16_add<LA>(pixel_fp_luma_bits(x2), off_a);
+                ya[3] = lshl16_add<LA>(pixel_fp_luma_bits(x3), off_a);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             u32 hq = 0;
             const u32 s0 = pixel_fp_back<0>(x0, r0, hq), s1 = pixel_fp_back<1>(x1, r1, hq);
             const u32 s2 = pixel_fp_back<2>(x2, r2, hq), s3 = pixel_fp_back<3>(x3, r3, hq);
@@ -490,6 +526,16 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
             o.h[q] = hq;
             o.s[q] = perm_b32(s23, s01, 0x05040100u);
             o.v[q] = perm_b32(v23, v01, 0x05040100u);
+            if constexpr (LUMA) {
+                // the histogram increments go last: LDS operations complete in order (see quad_fused)
+#if PSD_ABLATE & 16
+                asm volatile("" :: "v"(ya[0]), "v"(ya[1]), "v"(ya[2]), "v"(ya[3]));
+                continue;
+#endif
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    __hip_atomic_fetch_add((lds_u32_t)(uintptr_t)ya[k], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
         return;
     }
@@ -755,6 +801,10 @@ constexpr int ACD_MAX = 16;  // accumulator replicas
 #ifndef PSD_HSV_LC
 #define PSD_HSV_LC 4
 #endif
+#ifndef PSD_FUSED_WG
+#define PSD_FUSED_WG 1024   // threads per workgroup of the fused HSV + luma pass (PSD_FUSED_SMALL overrides with kHsvWG)
+#endif
+constexpr int kFusedWG = PSD_FUSED_WG;
 #ifndef PSD_FUSED_SMALL
 #define PSD_FUSED_SMALL 0   // 1: the fused HSV+luma variant also runs on kHsvWG-thread workgroups (measured: 4.32-4.43 ms
                             // vs 4.36 ms on 2048 x 1080p with 4 table / 8 histogram replicas -- no gain, off)
@@ -846,20 +896,37 @@ __device__ __forceinline__ void flush_slot(u32* slot_acc, psd_frame_scores* rec,
     }
 }
 
+// PSD_PHASE_TIMING (experiments): per-wave shader-clock time of each phase of a step, summed into g_phase and read back
+// with psd_debug_phases().  s_memtime shares lgkmcnt with the LDS queue, so the probes sit where the kernel drains it anyway.
+#ifndef PSD_PHASE_TIMING
+#define PSD_PHASE_TIMING 0
+#endif
+#if PSD_PHASE_TIMING
+__device__ unsigned long long g_phase[8];
+#define PT_INIT unsigned long long pt_acc[6] = {0, 0, 0, 0, 0, 0}; const unsigned long long pt_rt0 = wall_clock64(); unsigned long long pt_last = __builtin_readcyclecounter();
+#define PT(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_readcyclecounter(); pt_acc[i] += n_ - pt_last; pt_last = n_; }
+#define PT_DONE if (lane == 0) { for (int i = 0; i < 6; i++) atomicAdd(&g_phase[i], pt_acc[i]); atomicAdd(&g_phase[6], wall_clock64() - pt_rt0); atomicAdd(&g_phase[7], 1ull); }
+#else
+#define PT_INIT
+#define PT(i)
+#define PT_DONE
+#endif
+
 template <bool HSV, bool LUMA, int G, int WG>
-__global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams p)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((HSV && LUMA) ? 4 : 1)))
+void score_frames_dma_kernel(const ScoreParams p)
 {
     constexpr int NW = WG / 64;
     constexpr int ACD = (HSV && LUMA) ? PSD_FUSED_AC : (LUMA ? PSD_LUMA_AC : ACD_MAX);
     constexpr int LCD = (HSV && LUMA) ? PSD_FUSED_LC : (HSV && WG == kHsvWG ? PSD_HSV_LC : LCD_MAX);
-    static_assert(!(HSV && LUMA) || WG == kScoreWG || PSD_FUSED_SMALL, "");
+    static_assert(!(HSV && LUMA) || WG == kFusedWG || PSD_FUSED_SMALL, "");
     constexpr int NA = LUMA ? NACC : 4;       // accumulators per frame slot
     constexpr int F = LUMA ? (HSV ? PSD_FUSED_F : PSD_LUMA_F) : 8;   // frames per barrier
     constexpr int SLOTS = 2 * F;
     // nt policy on the frame stream: +2 % for the HSV pass, +5 % for the luma pass, but -3 % for the fused one (A/B)
     constexpr int DMA_AUX = (HSV && LUMA) ? 0 : PSD_DMA_AUX;
-    constexpr bool FPK = HSV && !LUMA && PSD_HSV_FP32;   // HSV-only: the fp32 formulation and its float tables
-    constexpr bool S1 = FPK && PSD_HSV_SINGLE_S && LCD == 4;   // one copy of the sdiv table, addressed without an addition
+    constexpr bool FPK = HSV && (LUMA ? PSD_FUSED_FP32 : PSD_HSV_FP32);   // the fp32 formulation and its float tables
+    constexpr bool S1 = FPK && !LUMA && PSD_HSV_SINGLE_S && LCD == 4;   // one copy of the sdiv table, addressed without an addition
     __shared__ __attribute__((aligned(1024))) u32 lut_s[HSV ? (S1 ? 256 : 256 * LCD) : 4];
     __shared__ __attribute__((aligned(16))) u32 lut_h[HSV ? 256 * LCD : 4];
     __shared__ __attribute__((aligned(16))) u32 acc[SLOTS][NA * ACD];
@@ -917,15 +984,19 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
     }
     if (t0 < t1) dma_issue<G, NW, DMA_AUX>(p, p.frames + (size_t)t0 * p.frame_stride, wave_group0, g1, wave, lane, stage);
 
+    PT_INIT
     for (int t = t0; t < t1; t++) {
         const int slot = (t - t0) % SLOTS;
         u32* my_acc = &acc[slot][0] + lacc;
         // Frame t has been in flight since the previous step; take it out of the staging slot and
         // immediately refill the slot with frame t+1.
 #if !(PSD_ABLATE & 4)
+        PT(5)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PT(0)
         stage_read<G, NW>(stage, wave, lane, cur);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PT(1)
         if (t + 1 < t1) dma_issue<G, NW, DMA_AUX>(p, p.frames + (size_t)(t + 1) * p.frame_stride, wave_group0, g1, wave, lane, stage);
 #else
 #pragma unroll
@@ -956,21 +1027,25 @@ __global__ __launch_bounds__(WG) void score_frames_dma_kernel(const ScoreParams 
         if (LUMA)
             __hip_atomic_fetch_add(&my_acc[(E0 + 3) * ACD], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         have_prev = true;
+        PT(2)
 #if !(PSD_ABLATE & 2)
         // Every F frames (and at the end of the chunk) the block's sums for the last <= F frames
         // are complete in one half of the slot ring: flush that half while the other half fills.
         const int done = t - t0 + 1;
         if (done % F == 0 || t + 1 == t1) {
             __syncthreads();
+            PT(3)
             const int nf = (done % F == 0) ? F : done % F;       // frames in this half
             const int first = done - nf;                          // chunk-relative index of the first
             for (int i = tid; i < nf * 2 * NA; i += WG) {
                 const int fi = i / (2 * NA), idx = i - fi * 2 * NA;
                 flush_slot<LUMA, ACD>(&acc[(first + fi) % SLOTS][0], p.out + t0 + first + fi, idx);
             }
+            PT(4)
         }
 #endif
     }
+    PT_DONE
 }
 
 // ---- luma histogram + byte sum without the time walk -------------------------------------------
@@ -1078,7 +1153,7 @@ static hipError_t launch_one(const ScoreParams& p, int grid, hipStream_t stream)
     constexpr int WG = kScoreWG;
     if constexpr (FAST) {
         if (!direct_loads()) {
-            constexpr int SWG = (HSV && (!LUMA || PSD_FUSED_SMALL)) ? kHsvWG : kScoreWG;
+            constexpr int SWG = (HSV && (!LUMA || PSD_FUSED_SMALL)) ? kHsvWG : (HSV && LUMA) ? kFusedWG : kScoreWG;
             hipLaunchKernelGGL((score_frames_dma_kernel<HSV, LUMA, G, SWG>), dim3(grid), dim3(SWG), 0, stream, p);
             return hipGetLastError();
         }
@@ -1110,11 +1185,13 @@ static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bo
                                bool fast, int target_blocks, hipStream_t stream)
 {
     // Tile geometry: spread the 16-px groups evenly over the fewest tiles that fit.
-    const int wg = (fast && hsv && (!luma || PSD_FUSED_SMALL) && !direct_loads()) ? kHsvWG : kScoreWG;
+    const bool staged = fast && !direct_loads();
+    const int wg = (staged && hsv && (!luma || PSD_FUSED_SMALL)) ? kHsvWG : (staged && hsv && luma) ? kFusedWG : kScoreWG;
+    const bool mid = wg != kScoreWG && wg != kHsvWG;   // a fused pass on PSD_FUSED_WG-thread workgroups keeps G and the walk rules
     // The small-workgroup HSV pass takes one group per lane unless PSD_SCORE_G says otherwise: 80 VGPRs and 24 KiB of
     // LDS, six workgroups (24 waves) per CU.  Sweep on 4096 x 1080p: G=1 5.71 ms, G=2 5.81 ms (1024-thread kernel 5.9-6.0).
     static const bool g_forced = getenv("PSD_SCORE_G") != nullptr;
-    const int gpl = !fast ? 1 : (wg != kScoreWG && !g_forced) ? 1 : groups_per_lane();
+    const int gpl = !fast ? 1 : (wg != kScoreWG && !mid && !g_forced) ? 1 : groups_per_lane();
     const int cap = wg * gpl;
     const int n_groups = group_end - group_begin;
     if (n_groups <= 0) return hipSuccess;
@@ -1125,7 +1202,8 @@ static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bo
     p.groups_per_tile = (n_groups + p.n_tiles - 1) / p.n_tiles;
     // Time chunks: enough workgroups to keep every CU busy for several rounds, but chunks long
     // enough that the re-read halo frame stays a small fraction.
-    if (wg != kScoreWG) {
+    if (mid) target_blocks *= kScoreWG / wg;
+    else if (wg != kScoreWG) {
         // small workgroups: several share a CU, so ask for proportionally more of them (PSD_HSV_BLOCKS overrides)
         static const int env_blocks = [] { const char* e = getenv("PSD_HSV_BLOCKS"); return e ? atoi(e) : 0; }();
         // sweep on 4096 x 1080p (G=1): 2048 blocks 6.13 ms, 8192 5.86, 16384 5.79, 32768 5.71, 65536 5.76
@@ -1138,9 +1216,9 @@ static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bo
     const int chunks_hi = (target_blocks + p.n_tiles - 1) / p.n_tiles;
     int chunks = chunks_hi;
     if (hsv) {
-        const int slots = (target_blocks_in / 8) * (wg != kScoreWG ? 6 : 1);   // target_blocks_in = 8 per CU
+        const int slots = (target_blocks_in / 8) * (mid ? kScoreWG / wg : wg != kScoreWG ? 6 : 1);   // target_blocks_in = 8 per CU
         const int chunks_lo = (slots + p.n_tiles - 1) / p.n_tiles;
-        const int walk = wg != kScoreWG ? 32 : 8;   // 16-wave workgroups (one per CU) need the parallelism more
+        const int walk = (wg != kScoreWG && !mid) ? 32 : 8;   // 16-wave workgroups (one per CU) need the parallelism more
         chunks = (p.n + walk - 1) / walk;
         if (chunks < chunks_lo) chunks = chunks_lo;
         if (chunks > chunks_hi) chunks = chunks_hi;
@@ -1183,3 +1261,19 @@ hipError_t launch_score_frames(ScoreParams p, bool hsv, bool luma, bool fast, in
 }
 
 }  // namespace psd
+
+#if PSD_PHASE_TIMING
+// phases: 0 wait for the frame's DMA, 1 staging slot -> registers, 2 arithmetic + LDS drain, 3 workgroup barrier, 4 flush,
+// 5 rest (loop overhead, DMA issue of the next frame is inside 2); [6] = the same span on the constant 100 MHz clock
+// (s_memrealtime), so sum(0..5) / [6] x 100 MHz is the shader clock the waves saw; [7] = waves counted.  reset != 0 clears the counters.
+extern "C" int psd_debug_phases(unsigned long long* out, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(psd::g_phase), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(psd::g_phase), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -69,7 +69,12 @@ def test_exhaustive_hsv_through_the_kernel(hip_engine):
     # row-wise too, so a compensating error inside the big sum cannot hide
     rows = cube.reshape(64, 64, 4096, 3)[:, 0]     # 64 slices of 4096 px
     fr2 = np.stack([np.zeros_like(rows[:, None]), rows[:, None]], axis=1).reshape(128, 1, 4096, 3)
-    same(hip_engine.score_host(fr2, flags=NOEDGE), orc.score_batch(fr2))
+    want2 = orc.score_batch(fr2)
+    same(hip_engine.score_host(fr2, flags=NOEDGE), want2)
+    # the HSV-only pass is its own kernel instantiation (fp32 formulation, single sdiv table): the same triples through it
+    sad = ("sad_h", "sad_s", "sad_v")
+    same(hip_engine.score_host(fr, flags=E.SCORE_HSV_SAD), got, sad)
+    same(hip_engine.score_host(fr2, flags=E.SCORE_HSV_SAD), want2, sad)
 
 
 def test_constant_and_extreme_frames(hip_engine):

@@ -10,6 +10,10 @@ HSV that the HSV-only scoring pass runs (pixel_fp_* in pyscenedetect_amd/csrc/ps
   H         -> t = fma(hraw, hdiv / 4096, 2^-13) (exact), low 16 bits of RNE(t + 1.5 * 2^23) = floor(x + .5) as a two's
                complement, then min(h, h + 180) on unsigned 16-bit values
 
+  luma      -> (fused all-detectors pass, pixel_fp_luma_bits) the BGR -> Y coefficients sum to 2^14, so
+               y = g + floor((-6767 p - 4899 q) / 16384 + 1/2); u = fma(p, -6767/16384, fma(q, -4899/16384, 2^-15)) is exact
+               and the low byte of RNE((2^23 + g) + u) is y
+
 Every fused multiply-add is evaluated in float64 and rounded once to float32 (exact products: 8 x 24 and 11 x 17 bits),
 which is what the hardware fma does.  The -m gpu test test_exhaustive_hsv_through_the_kernel runs the same triples
 through the kernel itself.
@@ -39,6 +43,7 @@ def fma(a, b, c):
 
 g8 = np.arange(256, dtype=np.uint8)
 bad = 0
+bad_y = 0
 BIAS = f32(8388608.0)
 for b0 in range(0, 256, 32):
     bb, gg, rr = np.meshgrid(g8[b0:b0 + 32], g8, g8, indexing="ij")
@@ -60,5 +65,11 @@ for b0 in range(0, 256, 32):
     h = np.minimum(hb, (hb + 180) & 0xFFFF)
     got = np.stack([h, s_bits, vi], axis=-1)
     bad += int(np.count_nonzero(got != want.astype(np.int64)))
+    u = fma(p, np.full_like(p, -6767.0 / 16384.0), fma(q, np.full_like(q, -4899.0 / 16384.0), f32(2.0 ** -15)))
+    y_bits = (G + u).view(np.uint32)
+    i64 = img.astype(np.int64)
+    want_y = (1868 * i64[..., 0] + 9617 * i64[..., 1] + 4899 * i64[..., 2] + 8192) >> 14   # oracle/cv2_restate.c: B2Y, G2Y, R2Y, shift 14
+    bad_y += int(np.count_nonzero((y_bits & 0xFF) != want_y)) + int(np.count_nonzero((y_bits >> 8) != (0x4B000000 >> 8)))
 print("fp32-pipe HSV formulation: mismatching channel values over all 2^24 triples:", bad)
-sys.exit(1 if bad else 0)
+print("fp32-pipe luma from the hue differences: mismatching values over all 2^24 triples:", bad_y)
+sys.exit(1 if bad or bad_y else 0)
