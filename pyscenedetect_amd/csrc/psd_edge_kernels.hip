@@ -467,6 +467,153 @@ __global__ __launch_bounds__(256) void sobel_nms_dword_kernel(const uint8_t* vpl
     }
 }
 
+// K3, full-width tiles (frames whose width is a multiple of the 128-px tile: 1080p, 4K, 720p, 640x360, 256x144 ...).
+// The same arithmetic as sobel_nms_dword_kernel with the per-wave instruction count cut by a third (the kernel is VALU
+// bound: 540 VALU instructions per wave, 85 % VALU-busy in profiles/r02_h_pmc_edges.txt):
+//   * tile load: two V rows per wave instruction (lanes 0-31 / 32-63 take the 32 dwords of a row, 72 threads the two dwords
+//     left over per row), row index clamped, the replicated column outside a left / right image edge made from the
+//     neighbouring dword -- six loads with a handful of address instructions instead of five (interior) or nineteen
+//     (border tiles: 18 % of a 1080p frame, byte by byte before) rounds of divide-by-34 indexing;
+//   * phase 1 is specialised for interior tiles (no "outside the image" masks) and leaves the magnitudes as the even /
+//     odd column pairs it computed them in (no re-interleave);
+//   * phase 2 takes eight pixels per thread and decides "no candidate among them" with four packed max + xor.
+__device__ __forceinline__ int mag_at(const uint2 (*smq)[N2_NCG], int row, int c)
+{
+    // column c of a magnitude row: quad c >> 2 holds {m0 | m2 << 16, m1 | m3 << 16}
+    const unsigned short* q = reinterpret_cast<const unsigned short*>(&smq[row][c >> 2]);
+    return q[((c & 1) << 1) | ((c >> 1) & 1)];
+}
+
+template <bool INNER>
+__device__ __forceinline__ void sobel_phase1_quads(const uint8_t (*sv)[N2_SVW], uint2 (*smq)[N2_NCG], int tid, int x0, int y0, int H, int W)
+{
+    if (tid >= N2_NCG * N2_NSEG) return;
+    const int cg = tid % N2_NCG, seg = tid / N2_NCG;
+    const int m0 = seg * N2_SEG, m1 = min(m0 + N2_SEG, N2_H + 2);
+    const int cl = max(cg - 1, 0) * 4, cm = cg * 4, cr = min(cg + 1, N2_NCG - 1) * 4;   // clamped neighbours only feed unused columns
+    u32 keepE = 0xffffffffu, keepO = 0xffffffffu;
+    if (!INNER) {   // "magnitude outside the image is 0"
+        const int xb = x0 - 4 + cm;
+        keepE = ((xb >= 0 && xb < W) ? 0xffffu : 0u) | ((xb + 2 >= 0 && xb + 2 < W) ? 0xffff0000u : 0u);
+        keepO = ((xb + 1 >= 0 && xb + 1 < W) ? 0xffffu : 0u) | ((xb + 3 >= 0 && xb + 3 < W) ? 0xffff0000u : 0u);
+    }
+    u32 h1E[3], h1O[3], h2E[3], h2O[3];
+    auto horiz = [&](int r, int slot) {
+        const u32 wl = *reinterpret_cast<const u32*>(&sv[r][cl]), wm = *reinterpret_cast<const u32*>(&sv[r][cm]),
+                  wr = *reinterpret_cast<const u32*>(&sv[r][cr]);
+        const u32 P1 = wm & 0x00ff00ffu, P2 = (wm >> 8) & 0x00ff00ffu;
+        const u32 P0 = __builtin_amdgcn_perm(wm, wl, 0x0c050c03u);   // [wl.b3, 0, wm.b1, 0]
+        const u32 P3 = __builtin_amdgcn_perm(wr, wm, 0x0c040c02u);   // [wm.b2, 0, wr.b0, 0]
+        h1E[slot] = pk_sub(P2, P0); h1O[slot] = pk_sub(P3, P1);
+        h2E[slot] = pk_add(pk_add2(P0, P1), P2); h2O[slot] = pk_add(pk_add2(P1, P2), P3);
+    };
+    horiz(m0, 0);
+    horiz(m0 + 1, 1);
+#pragma unroll
+    for (int k = 0; k < N2_SEG; k++) {
+        const int my = m0 + k;
+        if (my < m1) {
+            const int a = k % 3, b = (k + 1) % 3, c = (k + 2) % 3;
+            horiz(my + 2, c);
+            const u32 dxE = pk_add(pk_add2(h1E[a], h1E[b]), h1E[c]), dxO = pk_add(pk_add2(h1O[a], h1O[b]), h1O[c]);
+            const u32 dyE = pk_sub(h2E[c], h2E[a]), dyO = pk_sub(h2O[c], h2O[a]);
+            u32 mE = pk_add(pk_abs(dxE), pk_abs(dyE)), mO = pk_add(pk_abs(dxO), pk_abs(dyO));
+            if (!INNER) {
+                const int y = y0 - 1 + my;
+                if (y < 0 || y >= H) { mE = 0; mO = 0; }
+                mE &= keepE; mO &= keepO;
+            }
+            smq[my][cg] = make_uint2(mE, mO);
+        }
+    }
+}
+
+// grid = (W / 128, tiles_y, frames); requires W % 128 == 0
+__global__ __launch_bounds__(256) void sobel_nms_tile_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, uint8_t* map,
+                                                             uint8_t* dirty, int htiles_x, int htiles_per_frame)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sv[N2_H + 4][N2_SVW];   // rows y0-2 .. y0+33, cols x0-4 .. x0+131
+    __shared__ __attribute__((aligned(16))) uint2 smq[N2_H + 2][N2_NCG];    // rows y0-1 .. y0+32, magnitudes as even / odd pairs
+    const int j = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t* V = vplane + (size_t)j * g.npix;
+    const int x0 = blockIdx.x * N2_W, y0 = blockIdx.y * N2_H, H = g.height, W = g.width;
+    {
+        const int cw = lane & 31;
+        const int left = (x0 == 0 && cw == 0) ? 1 : 0;
+        const uint8_t* col = V + x0 - 4 + 4 * (cw + left);
+#pragma unroll
+        for (int it = 0; it < 5; it++) {
+            const int ly = 2 * (wave * 5 + it) + (lane >> 5);
+            if (ly < N2_H + 4) {
+                const int y = min(max(y0 + ly - 2, 0), H - 1);
+                u32 v = *reinterpret_cast<const u32*>(col + (size_t)y * W);
+                if (left) v = (v & 0xffu) * 0x01010101u;          // BORDER_REPLICATE: V[y][0] four times
+                *reinterpret_cast<u32*>(&sv[ly][4 * cw]) = v;
+            }
+        }
+        if (tid < 2 * (N2_H + 4)) {
+            const int ly = tid >> 1, c2 = 32 + (tid & 1);
+            const int right = (x0 + N2_W == W && c2 == 33) ? 1 : 0;
+            const int y = min(max(y0 + ly - 2, 0), H - 1);
+            u32 v = *reinterpret_cast<const u32*>(V + (size_t)y * W + x0 - 4 + 4 * (c2 - right));
+            if (right) v = (v >> 24) * 0x01010101u;               // V[y][W-1] four times
+            *reinterpret_cast<u32*>(&sv[ly][4 * c2]) = v;
+        }
+    }
+    __syncthreads();
+    const bool inner = x0 >= 4 && x0 + N2_W + 4 <= W && y0 >= 2 && y0 + N2_H + 2 <= H;
+    if (inner) sobel_phase1_quads<true>(sv, smq, tid, x0, y0, H, W);
+    else sobel_phase1_quads<false>(sv, smq, tid, x0, y0, H, W);
+    __syncthreads();
+    // ---- phase 2: non-maximum suppression, eight pixels of a row per thread and step
+    const int low = thr[j].x, high = thr[j].y;
+    const u32 lowpk = (u32)low * 0x10001u;
+#pragma unroll
+    for (int it = 0; it < N2_H * (N2_W / 8) / 256; it++) {
+        const int i = tid + it * 256;
+        const int ly = i >> 4, o = i & 15;
+        const int y = y0 + ly;
+        if (y >= H) continue;
+        const uint2 qa = smq[ly + 1][1 + 2 * o], qb = smq[ly + 1][2 + 2 * o];
+        // a half above `low` survives the max: (max(m, low) ^ low) != 0
+        const u32 any = (pk_max(qa.x, lowpk) ^ lowpk) | (pk_max(qa.y, lowpk) ^ lowpk) | (pk_max(qb.x, lowpk) ^ lowpk) | (pk_max(qb.y, lowpk) ^ lowpk);
+        u32 packed[2] = {0u, 0u};
+        if (any) {
+            const u32 w4[4] = {qa.x, qa.y, qb.x, qb.y};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int m = (int)((w4[2 * (k >> 2) + (k & 1)] >> (16 * ((k >> 1) & 1))) & 0xffffu);
+                if (m > low) {
+                    const int r = ly + 2, c = 4 + 8 * o + k;       // centre in sv; magnitude row ly + 1, column c
+                    const int tl = sv[r - 1][c - 1], tc = sv[r - 1][c], tr = sv[r - 1][c + 1], ml = sv[r][c - 1], mr = sv[r][c + 1],
+                              bl = sv[r + 1][c - 1], bc = sv[r + 1][c], br = sv[r + 1][c + 1];
+                    const int xs = (tr + 2 * mr + br) - (tl + 2 * ml + bl), ys = (bl + 2 * bc + br) - (tl + 2 * tc + tr);
+                    const int ax = abs(xs), ay = abs(ys) << 15;
+                    const int tg22x = ax * 13573;  // TG22 = round(tan(22.5 deg) * 2^15)
+                    bool is_max;
+                    if (ay < tg22x) {
+                        is_max = m > mag_at(smq, ly + 1, c - 1) && m >= mag_at(smq, ly + 1, c + 1);
+                    } else if (ay > tg22x + (ax << 16)) {
+                        is_max = m > mag_at(smq, ly, c) && m >= mag_at(smq, ly + 2, c);
+                    } else {
+                        const int sgn = (xs ^ ys) < 0 ? -1 : 1;
+                        is_max = m > mag_at(smq, ly, c - sgn) && m > mag_at(smq, ly + 2, c + sgn);
+                    }
+                    if (is_max) packed[k >> 2] |= (m > high ? 2u : 1u) << (8 * (k & 3));
+                }
+            }
+        }
+        const int xq = x0 + 8 * o;
+        *reinterpret_cast<uint2*>(map + (size_t)j * g.npix + (size_t)y * W + xq) = make_uint2(packed[0], packed[1]);
+        if (any) {
+            // a byte equal to 1 (weak): (packed ^ 0x01010101) has a zero byte there
+            const u32 z0 = packed[0] ^ 0x01010101u, z1 = packed[1] ^ 0x01010101u;
+            if ((((z0 - 0x01010101u) & ~z0) | ((z1 - 0x01010101u) & ~z1)) & 0x80808080u)
+                dirty[(size_t)j * htiles_per_frame + (size_t)(y / HT_TILE) * htiles_x + xq / HT_TILE] = 1;
+        }
+    }
+}
+
 // ---- K4: hysteresis -----------------------------------------------------------------------------
 
 constexpr int HT = 64;  // hysteresis tile edge
@@ -674,9 +821,17 @@ __global__ __launch_bounds__(256) void pack_dilate_kernel(const uint8_t* map, Ed
     for (int i = threadIdx.x; i < nrows * nw; i += 256) {
         const int rr = i / nw, w = i - rr * nw;
         const u32 lo = raw[rr * pitch + w], mid = raw[rr * pitch + w + 1], hi = raw[rr * pitch + w + 2];
-        u32 out = mid;
-        for (int sft = 1; sft <= right; sft++) out |= sft < 32 ? (u32)((((u64)hi << 32) | mid) >> sft) : (hi >> (sft - 32));
-        for (int sft = 1; sft <= left; sft++) out |= sft < 32 ? (u32)(((((u64)mid << 32) | lo) << sft) >> 32) : (lo << (sft - 32));
+        // OR of the shifts 0..n by doubling (x |= x >> 1, >> 2, >> 4 ... then one shift for the remainder) on the 64-bit
+        // pairs (hi:mid) and (mid:lo): 3 + 3 steps for k = 13 instead of 12 funnel shifts; windows reach at most one word
+        // across (k <= 63, enforced in psd_engine.cpp, keeps left and right below 32)
+        u64 r = ((u64)hi << 32) | mid, l = ((u64)mid << 32) | lo;
+        int cover = 1;
+        for (; 2 * cover <= right + 1; cover *= 2) r |= r >> cover;
+        if (cover < right + 1) r |= r >> (right + 1 - cover);
+        cover = 1;
+        for (; 2 * cover <= left + 1; cover *= 2) l |= l << cover;
+        if (cover < left + 1) l |= l << (left + 1 - cover);
+        u32 out = (u32)r | (u32)(l >> 32);
         const int xb = w * 32;
         if (xb + 32 > W) out &= (1u << (W - xb)) - 1u;
         hd[rr * pitch + w] = out;
@@ -845,6 +1000,11 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
     if ((g.width & 3) == 0 && (g.npix & 3) == 0 && !nms_bytes) {
         // the dword kernel reports which hysteresis tiles hold weak pixels: only those are looked at
         HIP_TRY(hipMemsetAsync(b.dirty[0], 0, dirty_bytes, stream));
+        static const bool no_tile = [] { const char* e = getenv("PSD_EDGE_NMS_DWORD"); return e && atoi(e) != 0; }();
+        if (g.width % N2_W == 0 && !no_tile)
+            hipLaunchKernelGGL(sobel_nms_tile_kernel, dim3(g.width / N2_W, (g.height + N2_H - 1) / N2_H, count), dim3(256), 0, stream,
+                               b.vplane, g, b.thr, b.map, b.dirty[0], (int)hgrid.x, (int)b.tiles_per_frame);
+        else
         hipLaunchKernelGGL(sobel_nms_dword_kernel, dim3((g.width + N2_W - 1) / N2_W, (g.height + N2_H - 1) / N2_H, count), dim3(256), 0,
                            stream, b.vplane, g, b.thr, b.map, b.dirty[0], (int)hgrid.x, (int)b.tiles_per_frame);
     } else {

@@ -185,6 +185,12 @@ def test_edge_maps_match_oracle(hip_engine):
     cases += [(f, 0) for f in frames]
     rng = np.random.default_rng(5)
     cases.append((rng.integers(0, 256, (70, 100, 3), dtype=np.uint8), 5))
+    # widths that are multiples of the 128-px tile take sobel_nms_tile_kernel: one, two and three tiles across, partial
+    # bottom tiles, noise (every pixel a candidate) and smoothed noise (sparse candidates next to the replicated borders)
+    cases.append((rng.integers(0, 256, (37, 128, 3), dtype=np.uint8), 3))
+    cases.append((rng.integers(0, 256, (100, 256, 3), dtype=np.uint8), 5))
+    coarse = rng.integers(0, 256, (9, 48, 3), dtype=np.uint8)
+    cases.append((np.repeat(np.repeat(coarse, 8, axis=0), 8, axis=1)[:67], 7))     # 67 x 384, blocky
     cases.append((np.full((40, 50, 3), 77, np.uint8), 0))
     cases.append((np.zeros((9, 9, 3), np.uint8), 3))
     for frame, k in cases:
