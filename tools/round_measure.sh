@@ -19,6 +19,7 @@ timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --mast
 timeout 300 python bench.py --downscale auto --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_downscale_auto.json
 timeout 300 python bench.py --detector all --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_all.json
 timeout 300 python tools/feed_bench.py 2>/dev/null | tail -1 > $O/feed_bench.json
+( for n in 64 256 1024; do ET_N=$n ET_SMOOTH=1 timeout 200 python tools/edge_time.py 2>/dev/null | tail -1 | sed "s/^/shot-like /"; done; ET_N=256 timeout 200 python tools/edge_time.py 2>/dev/null | tail -1 | sed "s/^/uniform noise /" ) > $O/edge_time.txt
 timeout 300 python tools/bbc_standin.py --dump $O/bbc_standin_predictions.json 2>/dev/null | tail -1 > $O/bbc_standin.json
 # kernel trace of the default bench command (headline only), then PMC passes of the HSV pass and of the downscale kernel
 cd /tmp; export TMPDIR=/tmp
