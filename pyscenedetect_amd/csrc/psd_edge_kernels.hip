@@ -629,7 +629,7 @@ static_assert(HT == HT_TILE, "");
 // itself it marks its neighbours in `dirty_out` and raises *changed.  A natural frame leaves a few per cent of the tiles
 // dirty: one wave reads the flags of the workgroup's range at once and the workgroup walks the set bits -- a launch over
 // 130 k tiles (256 x 1080p) is 8 k workgroups instead of 130 k that exit at once (30 us per launch, nine launches per call).
-__global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom g, const uint8_t* dirty_in, uint8_t* dirty_out,
+__global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom g, uint8_t* dirty_in, uint8_t* dirty_out,
                                                          int* changed, int tiles_x, int tiles_y, long n_tiles, int tpw)
 {
     // tile + 1-px halo; image column x0 sits at LDS column OX + 1 = 4 so interior rows are dword aligned
@@ -640,8 +640,12 @@ __global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom 
     const long first = (long)blockIdx.x * tpw;
     if (threadIdx.x < 64) {
         const long ti = first + threadIdx.x;
-        const unsigned long long m = __ballot((int)threadIdx.x < tpw && ti < n_tiles && dirty_in[ti] != 0);
+        const bool mine = (int)threadIdx.x < tpw && ti < n_tiles;
+        const bool set = mine && dirty_in[ti] != 0;
+        const unsigned long long m = __ballot(set);
         if (threadIdx.x == 0) todo_mask = m;
+        // consumed: leave the list empty, it is the next launch's dirty_out (nobody else touches this range of dirty_in)
+        if (set) dirty_in[ti] = 0;
     }
     __syncthreads();
     unsigned long long todo = todo_mask;
@@ -1039,11 +1043,12 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
     HIP_TRY(hipGetLastError());
     // hysteresis to the fix point: rounds of R launches (ping-pong dirty-tile lists, one flag per
     // launch); done when a launch promoted nothing on any tile border.
+    // every launch empties the list it read, so the two lists only need clearing once
+    HIP_TRY(hipMemsetAsync(b.dirty[1], 0, dirty_bytes, stream));
     int launch = 0;
     if (d_unconverged) {
         HIP_TRY(hipMemsetAsync(b.flags, 0, HYST_SPEC_LAUNCHES * sizeof(int), stream));
         for (; launch < HYST_SPEC_LAUNCHES; launch++) {
-            HIP_TRY(hipMemsetAsync(b.dirty[(launch + 1) & 1], 0, dirty_bytes, stream));
             hipLaunchKernelGGL(hysteresis_kernel, hyst_grid, dim3(256), 0, stream, b.map, g, b.dirty[launch & 1], b.dirty[(launch + 1) & 1],
                                b.flags + launch, (int)hgrid.x, (int)hgrid.y, hyst_tiles, hyst_tpw);
         }
@@ -1054,7 +1059,6 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
             constexpr int R = 3;
             HIP_TRY(hipMemsetAsync(b.flags, 0, R * sizeof(int), stream));
             for (int i = 0; i < R; i++, launch++) {
-                HIP_TRY(hipMemsetAsync(b.dirty[(launch + 1) & 1], 0, dirty_bytes, stream));
                 hipLaunchKernelGGL(hysteresis_kernel, hyst_grid, dim3(256), 0, stream, b.map, g, b.dirty[launch & 1], b.dirty[(launch + 1) & 1],
                                    b.flags + i, (int)hgrid.x, (int)hgrid.y, hyst_tiles, hyst_tpw);
             }
