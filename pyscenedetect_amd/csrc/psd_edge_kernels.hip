@@ -820,8 +820,13 @@ __global__ __launch_bounds__(256) void pack_dilate_kernel(const uint8_t* map, Ed
     u32* raw = pd_lds;                                             // [nrows][pitch], one zero word on each side
     u32* hd = pd_lds + (size_t)(band + k - 1) * pitch;             // [nrows][pitch] horizontally dilated
     const uint8_t* M = map + (size_t)j * g.npix;
-    for (int i = threadIdx.x; i < nrows * pitch; i += 256) {
-        const int rr = i / pitch, w = i - rr * pitch;
+    // rows by thread group, words by lane within the group (a power of two >= the row pitch, at most a wave): no division by
+    // the run-time pitch in the three loops
+    const int sh = pitch <= 8 ? 3 : pitch <= 16 ? 4 : pitch <= 32 ? 5 : 6;
+    const int lane = threadIdx.x & ((1 << sh) - 1), wave = threadIdx.x >> sh, nwave = 256 >> sh, lstep = 1 << sh;
+    for (int rr = wave; rr < nrows; rr += nwave)
+    for (int w = lane; w < pitch; w += lstep) {
+        const int i = rr * pitch + w;
         u32 bits = 0;
         if (w >= 1 && w <= nw) {
             const int xb = (w - 1) * 32;
@@ -843,8 +848,8 @@ __global__ __launch_bounds__(256) void pack_dilate_kernel(const uint8_t* map, Ed
     }
     __syncthreads();
     const int left = k / 2, right = k - 1 - k / 2;  // output x is set if any input in [x-left, x+right] is set
-    for (int i = threadIdx.x; i < nrows * nw; i += 256) {
-        const int rr = i / nw, w = i - rr * nw;
+    for (int rr = wave; rr < nrows; rr += nwave)
+    for (int w = lane; w < nw; w += lstep) {
         const u32 lo = raw[rr * pitch + w], mid = raw[rr * pitch + w + 1], hi = raw[rr * pitch + w + 2];
         // OR of the shifts 0..n by doubling (x |= x >> 1, >> 2, >> 4 ... then one shift for the remainder) on the 64-bit
         // pairs (hi:mid) and (mid:lo): 3 + 3 steps for k = 13 instead of 12 funnel shifts; windows reach at most one word
@@ -862,8 +867,8 @@ __global__ __launch_bounds__(256) void pack_dilate_kernel(const uint8_t* map, Ed
         hd[rr * pitch + w] = out;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (y1 - y0) * nw; i += 256) {
-        const int ly = i / nw, w = i - ly * nw;
+    for (int ly = wave; ly < y1 - y0; ly += nwave)
+    for (int w = lane; w < nw; w += lstep) {
         const int y = y0 + ly;
         const int ytop = max(y - up, 0), ybot = min(y + dn, H - 1);
         u32 v = 0;
