@@ -25,6 +25,9 @@ timeout 300 python tools/bbc_standin.py --dump $O/bbc_standin_predictions.json 2
 cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace -o t -- python $R/bench.py --no-cpu-baseline --no-secondary > $O/bench_under_rocprof.json 2>/dev/null
 cd $R; python tools/rocpd_summary.py $O/trace/*.db > $O/kernel_trace_default_bench.md 2>&1; grep -v "at::native\|rocclr" $O/kernel_trace_default_bench.md | cut -c1-220 | head -8
+( cd /tmp; ET_N=256 ET_SMOOTH=1 timeout 300 rocprofv3 --kernel-trace --stats -d $O/edge_trace -o t --output-format csv -- python $R/tools/edge_time.py > /dev/null 2>&1 )
+python tools/kernel_stats_md.py $O/edge_trace/t_kernel_stats.csv "rocprofv3 --kernel-trace --stats of ET_N=256 ET_SMOOTH=1 tools/edge_time.py (edge term alone, 3 calls of 256 x 1080p shot-like frames)" > $O/edge_pipeline_kernel_trace_shotlike_N256.md 2>&1; head -12 $O/edge_pipeline_kernel_trace_shotlike_N256.md | cut -c1-160
+rm -rf $O/edge_trace
 for what in content downscale; do
   if [ $what = content ]; then BA="--frames 4096 --steps 2 --warmup 1"; K=score_frames; else BA="--frames 4096 --steps 2 --warmup 1 --downscale auto"; K=resize_walk; fi
   P=$O/pmc_$what; mkdir -p $P
