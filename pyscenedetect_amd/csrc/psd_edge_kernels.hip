@@ -835,27 +835,51 @@ __global__ __launch_bounds__(256) void pack_dilate_kernel(const uint8_t* map, Ed
     // the run-time pitch in the three loops
     const int sh = pitch <= 8 ? 3 : pitch <= 16 ? 4 : pitch <= 32 ? 5 : 6;
     const int lane = threadIdx.x & ((1 << sh) - 1), wave = threadIdx.x >> sh, nwave = 256 >> sh, lstep = 1 << sh;
-    for (int rr = wave; rr < nrows; rr += nwave)
+    // four rows per step with all eight 16-byte loads issued before the first use: the loop is bound by load latency
+    // (one row per step: 18 dependent round trips per thread, 43 us per workgroup)
+    for (int rr0 = wave; rr0 < nrows; rr0 += 4 * nwave)
     for (int w = lane; w < pitch; w += lstep) {
-        const int i = rr * pitch + w;
-        u32 bits = 0;
-        if (w >= 1 && w <= nw) {
-            const int xb = (w - 1) * 32;
-            const uint8_t* row = M + (size_t)(r0 + rr) * W;
-            if (xb + 32 <= W && ((((uintptr_t)row) + xb) & 15) == 0) {
-                // 32 map bytes (values 0,1,2): bit 1 marks "strong"; gather one bit per byte with a multiply
-                const uint4 a = *reinterpret_cast<const uint4*>(row + xb), c = *reinterpret_cast<const uint4*>(row + xb + 16);
-                const u32 q[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        const int xb = (w - 1) * 32;
+        const bool inside = w >= 1 && w <= nw;
+        uint4 qa[4], qc[4];
+        bool fastp[4];
 #pragma unroll
-                for (int t = 0; t < 8; t++) bits |= ((((q[t] >> 1) & 0x01010101u) * 0x01020408u) >> 24) << (4 * t);
-            } else {
+        for (int u = 0; u < 4; u++) {
+            const int rr = rr0 + u * nwave;
+            const uint8_t* row = M + (size_t)(r0 + min(rr, nrows - 1)) * W;
+            fastp[u] = inside && rr < nrows && xb + 32 <= W && ((((uintptr_t)row) + xb) & 15) == 0;
+            // unconditional loads (a lane without a fast word reads the start of the map, always mapped and aligned): behind a
+            // branch hipcc puts an s_waitcnt vmcnt(0) in front of every pair and the eight loads go out one pair at a time
+            const uint8_t* src = fastp[u] ? row + xb : map;
+            qa[u] = *reinterpret_cast<const uint4*>(src);
+            qc[u] = *reinterpret_cast<const uint4*>(src + 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int rr = rr0 + u * nwave;
+            if (rr >= nrows) break;
+            u32 bits = 0;
+            if (fastp[u]) {
+                // 32 map bytes (values 0,1,2): bit 1 marks "strong".  v_dot4_u32_u8 gathers the bits: the bytes (0 or 2 after
+                // the mask) of two dwords times the weights 1..128 sum to twice the output byte (a 32-bit multiply per dword,
+                // the usual gather, runs at quarter rate here)
+                const u32 q[8] = {qa[u].x, qa[u].y, qa[u].z, qa[u].w, qc[u].x, qc[u].y, qc[u].z, qc[u].w};
+                u32 d[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    d[t] = __builtin_amdgcn_udot4(q[2 * t + 1] & 0x02020202u, 0x80402010u,
+                                                  __builtin_amdgcn_udot4(q[2 * t] & 0x02020202u, 0x08040201u, 0u, false), false);
+                // every d is even and <= 510: its bit 8 falls on the (zero) bit 0 of the next one, d[3] << 23 stays below 2^32
+                bits = ((d[0] | (d[1] << 8) | (d[2] << 16)) >> 1) | (d[3] << 23);
+            } else if (inside) {
+                const uint8_t* row = M + (size_t)(r0 + rr) * W;
                 for (int b = 0; b < 32; b++) {
                     const int x = xb + b;
                     if (x < W && row[x] == 2) bits |= 1u << b;
                 }
             }
+            raw[rr * pitch + w] = bits;
         }
-        raw[i] = bits;
     }
     __syncthreads();
     const int left = k / 2, right = k - 1 - k / 2;  // output x is set if any input in [x-left, x+right] is set
@@ -865,14 +889,15 @@ __global__ __launch_bounds__(256) void pack_dilate_kernel(const uint8_t* map, Ed
         // OR of the shifts 0..n by doubling (x |= x >> 1, >> 2, >> 4 ... then one shift for the remainder) on the 64-bit
         // pairs (hi:mid) and (mid:lo): 3 + 3 steps for k = 13 instead of 12 funnel shifts; windows reach at most one word
         // across (k <= 63, enforced in psd_engine.cpp, keeps left and right below 32)
-        u64 r = ((u64)hi << 32) | mid, l = ((u64)mid << 32) | lo;
+        // (as two 32-bit halves with v_alignbit_b32 funnel shifts: 64-bit shifts run at quarter rate)
+        u32 rl = mid, rh = hi, lh = mid, ll = lo;
         int cover = 1;
-        for (; 2 * cover <= right + 1; cover *= 2) r |= r >> cover;
-        if (cover < right + 1) r |= r >> (right + 1 - cover);
+        for (; 2 * cover <= right + 1; cover *= 2) { rl |= __builtin_amdgcn_alignbit(rh, rl, cover); rh |= rh >> cover; }
+        if (cover < right + 1) rl |= __builtin_amdgcn_alignbit(rh, rl, right + 1 - cover);
         cover = 1;
-        for (; 2 * cover <= left + 1; cover *= 2) l |= l << cover;
-        if (cover < left + 1) l |= l << (left + 1 - cover);
-        u32 out = (u32)r | (u32)(l >> 32);
+        for (; 2 * cover <= left + 1; cover *= 2) { lh |= __builtin_amdgcn_alignbit(lh, ll, 32 - cover); ll |= ll << cover; }
+        if (cover < left + 1) lh |= __builtin_amdgcn_alignbit(lh, ll, 32 - (left + 1 - cover));
+        u32 out = rl | lh;
         const int xb = w * 32;
         if (xb + 32 > W) out &= (1u << (W - xb)) - 1u;
         hd[rr * pitch + w] = out;
@@ -882,9 +907,16 @@ __global__ __launch_bounds__(256) void pack_dilate_kernel(const uint8_t* map, Ed
     for (int w = lane; w < nw; w += lstep) {
         const int y = y0 + ly;
         const int ytop = max(y - up, 0), ybot = min(y + dn, H - 1);
-        u32 v = 0;
-        for (int yy = ytop; yy <= ybot; yy++) v |= hd[(yy - r0) * pitch + w];
-        dil[((size_t)j * H + y) * nw + w] = v;
+        // four independent partial ORs: a single chain waits for one LDS round trip per row of the window
+        u32 v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        const u32* col = hd + (ytop - r0) * pitch + w;
+        const int nwin = ybot - ytop + 1;
+        int q = 0;
+        for (; q + 4 <= nwin; q += 4) {
+            v0 |= col[q * pitch]; v1 |= col[(q + 1) * pitch]; v2 |= col[(q + 2) * pitch]; v3 |= col[(q + 3) * pitch];
+        }
+        for (; q < nwin; q++) v0 |= col[q * pitch];
+        dil[((size_t)j * H + y) * nw + w] = (v0 | v1) | (v2 | v3);
     }
 }
 
