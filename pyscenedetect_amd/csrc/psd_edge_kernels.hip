@@ -552,24 +552,23 @@ __global__ __launch_bounds__(256) void sobel_nms_tile_kernel(const uint8_t* vpla
         const int cw = lane & 31;
         const int left = (x0 == 0 && cw == 0) ? 1 : 0;
         const uint8_t* col = V + x0 - 4 + 4 * (cw + left);
+        // all six loads go out before the first LDS write (the loads are unconditional on a clamped row, only the writes are
+        // predicated: behind a branch hipcc waits for every load before issuing the next -- six memory latencies per tile)
+        u32 v[5];
+#pragma unroll
+        for (int it = 0; it < 5; it++) {
+            const int ly = min(2 * (wave * 5 + it) + (lane >> 5), N2_H + 3);
+            v[it] = *reinterpret_cast<const u32*>(col + (size_t)min(max(y0 + ly - 2, 0), H - 1) * W);
+        }
+        const int tl = min(tid >> 1, N2_H + 3), c2 = 32 + (tid & 1);
+        const int right = (x0 + N2_W == W && c2 == 33) ? 1 : 0;
+        u32 vt = *reinterpret_cast<const u32*>(V + (size_t)min(max(y0 + tl - 2, 0), H - 1) * W + x0 - 4 + 4 * (c2 - right));
 #pragma unroll
         for (int it = 0; it < 5; it++) {
             const int ly = 2 * (wave * 5 + it) + (lane >> 5);
-            if (ly < N2_H + 4) {
-                const int y = min(max(y0 + ly - 2, 0), H - 1);
-                u32 v = *reinterpret_cast<const u32*>(col + (size_t)y * W);
-                if (left) v = (v & 0xffu) * 0x01010101u;          // BORDER_REPLICATE: V[y][0] four times
-                *reinterpret_cast<u32*>(&sv[ly][4 * cw]) = v;
-            }
+            if (ly < N2_H + 4) *reinterpret_cast<u32*>(&sv[ly][4 * cw]) = left ? __builtin_amdgcn_perm(v[it], v[it], 0u) : v[it];   // BORDER_REPLICATE: V[y][0] four times
         }
-        if (tid < 2 * (N2_H + 4)) {
-            const int ly = tid >> 1, c2 = 32 + (tid & 1);
-            const int right = (x0 + N2_W == W && c2 == 33) ? 1 : 0;
-            const int y = min(max(y0 + ly - 2, 0), H - 1);
-            u32 v = *reinterpret_cast<const u32*>(V + (size_t)y * W + x0 - 4 + 4 * (c2 - right));
-            if (right) v = (v >> 24) * 0x01010101u;               // V[y][W-1] four times
-            *reinterpret_cast<u32*>(&sv[ly][4 * c2]) = v;
-        }
+        if (tid < 2 * (N2_H + 4)) *reinterpret_cast<u32*>(&sv[tl][4 * c2]) = right ? __builtin_amdgcn_perm(vt, vt, 0x03030303u) : vt;   // V[y][W-1] four times
     }
     __syncthreads();
     const bool inner = x0 >= 4 && x0 + N2_W + 4 <= W && y0 >= 2 && y0 + N2_H + 2 <= H;
