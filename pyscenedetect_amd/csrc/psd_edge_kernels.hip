@@ -968,6 +968,8 @@ struct EdgeBuffers {
     uint8_t* vplane; uint8_t* map; u32* hist; int2* thr; u32* hbits; u32* dil; u32* carry;
     unsigned long long* xr; int* flags; int2* thr_tab; uint8_t* dirty[2];
     int cap_frames; size_t tiles_per_frame;
+    uint8_t* zero_begin; size_t zero_bytes;   // hist, xr, both tile lists and the flags: cleared by ONE memset per chunk
+    bool fresh;                               // the workspace was (re)allocated by this call
 };
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -990,29 +992,33 @@ static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeB
     const size_t need = per_frame * (size_t)frames + fixed;
     void** ws = engine_edge_ws(e);
     size_t* ws_bytes = engine_edge_ws_bytes(e);
+    b->fresh = false;
     if (*ws_bytes < need) {
         if (*ws) HIP_TRY(hipFree(*ws));
         *ws = nullptr; *ws_bytes = 0;
         HIP_TRY(hipMalloc(ws, need));
         *ws_bytes = need;
+        b->fresh = true;
     } else {
         // the cached workspace may fit more frames than computed for `want_frames`; keep `frames`
     }
     uint8_t* p = (uint8_t*)*ws;
     auto take = [&](size_t bytes) { uint8_t* r = p; p += align_up(bytes); return r; };
+    b->thr_tab = (int2*)take(511 * sizeof(int2));   // first: its place does not depend on the geometry (uploaded once)
     b->vplane = take((size_t)g.npix * frames);
     b->map = take((size_t)g.npix * frames);
-    b->hist = (u32*)take((size_t)frames * 256 * 4);
     b->thr = (int2*)take((size_t)frames * sizeof(int2));
     b->hbits = (u32*)take(words * 4 * frames);
     b->dil = (u32*)take(words * 4 * frames);
+    b->carry = (u32*)take(words * 4);
+    b->zero_begin = p;
+    b->hist = (u32*)take((size_t)frames * 256 * 4);
     b->xr = (unsigned long long*)take((size_t)frames * 8);
     b->dirty[0] = take(tiles * frames);
     b->dirty[1] = take(tiles * frames);
-    b->tiles_per_frame = tiles;
-    b->carry = (u32*)take(words * 4);
     b->flags = (int*)take(64 * sizeof(int));
-    b->thr_tab = (int2*)take(511 * sizeof(int2));
+    b->zero_bytes = (size_t)(p - b->zero_begin);
+    b->tiles_per_frame = tiles;
     b->cap_frames = frames;
     if ((size_t)(p - (uint8_t*)*ws) > *ws_bytes) { psd_set_error("edge workspace layout overflow"); return PSD_ERR_NOMEM; }
     return PSD_OK;
@@ -1050,7 +1056,7 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
                       int* d_unconverged = nullptr)
 {
     const size_t words = (size_t)g.height * g.words_per_row;
-    HIP_TRY(hipMemsetAsync(b.hist, 0, (size_t)count * 256 * 4, stream));
+    HIP_TRY(hipMemsetAsync(b.zero_begin, 0, b.zero_bytes, stream));   // histograms, XOR counters, both tile lists, flags
     // packed 16-byte aligned frames with a multiple of 16 pixels take the LDS-DMA streaming variant
     static const bool vp_direct = [] { const char* e = getenv("PSD_EDGE_VP_DIRECT"); return e && atoi(e) != 0; }();
     const bool vp_dma = !vp_direct && g.row_stride == (size_t)g.width * 3 && (g.npix & 15) == 0 && (g.frame_stride & 15) == 0 &&
@@ -1074,7 +1080,6 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
     const dim3 hyst_grid((unsigned)((hyst_tiles + hyst_tpw - 1) / hyst_tpw));
     if ((g.width & 3) == 0 && (g.npix & 3) == 0 && !nms_bytes) {
         // the dword kernel reports which hysteresis tiles hold weak pixels: only those are looked at
-        HIP_TRY(hipMemsetAsync(b.dirty[0], 0, dirty_bytes, stream));
         static const bool no_tile = [] { const char* e = getenv("PSD_EDGE_NMS_DWORD"); return e && atoi(e) != 0; }();
         if (g.width % N2_W == 0 && !no_tile)
             hipLaunchKernelGGL(sobel_nms_tile_kernel, dim3(g.width / N2_W, (g.height + N2_H - 1) / N2_H, count), dim3(256), 0, stream,
@@ -1090,11 +1095,9 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
     HIP_TRY(hipGetLastError());
     // hysteresis to the fix point: rounds of R launches (ping-pong dirty-tile lists, one flag per
     // launch); done when a launch promoted nothing on any tile border.
-    // every launch empties the list it read, so the two lists only need clearing once
-    HIP_TRY(hipMemsetAsync(b.dirty[1], 0, dirty_bytes, stream));
+    // every launch empties the list it read, so the two lists only need the clearing at the top of the chunk
     int launch = 0;
     if (d_unconverged) {
-        HIP_TRY(hipMemsetAsync(b.flags, 0, HYST_SPEC_LAUNCHES * sizeof(int), stream));
         for (; launch < HYST_SPEC_LAUNCHES; launch++) {
             hipLaunchKernelGGL(hysteresis_kernel, hyst_grid, dim3(256), 0, stream, b.map, g, b.dirty[launch & 1], b.dirty[(launch + 1) & 1],
                                b.flags + launch, (int)hgrid.x, (int)hgrid.y, hyst_tiles, hyst_tpw);
@@ -1104,13 +1107,15 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
         bool converged = false;
         for (int round = 0; round < 4096 && !converged; round++) {
             constexpr int R = 3;
-            HIP_TRY(hipMemsetAsync(b.flags, 0, R * sizeof(int), stream));
+            // a fresh flag per launch out of the 64 cleared at the top of the chunk (re-cleared every 21 rounds)
+            const int fbase = (round % (64 / R)) * R;
+            if (round > 0 && fbase == 0) HIP_TRY(hipMemsetAsync(b.flags, 0, 64 * sizeof(int), stream));
             for (int i = 0; i < R; i++, launch++) {
                 hipLaunchKernelGGL(hysteresis_kernel, hyst_grid, dim3(256), 0, stream, b.map, g, b.dirty[launch & 1], b.dirty[(launch + 1) & 1],
-                                   b.flags + i, (int)hgrid.x, (int)hgrid.y, hyst_tiles, hyst_tpw);
+                                   b.flags + fbase + i, (int)hgrid.x, (int)hgrid.y, hyst_tiles, hyst_tpw);
             }
             int flags[R];
-            HIP_TRY(hipMemcpyAsync(flags, b.flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(flags, b.flags + fbase, sizeof(flags), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             for (int i = 0; i < R; i++) converged = converged || !flags[i];   // a launch with nothing to pass on ends it
         }
@@ -1159,7 +1164,12 @@ int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
     // the 511 threshold pairs never change: built once, kept for the life of the process (no stack buffer behind an
     // asynchronous copy, no synchronisation on the call path)
     static const int2* tab = [] { int2* t = new int2[511]; threshold_table(t); return t; }();
-    HIP_TRY(hipMemcpyAsync(b.thr_tab, tab, 511 * sizeof(int2), hipMemcpyHostToDevice, stream));
+    // ... and uploaded once per workspace: the table sits at its start, whatever the geometry
+    static thread_local const void* tab_in_ws = nullptr;
+    if (b.fresh || tab_in_ws != (const void*)b.thr_tab) {
+        HIP_TRY(hipMemcpyAsync(b.thr_tab, tab, 511 * sizeof(int2), hipMemcpyHostToDevice, stream));
+        tab_in_ws = b.thr_tab;
+    }
     const size_t words = (size_t)g.height * g.words_per_row;
     int done = 0;          // virtual frames processed
     bool have_carry = false;
@@ -1172,7 +1182,6 @@ int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
         src.start = done - (d_prev ? 1 : 0) + src.first_is_prev;  // batch index of the first non-prev virtual frame
         rc = edge_chunk(g, src, count, k, b, stream, d_unconverged);
         if (rc != PSD_OK) return rc;
-        HIP_TRY(hipMemsetAsync(b.xr, 0, (size_t)count * 8, stream));
         hipLaunchKernelGGL(xor_count_kernel, dim3((unsigned)((words + 255) / 256), count), dim3(256), 0, stream, b.dil, (long)words,
                            b.carry, have_carry ? 1 : 0, b.xr);
         hipLaunchKernelGGL(store_xor_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, b.xr, count, src.first_is_prev,
