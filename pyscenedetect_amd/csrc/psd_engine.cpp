@@ -334,11 +334,12 @@ static int score_terms(psd_engine* e, psd_slot& s, const uint8_t* d_frames, int 
     }
     if (flags & PSD_SCORE_EDGES) {
         int* spec = nullptr;
-        // PSD_EDGE_SPECULATIVE=1: a fixed number of hysteresis launches and no host round trip inside the submission;
-        // psd_score_collect repeats the term on the exact path if a frame needed more.  Off by default -- measured on
-        // 1080p (tools/edge_time.py): shot-like content 119 k frames/s vs 126 k with the host-driven loop (which syncs
-        // once per ~190-frame chunk), uniform noise 23 k vs 55 k (noise needs the repeat every time).
-        static const bool speculative = [] { const char* v = getenv("PSD_EDGE_SPECULATIVE"); return v && atoi(v) != 0; }();
+        // A fixed number of hysteresis launches and no host round trip inside the submission; psd_score_collect repeats
+        // the term on the exact path if a frame needed more (tests/test_gpu_fullsize.py builds such a chain).  On by default
+        // since the hysteresis launches became cheap (5 us each: tools/edge_time.py on 1080p shot-like content 184 / 252 /
+        // 267 k frames/s at 64 / 256 / 1024 frames per call against 163 / 242 / 261 k with the host-driven loop, uniform noise
+        // 60 k either way); PSD_EDGE_SPECULATIVE=0 selects the host-driven loop.
+        static const bool speculative = [] { const char* v = getenv("PSD_EDGE_SPECULATIVE"); return !v || atoi(v) != 0; }();
         if (frames_outlive_collect && speculative) {
             // the caller keeps the frames until the submission is collected, so a non-converged hysteresis can be
             // repeated there
