@@ -375,9 +375,20 @@ __global__ __launch_bounds__(256) void sobel_nms_dword_kernel(const uint8_t* vpl
     const int x0 = blockIdx.x * N2_W, y0 = blockIdx.y * N2_H, H = g.height, W = g.width;
     const bool inner = x0 >= 4 && x0 + N2_W + 4 <= W && y0 >= 2 && y0 + N2_H + 2 <= H;
     if (inner) {
-        for (int i = tid; i < (N2_H + 4) * N2_NCG; i += 256) {
+        // all five loads before the first LDS write (as a loop, each load is waited for before the next is issued)
+        constexpr int NLD = ((N2_H + 4) * N2_NCG + 255) / 256;
+        u32 v[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; it++) {
+            const int i = min(tid + it * 256, (N2_H + 4) * N2_NCG - 1);
             const int ly = i / N2_NCG, lw = i - ly * N2_NCG;
-            *reinterpret_cast<u32*>(&sv[ly][lw * 4]) = *reinterpret_cast<const u32*>(V + (size_t)(y0 + ly - 2) * W + x0 - 4 + lw * 4);
+            v[it] = *reinterpret_cast<const u32*>(V + (size_t)(y0 + ly - 2) * W + x0 - 4 + lw * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NLD; it++) {
+            const int i = tid + it * 256;
+            const int ly = i / N2_NCG, lw = i - ly * N2_NCG;
+            if (i < (N2_H + 4) * N2_NCG) *reinterpret_cast<u32*>(&sv[ly][lw * 4]) = v[it];
         }
     } else {   // border tiles: replicate (BORDER_REPLICATE of cv2.Sobel inside Canny)
         for (int i = tid; i < (N2_H + 4) * N2_SVW; i += 256) {
@@ -548,6 +559,7 @@ __global__ __launch_bounds__(256) void sobel_nms_tile_kernel(const uint8_t* vpla
     const int j = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint8_t* V = vplane + (size_t)j * g.npix;
     const int x0 = blockIdx.x * N2_W, y0 = blockIdx.y * N2_H, H = g.height, W = g.width;
+    const int2 lohi = thr[j];   // read here: behind the barriers its latency would sit in front of phase 2
     {
         const int cw = lane & 31;
         const int left = (x0 == 0 && cw == 0) ? 1 : 0;
@@ -576,7 +588,7 @@ __global__ __launch_bounds__(256) void sobel_nms_tile_kernel(const uint8_t* vpla
     else sobel_phase1_quads<false>(sv, smq, tid, x0, y0, H, W);
     __syncthreads();
     // ---- phase 2: non-maximum suppression, eight pixels of a row per thread and step
-    const int low = thr[j].x, high = thr[j].y;
+    const int low = lohi.x, high = lohi.y;
     const u32 lowpk = (u32)low * 0x10001u;
 #pragma unroll
     for (int it = 0; it < N2_H * (N2_W / 8) / 256; it++) {
