@@ -35,6 +35,23 @@
 #ifndef PSD_PACK3
 #define PSD_PACK3 1
 #endif
+
+// Histogram increment in LDS that the compiler does not see as an LDS store.  hipcc orders every LDS store / atomic
+// behind all outstanding LDS-DMA (global_load_lds) with an s_waitcnt vmcnt(0) -- a write-after-write guard it applies without
+// looking at the addresses -- so a histogram update in the arithmetic of frame t waits for the staging slots of frame t + 1
+// to be filled: the prefetch is serialised with the arithmetic inside every wave (the fused pass: 7.8 ms; frame loads alone
+// 4.1 ms, arithmetic alone 5.8 ms).  The increments never touch the staging slots.  LDS operations of a wave complete in
+// order, so the compiler's own lgkmcnt bookkeeping stays conservative; what it can no longer know is that increments are
+// outstanding, hence lds_hidden_fence() in front of every barrier behind which another thread reads the accumulators.
+__device__ __forceinline__ void lds_add_hidden(const uint32_t* p, uint32_t inc)
+{
+    asm volatile("ds_add_u32 %0, %1" ::"v"((uint32_t)(uintptr_t)p), "v"(inc) : "memory");
+}
+__device__ __forceinline__ void lds_add_hidden_at(uint32_t lds_byte_address, uint32_t inc)
+{
+    asm volatile("ds_add_u32 %0, %1" ::"v"(lds_byte_address), "v"(inc) : "memory");
+}
+__device__ __forceinline__ void lds_hidden_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 #ifndef PSD_FUSED_PHASED
 #define PSD_FUSED_PHASED 1   // the fused HSV + luma quad in phases (quad_fused); 0 = pixel by pixel as in round 1
 #endif
@@ -200,7 +217,7 @@ __device__ __forceinline__ void pixel(const u32 (&d)[3], u32& hq, u32& sq, u32& 
         // (B2Y*b + G2Y*g + R2Y*r + 8192) >> 14; the rounding term rides on the first product
         const u32 y = mad_u24_vsv(r, kR2Y, mad_u24_vsv(gg, kG2Y, mad_u24_vvs(b, vgpr_b2y(), 8192u))) >> 14;
         // inc is 1, or 0 for a lane that owns no group here (cheaper than predicating every atomic)
-        __hip_atomic_fetch_add(&hist[y * AC], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_add_hidden(&hist[y * AC], inc);
     }
 #if PSD_ABLATE & 8
     if (HSV) { hq += b + (gg << 8); sq += r; vq ^= b; }
@@ -271,10 +288,25 @@ __device__ __forceinline__ u32 perm_b32(u32 s0, u32 s1, u32 sel) { return __buil
 #endif
 
 typedef const __attribute__((address_space(3))) float* lds_cf32_t;
+typedef const __attribute__((address_space(3))) char* lds_cc_t;
+typedef __attribute__((address_space(3))) char* lds_c_t;
+
+// The LDS word at the absolute LDS byte address `abs`, which lies inside the object `obj` points into.  Written as an
+// offset from `obj` (the arithmetic folds away: the address register is `abs` itself) so that the access keeps its
+// provenance: an LDS address made from an integer may alias the staging slots as far as the compiler can tell, and it then
+// puts an s_waitcnt vmcnt(0) -- "wait for the LDS-DMA of the NEXT frame" -- in front of the first table read of every step,
+// which serialises the prefetch with the arithmetic inside a wave.
+__device__ __forceinline__ float lds_f32_in(const u32* obj, u32 abs)
+{
+    const lds_cc_t b = (lds_cc_t)obj;
+    return *(lds_cf32_t)(b + (abs - (u32)(uintptr_t)b));
+}
 
 struct FpLane {          // per-lane constants of the fp32 formulation
     u32 bias;            // 0x4B000000: float 2^23 with a zero low byte
     u32 off_s, off_h;    // LDS byte address of this lane's replica of the two tables
+    const u32* obj_s;    // ... and the pointers they came from (provenance for lds_f32_in)
+    const u32* obj_h;
     float bias_h;        // LS == 4 only: 2^21 + off_h / 16 (see pixel_fp_front)
 };
 
@@ -355,8 +387,8 @@ __device__ __forceinline__ void pixel_fp_front(const u32 (&d)[3], const FpLane& 
     } else {
         a_h = lshl16_add<LS>(__float_as_uint(x.diff + 8388608.0f), fl.off_h);
     }
-    x.sdiv = *(lds_cf32_t)(uintptr_t)a_s;
-    x.hdiv = *(lds_cf32_t)(uintptr_t)a_h;
+    x.sdiv = lds_f32_in(fl.obj_s, a_s);
+    x.hdiv = lds_f32_in(fl.obj_h, a_h);
 }
 
 // phase 2: hraw = v == r ? g - b : v == g ? b - r + 2 diff : r - g + 4 diff (the biases cancel).
@@ -466,7 +498,7 @@ __device__ __forceinline__ void quad_fused(const u32 (&d)[3], u32& hq_out, u32& 
     // phase D: the histogram increments, behind the reads in the LDS queue
 #pragma unroll
     for (int k = 0; k < 4; k++)
-        __hip_atomic_fetch_add(&hist[y[k] * AC], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_add_hidden(&hist[y[k] * AC], inc);
 }
 
 // 8-bit BGR -> HSV exactly as OpenCV's RGB2HSV_b (hsv_shift = 12, hue range 180), plus luma
@@ -493,6 +525,8 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
         fl.off_s = (u32)(uintptr_t)lut_s;   // low half of a flat LDS address = the LDS byte address
         fl.bias = S1 ? (0x4B000000u | ((fl.off_s >> 10) << 8)) : 0x4B000000u;
         fl.off_h = (u32)(uintptr_t)lut_h;
+        fl.obj_s = lut_s;
+        fl.obj_h = lut_h;
         fl.bias_h = 2097152.0f + (float)fl.off_h * 0.0625f;   // exact: off_h is a multiple of 4 below 2^16
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -534,7 +568,7 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
 #endif
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    __hip_atomic_fetch_add((lds_u32_t)(uintptr_t)ya[k], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    lds_add_hidden_at(ya[k], inc);
             }
         }
         return;
@@ -756,6 +790,7 @@ __global__ __launch_bounds__(WG) void score_frames_kernel(const ScoreParams p)
             __hip_atomic_fetch_add(&my_hist[ACC_BYTES * COPIES], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         have_prev = true;
 #if !(PSD_ABLATE & 2)
+        if (LUMA) lds_hidden_fence();
         __syncthreads();
         // Frame t is complete in acc[buf]; frame t+1 accumulates into the other buffer, so no
         // second barrier is needed (the barrier of frame t+1 orders this flush before reuse).
@@ -990,6 +1025,9 @@ void score_frames_dma_kernel(const ScoreParams p)
         u32* my_acc = &acc[slot][0] + lacc;
         // Frame t has been in flight since the previous step; take it out of the staging slot and
         // immediately refill the slot with frame t+1.
+        // the first frame of a clip packed into the batch has no predecessor (p.seg, psd_score_segments_device); read before the
+        // wait below, which then covers it -- behind the DMA issue it would wait for the NEXT frame's staging as well
+        const bool clip_start = p.seg != nullptr && p.seg[t] != 0;
 #if !(PSD_ABLATE & 4)
         PT(5)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1005,8 +1043,7 @@ void score_frames_dma_kernel(const ScoreParams p)
             for (int i = 0; i < 12; i++) asm volatile("" : "+v"(cur[k].w[i]));
 #endif
         u32 sh = 0, ss = 0, sv = 0, bs = 0;
-        // the first frame of a clip packed into the batch has no predecessor (p.seg, psd_score_segments_device)
-        const bool chain = have_prev && !(p.seg != nullptr && p.seg[t] != 0);
+        const bool chain = have_prev && !clip_start;
 #pragma unroll
         for (int k = 0; k < G; k++) {
             if (HSV || live[k]) {
@@ -1033,6 +1070,7 @@ void score_frames_dma_kernel(const ScoreParams p)
         // are complete in one half of the slot ring: flush that half while the other half fills.
         const int done = t - t0 + 1;
         if (done % F == 0 || t + 1 == t1) {
+            if (LUMA) lds_hidden_fence();
             __syncthreads();
             PT(3)
             const int nf = (done % F == 0) ? F : done % F;       // frames in this half
@@ -1102,6 +1140,7 @@ __global__ __launch_bounds__(kLumaWG) void luma_hist_kernel(const ScoreParams p)
         }
     }
     __hip_atomic_fetch_add(&my_acc[ACC_BYTES * AC], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    lds_hidden_fence();
     __syncthreads();
     for (int i = tid; i < 2 * NACC; i += WG) flush_slot<true, AC>(acc, p.out + t, i);
 }
