@@ -198,7 +198,9 @@ __global__ __launch_bounds__(256) void value_plane_hist_dma_kernel(ChunkSrc src,
                     const u32 gg = (w[k][ig >> 2] >> ((ig & 3) * 8)) & 0xffu;
                     const u32 rr = (w[k][ir >> 2] >> ((ir & 3) * 8)) & 0xffu;
                     const u32 v = max(max(bb, gg), rr);
-                    __hip_atomic_fetch_add(&my_h[v * AC], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // (an LDS add the compiler does not see as an LDS store: it orders every LDS store behind all outstanding
+                    //  LDS-DMA with s_waitcnt vmcnt(0), i.e. behind the NEXT step's staging -- psd_score_kernels.hip, lds_add_hidden)
+                    asm volatile("ds_add_u32 %0, %1" ::"v"((u32)(uintptr_t)&my_h[v * AC]), "v"(1u) : "memory");
                     o[i >> 2] |= v << ((i & 3) * 8);
                 }
                 u32x4 pk;
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(256) void value_plane_hist_dma_kernel(ChunkSrc src,
             }
         }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the hidden increments, before anyone reads the histogram
     __syncthreads();
     {
         const int b = tid;
