@@ -10,6 +10,8 @@ if os.environ.get("ET_SMOOTH"):
     for i in range(N):
         x[i] = (base + torch.randn((H, W, 3), device="cuda") * 2).round().clamp(0, 255).to(torch.uint8)
 torch.cuda.synchronize()
-for _ in range(3):
-    t0 = time.perf_counter(); eng.score_device(x.data_ptr(), N, H, W, flags=E.SCORE_EDGES); dt = time.perf_counter() - t0
-print(f"edges N={N}: {dt*1e3:.2f} ms  {N/dt:.0f} fps")
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter(); eng.score_device(x.data_ptr(), N, H, W, flags=E.SCORE_EDGES); ts.append(time.perf_counter() - t0)
+dt = min(ts[1:])
+print(f"edges N={N}: {dt*1e3:.2f} ms  {N/dt:.0f} fps   (calls 2-5: {' '.join('%.2f' % (t * 1e3) for t in ts[1:])} ms)")
