@@ -1067,8 +1067,11 @@ constexpr int HYST_SPEC_LAUNCHES = 6;   // hysteresis launches of the speculativ
 // after every round (exact, blocks the calling thread).  Otherwise: HYST_SPEC_LAUNCHES launches are enqueued without
 // any host round trip and *d_unconverged is set if the last one still promoted pixels on a tile border -- the caller
 // then repeats the work on the exact path (weak-edge chains that long are rare: tests/test_gpu_fullsize.py builds one).
+// hsv != nullptr: the chunk's real frames get their V plane and V histogram from the HSV pass in V mode (one read of the
+// frames for both terms, psd_score_kernels.hip); only a predecessor frame standing in as virtual frame 0 still goes
+// through the V-plane kernel.
 static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, const EdgeBuffers& b, hipStream_t stream,
-                      int* d_unconverged = nullptr)
+                      int* d_unconverged = nullptr, const ScoreParams* hsv = nullptr, int target_blocks = 0, int* launches = nullptr)
 {
     const size_t words = (size_t)g.height * g.words_per_row;
     HIP_TRY(hipMemsetAsync(b.zero_begin, 0, b.zero_bytes, stream));   // histograms, XOR counters, both tile lists, flags
@@ -1076,16 +1079,18 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
     static const bool vp_direct = [] { const char* e = getenv("PSD_EDGE_VP_DIRECT"); return e && atoi(e) != 0; }();
     const bool vp_dma = !vp_direct && g.row_stride == (size_t)g.width * 3 && (g.npix & 15) == 0 && (g.frame_stride & 15) == 0 &&
                         ((uintptr_t)src.frames & 15) == 0 && (!src.first_is_prev || ((uintptr_t)src.prev & 15) == 0);
-    if (vp_dma) {
+    const int vp_count = hsv ? (src.first_is_prev ? 1 : 0) : count;   // virtual frames the V-plane kernel converts
+    if (vp_count > 0 && vp_dma) {
         const int n_groups = (int)(g.npix >> 4);
-        const int cap = VD_STEP * (count >= 32 ? VD_STEPS_PER_TILE : 1);
+        const int cap = VD_STEP * (vp_count >= 32 ? VD_STEPS_PER_TILE : 1);
         const int tiles = (n_groups + cap - 1) / cap;
         const int groups_per_tile = (n_groups + tiles - 1) / tiles;
-        hipLaunchKernelGGL(value_plane_hist_dma_kernel, dim3(tiles, count), dim3(256), 0, stream, src, g, groups_per_tile, b.vplane, b.hist);
-    } else {
-        hipLaunchKernelGGL(value_plane_hist_kernel, dim3((unsigned)((g.npix + 1024 * VP_ITER - 1) / (1024 * VP_ITER)), count), dim3(256), 0, stream, src, g,
+        hipLaunchKernelGGL(value_plane_hist_dma_kernel, dim3(tiles, vp_count), dim3(256), 0, stream, src, g, groups_per_tile, b.vplane, b.hist);
+    } else if (vp_count > 0) {
+        hipLaunchKernelGGL(value_plane_hist_kernel, dim3((unsigned)((g.npix + 1024 * VP_ITER - 1) / (1024 * VP_ITER)), vp_count), dim3(256), 0, stream, src, g,
                            b.vplane, b.hist);
     }
+    if (hsv) HIP_TRY(launch_score_frames(*hsv, true, false, true, target_blocks, stream, launches));
     hipLaunchKernelGGL(median_thresholds_kernel, dim3(count), dim3(256), 0, stream, b.hist, g.npix, b.thr_tab, b.thr);
     static const bool nms_bytes = [] { const char* e = getenv("PSD_EDGE_NMS_BYTES"); return e && atoi(e) != 0; }();
     const dim3 hgrid((g.width + HT - 1) / HT, (g.height + HT - 1) / HT, count);
@@ -1168,7 +1173,8 @@ static EdgeGeom make_geom(int height, int width, size_t row_stride, size_t frame
 
 int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
                 size_t frame_stride, const uint8_t* d_prev, int edge_kernel, psd_frame_scores* d_out,
-                hipStream_t stream, const uint8_t* d_seg, int* d_unconverged)
+                hipStream_t stream, const uint8_t* d_seg, int* d_unconverged, const ScoreParams* hsv, int target_blocks,
+                int* launches)
 {
     const EdgeGeom g = make_geom(height, width, row_stride, frame_stride);
     const int k = edge_kernel ? edge_kernel : estimated_kernel_size(width, height);
@@ -1195,7 +1201,19 @@ int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
         src.prev = d_prev;
         src.first_is_prev = (done == 0 && d_prev) ? 1 : 0;
         src.start = done - (d_prev ? 1 : 0) + src.first_is_prev;  // batch index of the first non-prev virtual frame
-        rc = edge_chunk(g, src, count, k, b, stream, d_unconverged);
+        ScoreParams cp;
+        if (hsv) {
+            // the HSV term of this chunk's real frames, in V mode: [src.start, src.start + count - first_is_prev) of the batch
+            cp = *hsv;
+            cp.n = count - src.first_is_prev;
+            cp.frames = hsv->frames + (size_t)src.start * frame_stride;
+            cp.prev = src.start == 0 ? hsv->prev : hsv->frames + (size_t)(src.start - 1) * frame_stride;
+            cp.out = hsv->out + src.start;
+            cp.seg = hsv->seg ? hsv->seg + src.start : nullptr;
+            cp.vout = b.vplane + (src.first_is_prev ? (size_t)g.npix : 0);
+            cp.vhist = b.hist + (src.first_is_prev ? 256 : 0);
+        }
+        rc = edge_chunk(g, src, count, k, b, stream, d_unconverged, hsv ? &cp : nullptr, target_blocks, launches);
         if (rc != PSD_OK) return rc;
         hipLaunchKernelGGL(xor_count_kernel, dim3((unsigned)((words + 255) / 256), count), dim3(256), 0, stream, b.dil, (long)words,
                            b.carry, have_carry ? 1 : 0, b.xr);

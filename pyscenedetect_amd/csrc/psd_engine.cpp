@@ -37,7 +37,8 @@ namespace psd {
 // psd_edge_kernels.hip
 int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
                 size_t frame_stride, const uint8_t* d_prev, int edge_kernel, psd_frame_scores* d_out,
-                hipStream_t stream, const uint8_t* d_seg, int* d_unconverged);
+                hipStream_t stream, const uint8_t* d_seg, int* d_unconverged, const ScoreParams* hsv = nullptr,
+                int target_blocks = 0, int* launches = nullptr);
 int edges_map(psd_engine* e, const uint8_t* d_frame, int height, int width, size_t row_stride,
               int edge_kernel, uint8_t* h_edges);
 void edges_release(psd_engine* e);
@@ -314,8 +315,9 @@ static int score_terms(psd_engine* e, psd_slot& s, const uint8_t* d_frames, int 
 {
     const bool hsv = flags & PSD_SCORE_HSV_SAD;
     const bool luma = flags & (PSD_SCORE_LUMA_HIST | PSD_SCORE_BYTE_SUM);
+    psd::ScoreParams p{};
+    bool hsv_with_edges = false;   // the HSV term is computed by the edge term's front end (V mode: one read of the frames)
     if (hsv || luma) {
-        psd::ScoreParams p{};
         p.frames = d_frames;
         p.prev = d_prev;
         p.seg = d_seg;
@@ -329,8 +331,13 @@ static int score_terms(psd_engine* e, psd_slot& s, const uint8_t* d_frames, int 
         p.n = n;
         const bool fast = row_stride == (size_t)width * 3 && ((uintptr_t)d_frames % 16 == 0) &&
                           (frame_stride % 16 == 0 || n == 1) && (!d_prev || (uintptr_t)d_prev % 16 == 0);
+        // ContentDetector with weights.delta_edges > 0 (or a StatsManager): the HSV pass also writes the V plane and the V
+        // histogram the edge term starts from (PSD_EDGE_FUSE_HSV=0: two separate reads of the frames, as before)
+        static const bool fuse_env = [] { const char* v = getenv("PSD_EDGE_FUSE_HSV"); return !v || atoi(v) != 0; }();
+        hsv_with_edges = hsv && (flags & PSD_SCORE_EDGES) && fast && fuse_env && psd::score_v_mode_available(p.npix);
         // ~8 workgroups per CU over the launch keeps the tail short (one 1024-thread WG per CU).
-        HIP_TRY(psd::launch_score_frames(p, hsv, luma, fast, e->num_cus * 8, stream, &s.launches));
+        if (!hsv_with_edges) HIP_TRY(psd::launch_score_frames(p, hsv, luma, fast, e->num_cus * 8, stream, &s.launches));
+        else if (luma) HIP_TRY(psd::launch_score_frames(p, false, true, fast, e->num_cus * 8, stream, &s.launches));
     }
     if (flags & PSD_SCORE_EDGES) {
         int* spec = nullptr;
@@ -354,7 +361,8 @@ static int score_terms(psd_engine* e, psd_slot& s, const uint8_t* d_frames, int 
             s.edge.n = n; s.edge.height = height; s.edge.width = width; s.edge.edge_kernel = edge_kernel;
             s.edge.row_stride = row_stride; s.edge.frame_stride = frame_stride; s.edge.stream = stream;
         }
-        int rc = psd::edges_score(e, d_frames, n, height, width, row_stride, frame_stride, d_prev, edge_kernel, s.d_recs, stream, d_seg, spec);
+        int rc = psd::edges_score(e, d_frames, n, height, width, row_stride, frame_stride, d_prev, edge_kernel, s.d_recs, stream, d_seg, spec,
+                                  hsv_with_edges ? &p : nullptr, e->num_cus * 8, &s.launches);
         if (rc != PSD_OK) return rc;
         if (spec) HIP_TRY(hipMemcpyAsync(s.h_edge_flag, s.d_edge_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
     }

@@ -31,6 +31,8 @@ struct ScoreParams {
     const uint32_t* lut;     // device, [0..255] = sdiv << 4, [256..511] = hdiv180 << 4
     const uint32_t* lutf;    // device, float32 bit patterns: [0..255] = nextafter(sdiv / 4096), [256..511] = hdiv180 / 4096
     const uint8_t* seg;      // device, n flags: frame t starts a clip (no predecessor), or nullptr
+    uint8_t* vout;           // V mode (HSV term + the edge term's front end in one pass): V plane of frame t at vout + t*npix,
+    uint32_t* vhist;         //   its 256-bin histogram at vhist + t*256 (zeroed by the caller); nullptr otherwise
     size_t frame_stride;
     size_t row_stride;
     long npix;               // height*width
@@ -46,6 +48,8 @@ struct ScoreParams {
 
 hipError_t launch_score_frames(ScoreParams p, bool hsv, bool luma, bool fast, int target_blocks,
                                hipStream_t stream, int* launches);
+// V mode (ScoreParams::vout) needs the staged kernel and frames made of whole 16-pixel groups
+bool score_v_mode_available(long npix);
 
 }  // namespace psd
 

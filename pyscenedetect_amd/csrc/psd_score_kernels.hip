@@ -503,17 +503,18 @@ __device__ __forceinline__ void quad_fused(const u32 (&d)[3], u32& hq_out, u32& 
 
 // 8-bit BGR -> HSV exactly as OpenCV's RGB2HSV_b (hsv_shift = 12, hue range 180), plus luma
 // histogram and byte sum.  lut_s/lut_h/hist are already offset by the lane's replica index.
-template <bool HSV, bool LUMA, int LC = COPIES, int AC = COPIES, bool FP = false, bool S1 = false>
+template <bool HSV, bool LUMA, int LC = COPIES, int AC = COPIES, bool FP = false, bool S1 = false, bool VM = false>
 __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __restrict__ lut_s,
                                               const u32* __restrict__ lut_h, u32* __restrict__ hist,
                                               u32& byte_sum, u32 inc = 1u)
 {
     if constexpr (FP) {
         static_assert(HSV && !(LUMA && S1), "");
+        static_assert(!VM || LUMA, "V mode rides on the histogram slots of the fused pass");
         constexpr int LA = AC == 4 ? 4 : AC == 8 ? 5 : AC == 16 ? 6 : AC == 32 ? 7 : AC == 2 ? 3 : AC == 1 ? 2 : -1;   // log2(bytes per bin)
         static_assert(!LUMA || LA > 0, "");
         const u32 off_a = LUMA ? (u32)(uintptr_t)hist : 0u;
-        if constexpr (LUMA) {
+        if constexpr (LUMA && !VM) {
             u32 local = 0;
 #pragma unroll
             for (int i = 0; i < 12; i++) local = __builtin_amdgcn_sad_u8(g.w[i], 0u, local);
@@ -546,10 +547,12 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
             const float r0 = pixel_fp_hraw(x0), r1 = pixel_fp_hraw(x1), r2 = pixel_fp_hraw(x2), r3 = pixel_fp_hraw(x3);
             u32 ya[4];
             if constexpr (LUMA) {
-                ya[0] = lshl16_add<LA>(pixel_fp_luma_bits(x0), off_a);
-                ya[1] = lshl16_add<LA>(pixel_fp_luma_bits(x1), off_a);
-                ya[2] = lshl16_add<LA>(pixel_fp_luma_bits(x2), off_a);
-                ya[3] = lshl16_add<LA>(pixel_fp_luma_bits(x3), off_a);
+                // V mode (the edge term's front end, psd_edge_kernels.hip): the histogram counts V = max(B, G, R), whose bits'
+                // low byte is v, instead of the luma
+                ya[0] = lshl16_add<LA>(VM ? __float_as_uint(x0.V) : pixel_fp_luma_bits(x0), off_a);
+                ya[1] = lshl16_add<LA>(VM ? __float_as_uint(x1.V) : pixel_fp_luma_bits(x1), off_a);
+                ya[2] = lshl16_add<LA>(VM ? __float_as_uint(x2.V) : pixel_fp_luma_bits(x2), off_a);
+                ya[3] = lshl16_add<LA>(VM ? __float_as_uint(x3.V) : pixel_fp_luma_bits(x3), off_a);
                 __builtin_amdgcn_sched_barrier(0);
             }
             u32 hq = 0;
@@ -893,7 +896,7 @@ __device__ __forceinline__ void stage_read(const uint8_t* stage, int wave, int l
 
 // Sum the AC replicas of one accumulator of one slot, zero them, add to the record.
 template <bool LUMA, int AC>
-__device__ __forceinline__ void flush_slot(u32* slot_acc, psd_frame_scores* rec, int idx)
+__device__ __forceinline__ void flush_slot(u32* slot_acc, psd_frame_scores* rec, int idx, u32* hist_dst = nullptr)
 {
     // idx in [0, 2*NA): accumulator a = idx >> 1, half = idx & 1 (AC/2 replicas each)
     const int a = idx >> 1, half = idx & 1;
@@ -919,7 +922,7 @@ __device__ __forceinline__ void flush_slot(u32* slot_acc, psd_frame_scores* rec,
     s += __shfl_xor(s, 1);
     if (half == 0 && s) {
         if (LUMA && a < 256) {
-            atomicAdd(&rec->hist[a], s);
+            atomicAdd(hist_dst ? &hist_dst[a] : &rec->hist[a], s);   // hist_dst: V mode, the edge term's per-frame V histogram
         } else {
             const int e = LUMA ? a - 256 : a;
             unsigned long long* dst = e == 0 ? (unsigned long long*)&rec->sad_h
@@ -947,10 +950,15 @@ __device__ unsigned long long g_phase[8];
 #define PT_DONE
 #endif
 
-template <bool HSV, bool LUMA, int G, int WG>
+// VM ("V mode", only with HSV && LUMA): the front end of the edge term rides on the HSV pass -- the histogram slots count
+// V = max(B, G, R) instead of the luma and go to p.vhist[t], the V plane (which the HSV conversion has packed already) is
+// stored to p.vout[t], no byte sum.  The frames are then read once for ContentDetector with weights.delta_edges > 0
+// instead of once by this pass and once by value_plane_hist_dma_kernel.
+template <bool HSV, bool LUMA, int G, int WG, bool VM = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((HSV && LUMA) ? 4 : 1)))
 void score_frames_dma_kernel(const ScoreParams p)
 {
+    static_assert(!VM || (HSV && LUMA), "");
     constexpr int NW = WG / 64;
     constexpr int ACD = (HSV && LUMA) ? PSD_FUSED_AC : (LUMA ? PSD_LUMA_AC : ACD_MAX);
     constexpr int LCD = (HSV && LUMA) ? PSD_FUSED_LC : (HSV && WG == kHsvWG ? PSD_HSV_LC : LCD_MAX);
@@ -1048,10 +1056,18 @@ void score_frames_dma_kernel(const ScoreParams p)
         for (int k = 0; k < G; k++) {
             if (HSV || live[k]) {
                 Hsv16 c;
-                convert_group<HSV, LUMA, LCD, ACD, FPK, S1>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs, live[k] ? 1u : 0u);
+                convert_group<HSV, LUMA, LCD, ACD, FPK, S1, VM>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs, live[k] ? 1u : 0u);
                 if (HSV) {
                     if (chain) sad_group(c, prev[k], sh, ss, sv);
                     prev[k] = c;
+                }
+                if constexpr (VM) {
+                    // 16 V bytes of the group, in pixel order (a group is 16 consecutive pixels: byte offset 16 * group)
+                    if (live[k]) {
+                        u32x4 pk;
+                        pk.x = c.v[0]; pk.y = c.v[1]; pk.z = c.v[2]; pk.w = c.v[3];
+                        *reinterpret_cast<u32x4*>(p.vout + (size_t)t * p.npix + (size_t)(wave_group0 + k * NW * 64 + lane) * 16) = pk;
+                    }
                 }
             }
         }
@@ -1077,7 +1093,8 @@ void score_frames_dma_kernel(const ScoreParams p)
             const int first = done - nf;                          // chunk-relative index of the first
             for (int i = tid; i < nf * 2 * NA; i += WG) {
                 const int fi = i / (2 * NA), idx = i - fi * 2 * NA;
-                flush_slot<LUMA, ACD>(&acc[(first + fi) % SLOTS][0], p.out + t0 + first + fi, idx);
+                flush_slot<LUMA, ACD>(&acc[(first + fi) % SLOTS][0], p.out + t0 + first + fi, idx,
+                                      VM ? p.vhist + (size_t)(t0 + first + fi) * 256 : nullptr);
             }
             PT(4)
         }
@@ -1190,6 +1207,12 @@ template <bool HSV, bool LUMA, int G, bool FAST>
 static hipError_t launch_one(const ScoreParams& p, int grid, hipStream_t stream)
 {
     constexpr int WG = kScoreWG;
+    if constexpr (FAST && HSV && LUMA) {
+        if (p.vout != nullptr) {   // V mode (launch_score_frames checked the preconditions)
+            hipLaunchKernelGGL((score_frames_dma_kernel<true, true, G, kFusedWG, true>), dim3(grid), dim3(kFusedWG), 0, stream, p);
+            return hipGetLastError();
+        }
+    }
     if constexpr (FAST) {
         if (!direct_loads()) {
             constexpr int SWG = (HSV && (!LUMA || PSD_FUSED_SMALL)) ? kHsvWG : (HSV && LUMA) ? kFusedWG : kScoreWG;
@@ -1272,11 +1295,19 @@ static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bo
                     : launch_flags<true, 1>(p, grid, hsv, luma, stream);
 }
 
+bool score_v_mode_available(long npix) { return !direct_loads() && npix % 16 == 0; }
+
 hipError_t launch_score_frames(ScoreParams p, bool hsv, bool luma, bool fast, int target_blocks,
                                hipStream_t stream, int* launches)
 {
     const int total_groups = (int)((p.npix + 15) / 16);
     const int full_groups = (int)(p.npix / 16);
+    if (p.vout != nullptr) {
+        // V mode: the HSV term and the edge term's V plane + V histogram from one pass (the staged kernel only, whole groups)
+        if (!hsv || luma || !fast || direct_loads() || total_groups != full_groups || p.vhist == nullptr) return hipErrorInvalidValue;
+        *launches += 1;
+        return launch_range(p, 0, full_groups, true, true, true, target_blocks, stream);
+    }
     if (!fast) {
         *launches += 1;
         return launch_range(p, 0, total_groups, hsv, luma, false, target_blocks, stream);
