@@ -89,7 +89,11 @@ void psd_destroy(psd_engine* e);
  *   out          host array of n records (written when the call returns).
  *   stream       hipStream_t to launch on, or NULL for the engine's own stream.
  * Fast path: 16-byte aligned base pointers, frame_stride % 16 == 0, row_stride == 3*width.
- * Anything else takes a slower generic path with identical results. */
+ * Anything else takes a slower generic path with identical results.
+ * PSD_SCORE_HSV_SAD | PSD_SCORE_EDGES together (ContentDetector with weights.delta_edges > 0 or a
+ * StatsManager: content_detector.py:155-174 computes both from the same frame) read the frames once on
+ * the fast path when the frame holds whole 16-pixel groups: the HSV pass also emits V = max(B,G,R) and
+ * its histogram, which is what numpy.median / cv2.Canny start from (content_detector.py:213-239). */
 int psd_score_batch_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width,
                            size_t row_stride, size_t frame_stride, const uint8_t* d_prev,
                            uint32_t flags, int edge_kernel, psd_frame_scores* out, void* stream);
