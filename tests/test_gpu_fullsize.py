@@ -384,3 +384,40 @@ def test_downscaled_scoring_properties_at_the_headline_size(hip_engine):
     for a in (30, 63, 2047):                 # around the ends of 32-frame walks
         _, want = oracle_downscaled(x[a:a + 3].cpu().numpy(), x[a - 1].cpu().numpy(), dh, dw)
         same(whole[a:a + 3], want, ("sad_h", "sad_s", "sad_v"))
+
+
+def test_hsv_and_edges_from_one_read_across_workspace_chunks():
+    """HSV + edge terms together take the V-mode HSV pass (one read of the frames).  With a 1 MiB edge workspace the batch
+    is cut into several chunks: the first starts with the predecessor frame as virtual frame 0, the later ones chain on
+    the frame in front of them.  Must equal the oracle and the two-read path (PSD_EDGE_FUSE_HSV=0).  Subprocess: the
+    environment switches are read once per process."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle.detectors_np import score_batch as oracle_score
+from pyscenedetect_amd import engine as E
+from pyscenedetect_amd.synth import make_clip
+frames, _ = make_clip(31, 121, 72, 128, shot_len=(9, 17))
+eng = E.ScoringEngine(0)
+want = oracle_score(frames, edges=True)
+fields = ("sad_h", "sad_s", "sad_v", "edge_xor")
+flags = E.SCORE_HSV_SAD | E.SCORE_EDGES
+got = eng.score_host(frames[1:], prev=frames[0], flags=flags)
+for f in fields:
+    assert np.array_equal(got[f], want[f][1:]), f
+got = eng.score_host(frames, flags=E.SCORE_ALL)
+for f in fields + ("byte_sum",):
+    assert np.array_equal(got[f], want[f]), f
+assert np.array_equal(got["hist"], want["hist"])
+print("ok")
+""" % root
+    for fuse in ("1", "0"):
+        env = dict(os.environ, PSD_EDGE_WS_MB="1", PSD_EDGE_FUSE_HSV=fuse)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (fuse, out.stdout[-400:], out.stderr[-1200:])
