@@ -693,25 +693,40 @@ __global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom 
     // (16 per row) and only the two halo columns as bytes; everything else goes byte by byte.
     const bool wide = (W & 3) == 0 && (g.npix & 3) == 0 && x0 + HT <= W;
     if (wide) {
-        for (int i = threadIdx.x; i < (HT + 2) * (HT / 4); i += 256) {
+        // all loads of the tile (five dwords and one halo byte per thread) go out before the first LDS write: unconditional
+        // on clamped coordinates, the out-of-image zero applied afterwards (a load behind a branch is waited for before the
+        // next one is issued: six memory latencies per dirty tile)
+        constexpr int NDW = ((HT + 2) * (HT / 4) + 255) / 256;
+        static_assert((HT + 2) * 2 <= 256, "");
+        u32 dw[NDW];
+#pragma unroll
+        for (int it = 0; it < NDW; it++) {
+            const int i = min((int)threadIdx.x + it * 256, (HT + 2) * (HT / 4) - 1);
             const int ly = i / (HT / 4), lw = i - ly * (HT / 4);
             const int y = y0 + ly - 1;
-            u32 v = 0;
-            if (y >= 0 && y < H) v = *reinterpret_cast<const u32*>(M + (size_t)y * W + x0 + lw * 4);
-            *reinterpret_cast<u32*>(&t[ly][OX + 1 + lw * 4]) = v;
-            // a byte equal to 1 inside the tile rows: (v ^ 0x01010101) has a zero byte there
-            if (ly >= 1 && ly <= HT) {
-                const u32 z = v ^ 0x01010101u;
-                if ((z - 0x01010101u) & ~z & 0x80808080u) weak_here = 1;
+            dw[it] = *reinterpret_cast<const u32*>(M + (size_t)min(max(y, 0), H - 1) * W + x0 + lw * 4);
+        }
+        const int hi = min((int)threadIdx.x, (HT + 2) * 2 - 1);
+        const int hly = hi >> 1, hside = hi & 1;
+        const int hy = y0 + hly - 1, hx = hside ? x0 + HT : x0 - 1;
+        uint8_t hb = M[(size_t)min(max(hy, 0), H - 1) * W + min(max(hx, 0), W - 1)];
+#pragma unroll
+        for (int it = 0; it < NDW; it++) {
+            const int i = (int)threadIdx.x + it * 256;
+            if (i < (HT + 2) * (HT / 4)) {
+                const int ly = i / (HT / 4), lw = i - ly * (HT / 4);
+                const int y = y0 + ly - 1;
+                const u32 v = (y >= 0 && y < H) ? dw[it] : 0u;
+                *reinterpret_cast<u32*>(&t[ly][OX + 1 + lw * 4]) = v;
+                // a byte equal to 1 inside the tile rows: (v ^ 0x01010101) has a zero byte there
+                if (ly >= 1 && ly <= HT) {
+                    const u32 z = v ^ 0x01010101u;
+                    if ((z - 0x01010101u) & ~z & 0x80808080u) weak_here = 1;
+                }
             }
         }
-        for (int i = threadIdx.x; i < (HT + 2) * 2; i += 256) {
-            const int ly = i >> 1, side = i & 1;
-            const int y = y0 + ly - 1, x = side ? x0 + HT : x0 - 1;
-            uint8_t v = 0;
-            if (y >= 0 && y < H && x >= 0 && x < W) v = M[(size_t)y * W + x];
-            t[ly][side ? OX + HT + 1 : OX] = v;
-        }
+        if ((int)threadIdx.x < (HT + 2) * 2)
+            t[hly][hside ? OX + HT + 1 : OX] = (hy >= 0 && hy < H && hx >= 0 && hx < W) ? hb : (uint8_t)0;
     } else {
         for (int i = threadIdx.x; i < (HT + 2) * (HT + 2); i += 256) {
             const int ly = i / (HT + 2), lx = i - ly * (HT + 2);
