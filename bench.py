@@ -1,7 +1,8 @@
 """bench.py -- frames/sec of the ContentDetector hot path on device-resident 1080p batches.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames 4096] [--dist U|S|K]
-                    [--detector content|hist|all|hash] [--res 1080p|4k] [--downscale auto|F] [--no-secondary]
+                    [--detector content|hist|all|hash|edges] [--res 1080p|4k] [--downscale auto|F] [--no-secondary]
+                    [--workload headline|corpus|bbc]
 
 Workload (BASELINE.json configs[1]): ContentDetector(threshold=27) over a synthetic
 1920x1080 BGR batch of 4096 frames per GPU, resident in HBM when the timed region starts.
@@ -14,10 +15,18 @@ the device->host copy of the per-frame records, and the native decision epilogue
 scene_manager.py:110,123-140,666-678: cv2.resize to about 256 pixels width, INTER_LINEAR); the roofline then counts the
 source rows that carry taps (2 per destination row), which is all that pipeline has to read.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scores its own batch
-(independent clips: weak scaling, no data-path collective) and the per-frame score vectors are
-all-gathered over RCCL each step straight from the device-resident records, so every rank could run the
-epilogue for all clips.
+N > 1: one rank per GPU.  Either the caller launches the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: RANK / WORLD_SIZE in the environment) or `python bench.py --gpus N` on its own starts them
+(it re-executes itself under torch.distributed.run on 127.0.0.1).  Every rank scores its own batch (independent clips:
+weak scaling, no data-path collective) and the per-frame score vectors are all-gathered over RCCL each step straight
+from the device-resident records, so every rank could run the epilogue for all clips.
+
+--workload corpus  BASELINE.json configs[4]: a mixed 1080p / 4K corpus of shot-like clips, all four detectors from one
+                   fused pass per resolution (clips packed back to back in one device batch), sharded by clip, the
+                   per-frame records all-gathered over RCCL, decisions on every rank.  Every rank holds its share of the
+                   8-GPU corpus (24 x 1080p x 2048 + 8 x 4K x 512 frames => 3 + 1 clips per GPU): weak scaling.
+--workload bbc     BASELINE.json configs[3]: AdaptiveDetector(window_width=2, min_content_val=15) over the 11-clip
+                   stand-in for the BBC set (640x360, generated on the device), sharded by clip: strong scaling.
 
 Prints ONE JSON line on rank 0.  At N = 1 the line also carries `secondary`: short runs of the other BASELINE
 configurations (4K Histogram + Threshold, all four detectors fused, shot-like and constant content, the default
@@ -76,7 +85,7 @@ def downscaled_size(h: int, w: int, downscale: str) -> tuple[int, int, float]:
     return max(1, round(h / factor)), max(1, round(w / factor)), factor
 
 
-def cpu_baseline(sample: np.ndarray, flags: int, threads: int) -> dict:
+def cpu_baseline(sample: np.ndarray, flags: int, threads: int, repeats: int = 3, model_frames: int = 256) -> dict:
     """The CPU side of the same workload on this box's host cores, bounded samples:
       * value / cores: the C oracle (restatement of the reference's cv2 / numpy pixel path) over all host cores
         (ctypes releases the GIL; disjoint frame ranges per thread, each with its one-frame halo);
@@ -100,29 +109,37 @@ def cpu_baseline(sample: np.ndarray, flags: int, threads: int) -> dict:
     single = max(2, n // 8) / t1
     bounds = [(i * n // threads, (i + 1) * n // threads) for i in range(threads)]
     bounds = [b for b in bounds if b[1] > b[0]]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        parts = list(ex.map(work, bounds))
-    dt = time.perf_counter() - t0
-    out = {"value": round(n / dt, 2), "unit": "frames/s", "cores": threads, "kind": "port",
-           "sample": f"{n} frames of the same batch through oracle/cv2_restate.c (gcc -O3), "
-                     f"{threads} threads; single thread: {single:.2f} frames/s; real OpenCV is not installed",
-           "single_thread_frames_per_s": round(single, 2),
+    rates = []
+    for _ in range(max(1, repeats)):
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            parts = list(ex.map(work, bounds))
+        rates.append(n / (time.perf_counter() - t0))
+    out = {"value": round(float(np.median(rates)), 2), "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": f"{n} frames of the same batch through oracle/cv2_restate.c (gcc -O3), {threads} threads, median of "
+                     f"{len(rates)} repeats ({min(rates):.0f}-{max(rates):.0f}); single thread: {single:.2f} frames/s; "
+                     "real OpenCV is not installed",
+           "single_thread_frames_per_s": round(single, 2), "repeats": [round(r, 1) for r in rates],
            "_records": np.concatenate(parts)}
-    if flags & 1:
+    if flags & 1 and model_frames > 0:
         shim = os.path.join(ROOT, "oracle", "cv2_shim")
         if shim not in sys.path:
             sys.path.append(shim)
         from oracle.reference_loop import time_models
 
-        m = time_models(sample[: min(n, 48)])
-        m.pop("_scores")
+        runs = []
+        for _ in range(max(1, repeats)):
+            m = time_models(sample[: min(n, model_frames)])
+            m.pop("_scores")
+            runs.append(m)
+        m = sorted(runs, key=lambda r: r["python_loop_frames_per_s"])[len(runs) // 2]
         out["reference_model"] = {
             "what": "ContentDetector.process_frame as the reference runs it (scene_manager.py:578-585): one Python process, "
                     "one frame at a time, cv2.cvtColor + cv2.split (C restatement) then 3x _mean_pixel_distance (the "
-                    "reference's numpy expression, content_detector.py:29-36)",
+                    "reference's numpy expression, content_detector.py:29-36); median of %d repeats" % len(runs),
             "frames_per_s": m["python_loop_frames_per_s"], "cores": 1, "frames": m["python_loop_frames"],
             "numpy_half_only_frames_per_s": m["numpy_half_frames_per_s"],
+            "repeats_frames_per_s": [r["python_loop_frames_per_s"] for r in runs],
         }
     return out
 
@@ -195,7 +212,35 @@ class Workload:
         return ms
 
 
-def quick_measure(wl: Workload, steps: int = 5, warmup: int = 2) -> dict:
+def parity_sample(wl: Workload, k: int) -> str:
+    """The first k frames of the workload's last step against the CPU oracle (the checker, outside every timed region)."""
+    from oracle import lib as orc
+    from oracle.detectors_np import score_batch as oracle_score
+
+    k = min(k, wl.n)
+    frames = wl.batch[:k].cpu().numpy()
+    if wl.detector == "hash":
+        bad = [] if np.array_equal(wl.state["thumbs"][:k], orc.hash_thumbs(frames, 16)) else ["thumbs"]
+        what = "thumbnails"
+    else:
+        if wl.downscale:
+            shim = os.path.join(ROOT, "oracle", "cv2_shim")
+            if shim not in sys.path:
+                sys.path.append(shim)
+            import cv2  # the oracle's shim: cv2.resize restated (scene_manager.py:670-678)
+
+            frames = np.stack([cv2.resize(f, (wl.sw, wl.sh)) for f in frames])
+        want = oracle_score(frames, edges=wl.detector == "edges")
+        fields = (["sad_h", "sad_s", "sad_v"] if wl.flags & 1 else []) + (["hist"] if wl.flags & 2 else []) + \
+                 (["byte_sum"] if wl.flags & 4 else []) + (["edge_xor"] if wl.flags & 8 else [])
+        got = wl.state["recs"]
+        bad = [f for f in fields if not np.array_equal(got[f][:k], want[f])]
+        what = "records (" + ", ".join(fields) + ")"
+    return ("%s of the first %d frames identical to the oracle" % (what, k)) if not bad else \
+        "MISMATCH vs oracle in %s (first %d frames)" % (bad, k)
+
+
+def quick_measure(wl: Workload, steps: int = 5, warmup: int = 2, parity_frames: int = 16) -> dict:
     """Short single-GPU measurement of a secondary workload: same step definition, two steps in flight."""
     def run(k, sink):
         if wl.detector == "hash":
@@ -217,12 +262,18 @@ def quick_measure(wl: Workload, steps: int = 5, warmup: int = 2) -> dict:
     dt = time.perf_counter() - t0
     k_ms = float(np.mean(ms))
     achieved = wl.algorithmic_bytes() / (k_ms * 1e-3) / 1e9
-    return {"value": round(wl.n * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 4),
-            "avg_launch_ms": round(k_ms, 4), "achieved_GBps": round(achieved, 1), "frac_of_8TBps": round(achieved / HBM_PEAK_GBS, 4),
-            "kernel": wl.kernel_name(), "cuts_found": len(wl.state["cuts"])}
+    out = {"value": round(wl.n * steps / dt, 1), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 4),
+           "avg_launch_ms": round(k_ms, 4), "achieved_GBps": round(achieved, 1), "frac_of_8TBps": round(achieved / HBM_PEAK_GBS, 4),
+           "kernel": wl.kernel_name(), "cuts_found": len(wl.state["cuts"])}
+    if parity_frames > 0:
+        try:
+            out["parity_sample"] = parity_sample(wl, parity_frames)
+        except Exception as ex:  # noqa: BLE001
+            out["parity_sample"] = "not checked: %s: %s" % (type(ex).__name__, ex)
+    return out
 
 
-def secondary_runs(eng, batch, E, epilogue, device, frames_small: int) -> dict:
+def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> dict:
     """The other BASELINE configurations, a few steps each (N = 1 only).  Failures are recorded, never fatal."""
     out = {}
     h, w = batch.shape[1], batch.shape[2]
@@ -263,41 +314,237 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int) -> dict:
         return r
     attempt("histogram_threshold_4k", f"BASELINE configs[2]: HistogramDetector + ThresholdDetector, {frames_small} x 3840x2160, uniform bytes", run_4k)
     torch.cuda.empty_cache()
+
+    def run_flow_small(kind):
+        import copy
+
+        a = copy.copy(args)
+        a.workload, a.corpus_frames, a.bbc_frames, a.steps, a.warmup, a.no_cpu_baseline = kind, 512, 2000, 3, 1, False
+        a.height = a.width = 0
+        a.cpu_sample = 256
+        r = run_flow(a, eng, device, 1, 0, device.index or 0, False, True)
+        torch.cuda.empty_cache()
+        return {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "cuts_found", "ground_truth", "parity_sample", "cpu_baseline")} | \
+            {"frames_1080p_equivalent_per_s": r["config"]["frames_1080p_equivalent_per_s"], "frames_total": r["config"]["frames_total"]}
+    attempt("corpus_mixed_1080p_4k_all_four", "BASELINE configs[4] at reduced length: 3 x 1080p x 512 + 1 x 4K x 128 shot-like frames, all four "
+            "detectors, clips packed per resolution (bench.py --workload corpus is the full-length run)", lambda: run_flow_small("corpus"))
+    attempt("bbc_standin_adaptive", "BASELINE configs[3] at reduced length: AdaptiveDetector over the 11-clip 640x360 stand-in, 2000+ frames per "
+            "clip (bench.py --workload bbc is the full-length run)", lambda: run_flow_small("bbc"))
     return out
 
 
-def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
-    """``engine_factory``/``cpu_dry_run`` exist for tests/test_bench_plumbing.py only: they run this very
-    control flow (pipelining, exchange, JSON) on CPU tensors over gloo with a stand-in engine, so the
-    N > 1 path is exercised without GPUs.  The measured path always uses the HIP engine on cuda."""
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU batch")
-    ap.add_argument("--dist", default="U", choices=["U", "K", "S"])
-    ap.add_argument("--detector", default="content", choices=["content", "hist", "all", "hash", "edges"],
-                    help="content = ContentDetector (headline); hist = Histogram+Threshold; all = all four fused; "
-                         "hash = HashDetector (thumbnail kernel + DCT epilogue); edges = ContentDetector with weights (1,1,1,1)")
-    ap.add_argument("--res", default="1080p", choices=["1080p", "4k"])
-    ap.add_argument("--downscale", default=None, help="'auto' (the reference's default: to about 256 px width) or a factor")
-    ap.add_argument("--cpu-sample", type=int, default=512)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configurations")
-    ap.add_argument("--secondary-frames", type=int, default=2048)
-    ap.add_argument("--height", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--width", type=int, default=0, help=argparse.SUPPRESS)
-    args = ap.parse_args(argv)
-    H, W = (2160, 3840) if args.res == "4k" else (1080, 1920)
-    if args.height and args.width:
-        H, W = args.height, args.width
-    on_gpu = not cpu_dry_run
+ALL_FOUR = {"content": {}, "adaptive": {}, "hist": {}, "threshold": {}}          # reference constructor defaults
+BBC_ADAPTIVE = {"adaptive": {"window_width": 2, "min_content_val": 15.0}}
 
+
+class FlowWorkload:
+    """BASELINE.json configs[3] / [4] as flows: a list of clips -> `corpus.detect_corpus` (pack by resolution, one fused
+    launch per term per resolution, all-gather of the per-frame records over the process group, native decision
+    epilogues on every rank) -> cut lists per clip and detector.  Every rank generates only the clips the greedy plan
+    (`distributed.assign_clips`, the same plan detect_corpus uses) gives it."""
+
+    def __init__(self, kind: str, eng, device, rank: int, world: int, args, small: bool = False):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import device_clips as DC
+        from pyscenedetect_amd.distributed import assign_clips
+
+        self.kind, self.eng, self.rank, self.world = kind, eng, rank, world
+        if kind == "corpus":
+            f = args.corpus_frames
+            hw = [(args.height, args.width), (2 * args.height, 2 * args.width)] if args.height and args.width else [(1080, 1920), (2160, 3840)]
+            # one GPU's share of the 8-GPU corpus (24 x 1080p x 2048 + 8 x 4K x 512): 3 + 1 clips; N ranks hold N shares
+            self.specs = [(f, *hw[0])] * (3 * world) + [(max(1, f // 4), *hw[1])] * world
+            self.detectors, self.scaling = ALL_FOUR, "weak"
+            self.what = (f"mixed corpus, all four detectors: {3 * world} x {hw[0][1]}x{hw[0][0]} x {f} + {world} x {hw[1][1]}x{hw[1][0]} x "
+                         f"{max(1, f // 4)} shot-like frames (3 + 1 clips per GPU: the per-GPU share of BASELINE.json configs[4] "
+                         "at 8 GPUs), clips of one resolution packed into one device batch, sharded by clip, records all-gathered")
+            shot_len = (40, 400)
+        else:
+            hw = (args.height, args.width) if args.height and args.width else (360, 640)
+            self.specs = [(args.bbc_frames + 137 * i, *hw) for i in range(11)]
+            self.detectors, self.scaling = BBC_ADAPTIVE, "strong"
+            self.what = (f"AdaptiveDetector(window_width=2, min_content_val=15) on the 11-clip stand-in for the BBC set "
+                         f"({hw[1]}x{hw[0]}, {sum(x[0] for x in self.specs)} frames, generated on the device; the real set "
+                         "and a decoder are not in this image), sharded by clip (BASELINE.json configs[3])")
+            shot_len = (40, 400)
+        if small:
+            shot_len = (8, 40)
+        self.plan = assign_clips([n * h * w for n, h, w in self.specs], world)
+        mine = self.plan[rank]
+        built, truths = DC.make_packed_clips([self.specs[i] for i in mine], [5000 + i for i in mine], device, shot_len)
+        self.clips = [DC.LazyClip(*sp) for sp in self.specs]
+        self.truth = {}
+        for i, c, t in zip(mine, built, truths):
+            self.clips[i] = c
+            self.truth[i] = t
+        self.frames_total = sum(sp[0] for sp in self.specs)
+        self.result = None
+
+    def my_bytes(self) -> int:
+        return sum(self.specs[i][0] * self.specs[i][1] * self.specs[i][2] * 3 for i in self.plan[self.rank])
+
+    def step(self) -> float:
+        """One pass over the whole corpus; returns this rank's kernel time (ms, HIP events, summed over its launches)."""
+        from pyscenedetect_amd.corpus import detect_corpus
+
+        if hasattr(self.eng, "kernel_ms_acc"):
+            self.eng.kernel_ms_acc = 0.0
+        self.result = detect_corpus(self.eng, self.clips, 25.0, self.detectors)
+        return float(getattr(self.eng, "kernel_ms_acc", 0.0))
+
+    def parity(self, budget_frames: int, threads: int) -> tuple[str, dict]:
+        """This rank's first clip of every resolution, a prefix of `budget_frames` 1080p-equivalents each, through the CPU
+        oracle: records and the cut lists decided from them must equal what the flow produced for that prefix."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        from oracle import lib as orc
+        from pyscenedetect_amd import corpus
+        from pyscenedetect_amd.corpus import required_flags
+
+        flags = required_flags(self.detectors)
+        fields = (["sad_h", "sad_s", "sad_v"] if flags & 1 else []) + (["hist"] if flags & 2 else []) + (["byte_sum"] if flags & 4 else [])
+        seen, notes, bad = set(), [], []
+        t_cpu = n_cpu = 0.0
+        for i in self.plan[self.rank]:
+            n, h, w = self.specs[i]
+            if (h, w) in seen:
+                continue
+            seen.add((h, w))
+            k = int(max(2, min(n, budget_frames * (1080 * 1920) // (h * w))))
+            frames = self.clips[i][:k].cpu().numpy()
+            bounds = [(j * k // threads, (j + 1) * k // threads) for j in range(threads)]
+            bounds = [b for b in bounds if b[1] > b[0]]
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(threads) as ex:
+                parts = list(ex.map(lambda r: orc.score_batch(frames[r[0]:r[1]], frames[r[0] - 1] if r[0] else None, flags=flags & 7), bounds))
+            t_cpu += time.perf_counter() - t0
+            n_cpu += k * (h * w) / (1080 * 1920)
+            want = np.concatenate(parts)
+            got = self._records_of(i)[:k]
+            if any(not np.array_equal(got[f], want[f]) for f in fields):
+                bad.append(f"records of clip {i}")
+            want_cuts = corpus.decide(want, h, w, 25.0, self.detectors)
+            if corpus.decide(got, h, w, 25.0, self.detectors) != want_cuts:
+                bad.append(f"cuts of clip {i}")
+            # ... and what the timed flow itself returned for this clip (every detector decides causally up to a short
+            # look-ahead, so away from the end of the prefix the lists must agree)
+            for name, cuts in want_cuts.items():
+                if [c for c in self.result[i][name] if c < k - 32] != [c for c in cuts if c < k - 32]:
+                    bad.append(f"{name} cuts the flow returned for clip {i}")
+            notes.append(f"clip {i} ({w}x{h}): first {k} frames")
+        msg = ("records and cut lists identical to the oracle: " + "; ".join(notes)) if not bad else "MISMATCH vs oracle: " + ", ".join(bad)
+        cpu = {"value": round(n_cpu / t_cpu, 2) if t_cpu > 0 else None, "unit": "1080p-equivalent frames/s", "cores": threads, "kind": "port",
+               "sample": "the parity prefixes (" + "; ".join(notes) + f") through oracle/cv2_restate.c, {threads} threads, pixel work only"}
+        return msg, cpu
+
+    def _records_of(self, i: int):
+        # the flow returns decisions; the records they came from are re-scored for the parity prefix (same engine calls)
+        from pyscenedetect_amd import corpus
+
+        return corpus.score_clip(self.eng, self.clips[i], corpus.required_flags(self.detectors))
+
+    def truth_f1(self) -> dict | None:
+        """Precision / recall / F1 of this rank's clips against the generator's ground truth (exact frame match)."""
+        tp = npred = ntrue = 0
+        for i, t in self.truth.items():
+            name = "adaptive" if "adaptive" in self.detectors else "content"
+            pred = self.result[i][name]
+            tp += len(set(pred) & set(t))
+            npred += len(pred)
+            ntrue += len(t)
+        if not npred or not ntrue:
+            return None
+        p, r = tp / npred, tp / ntrue
+        return {"detector": name, "precision": round(p, 4), "recall": round(r, 4), "f1": round(2 * p * r / (p + r), 4) if p + r else 0.0,
+                "true_cuts": ntrue, "detected": npred, "scope": "clips of rank 0"}
+
+
+def run_flow(args, eng, device, world, rank, local_rank, use_dist, on_gpu) -> dict | None:
+    """--workload corpus|bbc: W untimed passes, then K timed passes between barriers; MAX over ranks; rank 0 reports."""
+    fw = FlowWorkload(args.workload, eng, device, rank, world, args, small=not on_gpu)
+
+    def barrier():
+        if use_dist:
+            import torch.distributed as dist
+
+            dist.barrier(device_ids=[local_rank]) if on_gpu else dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        fw.step()
+    barrier()
+    kms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kms.append(fw.step())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    k_ms = float(np.mean(kms)) if kms else float("nan")
+    algo = fw.my_bytes()
+    achieved = algo / (k_ms * 1e-3) / 1e9 if k_ms > 0 else None      # (the CPU dry run has no kernel clock)
+    px_total = sum(n * h * w for n, h, w in fw.specs)
+    out = {
+        "metric": "frames/sec (mixed 1080p/4K corpus, all four detectors)" if args.workload == "corpus" else
+                  "frames/sec (AdaptiveDetector, BBC stand-in, sharded by clip)",
+        "value": round(fw.frames_total * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": fw.scaling, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": fw.what, "clips": len(fw.specs), "frames_total": fw.frames_total,
+                   "frames_1080p_equivalent_per_s": round(px_total / (1080 * 1920) * args.steps / elapsed, 1),
+                   "detectors": sorted(fw.detectors), "ranks_seen": world,
+                   "parallelism": (f"clips sharded over {world} GPU(s) (greedy by frames x pixels), all-gather of the per-frame records "
+                                   "(RCCL), decisions on every rank") if use_dist else "1 GPU",
+                   "clips_of_rank0": fw.plan[0]},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+                     "traffic_source": "not counted for this workload (same kernels as --detector all / content: profiles/hbm_traffic.json)",
+                     "kernel": "psd::score_frames_dma_kernel (one launch per resolution, clips packed; rank 0's launches)",
+                     "avg_launch_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": algo,
+                     "note": "per step of rank 0: 3 B/px of its clips / the summed HIP-event time of its launches"},
+        "cuts_found": sum(len(v) for r in (fw.result or []) for v in r.values()),
+        "ground_truth": fw.truth_f1(),
+    }
+    if args.no_cpu_baseline:
+        out["cpu_baseline"] = None
+    else:
+        out["parity_sample"], out["cpu_baseline"] = fw.parity(args.cpu_sample // 4, os.cpu_count() or 1)
+    return out
+
+
+def respawn_one_rank_per_gpu(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start N ranks of THIS script under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1, a free port) and hand their exit code back.  The ranks inherit
+    stdout, and only rank 0 prints, so the caller still sees exactly one JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["PSD_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(sys.argv[0]), *argv]
+    return subprocess.call(cmd, env=env)
+
+
+def init_ranks(on_gpu: bool):
+    """(world, rank, local_rank, use_dist).  Under a launcher (RANK set) the process group is always created, even for
+    one rank, so the exchange path is the same code for N = 1 (launched that way) and N = 8."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # Under torchrun (RANK set) the RCCL process group is always created, even for one rank, so the
-    # exchange path below is the same code for N = 1 (launched that way) and N = 8.
     use_dist = world > 1 or "RANK" in os.environ
     if use_dist:
         import torch.distributed as dist
@@ -322,6 +569,48 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
+    return world, rank, local_rank, use_dist
+
+
+def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
+    """``engine_factory``/``cpu_dry_run`` exist for tests/test_bench_plumbing.py only: they run this very
+    control flow (pipelining, exchange, JSON) on CPU tensors over gloo with a stand-in engine, so the
+    N > 1 path is exercised without GPUs.  The measured path always uses the HIP engine on cuda."""
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU batch")
+    ap.add_argument("--dist", default="U", choices=["U", "K", "S"])
+    ap.add_argument("--detector", default="content", choices=["content", "hist", "all", "hash", "edges"],
+                    help="content = ContentDetector (headline); hist = Histogram+Threshold; all = all four fused; "
+                         "hash = HashDetector (thumbnail kernel + DCT epilogue); edges = ContentDetector with weights (1,1,1,1)")
+    ap.add_argument("--res", default="1080p", choices=["1080p", "4k"])
+    ap.add_argument("--downscale", default=None, help="'auto' (the reference's default: to about 256 px width) or a factor")
+    ap.add_argument("--cpu-sample", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short runs of the other BASELINE configurations")
+    ap.add_argument("--secondary-frames", type=int, default=2048)
+    ap.add_argument("--workload", default="headline", choices=["headline", "corpus", "bbc"],
+                    help="headline = one resident batch (BASELINE configs[1], or what --detector/--res/--downscale select); "
+                         "corpus = configs[4] (mixed 1080p/4K clips, four detectors, sharded by clip); bbc = configs[3]")
+    ap.add_argument("--corpus-frames", type=int, default=2048, help="frames per 1080p clip of --workload corpus (4K clips: a quarter)")
+    ap.add_argument("--bbc-frames", type=int, default=6000, help="frames of the shortest of the 11 clips of --workload bbc")
+    ap.add_argument("--height", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--width", type=int, default=0, help=argparse.SUPPRESS)
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = ap.parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # nobody launched the ranks for us: do it ourselves (one process per GPU) and pass their result through
+        sys.exit(respawn_one_rank_per_gpu(args.gpus, argv))
+    H, W = (2160, 3840) if args.res == "4k" else (1080, 1920)
+    if args.height and args.width:
+        H, W = args.height, args.width
+    on_gpu = not cpu_dry_run
+
+    world, rank, local_rank, use_dist = init_ranks(on_gpu)
+    if args.gpus != world and rank == 0:
+        print(f"bench: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     device = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
     if on_gpu:
         torch.cuda.set_device(device)
@@ -330,6 +619,17 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
     from pyscenedetect_amd import epilogue
 
     eng = engine_factory(local_rank) if engine_factory else E.ScoringEngine(local_rank)
+    if args.workload != "headline":
+        out = run_flow(args, eng, device, world, rank, local_rank, use_dist, on_gpu)
+        eng.close()
+        if use_dist:
+            import torch.distributed as dist
+
+            dist.barrier(device_ids=[local_rank]) if on_gpu else dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(out))
+        return
     n = args.frames
     batch = make_batch(n, args.dist, 20250921 + rank, device, H, W)
     wl = Workload(eng, batch, args.detector, args.downscale, epilogue, E)
@@ -427,7 +727,7 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
 
     out = None
     if rank == 0:
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -435,6 +735,8 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
                     tj = json.load(f)
                 key = f"{args.detector}_{args.res}_{args.dist}_{n}" + (f"_downscale_{args.downscale}" if args.downscale else "")
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                traffic_source = ("profiles/hbm_traffic.json[%r]: %s -- a committed PMC measurement of this kernel and "
+                                  "shape, not counted in this run" % (key, tj[key].get("source", "?"))) if key in tj else None
             except Exception:
                 traffic = None
         headline = (args.detector, args.res, args.downscale) == ("content", "1080p", None)
@@ -458,7 +760,7 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
                 "workload": (f"ContentDetector(threshold=27) on {n} x 1920x1080 BGR frames per GPU, device-resident "
                              f"(BASELINE.json configs[1]); distribution {args.dist}") if headline else
                             f"{what} on {n} x {W}x{H} BGR frames per GPU, device-resident; distribution {args.dist}",
-                "frames_per_gpu": n, "height": H, "width": W, "distribution": args.dist,
+                "frames_per_gpu": n, "height": H, "width": W, "distribution": args.dist, "ranks_seen": world,
                 "parallelism": f"clips sharded over {world} GPU(s), RCCL all-gather of score vectors (device-resident records)"
                                if use_dist else "1 GPU",
                 "pipeline_depth": 1 if args.detector == "hash" else 2,
@@ -472,6 +774,7 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel": wl.kernel_name(),
                 "avg_launch_ms": round(avg_kernel_ms, 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
@@ -504,7 +807,7 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
         else:
             out["cpu_baseline"] = None
         if on_gpu and world == 1 and not use_dist and not args.no_secondary and headline:
-            out["secondary"] = secondary_runs(eng, batch, E, epilogue, device, min(args.secondary_frames, n))
+            out["secondary"] = secondary_runs(eng, batch, E, epilogue, device, min(args.secondary_frames, n), args)
     eng.close()
     if use_dist:
         import torch.distributed as dist

@@ -86,6 +86,7 @@ class ScoringEngine:
         # makes an engine that ends up shared between threads safe, one at a time (distinct engines run concurrently)
         self._lock = threading.RLock()
         self._pinned: list[int] = []
+        self.kernel_ms_acc = 0.0
 
     def close(self) -> None:
         for buf in self.__dict__.pop("_scratch_bufs", {}).values():
@@ -443,6 +444,7 @@ class ScoringEngine:
     def collect(self, n: int) -> np.ndarray:
         out = np.zeros(n, RECORD_DTYPE)
         _native.check(self._lib.psd_score_collect(self._h, out.ctypes.data if n else None, int(n)))
+        self.kernel_ms_acc += self.last_kernel_ms()[0]      # callers that time a flow of several submissions reset and read this
         return out
 
     def last_records_device(self) -> tuple[int, int]:

@@ -24,6 +24,10 @@ class StandInEngine:
         frames = np.frombuffer(buf, np.uint8).reshape(n, h, w, 3)
         self._pending.append(orc.score_batch(frames, flags=flags & 7))
 
+    def score_device(self, ptr, n, h, w, row_stride=None, frame_stride=None, d_prev=None, flags=7, edge_kernel=0, stream=None):
+        self.submit_device(ptr, n, h, w, flags=flags)
+        return self.collect(n)
+
     def collect(self, n):
         rec = self._pending.pop(0)
         assert len(rec) == n
