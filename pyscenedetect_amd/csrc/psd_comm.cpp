@@ -10,7 +10,9 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "psd_internal.h"
@@ -41,27 +43,39 @@ struct Rccl {
     fn_error_string error_string = nullptr;
 };
 
-Rccl* rccl()
+std::string g_rccl_why;   // why loading failed (dlerror() captured ONCE: a second call returns NULL)
+
+void rccl_load(Rccl& r)
 {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.handle ? &r : nullptr;
-    tried = true;
     // a copy that is already in the process first (RTLD_NOLOAD), then the system's
     const char* names[] = {"librccl.so", "librccl.so.1"};
     for (const char* n : names)
         if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     const char* paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* p : paths)
-        if (!r.handle) r.handle = dlopen(p, RTLD_NOW | RTLD_GLOBAL);
-    if (!r.handle) return nullptr;
+        if (!r.handle) {
+            r.handle = dlopen(p, RTLD_NOW | RTLD_GLOBAL);
+            if (!r.handle) { const char* why = dlerror(); g_rccl_why = why ? why : "not found"; }
+        }
+    if (!r.handle) return;
     r.get_unique_id = (fn_get_unique_id)dlsym(r.handle, "ncclGetUniqueId");
     r.comm_init_rank = (fn_comm_init_rank)dlsym(r.handle, "ncclCommInitRank");
     r.all_gather = (fn_all_gather)dlsym(r.handle, "ncclAllGather");
     r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
     r.error_string = (fn_error_string)dlsym(r.handle, "ncclGetErrorString");
-    if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy) { r.handle = nullptr; return nullptr; }
-    return &r;
+    if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy) {
+        g_rccl_why = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
+        dlclose(r.handle);
+        r.handle = nullptr;
+    }
+}
+
+Rccl* rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_load(r); });
+    return r.handle ? &r : nullptr;
 }
 
 int rccl_fail(Rccl* r, const char* what, int rc)
@@ -97,7 +111,7 @@ int psd_comm_unique_id(void* id128)
 {
     if (!id128) { psd_set_error("psd_comm_unique_id: null argument"); return PSD_ERR_INVALID; }
     Rccl* r = rccl();
-    if (!r) { psd_set_error("RCCL (librccl.so) is not available: %s", dlerror() ? dlerror() : "not found"); return PSD_ERR_UNSUPPORTED; }
+    if (!r) { psd_set_error("RCCL (librccl.so) is not available: %s", g_rccl_why.c_str()); return PSD_ERR_UNSUPPORTED; }
     NcclUniqueId id;
     const int rc = r->get_unique_id(&id);
     if (rc != 0) return rccl_fail(r, "ncclGetUniqueId", rc);
@@ -113,7 +127,7 @@ int psd_comm_create(psd_engine* e, int n_ranks, int rank, const void* id128, psd
     }
     *out = nullptr;
     Rccl* r = rccl();
-    if (!r) { psd_set_error("RCCL (librccl.so) is not available"); return PSD_ERR_UNSUPPORTED; }
+    if (!r) { psd_set_error("RCCL (librccl.so) is not available: %s", g_rccl_why.c_str()); return PSD_ERR_UNSUPPORTED; }
     HIP_TRY(hipSetDevice(psd::engine_device(e)));
     psd_comm* c = new (std::nothrow) psd_comm();
     if (!c) { psd_set_error("out of memory"); return PSD_ERR_NOMEM; }
@@ -141,13 +155,23 @@ void psd_comm_destroy(psd_comm* c)
 
 int psd_allgather_scores(psd_comm* c, const psd_frame_scores* d_local, int n_local, const int* counts, psd_frame_scores* h_all)
 {
-    if (!c || !counts || n_local < 0 || (n_local > 0 && !d_local)) { psd_set_error("psd_allgather_scores: invalid argument"); return PSD_ERR_INVALID; }
-    if (counts[c->rank] != n_local) {
-        psd_set_error("psd_allgather_scores: counts[%d] = %d but this rank contributes %d records", c->rank, counts[c->rank], n_local);
-        return PSD_ERR_INVALID;
+    // Argument errors that only THIS rank can see must not keep it out of the collective (the other ranks would hang in
+    // ncclAllGather): as long as the communicator and the counts are usable the rank takes part -- with what it has,
+    // zero-filled -- and reports its error afterwards.
+    if (!c || !counts) { psd_set_error("psd_allgather_scores: invalid argument"); return PSD_ERR_INVALID; }
+    bool local_error = false;
+    char local_msg[160] = "";
+    if (n_local < 0 || (n_local > 0 && !d_local)) {
+        snprintf(local_msg, sizeof local_msg, "psd_allgather_scores: invalid local records (n_local = %d)", n_local);
+        local_error = true; n_local = 0;
+    } else if (counts[c->rank] != n_local) {
+        snprintf(local_msg, sizeof local_msg, "psd_allgather_scores: counts[%d] = %d but this rank contributes %d records",
+                 c->rank, counts[c->rank], n_local);
+        local_error = true;
+        if (counts[c->rank] >= 0 && n_local > counts[c->rank]) n_local = counts[c->rank];
     }
     Rccl* r = rccl();
-    if (!r) { psd_set_error("RCCL (librccl.so) is not available"); return PSD_ERR_UNSUPPORTED; }
+    if (!r) { psd_set_error("RCCL (librccl.so) is not available: %s", g_rccl_why.c_str()); return PSD_ERR_UNSUPPORTED; }
     size_t cap = 1, total = 0;
     for (int i = 0; i < c->n_ranks; i++) {
         if (counts[i] < 0) { psd_set_error("psd_allgather_scores: negative count"); return PSD_ERR_INVALID; }
@@ -171,11 +195,13 @@ int psd_allgather_scores(psd_comm* c, const psd_frame_scores* d_local, int n_loc
     }
     // ragged blocks padded to the largest: one fused collective (the point-to-point xGMI mesh makes a ring pay a hop per
     // rank; at these sizes latency is everything)
+    if (local_error) HIP_TRY(hipMemsetAsync(c->d_send, 0, c->cap * rec, stream));
     if (n_local > 0) HIP_TRY(hipMemcpyAsync(c->d_send, d_local, (size_t)n_local * rec, hipMemcpyDeviceToDevice, stream));
     const int rc = r->all_gather(c->d_send, c->d_recv, c->cap * rec, 0 /* ncclChar */, c->comm, stream);
     if (rc != 0) return rccl_fail(r, "ncclAllGather", rc);
     HIP_TRY(hipMemcpyAsync(c->h_recv, c->d_recv, c->cap * rec * c->n_ranks, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    if (local_error) { psd_set_error("%s (the collective was completed with zero-filled records)", local_msg); return PSD_ERR_INVALID; }
     size_t off = 0;
     for (int i = 0; i < c->n_ranks; i++) {
         memcpy(h_all + off, c->h_recv + (size_t)i * c->cap * rec, (size_t)counts[i] * rec);

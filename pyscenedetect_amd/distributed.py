@@ -163,23 +163,40 @@ class NativeComm:
 
     def all_gather_records(self, counts, local: np.ndarray | None = None, device_records: tuple[int, int] | None = None) -> list[np.ndarray]:
         """Every rank's records, in rank order.  ``counts[r]`` = number of records of rank r (the same list on every
-        rank); this rank's come from ``device_records`` (default: the engine's last collected submission, still in HBM)."""
-        import ctypes
+        rank); this rank's come from ``device_records`` (default: the engine's last collected submission, still in HBM).
 
+        The device-resident source covers ONE submission: a rank whose share was scored in several submissions
+        (``score_clips`` over several resolutions, chunked host input) passes ``device_records`` of a buffer it
+        assembled itself, or uses :func:`all_gather_records` (host records).  A rank with nothing to contribute
+        (``counts[rank] == 0``: more ranks than clips) does not consult the engine at all.  Whatever is wrong on THIS
+        rank -- nothing collected yet, a stale submission, ``local`` of another length -- the rank still enters the
+        collective (zero-filled) and raises afterwards, so the other ranks are never left waiting in ncclAllGather."""
         from pyscenedetect_amd import _native
 
         counts = np.ascontiguousarray(counts, dtype=np.int32)
-        ptr, n = device_records if device_records is not None else self._engine.last_records_device()
-        if local is not None and len(local) != n:
-            raise ValueError("local records and device records disagree")
+        if counts.shape != (self.n_ranks,):
+            raise ValueError("counts must hold one entry per rank")     # (the same array everywhere: every rank raises)
+        mine = int(counts[self.rank])
+        ptr, n, problem = None, 0, None
+        if device_records is not None:
+            ptr, n = device_records
+        elif mine > 0:
+            try:
+                ptr, n = self._engine.last_records_device()
+            except Exception as ex:  # noqa: BLE001 -- reported after the collective
+                ptr, n, problem = None, -1, f"no device-resident records on rank {self.rank}: {ex}"
+        if problem is None and local is not None and len(local) != n:
+            ptr, n, problem = None, -1, f"local records ({len(local)}) and device records ({n}) disagree on rank {self.rank}"
         out = np.zeros(int(counts.sum()), RECORD_DTYPE)
-        _native.check(self._lib.psd_allgather_scores(self._h, ptr if n else None, int(n), counts.ctypes.data,
-                                                     out.ctypes.data if len(out) else None))
+        rc = self._lib.psd_allgather_scores(self._h, ptr if n > 0 else None, int(n), counts.ctypes.data,
+                                            out.ctypes.data if len(out) else None)
+        if problem is not None:
+            raise ValueError(problem)
+        _native.check(rc)
         parts, off = [], 0
         for c in counts:
             parts.append(out[off:off + int(c)])
             off += int(c)
-        _ = ctypes
         return parts
 
     def close(self) -> None:

@@ -89,13 +89,19 @@ class ScoringEngine:
         self.kernel_ms_acc = 0.0
 
     def close(self) -> None:
-        for buf in self.__dict__.pop("_scratch_bufs", {}).values():
-            buf.free()
-        if getattr(self, "_h", None):
-            for p in self.__dict__.pop("_pinned", []):
-                self._lib.psd_host_free(self._h, p)
-            self._lib.psd_destroy(self._h)
-            self._h = None
+        """Destroy the engine (idempotent).  Waits for a composite call another thread may be inside (``_lock``); buffers
+        and pinned memory handed out by this engine must not be used afterwards."""
+        lock = self.__dict__.get("_lock")
+        if lock is None:                       # __init__ failed before the engine existed
+            return
+        with lock:
+            for buf in self.__dict__.pop("_scratch_bufs", {}).values():
+                buf.free()
+            if getattr(self, "_h", None):
+                for p in self.__dict__.pop("_pinned", []):
+                    self._lib.psd_host_free(self._h, p)
+                self._lib.psd_destroy(self._h)
+                self._h = None
 
     def __del__(self):
         try:
@@ -486,32 +492,29 @@ for _name in ("score_host", "_score_host_downscaled", "analyze_frames", "hash_th
               "score_device_downscaled", "score_device_segments", "score_clips", "edge_map", "resize_device"):
     setattr(ScoringEngine, _name, _locked(getattr(ScoringEngine, _name)))
 
-_default_lock = threading.Lock()
-_default_engines: dict[tuple[int, int], ScoringEngine] = {}
+_default_tls = threading.local()
 
 
 def default_engine(device: int | None = None) -> ScoringEngine:
     """The calling THREAD's engine for ``device`` (default: ``LOCAL_RANK`` or 0).  An engine keeps state between the
     steps of a call (record slots, staging buffers), so threads do not share one: two SceneManagers or detectors running
     on different threads each get their own stream and buffers (the reference runs one detector set per thread,
-    ``benchmark/sweep.py:160-180``).  Raises without a GPU."""
+    ``benchmark/sweep.py:160-180``).  Raises without a GPU.
+
+    Lifetime: the thread's slot and every object that cached the engine (a SceneManager, a detector) hold ordinary
+    references; the engine is destroyed when the last of them lets go -- never from another thread's call to this
+    function (a SceneManager built on a worker thread stays usable after that thread has ended)."""
     import os
 
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
         if device >= max(device_count(), 1):
             device = 0
-    key = (threading.get_ident(), device)
-    with _default_lock:
-        eng = _default_engines.get(key)
-        if eng is None:
-            # drop engines of threads that are gone
-            alive = {t.ident for t in threading.enumerate()}
-            for k in [k for k in _default_engines if k[0] not in alive]:
-                _default_engines.pop(k).close()
-            eng = ScoringEngine(device)
-            _default_engines[key] = eng
-        return eng
+    cache = _default_tls.__dict__.setdefault("engines", {})
+    eng = cache.get(device)
+    if eng is None or eng._h is None:          # (closed by its user: make a fresh one)
+        eng = cache[device] = ScoringEngine(device)
+    return eng
 
 
 def hsv_tables() -> tuple[np.ndarray, np.ndarray]:

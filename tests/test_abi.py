@@ -97,3 +97,37 @@ def test_missing_library_fails_loudly(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
     assert out.stdout.startswith("NativeLibraryError"), out.stdout + out.stderr
     assert "no CPU fallback" in out.stdout
+
+
+def test_default_engine_is_per_thread_and_never_closed_from_another_thread(monkeypatch):
+    """Host logic of `engine.default_engine` without a GPU (the engine class is replaced by a stand-in)."""
+    import threading
+
+    from pyscenedetect_amd import engine as E
+
+    made = []
+
+    class Fake:
+        def __init__(self, device):
+            self.device, self._h, self.closed = device, object(), False
+            made.append(self)
+
+        def close(self):
+            self._h, self.closed = None, True
+
+    monkeypatch.setattr(E, "ScoringEngine", Fake)
+    monkeypatch.setattr(E, "device_count", lambda: 2)
+    monkeypatch.setattr(E, "_default_tls", threading.local())
+    a = E.default_engine(0)
+    assert E.default_engine(0) is a and E.default_engine(1) is not a
+    held = {}
+    t = threading.Thread(target=lambda: held.setdefault("e", E.default_engine(0)))
+    t.start()
+    t.join()
+    assert held["e"] is not a
+    t2 = threading.Thread(target=lambda: E.default_engine(0))     # used to close the engines of dead threads
+    t2.start()
+    t2.join()
+    assert not held["e"].closed and held["e"]._h is not None
+    a.close()
+    assert E.default_engine(0) is not a                            # a closed engine is replaced, not handed out

@@ -421,3 +421,40 @@ print("ok")
         env = dict(os.environ, PSD_EDGE_WS_MB="1", PSD_EDGE_FUSE_HSV=fuse)
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (fuse, out.stdout[-400:], out.stderr[-1200:])
+
+
+def test_a_scene_manager_outlives_the_thread_that_built_it(golden):
+    """Advisor, round 2: default_engine() used to destroy the engines of dead threads, so a SceneManager first used on a
+    worker thread lost its engine as soon as any other thread asked for a new one.  The engine now lives as long as
+    something holds it."""
+    import threading
+
+    import pyscenedetect_amd as psd
+    from pyscenedetect_amd.engine import default_engine
+    from tests.conftest import golden_clip
+
+    frames = golden_clip(golden, "scenes_a")
+    want = golden["clips"]["scenes_a"]["results"]["content_default"]["cuts"]
+    box = {}
+
+    def build():
+        sm = psd.SceneManager(batch_frames=16)
+        sm.auto_downscale = False
+        sm.add_detector(psd.ContentDetector())
+        sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+        box["sm"], box["engine"] = sm, default_engine()
+
+    t = threading.Thread(target=build)
+    t.start()
+    t.join()
+    other = threading.Thread(target=lambda: box.setdefault("other", default_engine()))   # a NEW engine on a new thread
+    other.start()
+    other.join()
+    assert box["engine"]._h is not None and box["other"] is not box["engine"]
+    sm = box["sm"]
+    assert [c.frame_num for c in sm.get_cut_list()] == want
+    sm2 = psd.SceneManager(engine=box["engine"], batch_frames=16)       # and the dead thread's engine still scores
+    sm2.auto_downscale = False
+    sm2.add_detector(psd.ContentDetector(engine=box["engine"]))
+    sm2.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+    assert [c.frame_num for c in sm2.get_cut_list()] == want
