@@ -4,17 +4,18 @@
 //     edges_t   = cv2.dilate(cv2.Canny(V_t, low, high), ones(k,k))   with low/high from numpy.median(V_t)
 //     delta_edges = mean |edges_t - edges_{t-1}| = 255 * popcount(edges_t XOR edges_{t-1}) / (H*W)
 // Device pipeline per chunk of frames (everything integer, so the result is exact):
-//   K1 value_plane_hist   V = max(B,G,R) -> u8 plane + per-frame 256-bin histogram (for the median)
+//   K1 value_plane_hist   V = max(B,G,R) -> u8 plane + per-frame 256-bin histogram (for the median); with the HSV term in
+//                         the same call the HSV pass writes both (V mode, psd_score_kernels.hip)
 //   K2 median_thresholds  exact numpy.median from the histogram -> (low, high) via a host-built table
-//   K3 sobel_nms          Sobel 3x3 (replicate border), |dx|+|dy|, non-maximum suppression with
-//                         OpenCV's TG22 fixed point -> map {0 none, 1 weak, 2 strong}; LDS tiles with halo
-//   K4 hysteresis         8-connected growth of strong into weak: in-LDS fix point per 64x64 tile,
-//                         relaunched until no tile changes (the result is order independent)
-//   K5 pack_hdilate       strong pixels -> bit rows, horizontal OR over the k-window (bit shifts)
-//   K6 vdilate_xor        vertical OR over the k-window, XOR with the previous frame's dilated bits,
-//                         popcount -> edge_xor; the dilated bits stay resident for the next frame
-// Algorithmic traffic is 5 B/px (3 read + edge map write + previous edge map read);
-// the intermediate planes are implementation overhead.
+//   K3 sobel_nms_bits     Sobel 3x3 (replicate border), |dx|+|dy|, non-maximum suppression with OpenCV's TG22 fixed point
+//                         -> TWO BIT PLANES, strong (m > high) and weak (low < m <= high); LDS tiles with halo, tiles
+//                         handed out so that neighbours share an XCD's L2
+//   K4 hysteresis_bits    8-connected growth of strong into weak: one wave per 64x64 tile, one row per lane, 64-bit
+//                         word-parallel steps with carry-chain run filling; relaunched until no tile border changes
+//   K5 dilate_xor         k x k dilation of the strong bits and XOR count against the previous frame's dilated bits, bands
+//                         of rows walking the time axis; the dilated map stays in LDS
+// Algorithmic traffic is 5 B/px (3 read + edge map write + previous edge map read); the V plane (1 B/px out
+// and in) and the bit planes (0.25 B/px) are implementation overhead.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -220,6 +221,44 @@ __global__ __launch_bounds__(256) void value_plane_hist_dma_kernel(ChunkSrc src,
     }
 }
 
+// Histogram of V planes that already exist (written by the HSV pass in V mode): one 4-wave workgroup per (tile, frame),
+// 16-byte loads (16 pixels per lane and load, four in flight), 16x replicated LDS histogram, one flush.  2 B/px of traffic
+// against the 5+ B/px of value_plane_hist_dma_kernel; the HSV pass then needs no per-pixel LDS atomics at all.
+constexpr int VH_UNROLL = 4;
+__global__ __launch_bounds__(256) void v_hist_kernel(const uint8_t* vplane, long npix, int groups_per_tile, u32* hist)
+{
+    constexpr int AC = 16;
+    __shared__ __attribute__((aligned(16))) u32 lh[256 * AC];
+    const int tid = threadIdx.x, j = blockIdx.y;
+    for (int i = tid; i < 256 * AC; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int n_groups = (int)(npix >> 4);
+    const int g0 = blockIdx.x * groups_per_tile, g1 = min(n_groups, g0 + groups_per_tile);
+    const u32x4* V = reinterpret_cast<const u32x4*>(vplane + (size_t)j * npix);
+    u32* my_h = lh + (tid & (AC - 1));
+    for (int gb = g0; gb < g1; gb += 256 * VH_UNROLL) {
+        u32x4 q[VH_UNROLL];
+#pragma unroll
+        for (int u = 0; u < VH_UNROLL; u++)   // unconditional on a clamped index: the loads go out together
+            q[u] = __builtin_nontemporal_load(V + min(gb + u * 256 + tid, g1 - 1));
+#pragma unroll
+        for (int u = 0; u < VH_UNROLL; u++) {
+            if (gb + u * 256 + tid < g1) {
+                const u32 w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
+#pragma unroll
+                for (int i = 0; i < 16; i++) atomicAdd(&my_h[((w[i >> 2] >> ((i & 3) * 8)) & 0xffu) * AC], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        u32 sum = 0;
+#pragma unroll
+        for (int r = 0; r < AC; r++) sum += lh[tid * AC + ((r + tid) & (AC - 1))];
+        if (sum) atomicAdd(&hist[(size_t)j * 256 + tid], sum);
+    }
+}
+
 // ---- K2: median -> Canny thresholds ------------------------------------------------------------
 
 // numpy.median of the V plane: for an even count the mean of the two middle order statistics, so
@@ -341,156 +380,27 @@ __global__ __launch_bounds__(256) void sobel_nms_kernel(const uint8_t* vplane, E
     }
 }
 
-// K3, dword form (frames whose width and pixel count are multiples of 4: 1080p, 4K, 720p, 256x144 ...).
-// 128 x 32 tiles.  Phase 1 computes only the magnitude |dx| + |dy| of the tile plus a 1-px ring, four pixels of a row
-// per work item as two packed 16-bit pairs (even / odd columns), rolling down the rows of a 5-row segment: per row three
-// dword reads of V, two v_perm + two masks to get the four column pairs, packed adds / multiply-adds for the separable
-// Sobel sums.  Phase 2 suppresses non-maxima: a pixel whose magnitude is not above `low` is done after one read (almost
-// all of a natural frame); the others recompute dx, dy from the 3x3 V neighbourhood, classify the direction with OpenCV's
-// TG22 fixed point and compare with the two neighbours along it.  Results leave as dwords.  Same integers as
-// sobel_nms_kernel, a quarter of its instructions.
+// ---- K3, fast form: Sobel + NMS of 128 x 32 tiles straight into BIT PLANES -------------------------------------------------
+// (frames whose rows are dword aligned: width % 4 == 0 -- 1080p, 4K, 720p, 1440, 640x360, 256x144 ...; anything else goes
+//  through the byte kernel above and map_to_bits_kernel.)
+// The Canny map never exists as bytes: a pixel is "strong" (m > high), "weak" (low < m <= high) or nothing, so the kernel
+// writes two bit rows per image row -- strong[y][x >> 5] bit (x & 31), weak likewise -- 0.25 B/px instead of 1 B/px, and
+// everything behind it (hysteresis, dilation, XOR count) is word-parallel.
+// Phase 1 computes only the magnitude |dx| + |dy| of the tile plus a 1-px ring, four pixels of a row per work item as two
+// packed 16-bit pairs (even / odd columns), rolling down the rows of a 5-row segment; phase 2 suppresses non-maxima: a pixel
+// whose magnitude is not above `low` is done after one read (almost all of a natural frame), the others recompute dx, dy
+// from the 3x3 V neighbourhood, classify the direction with OpenCV's TG22 fixed point and compare with the two neighbours
+// along it.
 constexpr int HT_TILE = 64;   // = HT, the hysteresis tile edge (defined below)
 constexpr int N2_W = 128, N2_H = 32, N2_SVW = N2_W + 8, N2_SEG = 5, N2_NSEG = 7, N2_NCG = N2_SVW / 4;
 static_assert(N2_NCG * N2_NSEG <= 256 && N2_SEG * N2_NSEG >= N2_H + 2, "one pass of 256 threads covers the ring");
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-// packed 16-bit arithmetic through clang's vector types (v_pk_add_u16 / v_pk_sub_i16 / v_pk_max_i16 without inline asm,
-// which hipcc would pad with s_nop and could not schedule across)
-__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { return __builtin_bit_cast(u32, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b))); }
-__device__ __forceinline__ u32 pk_sub(u32 a, u32 b) { return __builtin_bit_cast(u32, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b))); }
+// packed 16-bit max through clang's vector types (v_pk_max_i16 without inline asm, which hipcc would pad with s_nop and
+// could not schedule across)
 __device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b))); }
-// a + 2 b on both halves
-__device__ __forceinline__ u32 pk_add2(u32 a, u32 b) { return pk_add(a, pk_add(b, b)); }
-__device__ __forceinline__ u32 pk_abs(u32 a) { return pk_max(a, pk_sub(0u, a)); }
 
-// grid = (tiles_x, tiles_y, frames)
-// `dirty` (zeroed by the caller): one flag per 64x64 hysteresis tile of the frame, set where this tile leaves a weak pixel --
-// the first hysteresis launch then only looks at tiles that can change at all (a natural frame has few of them).
-__global__ __launch_bounds__(256) void sobel_nms_dword_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, uint8_t* map,
-                                                              uint8_t* dirty, int htiles_x, int htiles_per_frame)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t sv[N2_H + 4][N2_SVW];          // rows y0-2 .. y0+33, cols x0-4 .. x0+131
-    __shared__ __attribute__((aligned(16))) unsigned short smag[N2_H + 2][N2_SVW]; // rows y0-1 .. y0+32, same columns
-    const int j = blockIdx.z, tid = threadIdx.x;
-    const uint8_t* V = vplane + (size_t)j * g.npix;
-    const int x0 = blockIdx.x * N2_W, y0 = blockIdx.y * N2_H, H = g.height, W = g.width;
-    const bool inner = x0 >= 4 && x0 + N2_W + 4 <= W && y0 >= 2 && y0 + N2_H + 2 <= H;
-    if (inner) {
-        // all five loads before the first LDS write (as a loop, each load is waited for before the next is issued)
-        constexpr int NLD = ((N2_H + 4) * N2_NCG + 255) / 256;
-        u32 v[NLD];
-#pragma unroll
-        for (int it = 0; it < NLD; it++) {
-            const int i = min(tid + it * 256, (N2_H + 4) * N2_NCG - 1);
-            const int ly = i / N2_NCG, lw = i - ly * N2_NCG;
-            v[it] = *reinterpret_cast<const u32*>(V + (size_t)(y0 + ly - 2) * W + x0 - 4 + lw * 4);
-        }
-#pragma unroll
-        for (int it = 0; it < NLD; it++) {
-            const int i = tid + it * 256;
-            const int ly = i / N2_NCG, lw = i - ly * N2_NCG;
-            if (i < (N2_H + 4) * N2_NCG) *reinterpret_cast<u32*>(&sv[ly][lw * 4]) = v[it];
-        }
-    } else {   // border tiles: replicate (BORDER_REPLICATE of cv2.Sobel inside Canny)
-        for (int i = tid; i < (N2_H + 4) * N2_SVW; i += 256) {
-            const int ly = i / N2_SVW, lx = i - ly * N2_SVW;
-            const int y = min(max(y0 + ly - 2, 0), H - 1), x = min(max(x0 + lx - 4, 0), W - 1);
-            sv[ly][lx] = V[(size_t)y * W + x];
-        }
-    }
-    __syncthreads();
-    // ---- phase 1: magnitudes of smag rows [5 seg, 5 seg + 5), columns 4 cg .. 4 cg + 3
-    if (tid < N2_NCG * N2_NSEG) {
-        const int cg = tid % N2_NCG, seg = tid / N2_NCG;
-        const int m0 = seg * N2_SEG, m1 = min(m0 + N2_SEG, N2_H + 2);
-        const int cl = max(cg - 1, 0) * 4, cm = cg * 4, cr = min(cg + 1, N2_NCG - 1) * 4;   // clamped neighbours only feed unused columns
-        // columns of the four outputs in the image, for the "magnitude outside the image is 0" rule
-        const int xb = x0 - 4 + cm;
-        const u32 keepE = ((xb >= 0 && xb < W) ? 0xffffu : 0u) | ((xb + 2 >= 0 && xb + 2 < W) ? 0xffff0000u : 0u);
-        const u32 keepO = ((xb + 1 >= 0 && xb + 1 < W) ? 0xffffu : 0u) | ((xb + 3 >= 0 && xb + 3 < W) ? 0xffff0000u : 0u);
-        u32 h1E[3], h1O[3], h2E[3], h2O[3];
-        auto horiz = [&](int r, int slot) {
-            const u32 wl = *reinterpret_cast<const u32*>(&sv[r][cl]), wm = *reinterpret_cast<const u32*>(&sv[r][cm]),
-                      wr = *reinterpret_cast<const u32*>(&sv[r][cr]);
-            // pixels a0 = wl.b3, a1..a4 = wm, a5 = wr.b0; pairs P0 = (a0,a2) P1 = (a1,a3) P2 = (a2,a4) P3 = (a3,a5)
-            const u32 P1 = wm & 0x00ff00ffu, P2 = (wm >> 8) & 0x00ff00ffu;
-            const u32 P0 = __builtin_amdgcn_perm(wm, wl, 0x0c050c03u);   // [wl.b3, 0, wm.b1, 0]
-            const u32 P3 = __builtin_amdgcn_perm(wr, wm, 0x0c040c02u);   // [wm.b2, 0, wr.b0, 0]
-            h1E[slot] = pk_sub(P2, P0); h1O[slot] = pk_sub(P3, P1);      // right - left
-            h2E[slot] = pk_add(pk_add2(P0, P1), P2); h2O[slot] = pk_add(pk_add2(P1, P2), P3);   // left + 2 mid + right
-        };
-        horiz(m0, 0);
-        horiz(m0 + 1, 1);
-#pragma unroll
-        for (int k = 0; k < N2_SEG; k++) {
-            const int my = m0 + k;
-            if (my < m1) {
-                const int a = k % 3, b = (k + 1) % 3, c = (k + 2) % 3;
-                horiz(my + 2, c);
-                const u32 dxE = pk_add(pk_add2(h1E[a], h1E[b]), h1E[c]), dxO = pk_add(pk_add2(h1O[a], h1O[b]), h1O[c]);
-                const u32 dyE = pk_sub(h2E[c], h2E[a]), dyO = pk_sub(h2O[c], h2O[a]);
-                u32 mE = pk_add(pk_abs(dxE), pk_abs(dyE)), mO = pk_add(pk_abs(dxO), pk_abs(dyO));
-                const int y = y0 - 1 + my;
-                if (y < 0 || y >= H) { mE = 0; mO = 0; }
-                mE &= keepE; mO &= keepO;
-                uint2 out;
-                out.x = __builtin_amdgcn_perm(mO, mE, 0x05040100u);    // mag[c], mag[c+1]
-                out.y = __builtin_amdgcn_perm(mO, mE, 0x07060302u);    // mag[c+2], mag[c+3]
-                *reinterpret_cast<uint2*>(&smag[my][cm]) = out;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- phase 2: non-maximum suppression, four pixels of a row per thread and step
-    const int low = thr[j].x, high = thr[j].y;
-    for (int i = tid; i < N2_H * (N2_W / 4); i += 256) {
-        const int ly = i / (N2_W / 4), q = i - ly * (N2_W / 4);
-        const int y = y0 + ly, xq = x0 + 4 * q;
-        if (y >= H || xq >= W) continue;
-        const uint2 m4 = *reinterpret_cast<const uint2*>(&smag[ly + 1][4 + 4 * q]);
-        const int mm[4] = {(int)(m4.x & 0xffffu), (int)(m4.x >> 16), (int)(m4.y & 0xffffu), (int)(m4.y >> 16)};
-        u32 packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int m = mm[k];
-            if (m > low) {
-                const int r = ly + 2, c = 4 + 4 * q + k;       // centre in sv; magnitude at smag[ly + 1][c]
-                const int tl = sv[r - 1][c - 1], tc = sv[r - 1][c], tr = sv[r - 1][c + 1], ml = sv[r][c - 1], mr = sv[r][c + 1],
-                          bl = sv[r + 1][c - 1], bc = sv[r + 1][c], br = sv[r + 1][c + 1];
-                const int xs = (tr + 2 * mr + br) - (tl + 2 * ml + bl), ys = (bl + 2 * bc + br) - (tl + 2 * tc + tr);
-                const int ax = abs(xs), ay = abs(ys) << 15;
-                const int tg22x = ax * 13573;  // TG22 = round(tan(22.5 deg) * 2^15)
-                bool is_max;
-                if (ay < tg22x) {
-                    is_max = m > smag[ly + 1][c - 1] && m >= smag[ly + 1][c + 1];
-                } else if (ay > tg22x + (ax << 16)) {
-                    is_max = m > smag[ly][c] && m >= smag[ly + 2][c];
-                } else {
-                    const int sgn = (xs ^ ys) < 0 ? -1 : 1;
-                    is_max = m > smag[ly][c - sgn] && m > smag[ly + 2][c + sgn];
-                }
-                if (is_max) packed |= (m > high ? 2u : 1u) << (8 * k);
-            }
-        }
-        *reinterpret_cast<u32*>(map + (size_t)j * g.npix + (size_t)y * W + xq) = packed;
-        // a byte equal to 1 (weak): (packed ^ 0x01010101) has a zero byte there
-        const u32 z = packed ^ 0x01010101u;
-        if ((z - 0x01010101u) & ~z & 0x80808080u) dirty[(size_t)j * htiles_per_frame + (size_t)(y / HT_TILE) * htiles_x + xq / HT_TILE] = 1;
-    }
-}
-
-// K3, full-width tiles (frames whose width is a multiple of the 128-px tile: 1080p, 4K, 720p, 640x360, 256x144 ...).
-// The same arithmetic as sobel_nms_dword_kernel with the per-wave instruction count cut by a third (the kernel is VALU
-// bound: 540 VALU instructions per wave, 85 % VALU-busy in profiles/r02_h_pmc_edges.txt):
-//   * tile load: two V rows per wave instruction (lanes 0-31 / 32-63 take the 32 dwords of a row, 72 threads the two dwords
-//     left over per row), row index clamped, the replicated column outside a left / right image edge made from the
-//     neighbouring dword -- six loads with a handful of address instructions instead of five (interior) or nineteen
-//     (border tiles: 18 % of a 1080p frame, byte by byte before) rounds of divide-by-34 indexing;
-//   * phase 1 is specialised for interior tiles (no "outside the image" masks) and leaves the magnitudes as the even /
-//     odd column pairs it computed them in (no re-interleave);
-//   * phase 2 takes eight pixels per thread and decides "no candidate among them" with four packed max + xor.
 __device__ __forceinline__ int mag_at(const uint2 (*smq)[N2_NCG], int row, int c)
 {
     // column c of a magnitude row: quad c >> 2 holds {m0 | m2 << 16, m1 | m3 << 16}
@@ -516,7 +426,7 @@ __device__ __forceinline__ void sobel_phase1_quads(const uint8_t (*sv)[N2_SVW], 
     // 3), every Sobel quantity is an integer of magnitude <= 2040, so sums, differences and the fused x2 are exact and the
     // result's bits ARE the integer -- in sign-magnitude, which makes |x| one full-rate v_and_b32 instead of a packed
     // negate + max, and a + 2 b one v_pk_fma_f16 instead of a packed shift + add (7 half-rate + 2 full-rate instructions per
-    // pixel pair and row instead of 13 half-rate ones).  The magnitudes that leave are the same 16-bit integers as before.
+    // pixel pair and row instead of 13 half-rate ones).  The magnitudes that leave are plain 16-bit integers.
     typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
     auto H2 = [](u32 a) { return __builtin_bit_cast(h16x2, a); };
     auto U = [](h16x2 a) { return __builtin_bit_cast(u32, a); };
@@ -525,6 +435,7 @@ __device__ __forceinline__ void sobel_phase1_quads(const uint8_t (*sv)[N2_SVW], 
     auto horiz = [&](int r, int slot) {
         const u32 wl = *reinterpret_cast<const u32*>(&sv[r][cl]), wm = *reinterpret_cast<const u32*>(&sv[r][cm]),
                   wr = *reinterpret_cast<const u32*>(&sv[r][cr]);
+        // pixels a0 = wl.b3, a1..a4 = wm, a5 = wr.b0; pairs P0 = (a0,a2) P1 = (a1,a3) P2 = (a2,a4) P3 = (a3,a5)
         const h16x2 P1 = H2(wm & 0x00ff00ffu), P2 = H2((wm >> 8) & 0x00ff00ffu);
         const h16x2 P0 = H2(__builtin_amdgcn_perm(wm, wl, 0x0c050c03u));   // [wl.b3, 0, wm.b1, 0]
         const h16x2 P3 = H2(__builtin_amdgcn_perm(wr, wm, 0x0c040c02u));   // [wm.b2, 0, wr.b0, 0]
@@ -553,22 +464,33 @@ __device__ __forceinline__ void sobel_phase1_quads(const uint8_t (*sv)[N2_SVW], 
     }
 }
 
-// grid = (W / 128, tiles_y, frames); requires W % 128 == 0
-__global__ __launch_bounds__(256) void sobel_nms_tile_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, uint8_t* map,
-                                                             uint8_t* dirty, int htiles_x, int htiles_per_frame)
+// grid = (tiles_x * tiles_y, frames).  (Handing the tiles out so that every XCD walks one contiguous run of them -- the
+// 128-byte lines a tile shares with its left / right neighbour then hit in that XCD's L2 -- measured no difference: 299.5 k
+// vs 299-301 k frames/s on 2048 x 1080p; the 2 MB V plane of a frame sits in the Infinity Cache either way.)
+// `dirty` (zeroed by the caller): one flag per 64x64 hysteresis tile, set where this tile leaves a weak pixel -- the first
+// hysteresis launch then only looks at tiles that can change at all (a natural frame has few of them).
+// tiles_x_magic = ceil(2^32 / tiles_x): tile / tiles_x as one multiply-high (exact for tile < 2^20).
+__global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, u32* strong, u32* weak,
+                                                             uint8_t* dirty, int tiles_x, u32 tiles_x_magic, int htiles_x, int htiles_per_frame)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sv[N2_H + 4][N2_SVW];   // rows y0-2 .. y0+33, cols x0-4 .. x0+131
     __shared__ __attribute__((aligned(16))) uint2 smq[N2_H + 2][N2_NCG];    // rows y0-1 .. y0+32, magnitudes as even / odd pairs
-    const int j = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) uint8_t obits[2][N2_H][N2_W / 8]; // [strong | weak][row][8 pixels]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, j = blockIdx.y;
+    const int ty = tiles_x == 1 ? tile : (int)__umulhi((u32)tile, tiles_x_magic), tx = tile - ty * tiles_x;
     const uint8_t* V = vplane + (size_t)j * g.npix;
-    const int x0 = blockIdx.x * N2_W, y0 = blockIdx.y * N2_H, H = g.height, W = g.width;
+    const int x0 = tx * N2_W, y0 = ty * N2_H, H = g.height, W = g.width;
     const int2 lohi = thr[j];   // read here: behind the barriers its latency would sit in front of phase 2
     {
+        // 36 rows x 34 dwords, BORDER_REPLICATE (cv2.Sobel inside cv2.Canny): two V rows per wave instruction (lanes 0-31 /
+        // 32-63 take the first 32 dwords of a row, 72 threads the two dwords left over per row), the row and the dword
+        // position clamped into the image and, where the position was clamped, the edge pixel replicated.  All six loads go
+        // out before the first LDS write (unconditional on clamped coordinates; behind a branch hipcc waits for every load
+        // before issuing the next -- six memory latencies per tile).
         const int cw = lane & 31;
-        const int left = (x0 == 0 && cw == 0) ? 1 : 0;
-        const uint8_t* col = V + x0 - 4 + 4 * (cw + left);
-        // all six loads go out before the first LDS write (the loads are unconditional on a clamped row, only the writes are
-        // predicated: behind a branch hipcc waits for every load before issuing the next -- six memory latencies per tile)
+        const int xa = x0 - 4 + 4 * cw;
+        const uint8_t* col = V + min(max(xa, 0), W - 4);
         u32 v[5];
 #pragma unroll
         for (int it = 0; it < 5; it++) {
@@ -576,14 +498,17 @@ __global__ __launch_bounds__(256) void sobel_nms_tile_kernel(const uint8_t* vpla
             v[it] = *reinterpret_cast<const u32*>(col + (size_t)min(max(y0 + ly - 2, 0), H - 1) * W);
         }
         const int tl = min(tid >> 1, N2_H + 3), c2 = 32 + (tid & 1);
-        const int right = (x0 + N2_W == W && c2 == 33) ? 1 : 0;
-        u32 vt = *reinterpret_cast<const u32*>(V + (size_t)min(max(y0 + tl - 2, 0), H - 1) * W + x0 - 4 + 4 * (c2 - right));
+        const int xb = x0 - 4 + 4 * c2;
+        u32 vt = *reinterpret_cast<const u32*>(V + (size_t)min(max(y0 + tl - 2, 0), H - 1) * W + min(xb, W - 4));
 #pragma unroll
         for (int it = 0; it < 5; it++) {
             const int ly = 2 * (wave * 5 + it) + (lane >> 5);
-            if (ly < N2_H + 4) *reinterpret_cast<u32*>(&sv[ly][4 * cw]) = left ? __builtin_amdgcn_perm(v[it], v[it], 0u) : v[it];   // BORDER_REPLICATE: V[y][0] four times
+            u32 w = v[it];
+            if (xa < 0) w = __builtin_amdgcn_perm(w, w, 0u);                    // V[y][0] four times
+            else if (xa >= W) w = __builtin_amdgcn_perm(w, w, 0x03030303u);     // V[y][W-1] four times
+            if (ly < N2_H + 4) *reinterpret_cast<u32*>(&sv[ly][4 * cw]) = w;
         }
-        if (tid < 2 * (N2_H + 4)) *reinterpret_cast<u32*>(&sv[tl][4 * c2]) = right ? __builtin_amdgcn_perm(vt, vt, 0x03030303u) : vt;   // V[y][W-1] four times
+        if (tid < 2 * (N2_H + 4)) *reinterpret_cast<u32*>(&sv[tl][4 * c2]) = xb >= W ? __builtin_amdgcn_perm(vt, vt, 0x03030303u) : vt;
     }
     __syncthreads();
     const bool inner = x0 >= 4 && x0 + N2_W + 4 <= W && y0 >= 2 && y0 + N2_H + 2 <= H;
@@ -593,16 +518,15 @@ __global__ __launch_bounds__(256) void sobel_nms_tile_kernel(const uint8_t* vpla
     // ---- phase 2: non-maximum suppression, eight pixels of a row per thread and step
     const int low = lohi.x, high = lohi.y;
     const u32 lowpk = (u32)low * 0x10001u;
+    bool any_weak = false;
 #pragma unroll
     for (int it = 0; it < N2_H * (N2_W / 8) / 256; it++) {
         const int i = tid + it * 256;
         const int ly = i >> 4, o = i & 15;
-        const int y = y0 + ly;
-        if (y >= H) continue;
         const uint2 qa = smq[ly + 1][1 + 2 * o], qb = smq[ly + 1][2 + 2 * o];
-        // a half above `low` survives the max: (max(m, low) ^ low) != 0
+        // a half above `low` survives the max: (max(m, low) ^ low) != 0   (magnitudes outside the image are 0: never above)
         const u32 any = (pk_max(qa.x, lowpk) ^ lowpk) | (pk_max(qa.y, lowpk) ^ lowpk) | (pk_max(qb.x, lowpk) ^ lowpk) | (pk_max(qb.y, lowpk) ^ lowpk);
-        u32 packed[2] = {0u, 0u};
+        u32 sb = 0, wb = 0;
         if (any) {
             const u32 w4[4] = {qa.x, qa.y, qb.x, qb.y};
 #pragma unroll
@@ -624,44 +548,91 @@ __global__ __launch_bounds__(256) void sobel_nms_tile_kernel(const uint8_t* vpla
                         const int sgn = (xs ^ ys) < 0 ? -1 : 1;
                         is_max = m > mag_at(smq, ly, c - sgn) && m > mag_at(smq, ly + 2, c + sgn);
                     }
-                    if (is_max) packed[k >> 2] |= (m > high ? 2u : 1u) << (8 * (k & 3));
+                    if (is_max) {
+                        if (m > high) sb |= 1u << k;
+                        else wb |= 1u << k;
+                    }
                 }
             }
         }
-        const int xq = x0 + 8 * o;
-        *reinterpret_cast<uint2*>(map + (size_t)j * g.npix + (size_t)y * W + xq) = make_uint2(packed[0], packed[1]);
-        if (any) {
-            // a byte equal to 1 (weak): (packed ^ 0x01010101) has a zero byte there
-            const u32 z0 = packed[0] ^ 0x01010101u, z1 = packed[1] ^ 0x01010101u;
-            if ((((z0 - 0x01010101u) & ~z0) | ((z1 - 0x01010101u) & ~z1)) & 0x80808080u)
-                dirty[(size_t)j * htiles_per_frame + (size_t)(y / HT_TILE) * htiles_x + xq / HT_TILE] = 1;
+        obits[0][ly][o] = (uint8_t)sb;
+        obits[1][ly][o] = (uint8_t)wb;
+        if (wb) {
+            any_weak = true;
+            const int y = y0 + ly, xq = x0 + 8 * o;
+            if (y < H && xq < W) dirty[(size_t)j * htiles_per_frame + (size_t)(y / HT_TILE) * htiles_x + xq / HT_TILE] = 1;
+        }
+    }
+    (void)any_weak;
+    __syncthreads();
+    {
+        // 2 planes x 32 rows x 4 words = 256 words, one per thread
+        const int plane = tid >> 7, ly = (tid >> 2) & 31, wq = tid & 3;
+        const int y = y0 + ly, w = (x0 >> 5) + wq;
+        if (y < H && w < g.words_per_row) {
+            const u32 bits = *reinterpret_cast<const u32*>(&obits[plane][ly][4 * wq]);
+            (plane ? weak : strong)[((size_t)j * H + y) * g.words_per_row + w] = bits;
         }
     }
 }
 
-// ---- K4: hysteresis -----------------------------------------------------------------------------
+// Byte map (0 none, 1 weak, 2 strong: sobel_nms_kernel, any frame size) -> the bit planes and the dirty-tile flags of the
+// fast form.  One thread per 32-pixel word; grid = (ceil(words_per_frame / 256), frames).
+__global__ __launch_bounds__(256) void map_to_bits_kernel(const uint8_t* map, EdgeGeom g, u32* strong, u32* weak, uint8_t* dirty,
+                                                          int htiles_x, int htiles_per_frame)
+{
+    const int j = blockIdx.y, nw = g.words_per_row;
+    const long words = (long)g.height * nw;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= words) return;
+    const int y = (int)(i / nw), w = (int)(i - (long)y * nw);
+    const uint8_t* M = map + (size_t)j * g.npix + (size_t)y * g.width;
+    u32 sb = 0, wb = 0;
+    for (int b = 0; b < 32; b++) {
+        const int x = w * 32 + b;
+        if (x < g.width) {
+            const uint8_t m = M[x];
+            if (m == 2) sb |= 1u << b;
+            else if (m == 1) wb |= 1u << b;
+        }
+    }
+    strong[(size_t)j * words + i] = sb;
+    weak[(size_t)j * words + i] = wb;
+    if (wb) {
+        // (a 32-pixel word lies inside one 64-pixel tile)
+        dirty[(size_t)j * htiles_per_frame + (size_t)(y / HT_TILE) * htiles_x + (w * 32) / HT_TILE] = 1;
+    }
+}
 
-constexpr int HT = 64;  // hysteresis tile edge
+// ---- K4: hysteresis on the bit planes -------------------------------------------------------------------------------------
+
+constexpr int HT = 64;  // hysteresis tile edge: 64 rows (one per lane of a wave) x 64 columns (two words, one 64-bit value per lane)
 static_assert(HT == HT_TILE, "");
 
-// grid = ceil(tiles / tpw) workgroups, each responsible for tpw <= 64 consecutive tiles of the (frame, tile_y, tile_x) order
-// (16: sweep on 256 x 1080p, shot-like / all-dirty noise: 64 -> 1.27 / 4.94 ms per call, 32 -> 1.22 / 4.61, 16 -> 1.23 / 4.41,
-// 8 -> 1.25 / 4.37; one workgroup per tile, as before: 1.30 / 4.36).
-// Grows strong (2) into 8-connected weak (1) pixels inside a tile until nothing changes, using the neighbouring
-// tiles' current state as a read-only halo.
-// Work list: a tile is only looked at when `dirty_in` says it holds weak pixels (first launch: flags from the NMS kernel)
-// or one of its neighbours promoted a pixel on the shared border in the previous launch; when it promotes border pixels
-// itself it marks its neighbours in `dirty_out` and raises *changed.  A natural frame leaves a few per cent of the tiles
-// dirty: one wave reads the flags of the workgroup's range at once and the workgroup walks the set bits -- a launch over
-// 130 k tiles (256 x 1080p) is 8 k workgroups instead of 130 k that exit at once (30 us per launch, nine launches per call).
-__global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom g, uint8_t* dirty_in, uint8_t* dirty_out,
-                                                         int* changed, int tiles_x, int tiles_y, long n_tiles, int tpw)
+// Grows strong into 8-connected weak pixels inside 64x64 tiles until nothing changes, using the neighbouring tiles'
+// current state as a read-only halo (OpenCV's stack flood fill computes 8-connected reachability from the strong pixels,
+// which is order independent, so any schedule that reaches the fix point gives the same map).
+// ONE WAVE PER TILE, one image row per lane: the row's 64 strong / weak bits are one 64-bit register each, the halo column
+// left and right one bit each, the rows above / below come from the neighbouring lanes (DPP / ds_bpermute shuffles) and,
+// for lanes 0 and 63, from the halo rows read with the tile.  One step is a dozen 64-bit operations per lane for all 4096
+// pixels; horizontal runs of weak pixels are filled in ONE step by a carry chain (seed + weak ripples through the run, in
+// both directions via a bit reversal).  No LDS, no barriers.
+// Work list as before: a tile is only looked at when `dirty_in` says so (first launch: flags from the NMS kernel; later: a
+// neighbour promoted a pixel on the shared border in the previous launch); a tile that promotes border pixels marks its
+// neighbours in `dirty_out` and raises *changed.  grid = ceil(tiles / tpw) workgroups of 4 waves, each responsible for
+// tpw <= 64 consecutive tiles of the (frame, tile_y, tile_x) order: one wave reads their flags with one load + ballot and the
+// four waves take the set bits in turn.
+__device__ __forceinline__ unsigned long long fill_runs_up(unsigned long long seeds, unsigned long long run)
 {
-    // tile + 1-px halo; image column x0 sits at LDS column OX + 1 = 4 so interior rows are dword aligned
-    constexpr int OX = 3;
-    __shared__ __attribute__((aligned(16))) uint8_t t[HT + 2][HT + 8];
-    __shared__ int any_weak, tile_changed, border_changed, round_changed;
+    // every bit of `run` reachable from a seed bit (seeds subset of run) by walking towards the MSB through set bits of `run`
+    return (((seeds + run) ^ run) & run) | seeds;
+}
+
+__global__ __launch_bounds__(256) void hysteresis_bits_kernel(u32* strong, const u32* weak, EdgeGeom g, uint8_t* dirty_in, uint8_t* dirty_out,
+                                                              int* changed, int tiles_x, int tiles_y, long n_tiles, int tpw)
+{
     __shared__ unsigned long long todo_mask;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long first = (long)blockIdx.x * tpw;
     if (threadIdx.x < 64) {
         const long ti = first + threadIdx.x;
@@ -674,301 +645,208 @@ __global__ __launch_bounds__(256) void hysteresis_kernel(uint8_t* map, EdgeGeom 
     }
     __syncthreads();
     unsigned long long todo = todo_mask;
-    const int H = g.height, W = g.width;
+    const int H = g.height, nw = g.words_per_row;
     const int per_frame = tiles_x * tiles_y;
-  while (todo) {
-    const int bit = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    const long ti = first + bit;
-    const int j = (int)(ti / per_frame), rem = (int)(ti - (long)j * per_frame);
-    const int by = rem / tiles_x, bx = rem - by * tiles_x;
-    const size_t tile_base = (size_t)j * per_frame;
-    uint8_t* M = map + (size_t)j * g.npix;
-    const int x0 = bx * HT, y0 = by * HT;
-    __syncthreads();   // the previous tile of this workgroup is done with t[] and the flags
-    if (threadIdx.x == 0) { any_weak = 0; tile_changed = 0; border_changed = 0; }
-    __syncthreads();
-    int weak_here = 0;
-    // Tiles whose 64 columns are all inside a frame with 4-byte aligned rows load their interior as dwords
-    // (16 per row) and only the two halo columns as bytes; everything else goes byte by byte.
-    const bool wide = (W & 3) == 0 && (g.npix & 3) == 0 && x0 + HT <= W;
-    if (wide) {
-        // all loads of the tile (five dwords and one halo byte per thread) go out before the first LDS write: unconditional
-        // on clamped coordinates, the out-of-image zero applied afterwards (a load behind a branch is waited for before the
-        // next one is issued: six memory latencies per dirty tile)
-        constexpr int NDW = ((HT + 2) * (HT / 4) + 255) / 256;
-        static_assert((HT + 2) * 2 <= 256, "");
-        u32 dw[NDW];
-#pragma unroll
-        for (int it = 0; it < NDW; it++) {
-            const int i = min((int)threadIdx.x + it * 256, (HT + 2) * (HT / 4) - 1);
-            const int ly = i / (HT / 4), lw = i - ly * (HT / 4);
-            const int y = y0 + ly - 1;
-            dw[it] = *reinterpret_cast<const u32*>(M + (size_t)min(max(y, 0), H - 1) * W + x0 + lw * 4);
+    int turn = 0;
+    while (todo) {
+        const int bit = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        if ((turn++ & 3) != wave) continue;
+        const long ti = first + bit;
+        const int j = (int)(ti / per_frame), rem = (int)(ti - (long)j * per_frame);
+        const int by = rem / tiles_x, bx = rem - by * tiles_x;
+        u32* S = strong + (size_t)j * H * nw;
+        const u32* Wk = weak + (size_t)j * H * nw;
+        const int w0 = 2 * bx, y0 = by * HT;
+        // this lane's row, and (lanes 0 / 63) the halo rows above / below; words outside the image read as 0
+        const int y = y0 + lane;
+        const bool row_in = y < H;
+        const int yc = min(y, H - 1);
+        const bool has_hi = w0 + 1 < nw, has_l = w0 > 0, has_r = w0 + 2 < nw;
+        const u32* srow = S + (size_t)yc * nw;
+        const u32* wrow = Wk + (size_t)yc * nw;
+        // unconditional loads on clamped indices (they go out together), masked afterwards
+        u32 s_lo = srow[w0], s_hi = srow[min(w0 + 1, nw - 1)], s_l = srow[max(w0 - 1, 0)], s_r = srow[min(w0 + 2, nw - 1)];
+        u32 k_lo = wrow[w0], k_hi = wrow[min(w0 + 1, nw - 1)];
+        const int yh = lane == 0 ? y0 - 1 : y0 + HT;          // halo row of lane 0 (above) / lane 63 (below)
+        const bool halo_lane = lane == 0 || lane == 63;
+        const bool halo_in = halo_lane && yh >= 0 && yh < H;
+        const u32* hrow = S + (size_t)min(max(yh, 0), H - 1) * nw;
+        u32 h_lo = hrow[w0], h_hi = hrow[min(w0 + 1, nw - 1)], h_l = hrow[max(w0 - 1, 0)], h_r = hrow[min(w0 + 2, nw - 1)];
+        if (!row_in) { s_lo = s_hi = s_l = s_r = k_lo = k_hi = 0; }
+        if (!has_hi) { s_hi = 0; k_hi = 0; h_hi = 0; }
+        if (!has_l) { s_l = 0; h_l = 0; }
+        if (!has_r) { s_r = 0; h_r = 0; }
+        if (!halo_in) { h_lo = h_hi = h_l = h_r = 0; }
+        unsigned long long Sv = ((unsigned long long)s_hi << 32) | s_lo;
+        const unsigned long long Kv = ((unsigned long long)k_hi << 32) | k_lo;
+        const unsigned long long S0 = Sv;
+        const u32 eL = s_l >> 31, eR = s_r & 1u;              // strong state of the pixels left / right of this row (fixed here)
+        const unsigned long long Hv = ((unsigned long long)h_hi << 32) | h_lo;
+        const u32 hL = h_l >> 31, hR = h_r & 1u;
+        if (__ballot(Kv != 0) == 0) continue;                  // no weak pixel in the tile: nothing can change
+        for (;;) {
+            // rows above / below: neighbouring lanes, the halo rows at the ends
+            unsigned long long up = __shfl_up(Sv, 1), dn = __shfl_down(Sv, 1);
+            u32 upL = __shfl_up(eL, 1), upR = __shfl_up(eR, 1), dnL = __shfl_down(eL, 1), dnR = __shfl_down(eR, 1);
+            if (lane == 0) { up = Hv; upL = hL; upR = hR; }
+            if (lane == 63) { dn = Hv; dnL = hL; dnR = hR; }
+            const unsigned long long n = up | Sv | dn;                                   // strong in the three rows, same column
+            const unsigned long long nl = (u64)((upL | eL | dnL) & 1u), nr = (u64)((upR | eR | dnR) & 1u);
+            const unsigned long long near = n | (n << 1) | (n >> 1) | nl | (nr << 63);   // ... or a column next to it
+            unsigned long long grown = Sv | (Kv & near);
+            // horizontal runs of weak pixels in one go: promoted pixels are seeds inside the weak runs
+            const unsigned long long seeds = grown & Kv;
+            grown |= fill_runs_up(seeds, Kv);
+            grown |= __brevll(fill_runs_up(__brevll(seeds), __brevll(Kv)));
+            const bool ch = grown != Sv;
+            Sv = grown;
+            if (__ballot(ch) == 0) break;
         }
-        const int hi = min((int)threadIdx.x, (HT + 2) * 2 - 1);
-        const int hly = hi >> 1, hside = hi & 1;
-        const int hy = y0 + hly - 1, hx = hside ? x0 + HT : x0 - 1;
-        uint8_t hb = M[(size_t)min(max(hy, 0), H - 1) * W + min(max(hx, 0), W - 1)];
-#pragma unroll
-        for (int it = 0; it < NDW; it++) {
-            const int i = (int)threadIdx.x + it * 256;
-            if (i < (HT + 2) * (HT / 4)) {
-                const int ly = i / (HT / 4), lw = i - ly * (HT / 4);
-                const int y = y0 + ly - 1;
-                const u32 v = (y >= 0 && y < H) ? dw[it] : 0u;
-                *reinterpret_cast<u32*>(&t[ly][OX + 1 + lw * 4]) = v;
-                // a byte equal to 1 inside the tile rows: (v ^ 0x01010101) has a zero byte there
-                if (ly >= 1 && ly <= HT) {
-                    const u32 z = v ^ 0x01010101u;
-                    if ((z - 0x01010101u) & ~z & 0x80808080u) weak_here = 1;
-                }
+        const unsigned long long added = Sv & ~S0;
+        const unsigned long long any_added = __ballot(added != 0);
+        if (any_added == 0) continue;
+        if (added != 0 && row_in) {
+            if ((u32)added) S[(size_t)y * nw + w0] = (u32)Sv;
+            if ((u32)(added >> 32) && has_hi) S[(size_t)y * nw + w0 + 1] = (u32)(Sv >> 32);
+        }
+        // promoted pixels on the tile border: the neighbours have to look again
+        const bool border = (added != 0 && (lane == 0 || lane == 63)) || ((added & 0x8000000000000001ull) != 0);
+        if (__ballot(border) != 0) {
+            if (lane < 9 && lane != 4) {
+                const int ny = by + lane / 3 - 1, nx = bx + lane % 3 - 1;
+                if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) dirty_out[(size_t)j * per_frame + (size_t)ny * tiles_x + nx] = 1;
             }
+            // (a plain store: every writer stores the same 1; one atomic per tile on ONE word serialised uniform-noise frames --
+            //  half a million tiles per launch -- behind the L2's atomic unit)
+            if (lane == 0) *changed = 1;
         }
-        if ((int)threadIdx.x < (HT + 2) * 2)
-            t[hly][hside ? OX + HT + 1 : OX] = (hy >= 0 && hy < H && hx >= 0 && hx < W) ? hb : (uint8_t)0;
-    } else {
-        for (int i = threadIdx.x; i < (HT + 2) * (HT + 2); i += 256) {
-            const int ly = i / (HT + 2), lx = i - ly * (HT + 2);
-            const int y = y0 + ly - 1, x = x0 + lx - 1;
-            uint8_t v = 0;
-            if (y >= 0 && y < H && x >= 0 && x < W) v = M[(size_t)y * W + x];
-            t[ly][OX + lx] = v;
-            if (v == 1 && ly >= 1 && ly <= HT && lx >= 1 && lx <= HT) weak_here = 1;
-        }
-    }
-    if (weak_here) any_weak = 1;
-    __syncthreads();
-    if (!any_weak) continue;
-    // each thread owns a 4x4 patch of the 64x64 tile
-    const int py = (threadIdx.x >> 4) * 4 + 1, px = (threadIdx.x & 15) * 4 + 1 + OX;
-    for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) round_changed = 0;
-        __syncthreads();
-        int ch = 0, bch = 0;
-#pragma unroll
-        for (int dy = 0; dy < 4; dy++)
-#pragma unroll
-            for (int dx = 0; dx < 4; dx++) {
-                const int y = py + dy, x = px + dx;
-                if (t[y][x] == 1) {
-                    const int s = (t[y - 1][x - 1] | t[y - 1][x] | t[y - 1][x + 1] | t[y][x - 1] | t[y][x + 1] |
-                                   t[y + 1][x - 1] | t[y + 1][x] | t[y + 1][x + 1]) & 2;
-                    if (s) {
-                        t[y][x] = 2;  // racing writers only ever store 2: benign
-                        ch = 1;
-                        if (y == 1 || y == HT || x == OX + 1 || x == OX + HT) bch = 1;
-                    }
-                }
-            }
-        if (ch) round_changed = 1;
-        if (bch) border_changed = 1;
-        __syncthreads();
-        if (!round_changed) break;
-        if (threadIdx.x == 0) tile_changed = 1;
-    }
-    __syncthreads();
-    if (tile_changed) {
-        for (int i = threadIdx.x; i < HT * HT; i += 256) {
-            const int ly = i / HT, lx = i - ly * HT;
-            const int y = y0 + ly, x = x0 + lx;
-            if (y < H && x < W && t[ly + 1][OX + lx + 1] == 2) M[(size_t)y * W + x] = 2;
-        }
-        if (border_changed && threadIdx.x < 9 && threadIdx.x != 4) {
-            const int ny = by + (int)threadIdx.x / 3 - 1, nx = bx + (int)threadIdx.x % 3 - 1;
-            if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) dirty_out[tile_base + (size_t)ny * tiles_x + nx] = 1;
-        }
-        if (border_changed && threadIdx.x == 0) atomicOr(changed, 1);
-    }
-  }
-}
-
-// ---- K5: pack strong pixels into bit rows + horizontal dilation ---------------------------------
-
-// grid = (height, frames); one block per image row.  anchor = k/2; window [x-anchor, x-anchor+k-1].
-__global__ __launch_bounds__(256) void pack_hdilate_kernel(const uint8_t* map, EdgeGeom g, int k, u32* hbits)
-{
-    extern __shared__ u32 rowbits[];  // words_per_row + 2 (one zero word of padding on each side)
-    const int j = blockIdx.y, y = blockIdx.x, W = g.width, nw = g.words_per_row;
-    const uint8_t* M = map + (size_t)j * g.npix + (size_t)y * W;
-    const bool wide = (((uintptr_t)M) & 15) == 0;
-    for (int w = threadIdx.x; w < nw + 2; w += 256) {
-        u32 bits = 0;
-        if (w >= 1 && w <= nw) {
-            const int xb = (w - 1) * 32;
-            if (wide && xb + 32 <= W) {
-                // 32 map bytes (values 0,1,2): bit 1 marks "strong"; gather one bit per byte with a multiply
-                const uint4 a = *reinterpret_cast<const uint4*>(M + xb), c = *reinterpret_cast<const uint4*>(M + xb + 16);
-                const u32 q[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-#pragma unroll
-                for (int i = 0; i < 8; i++) bits |= ((((q[i] >> 1) & 0x01010101u) * 0x01020408u) >> 24) << (4 * i);
-            } else {
-#pragma unroll 8
-                for (int b = 0; b < 32; b++) {
-                    const int x = xb + b;
-                    if (x < W && M[x] == 2) bits |= 1u << b;
-                }
-            }
-        }
-        rowbits[w] = bits;
-    }
-    __syncthreads();
-    const int left = k / 2, right = k - 1 - k / 2;  // output x is set if any input in [x-left, x+right] is set
-    for (int w = threadIdx.x; w < nw; w += 256) {
-        const u32 lo = rowbits[w], mid = rowbits[w + 1], hi = rowbits[w + 2];
-        u32 out = mid;
-        // input at x+s (s>0) contributes: shift the (mid,hi) pair right by s
-        for (int s = 1; s <= right; s++) out |= s < 32 ? (u32)((((u64)hi << 32) | mid) >> s) : (hi >> (s - 32));
-        // input at x-s contributes: shift the (lo,mid) pair left by s
-        for (int s = 1; s <= left; s++) out |= s < 32 ? (u32)(((((u64)mid << 32) | lo) << s) >> 32) : (lo << (s - 32));
-        const int xb = w * 32;
-        if (xb + 32 > W) out &= (W - xb >= 32) ? 0xffffffffu : ((1u << (W - xb)) - 1u);
-        hbits[((size_t)j * g.height + y) * nw + w] = out;
     }
 }
 
-// ---- K6: vertical dilation, then XOR count ------------------------------------------------------
+// ---- K5 + K6: dilation and XOR count on the bit planes, walking the time axis ---------------------------------------------
 
-// grid = (ceil(words_per_frame/256), frames).  dil[j] = OR of hbits rows [y-anchor, y-anchor+k-1].
-__global__ __launch_bounds__(256) void vdilate_kernel(const u32* hbits, EdgeGeom g, int k, u32* dil)
-{
-    const int j = blockIdx.y, nw = g.words_per_row;
-    const long words = (long)g.height * nw;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= words) return;
-    const int y = (int)(i / nw), w = (int)(i - (long)y * nw);
-    const int ytop = max(y - k / 2, 0), ybot = min(y - k / 2 + k - 1, g.height - 1);
-    const u32* hb = hbits + (size_t)j * words;
-    u32 v = 0;
-    for (int yy = ytop; yy <= ybot; yy++) v |= hb[(size_t)yy * nw + w];
-    dil[(size_t)j * words + i] = v;
-}
+// cv2.dilate(edges, ones(k, k)) (anchor at the centre, outside the image ignored) and the XOR count against the previous
+// frame's dilated edges (content_detector.py:170-174, 239), word-parallel and entirely in registers.
+// A WAVE owns DX_R image rows x a strip of DX_STRIP words (lane l holds word strip0 - 1 + l: the first and the last lane are
+// the halo words of the horizontal window) and WALKS the frames of a chunk.  Per frame every lane reads the DX_R + k - 1 words
+// of its column that the vertical window needs (one coalesced 256-byte row segment per load instruction, the next frame's
+// loads in flight while this one is worked on), ORs them into the DX_R vertically dilated words -- a common core plus suffix /
+// prefix ORs, about 4 ORs per output word for k = 13 instead of 12 --, takes the horizontal neighbours from the adjacent lanes
+// (two wave shifts per word), ORs the k-window horizontally by doubling (x |= x >> 1, >> 2, >> 4 ..., then one shift for the
+// remainder, on 32-bit halves with v_alignbit_b32), XORs with the previous frame's dilated words -- which never left the
+// lane's registers -- and counts.  No LDS, no barriers; the dilated map goes to memory only when a caller wants to see it
+// (psd_edge_map_device).  Per frame the pass reads 0.25 bit/px a few times over (L2 hits) and writes nothing (round 2: byte
+// map 1 B/px in, dilated bits out and in again).  The frame in front of a walk is dilated once more as its halo (`carry` =
+// the Canny bits of the frame before virtual frame 0, when there is one).
+// K = the dilation size at compile time for the sizes the reference's _estimated_kernel_size produces up to 8K frames, 0 =
+// any size at run time (slower: one compare + OR per (window row, output row)).
+// grid = (ceil(H / (4 DX_R)) * strips, walks), 4 waves per workgroup (4 consecutive row groups).
+constexpr int DX_R = 8, DX_STRIP = 62;
 
-// K5 + K6 in one kernel: a workgroup takes a band of `band` image rows, packs the strong pixels of the rows it needs
-// (band + the k/2 rows above and below) into bit rows in LDS, dilates them horizontally (second LDS array), then ORs
-// the k-window vertically and writes the band's dilated bit rows.  The bit rows never travel through HBM and a frame is
-// ~17-34 workgroups instead of one per image row.  grid = (bands, frames); dynamic LDS = 2 * (band + k - 1) * (nw + 2) words.
-__global__ __launch_bounds__(256) void pack_dilate_kernel(const uint8_t* map, EdgeGeom g, int k, int band, u32* dil)
+template <int K>
+__global__ __launch_bounds__(256) void dilate_xor_kernel(const u32* strong, EdgeGeom g, int k_rt, int strips, int frames_per_walk,
+                                                         int count, const u32* carry, unsigned long long* out_xor, u32* dil_out)
 {
-    extern __shared__ u32 pd_lds[];
-    const int j = blockIdx.y, W = g.width, H = g.height, nw = g.words_per_row, pitch = nw + 2;
-    const int y0 = blockIdx.x * band, y1 = min(H, y0 + band);
-    const int up = k / 2, dn = k - 1 - k / 2;
-    const int r0 = max(0, y0 - up), r1 = min(H, y1 + dn);          // rows [r0, r1) are needed
-    const int nrows = r1 - r0;
-    u32* raw = pd_lds;                                             // [nrows][pitch], one zero word on each side
-    u32* hd = pd_lds + (size_t)(band + k - 1) * pitch;             // [nrows][pitch] horizontally dilated
-    const uint8_t* M = map + (size_t)j * g.npix;
-    // rows by thread group, words by lane within the group (a power of two >= the row pitch, at most a wave): no division by
-    // the run-time pitch in the three loops
-    const int sh = pitch <= 8 ? 3 : pitch <= 16 ? 4 : pitch <= 32 ? 5 : 6;
-    const int lane = threadIdx.x & ((1 << sh) - 1), wave = threadIdx.x >> sh, nwave = 256 >> sh, lstep = 1 << sh;
-    // four rows per step with all eight 16-byte loads issued before the first use: the loop is bound by load latency
-    // (one row per step: 18 dependent round trips per thread, 43 us per workgroup)
-    for (int rr0 = wave; rr0 < nrows; rr0 += 4 * nwave)
-    for (int w = lane; w < pitch; w += lstep) {
-        const int xb = (w - 1) * 32;
-        const bool inside = w >= 1 && w <= nw;
-        uint4 qa[4], qc[4];
-        bool fastp[4];
+    constexpr int KMAX = K ? K : 63, NIN = DX_R + KMAX - 1;
+    const int k = K ? K : k_rt;
+    const int H = g.height, nw = g.words_per_row, W = g.width;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bi = blockIdx.x / strips, si = blockIdx.x - bi * strips;
+    const int y0 = (bi * 4 + wave) * DX_R;
+    if (y0 >= H) return;                                     // (whole waves; nothing below synchronises across waves)
+    const int w = si * DX_STRIP - 1 + lane;                  // this lane's word; lanes 0 and 63 only feed their neighbours
+    const bool w_in = w >= 0 && w < nw;
+    const bool out_lane = lane >= 1 && lane <= DX_STRIP && w_in;
+    const int up = k / 2, dn = k - 1 - k / 2;                // rows [y - up, y + dn], columns [x - left, x + right]
+    const int left = up, right = dn;
+    const int nin = DX_R + k - 1;
+    const int t0 = blockIdx.y * frames_per_walk, t1 = min(count, t0 + frames_per_walk);
+    const size_t words = (size_t)H * nw;
+    const int wc = min(max(w, 0), nw - 1);
+    u32 lastmask = 0xffffffffu;
+    if (w_in && w * 32 + 32 > W) lastmask = (1u << (W - w * 32)) - 1u;
+    auto src_of = [&](int t) { return t >= 0 ? strong + (size_t)t * words : carry; };
+    u32 pre[NIN];
+    auto fetch = [&](const u32* src) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int rr = rr0 + u * nwave;
-            const uint8_t* row = M + (size_t)(r0 + min(rr, nrows - 1)) * W;
-            fastp[u] = inside && rr < nrows && xb + 32 <= W && ((((uintptr_t)row) + xb) & 15) == 0;
-            // unconditional loads (a lane without a fast word reads the start of the map, always mapped and aligned): behind a
-            // branch hipcc puts an s_waitcnt vmcnt(0) in front of every pair and the eight loads go out one pair at a time
-            const uint8_t* src = fastp[u] ? row + xb : map;
-            qa[u] = *reinterpret_cast<const uint4*>(src);
-            qc[u] = *reinterpret_cast<const uint4*>(src + 16);
+        for (int r = 0; r < NIN; r++)
+            if (K || r < nin) pre[r] = src[(size_t)min(max(y0 - up + r, 0), H - 1) * nw + wc];   // unconditional, clamped
+    };
+    u32 prevd[DX_R];
+#pragma unroll
+    for (int i = 0; i < DX_R; i++) prevd[i] = 0;
+    bool have_prev = false;
+    // frame t0 - 1 first (halo of the walk: dilated, not counted; the very first frame has no predecessor), then t0 .. t1 - 1
+    int t = t0 - 1;
+    if (src_of(t) == nullptr) t++;
+    if (t < t1) fetch(src_of(t));
+    for (; t < t1; t++) {
+        u32 h[NIN];
+#pragma unroll
+        for (int r = 0; r < NIN; r++) {
+            const int y = y0 - up + r;
+            h[r] = (K || r < nin) && w_in && y >= 0 && y < H ? pre[r] : 0u;
         }
+        if (t + 1 < t1) fetch(src_of(t + 1));                // in flight while this frame is worked on
+        // ---- vertical OR: out[i] = OR h[i .. i + k - 1]
+        u32 v[DX_R];
+        if constexpr (K >= DX_R) {
+            u32 core = h[DX_R - 1];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int rr = rr0 + u * nwave;
-            if (rr >= nrows) break;
-            u32 bits = 0;
-            if (fastp[u]) {
-                // 32 map bytes (values 0,1,2): bit 1 marks "strong".  v_dot4_u32_u8 gathers the bits: the bytes (0 or 2 after
-                // the mask) of two dwords times the weights 1..128 sum to twice the output byte (a 32-bit multiply per dword,
-                // the usual gather, runs at quarter rate here)
-                const u32 q[8] = {qa[u].x, qa[u].y, qa[u].z, qa[u].w, qc[u].x, qc[u].y, qc[u].z, qc[u].w};
-                u32 d[4];
+            for (int r = DX_R; r <= K - 1; r++) core |= h[r];
+            u32 suf[DX_R], pfx[DX_R];                        // suf[i] = OR h[i .. DX_R-2], pfx[i] = OR h[K .. i+K-1]
+            suf[DX_R - 1] = 0;
 #pragma unroll
-                for (int t = 0; t < 4; t++)
-                    d[t] = __builtin_amdgcn_udot4(q[2 * t + 1] & 0x02020202u, 0x80402010u,
-                                                  __builtin_amdgcn_udot4(q[2 * t] & 0x02020202u, 0x08040201u, 0u, false), false);
-                // every d is even and <= 510: its bit 8 falls on the (zero) bit 0 of the next one, d[3] << 23 stays below 2^32
-                bits = ((d[0] | (d[1] << 8) | (d[2] << 16)) >> 1) | (d[3] << 23);
-            } else if (inside) {
-                const uint8_t* row = M + (size_t)(r0 + rr) * W;
-                for (int b = 0; b < 32; b++) {
-                    const int x = xb + b;
-                    if (x < W && row[x] == 2) bits |= 1u << b;
-                }
+            for (int i = DX_R - 2; i >= 0; i--) suf[i] = suf[i + 1] | h[i];
+            pfx[0] = 0;
+#pragma unroll
+            for (int i = 1; i < DX_R; i++) pfx[i] = pfx[i - 1] | h[i + K - 1];
+#pragma unroll
+            for (int i = 0; i < DX_R; i++) v[i] = core | suf[i] | pfx[i];
+        } else if constexpr (K > 0) {
+#pragma unroll
+            for (int i = 0; i < DX_R; i++) {
+                u32 a = h[i];
+#pragma unroll
+                for (int r = 1; r < K; r++) a |= h[i + r];
+                v[i] = a;
             }
-            raw[rr * pitch + w] = bits;
+        } else {
+#pragma unroll
+            for (int i = 0; i < DX_R; i++) v[i] = 0;
+            for (int r = 0; r < nin; r++) {
+                u32 hr = 0;
+#pragma unroll
+                for (int q = 0; q < NIN; q++) hr = q == r ? h[q] : hr;   // (register arrays cannot be indexed at run time)
+#pragma unroll
+                for (int i = 0; i < DX_R; i++) v[i] |= (r >= i && r < i + k) ? hr : 0u;
+            }
         }
-    }
-    __syncthreads();
-    const int left = k / 2, right = k - 1 - k / 2;  // output x is set if any input in [x-left, x+right] is set
-    for (int rr = wave; rr < nrows; rr += nwave)
-    for (int w = lane; w < nw; w += lstep) {
-        const u32 lo = raw[rr * pitch + w], mid = raw[rr * pitch + w + 1], hi = raw[rr * pitch + w + 2];
-        // OR of the shifts 0..n by doubling (x |= x >> 1, >> 2, >> 4 ... then one shift for the remainder) on the 64-bit
-        // pairs (hi:mid) and (mid:lo): 3 + 3 steps for k = 13 instead of 12 funnel shifts; windows reach at most one word
-        // across (k <= 63, enforced in psd_engine.cpp, keeps left and right below 32)
-        // (as two 32-bit halves with v_alignbit_b32 funnel shifts: 64-bit shifts run at quarter rate)
-        u32 rl = mid, rh = hi, lh = mid, ll = lo;
-        int cover = 1;
-        for (; 2 * cover <= right + 1; cover *= 2) { rl |= __builtin_amdgcn_alignbit(rh, rl, cover); rh |= rh >> cover; }
-        if (cover < right + 1) rl |= __builtin_amdgcn_alignbit(rh, rl, right + 1 - cover);
-        cover = 1;
-        for (; 2 * cover <= left + 1; cover *= 2) { lh |= __builtin_amdgcn_alignbit(lh, ll, 32 - cover); ll |= ll << cover; }
-        if (cover < left + 1) lh |= __builtin_amdgcn_alignbit(lh, ll, 32 - (left + 1 - cover));
-        u32 out = rl | lh;
-        const int xb = w * 32;
-        if (xb + 32 > W) out &= (1u << (W - xb)) - 1u;
-        hd[rr * pitch + w] = out;
-    }
-    __syncthreads();
-    for (int ly = wave; ly < y1 - y0; ly += nwave)
-    for (int w = lane; w < nw; w += lstep) {
-        const int y = y0 + ly;
-        const int ytop = max(y - up, 0), ybot = min(y + dn, H - 1);
-        // four independent partial ORs: a single chain waits for one LDS round trip per row of the window
-        u32 v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-        const u32* col = hd + (ytop - r0) * pitch + w;
-        const int nwin = ybot - ytop + 1;
-        int q = 0;
-        for (; q + 4 <= nwin; q += 4) {
-            v0 |= col[q * pitch]; v1 |= col[(q + 1) * pitch]; v2 |= col[(q + 2) * pitch]; v3 |= col[(q + 3) * pitch];
+        // ---- horizontal OR over [x - left, x + right], XOR with the previous frame, count
+        u32 diff = 0;
+#pragma unroll
+        for (int i = 0; i < DX_R; i++) {
+            const u32 mid = v[i], lo = __shfl_up(mid, 1), hi = __shfl_down(mid, 1);
+            // (windows reach at most one word across: k <= 63, enforced in psd_engine.cpp, keeps left and right below 32)
+            u32 rl = mid, rh = hi, lh = mid, ll = lo;
+            int cover = 1;
+            for (; 2 * cover <= right + 1; cover *= 2) { rl |= __builtin_amdgcn_alignbit(rh, rl, cover); rh |= rh >> cover; }
+            if (cover < right + 1) rl |= __builtin_amdgcn_alignbit(rh, rl, right + 1 - cover);
+            cover = 1;
+            for (; 2 * cover <= left + 1; cover *= 2) { lh |= __builtin_amdgcn_alignbit(lh, ll, 32 - cover); ll |= ll << cover; }
+            if (cover < left + 1) lh |= __builtin_amdgcn_alignbit(lh, ll, 32 - (left + 1 - cover));
+            const u32 d = (rl | lh) & lastmask;
+            const bool row_in = y0 + i < H;
+            if (have_prev && out_lane && row_in) diff += __popc(d ^ prevd[i]);
+            prevd[i] = d;
+            if (dil_out != nullptr && t >= t0 && out_lane && row_in) dil_out[(size_t)t * words + (size_t)(y0 + i) * nw + w] = d;
         }
-        for (; q < nwin; q++) v0 |= col[q * pitch];
-        dil[((size_t)j * H + y) * nw + w] = (v0 | v1) | (v2 | v3);
-    }
-}
-
-// Number of pixels whose dilated edge bit differs between virtual frame j and its predecessor
-// (dil[j-1], or `carry` = last frame of the previous chunk for j == 0).
-__global__ __launch_bounds__(256) void xor_count_kernel(const u32* dil, long words, const u32* carry, int have_carry,
-                                                         unsigned long long* out_xor)
-{
-    const int j = blockIdx.y;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    u32 diff = 0;
-    if (i < words) {
-        const u32 v = dil[(size_t)j * words + i];
-        if (j > 0) diff = __popc(v ^ dil[(size_t)(j - 1) * words + i]);
-        else if (have_carry) diff = __popc(v ^ carry[i]);
-    }
-    __shared__ u32 red[4];
-    for (int o = 32; o > 0; o >>= 1) diff += __shfl_down(diff, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = diff;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const u32 s = red[0] + red[1] + red[2] + red[3];
-        if (s) atomicAdd(&out_xor[j], (unsigned long long)s);
+        if (have_prev && t >= t0) {
+            for (int o = 32; o > 0; o >>= 1) diff += __shfl_down(diff, o);
+            if (lane == 0 && diff) atomicAdd(&out_xor[t], (unsigned long long)diff);
+        }
+        have_prev = true;
     }
 }
 
@@ -995,7 +873,7 @@ static int estimated_kernel_size(int width, int height)
 }
 
 struct EdgeBuffers {
-    uint8_t* vplane; uint8_t* map; u32* hist; int2* thr; u32* hbits; u32* dil; u32* carry;
+    uint8_t* vplane; uint8_t* map; u32* strong; u32* weak; u32* hist; int2* thr; u32* carry; u32* dil1;
     unsigned long long* xr; int* flags; int2* thr_tab; uint8_t* dirty[2];
     int cap_frames; size_t tiles_per_frame;
     uint8_t* zero_begin; size_t zero_bytes;   // hist, xr, both tile lists and the flags: cleared by ONE memset per chunk
@@ -1004,21 +882,24 @@ struct EdgeBuffers {
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// frames whose rows are dword aligned take sobel_nms_bits_kernel; the others the byte kernel + map_to_bits_kernel
+static bool bits_direct(const EdgeGeom& g) { return (g.width & 3) == 0; }
+
 static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeBuffers* b)
 {
     const size_t words = (size_t)g.height * g.words_per_row;
     const size_t tiles = (size_t)((g.width + HT - 1) / HT) * ((g.height + HT - 1) / HT);
-    const size_t per_frame = align_up((size_t)g.npix) * 2 + align_up(256 * 4) + align_up(sizeof(int2)) +
+    const bool need_map = !bits_direct(g);
+    const size_t per_frame = align_up((size_t)g.npix) * (need_map ? 2 : 1) + align_up(256 * 4) + align_up(sizeof(int2)) +
                              align_up(words * 4) * 2 + align_up(8) + 2 * align_up(tiles);
-    // bound the workspace (default 4 GiB of the 288 GB; PSD_EDGE_WS_MB overrides) unless a single frame needs
-    // more: longer chunks amortise the host round trips of the hysteresis rounds
+    // bound the workspace (default 4 GiB of the 288 GB; PSD_EDGE_WS_MB overrides) unless a single frame needs more
     static const size_t ws_cap = [] {
         const char* e = getenv("PSD_EDGE_WS_MB");
         const long mb = e ? atol(e) : 4096;
         return (size_t)(mb > 0 ? mb : 4096) << 20;
     }();
     int frames = (int)std::max<size_t>(1, std::min<size_t>((size_t)want_frames, ws_cap / per_frame));
-    const size_t fixed = align_up(words * 4) + align_up(64 * sizeof(int)) + align_up(511 * sizeof(int2));
+    const size_t fixed = 2 * align_up(words * 4) + align_up(64 * sizeof(int)) + align_up(511 * sizeof(int2)) + 16 * 256;
     const size_t need = per_frame * (size_t)frames + fixed;
     void** ws = engine_edge_ws(e);
     size_t* ws_bytes = engine_edge_ws_bytes(e);
@@ -1029,18 +910,17 @@ static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeB
         HIP_TRY(hipMalloc(ws, need));
         *ws_bytes = need;
         b->fresh = true;
-    } else {
-        // the cached workspace may fit more frames than computed for `want_frames`; keep `frames`
     }
     uint8_t* p = (uint8_t*)*ws;
     auto take = [&](size_t bytes) { uint8_t* r = p; p += align_up(bytes); return r; };
     b->thr_tab = (int2*)take(511 * sizeof(int2));   // first: its place does not depend on the geometry (uploaded once)
     b->vplane = take((size_t)g.npix * frames);
-    b->map = take((size_t)g.npix * frames);
+    b->map = need_map ? take((size_t)g.npix * frames) : nullptr;
     b->thr = (int2*)take((size_t)frames * sizeof(int2));
-    b->hbits = (u32*)take(words * 4 * frames);
-    b->dil = (u32*)take(words * 4 * frames);
+    b->strong = (u32*)take(words * 4 * frames);
+    b->weak = (u32*)take(words * 4 * frames);
     b->carry = (u32*)take(words * 4);
+    b->dil1 = (u32*)take(words * 4);
     b->zero_begin = p;
     b->hist = (u32*)take((size_t)frames * 256 * 4);
     b->xr = (unsigned long long*)take((size_t)frames * 8);
@@ -1076,23 +956,22 @@ __global__ void note_unconverged_kernel(const int* last_flag, int* unconverged)
 }
 
 constexpr int HYST_SPEC_LAUNCHES = 6;   // hysteresis launches of the speculative path: chains that cross up to 5 tile borders
+constexpr int HYST_TPW = 16;            // tiles per hysteresis workgroup (one flag load + ballot covers them)
 
-// Runs K1..K6a for `count` virtual frames; on return (stream-ordered) b.dil holds their dilated bits.
+// K1..K4 for `count` virtual frames; on return (stream-ordered) b.strong holds their final Canny edges as bit rows.
 // d_unconverged == nullptr: the hysteresis is relaunched until a launch changes nothing, the host reading the flags
 // after every round (exact, blocks the calling thread).  Otherwise: HYST_SPEC_LAUNCHES launches are enqueued without
 // any host round trip and *d_unconverged is set if the last one still promoted pixels on a tile border -- the caller
 // then repeats the work on the exact path (weak-edge chains that long are rare: tests/test_gpu_fullsize.py builds one).
-// hsv != nullptr: the chunk's real frames get their V plane and V histogram from the HSV pass in V mode (one read of the
+// hsv != nullptr: the chunk's real frames get their V plane (and V histogram) from the HSV pass in V mode (one read of the
 // frames for both terms, psd_score_kernels.hip); only a predecessor frame standing in as virtual frame 0 still goes
 // through the V-plane kernel.
-static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, const EdgeBuffers& b, hipStream_t stream,
+static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, const EdgeBuffers& b, hipStream_t stream,
                       int* d_unconverged = nullptr, const ScoreParams* hsv = nullptr, int target_blocks = 0, int* launches = nullptr)
 {
-    const size_t words = (size_t)g.height * g.words_per_row;
     HIP_TRY(hipMemsetAsync(b.zero_begin, 0, b.zero_bytes, stream));   // histograms, XOR counters, both tile lists, flags
     // packed 16-byte aligned frames with a multiple of 16 pixels take the LDS-DMA streaming variant
-    static const bool vp_direct = [] { const char* e = getenv("PSD_EDGE_VP_DIRECT"); return e && atoi(e) != 0; }();
-    const bool vp_dma = !vp_direct && g.row_stride == (size_t)g.width * 3 && (g.npix & 15) == 0 && (g.frame_stride & 15) == 0 &&
+    const bool vp_dma = g.row_stride == (size_t)g.width * 3 && (g.npix & 15) == 0 && (g.frame_stride & 15) == 0 &&
                         ((uintptr_t)src.frames & 15) == 0 && (!src.first_is_prev || ((uintptr_t)src.prev & 15) == 0);
     const int vp_count = hsv ? (src.first_is_prev ? 1 : 0) : count;   // virtual frames the V-plane kernel converts
     if (vp_count > 0 && vp_dma) {
@@ -1105,37 +984,50 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
         hipLaunchKernelGGL(value_plane_hist_kernel, dim3((unsigned)((g.npix + 1024 * VP_ITER - 1) / (1024 * VP_ITER)), vp_count), dim3(256), 0, stream, src, g,
                            b.vplane, b.hist);
     }
-    if (hsv) HIP_TRY(launch_score_frames(*hsv, true, false, true, target_blocks, stream, launches));
+    if (hsv) {
+        HIP_TRY(launch_score_frames(*hsv, true, false, true, target_blocks, stream, launches));
+        if (hsv->vhist == nullptr) {
+            // the HSV-only kernel stored the V planes of the chunk's real frames; their histograms come from the planes
+            const int real = count - src.first_is_prev;
+            const int n_groups = (int)(g.npix >> 4);
+            const int cap = 256 * VH_UNROLL * (real >= 32 ? 4 : 1);
+            const int tiles = (n_groups + cap - 1) / cap;
+            hipLaunchKernelGGL(v_hist_kernel, dim3(tiles, real), dim3(256), 0, stream, b.vplane + (src.first_is_prev ? (size_t)g.npix : 0),
+                               g.npix, (n_groups + tiles - 1) / tiles, b.hist + (src.first_is_prev ? 256 : 0));
+        }
+    }
     hipLaunchKernelGGL(median_thresholds_kernel, dim3(count), dim3(256), 0, stream, b.hist, g.npix, b.thr_tab, b.thr);
-    static const bool nms_bytes = [] { const char* e = getenv("PSD_EDGE_NMS_BYTES"); return e && atoi(e) != 0; }();
-    const dim3 hgrid((g.width + HT - 1) / HT, (g.height + HT - 1) / HT, count);
-    const size_t dirty_bytes = b.tiles_per_frame * (size_t)count;
-    const long hyst_tiles = (long)hgrid.x * hgrid.y * count;
-    static const int hyst_tpw = [] { const char* e = getenv("PSD_EDGE_HYST_TPW"); const int v = e ? atoi(e) : 16; return v >= 1 && v <= 64 ? v : 16; }();
-    const dim3 hyst_grid((unsigned)((hyst_tiles + hyst_tpw - 1) / hyst_tpw));
-    if ((g.width & 3) == 0 && (g.npix & 3) == 0 && !nms_bytes) {
-        // the dword kernel reports which hysteresis tiles hold weak pixels: only those are looked at
-        static const bool no_tile = [] { const char* e = getenv("PSD_EDGE_NMS_DWORD"); return e && atoi(e) != 0; }();
-        if (g.width % N2_W == 0 && !no_tile)
-            hipLaunchKernelGGL(sobel_nms_tile_kernel, dim3(g.width / N2_W, (g.height + N2_H - 1) / N2_H, count), dim3(256), 0, stream,
-                               b.vplane, g, b.thr, b.map, b.dirty[0], (int)hgrid.x, (int)b.tiles_per_frame);
-        else
-        hipLaunchKernelGGL(sobel_nms_dword_kernel, dim3((g.width + N2_W - 1) / N2_W, (g.height + N2_H - 1) / N2_H, count), dim3(256), 0,
-                           stream, b.vplane, g, b.thr, b.map, b.dirty[0], (int)hgrid.x, (int)b.tiles_per_frame);
+    const int htx = (g.width + HT - 1) / HT, hty = (g.height + HT - 1) / HT;
+    const long hyst_tiles = (long)htx * hty * count;
+    const dim3 hyst_grid((unsigned)((hyst_tiles + HYST_TPW - 1) / HYST_TPW));
+    if (bits_direct(g)) {
+        const int tx = (g.width + N2_W - 1) / N2_W, ty = (g.height + N2_H - 1) / N2_H;
+        const int per_frame = tx * ty;
+        if (per_frame >= (1 << 20)) { psd_set_error("frame too large for the edge term"); return PSD_ERR_UNSUPPORTED; }
+        const u32 magic = tx == 1 ? 0u : (u32)((0x100000000ull + (unsigned long long)tx - 1) / (unsigned long long)tx);   // ceil(2^32 / tx)
+        for (int f0 = 0; f0 < count; f0 += 32768) {   // grid.y limit
+            const int nf = std::min(32768, count - f0);
+            hipLaunchKernelGGL(sobel_nms_bits_kernel, dim3(per_frame, nf), dim3(256), 0, stream,
+                               b.vplane + (size_t)f0 * g.npix, g, b.thr + f0, b.strong + (size_t)f0 * g.height * g.words_per_row,
+                               b.weak + (size_t)f0 * g.height * g.words_per_row, b.dirty[0] + (size_t)f0 * b.tiles_per_frame, tx,
+                               magic, htx, (int)b.tiles_per_frame);
+        }
     } else {
-        HIP_TRY(hipMemsetAsync(b.dirty[0], 1, dirty_bytes, stream));
+        const size_t words = (size_t)g.height * g.words_per_row;
         hipLaunchKernelGGL(sobel_nms_kernel, dim3((g.width + NT_W - 1) / NT_W, (g.height + NT_H - 1) / NT_H, count), dim3(256), 0,
                            stream, b.vplane, g, b.thr, b.map);
+        hipLaunchKernelGGL(map_to_bits_kernel, dim3((unsigned)((words + 255) / 256), count), dim3(256), 0, stream, b.map, g, b.strong, b.weak,
+                           b.dirty[0], htx, (int)b.tiles_per_frame);
     }
     HIP_TRY(hipGetLastError());
-    // hysteresis to the fix point: rounds of R launches (ping-pong dirty-tile lists, one flag per
-    // launch); done when a launch promoted nothing on any tile border.
-    // every launch empties the list it read, so the two lists only need the clearing at the top of the chunk
+    // hysteresis to the fix point: launches ping-pong the two dirty-tile lists (every launch empties the list it read, so the
+    // lists only need the clearing at the top of the chunk), one flag per launch; done when a launch promoted nothing on
+    // any tile border.
     int launch = 0;
     if (d_unconverged) {
         for (; launch < HYST_SPEC_LAUNCHES; launch++) {
-            hipLaunchKernelGGL(hysteresis_kernel, hyst_grid, dim3(256), 0, stream, b.map, g, b.dirty[launch & 1], b.dirty[(launch + 1) & 1],
-                               b.flags + launch, (int)hgrid.x, (int)hgrid.y, hyst_tiles, hyst_tpw);
+            hipLaunchKernelGGL(hysteresis_bits_kernel, hyst_grid, dim3(256), 0, stream, b.strong, b.weak, g, b.dirty[launch & 1],
+                               b.dirty[(launch + 1) & 1], b.flags + launch, htx, hty, hyst_tiles, HYST_TPW);
         }
         hipLaunchKernelGGL(note_unconverged_kernel, dim3(1), dim3(1), 0, stream, b.flags + HYST_SPEC_LAUNCHES - 1, d_unconverged);
     } else {
@@ -1146,8 +1038,8 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
             const int fbase = (round % (64 / R)) * R;
             if (round > 0 && fbase == 0) HIP_TRY(hipMemsetAsync(b.flags, 0, 64 * sizeof(int), stream));
             for (int i = 0; i < R; i++, launch++) {
-                hipLaunchKernelGGL(hysteresis_kernel, hyst_grid, dim3(256), 0, stream, b.map, g, b.dirty[launch & 1], b.dirty[(launch + 1) & 1],
-                                   b.flags + fbase + i, (int)hgrid.x, (int)hgrid.y, hyst_tiles, hyst_tpw);
+                hipLaunchKernelGGL(hysteresis_bits_kernel, hyst_grid, dim3(256), 0, stream, b.strong, b.weak, g, b.dirty[launch & 1],
+                                   b.dirty[(launch + 1) & 1], b.flags + fbase + i, htx, hty, hyst_tiles, HYST_TPW);
             }
             int flags[R];
             HIP_TRY(hipMemcpyAsync(flags, b.flags + fbase, sizeof(flags), hipMemcpyDeviceToHost, stream));
@@ -1159,20 +1051,27 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, int k, 
             return PSD_ERR_HIP;
         }
     }
-    // band height of the fused pack + dilate kernel: as tall as two LDS arrays of (band + k - 1) bit rows allow within ~56 KiB
-    const size_t pitch = (size_t)g.words_per_row + 2;
-    int band = (int)((56u << 10) / (2 * pitch * sizeof(u32))) - (k - 1);
-    static const bool split_dilate = [] { const char* e = getenv("PSD_EDGE_SPLIT_DILATE"); return e && atoi(e) != 0; }();
-    if (band >= 8 && !split_dilate) {
-        if (band > 64) band = 64;
-        if (band > g.height) band = g.height;
-        hipLaunchKernelGGL(pack_dilate_kernel, dim3((g.height + band - 1) / band, count), dim3(256),
-                           2 * (size_t)(band + k - 1) * pitch * sizeof(u32), stream, b.map, g, k, band, b.dil);
-    } else {
-        hipLaunchKernelGGL(pack_hdilate_kernel, dim3(g.height, count), dim3(256), (g.words_per_row + 2) * sizeof(u32), stream, b.map, g,
-                           k, b.hbits);
-        hipLaunchKernelGGL(vdilate_kernel, dim3((unsigned)((words + 255) / 256), count), dim3(256), 0, stream, b.hbits, g, k, b.dil);
+    HIP_TRY(hipGetLastError());
+    return PSD_OK;
+}
+
+// dilation + XOR count of `count` virtual frames whose Canny bits are in b.strong; `carry` = the Canny bits of the frame
+// before virtual frame 0 (or nullptr); dil_out = nullptr unless the dilated maps themselves are wanted
+static int launch_dilate_xor(const EdgeGeom& g, int k, int count, const EdgeBuffers& b, const u32* carry, u32* dil_out, hipStream_t stream)
+{
+    const int strips = (g.words_per_row + DX_STRIP - 1) / DX_STRIP;
+    const int bands = (g.height + 4 * DX_R - 1) / (4 * DX_R);
+    // frames per walk: about 8 k workgroups per launch (a walk also dilates the frame in front of it, so not below 8 frames)
+    int walk = (int)(((long)count * bands * strips + 8191) / 8192);
+    walk = walk < 8 ? 8 : walk > 64 ? 64 : walk;
+    const dim3 grid(bands * strips, (count + walk - 1) / walk);
+#define PSD_DX_CASE(K) case K: hipLaunchKernelGGL(dilate_xor_kernel<K>, grid, dim3(256), 0, stream, b.strong, g, k, strips, walk, count, carry, b.xr, dil_out); break;
+    switch (k) {
+        PSD_DX_CASE(3) PSD_DX_CASE(5) PSD_DX_CASE(7) PSD_DX_CASE(9) PSD_DX_CASE(11) PSD_DX_CASE(13) PSD_DX_CASE(15) PSD_DX_CASE(17)
+        PSD_DX_CASE(19) PSD_DX_CASE(21) PSD_DX_CASE(23) PSD_DX_CASE(25) PSD_DX_CASE(27) PSD_DX_CASE(29) PSD_DX_CASE(31) PSD_DX_CASE(33) PSD_DX_CASE(35)
+        default: hipLaunchKernelGGL(dilate_xor_kernel<0>, grid, dim3(256), 0, stream, b.strong, g, k, strips, walk, count, carry, b.xr, dil_out);
     }
+#undef PSD_DX_CASE
     HIP_TRY(hipGetLastError());
     return PSD_OK;
 }
@@ -1226,16 +1125,20 @@ int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
             cp.out = hsv->out + src.start;
             cp.seg = hsv->seg ? hsv->seg + src.start : nullptr;
             cp.vout = b.vplane + (src.first_is_prev ? (size_t)g.npix : 0);
-            cp.vhist = b.hist + (src.first_is_prev ? 256 : 0);
+            // PSD_EDGE_VHIST_FUSED=0: the HSV-only kernel stores the V plane and v_hist_kernel counts it; default: the 16-wave
+            // fused kernel counts the V histogram itself (A/B on 2048 x 1080p shot-like frames: 262-265 k vs 257 k frames/s)
+            static const bool vhist_fused = [] { const char* v = getenv("PSD_EDGE_VHIST_FUSED"); return !v || atoi(v) != 0; }();
+            cp.vhist = vhist_fused ? b.hist + (src.first_is_prev ? 256 : 0) : nullptr;
         }
-        rc = edge_chunk(g, src, count, k, b, stream, d_unconverged, hsv ? &cp : nullptr, target_blocks, launches);
+        rc = edge_chunk(g, src, count, b, stream, d_unconverged, hsv ? &cp : nullptr, target_blocks, launches);
         if (rc != PSD_OK) return rc;
-        hipLaunchKernelGGL(xor_count_kernel, dim3((unsigned)((words + 255) / 256), count), dim3(256), 0, stream, b.dil, (long)words,
-                           b.carry, have_carry ? 1 : 0, b.xr);
+        rc = launch_dilate_xor(g, k, count, b, have_carry ? b.carry : nullptr, nullptr, stream);
+        if (rc != PSD_OK) return rc;
         hipLaunchKernelGGL(store_xor_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, b.xr, count, src.first_is_prev,
                            have_carry ? 1 : 0, src.start, d_out, d_seg);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(b.carry, b.dil + (size_t)(count - 1) * words, words * 4, hipMemcpyDeviceToDevice, stream));
+        // the next chunk compares its first frame with this chunk's last: keep that frame's Canny bits
+        HIP_TRY(hipMemcpyAsync(b.carry, b.strong + (size_t)(count - 1) * words, words * 4, hipMemcpyDeviceToDevice, stream));
         have_carry = true;
         done += count;
     }
@@ -1256,11 +1159,13 @@ int edges_map(psd_engine* e, const uint8_t* d_frame, int height, int width, size
     HIP_TRY(hipMemcpyAsync(b.thr_tab, tab, sizeof(tab), hipMemcpyHostToDevice, stream));
     ChunkSrc src;
     src.frames = d_frame; src.prev = nullptr; src.start = 0; src.first_is_prev = 0;
-    rc = edge_chunk(g, src, 1, k, b, stream);
+    rc = edge_chunk(g, src, 1, b, stream);
+    if (rc != PSD_OK) return rc;
+    rc = launch_dilate_xor(g, k, 1, b, nullptr, b.dil1, stream);
     if (rc != PSD_OK) return rc;
     const size_t words = (size_t)g.height * g.words_per_row;
     std::vector<u32> bits(words);
-    HIP_TRY(hipMemcpyAsync(bits.data(), b.dil, words * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(bits.data(), b.dil1, words * 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++)
