@@ -40,7 +40,8 @@
 extern "C" {
 #endif
 
-#define PSD_ABI_VERSION 2 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records) */
+#define PSD_ABI_VERSION 3 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records);
+                            * 3: additive over 2 (psd_frame_sums: records without the histogram, psd_score_collect_sums, psd_epilogue_*_sums) */
 
 typedef enum psd_status {
     PSD_OK = 0,
@@ -70,6 +71,15 @@ typedef struct psd_frame_scores {
     uint64_t byte_sum;
     uint32_t hist[256];
 } psd_frame_scores; /* 1064 bytes */
+
+/* The head of a record: everything ContentDetector / AdaptiveDetector (content_detector.py:177-190,
+ * adaptive_detector.py:100-143) and ThresholdDetector (threshold_detector.py:127) decide from.  A corpus run moves 40
+ * instead of 1064 bytes per frame to the host with it (psd_score_collect_sums). */
+typedef struct psd_frame_sums {
+    uint64_t sad_h, sad_s, sad_v;
+    uint64_t edge_xor;
+    uint64_t byte_sum;
+} psd_frame_sums; /* 40 bytes, the first 40 of psd_frame_scores */
 
 typedef struct psd_engine psd_engine;
 
@@ -107,6 +117,10 @@ int psd_score_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int h
                             size_t row_stride, size_t frame_stride, const uint8_t* d_prev,
                             uint32_t flags, int edge_kernel, void* stream);
 int psd_score_collect(psd_engine* e, psd_frame_scores* out, int n);
+/* Same, but only the five sums of every record.  A submission that asked for neither PSD_SCORE_LUMA_HIST nor
+ * PSD_SCORE_BYTE_SUM (the luma pass did not run: hist is all zero) moves only these 40 bytes per frame from the device to
+ * the host in the first place; psd_score_collect() then returns them with a zero histogram, as before. */
+int psd_score_collect_sums(psd_engine* e, psd_frame_sums* out, int n);
 
 /* MANY clips of one resolution packed into ONE batch (north_star: "frames from many videos are packed into one device
  * batch"; the reference scores one video per SceneManager, scene_manager.py:578-597, and benchmark/sweep.py:142-187 runs
@@ -252,6 +266,13 @@ int psd_epilogue_content_scores(const psd_frame_scores* recs, int n, int height,
                                 double* delta_hue, double* delta_sat, double* delta_lum,
                                 double* delta_edges);
 
+/* Same from sums: element t sits at (const char*)sums + t * stride_bytes -- sizeof(psd_frame_sums) for what
+ * psd_score_collect_sums returned, sizeof(psd_frame_scores) to read the heads of full records in place. */
+int psd_epilogue_content_scores_sums(const psd_frame_sums* sums, size_t stride_bytes, int n, int height, int width,
+                                     const double weights[4], int first_has_prev, double* content_val,
+                                     double* delta_hue, double* delta_sat, double* delta_lum,
+                                     double* delta_edges);
+
 int psd_epilogue_content_cuts(const double* content_val, int n, int64_t first_frame, int64_t fps_num,
                               int64_t fps_den, const psd_content_params* p, int64_t* cuts,
                               int* n_cuts);
@@ -300,6 +321,10 @@ int psd_epilogue_threshold_cuts(const psd_frame_scores* recs, int n, int height,
                                 int64_t first_frame, int64_t fps_num, int64_t fps_den,
                                 const psd_threshold_params* p, double* average_rgb, int64_t* cuts,
                                 int* n_cuts);
+int psd_epilogue_threshold_cuts_sums(const psd_frame_sums* sums, size_t stride_bytes, int n, int height, int width,
+                                     int64_t first_frame, int64_t fps_num, int64_t fps_den,
+                                     const psd_threshold_params* p, double* average_rgb, int64_t* cuts,
+                                     int* n_cuts);
 
 /* HashDetector.hash_frame, back half (hash_detector.py:131-151): scale by the maximum, 2-D DCT-II, keep
  * the hash_size x hash_size low frequencies, threshold at their median.  bits: uint8[n][hash_size^2] of 0/1.

@@ -41,6 +41,11 @@ RECORD_DTYPE = np.dtype(
 )
 assert RECORD_DTYPE.itemsize == 1064
 
+#: numpy view of ``psd_frame_sums`` (40 bytes): a record without its histogram -- what ContentDetector, AdaptiveDetector and
+#: ThresholdDetector decide from (``psd_score_collect_sums``).
+SUMS_DTYPE = np.dtype([(name, "<u8") for name in ("sad_h", "sad_s", "sad_v", "edge_xor", "byte_sum")])
+assert SUMS_DTYPE.itemsize == 40 and all(SUMS_DTYPE.fields[k][1] == RECORD_DTYPE.fields[k][1] for k in SUMS_DTYPE.names)
+
 
 class ContentParams(ctypes.Structure):
     _fields_ = [
@@ -112,6 +117,7 @@ SYMBOLS = {
     "psd_score_segments_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _i, _u32, _i, _vp, _vp]),
     "psd_score_segments_submit_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _i, _u32, _i, _vp]),
     "psd_score_collect": (_i, [_vp, _vp, _i]),
+    "psd_score_collect_sums": (_i, [_vp, _vp, _i]),
     "psd_score_batch": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _vp, _u32, _i, _vp]),
     "psd_comm_unique_id": (_i, [_vp]),
     "psd_comm_create": (_i, [_vp, _i, _i, _vp, _P(_vp)]),
@@ -139,6 +145,8 @@ SYMBOLS = {
     "psd_hash_thumbs_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp]),
     "psd_hash_thumbs": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp]),
     "psd_epilogue_content_scores": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "psd_epilogue_content_scores_sums": (_i, [_vp, _sz, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "psd_epilogue_threshold_cuts_sums": (_i, [_vp, _sz, _i, _i, _i, _i64, _i64, _i64, _P(ThresholdParams), _vp, _vp, _P(_i)]),
     "psd_epilogue_content_cuts": (_i, [_vp, _i, _i64, _i64, _i64, _P(ContentParams), _vp, _P(_i)]),
     "psd_epilogue_adaptive_cuts": (_i, [_vp, _i, _i64, _i64, _i64, _P(AdaptiveParams), _vp, _vp, _P(_i)]),
     "psd_epilogue_hist_cuts": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _P(HistParams), _vp, _vp, _P(_i)]),
@@ -206,8 +214,8 @@ def load() -> ctypes.CDLL:
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from ex
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.psd_abi_version() != 2:
-        raise NativeLibraryError(f"ABI version mismatch: library has {lib.psd_abi_version()}, binding wants 2")
+    if lib.psd_abi_version() != 3:
+        raise NativeLibraryError(f"ABI version mismatch: library has {lib.psd_abi_version()}, binding wants 3")
     _lib = lib
     return lib
 

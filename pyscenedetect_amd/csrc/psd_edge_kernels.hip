@@ -473,7 +473,7 @@ __device__ __forceinline__ void sobel_phase1_quads(const uint8_t (*sv)[N2_SVW], 
 __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, u32* strong, u32* weak,
                                                              uint8_t* dirty, int tiles_x, u32 tiles_x_magic, int htiles_x, int htiles_per_frame)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t sv[N2_H + 4][N2_SVW];   // rows y0-2 .. y0+33, cols x0-4 .. x0+131
+    __shared__ __attribute__((aligned(16))) uint8_t sv[N2_H + 8][N2_SVW];   // rows y0-2 .. y0+33, cols x0-4 .. x0+131 (+ 4 scratch rows)
     __shared__ __attribute__((aligned(16))) uint2 smq[N2_H + 2][N2_NCG];    // rows y0-1 .. y0+32, magnitudes as even / odd pairs
     __shared__ __attribute__((aligned(16))) uint8_t obits[2][N2_H][N2_W / 8]; // [strong | weak][row][8 pixels]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -506,9 +506,12 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
             u32 w = v[it];
             if (xa < 0) w = __builtin_amdgcn_perm(w, w, 0u);                    // V[y][0] four times
             else if (xa >= W) w = __builtin_amdgcn_perm(w, w, 0x03030303u);     // V[y][W-1] four times
-            if (ly < N2_H + 4) *reinterpret_cast<u32*>(&sv[ly][4 * cw]) = w;
+            // (unconditional: rows 36..39 of sv are scratch for the last wave's surplus rows -- behind a predicate hipcc sinks
+            //  the load into the branch and waits for it there)
+            *reinterpret_cast<u32*>(&sv[ly][4 * cw]) = w;
         }
-        if (tid < 2 * (N2_H + 4)) *reinterpret_cast<u32*>(&sv[tl][4 * c2]) = xb >= W ? __builtin_amdgcn_perm(vt, vt, 0x03030303u) : vt;
+        // (unconditional as well: threads 72.. repeat what threads 70 / 71 load and write)
+        *reinterpret_cast<u32*>(&sv[tl][4 * c2]) = xb >= W ? __builtin_amdgcn_perm(vt, vt, 0x03030303u) : vt;
     }
     __syncthreads();
     const bool inner = x0 >= 4 && x0 + N2_W + 4 <= W && y0 >= 2 && y0 + N2_H + 2 <= H;

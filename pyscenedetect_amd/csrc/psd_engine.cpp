@@ -58,7 +58,9 @@ size_t hash_tab_bytes(int size);
 
 struct psd_slot {
     psd_frame_scores* d_recs = nullptr;
-    psd_frame_scores* h_recs = nullptr;  // pinned
+    uint8_t* h_recs = nullptr;           // pinned mirror: n records, or n 40-byte heads (psd_frame_sums) when heads_only
+    size_t h_bytes = 0;
+    bool heads_only = false;             // the submission has no luma histogram: only the sums travel to the host
     int cap = 0;
     int n = 0;
     bool pending = false;
@@ -116,17 +118,25 @@ static void fill_tables(int32_t* sdiv, int32_t* hdiv)
     }
 }
 
-static int ensure_slot(psd_engine* e, psd_slot& s, int n)
+static int ensure_slot(psd_engine* e, psd_slot& s, int n, bool heads_only)
 {
-    if (s.cap >= n) return PSD_OK;
-    int cap = n < 64 ? 64 : n;
-    if (s.d_recs) HIP_TRY(hipFree(s.d_recs));
-    if (s.h_recs) HIP_TRY(hipHostFree(s.h_recs));
-    s.d_recs = nullptr; s.h_recs = nullptr; s.cap = 0;
-    HIP_TRY(hipMalloc((void**)&s.d_recs, (size_t)cap * sizeof(psd_frame_scores)));
-    HIP_TRY(hipHostMalloc((void**)&s.h_recs, (size_t)cap * sizeof(psd_frame_scores), hipHostMallocDefault));
-    s.cap = cap;
     (void)e;
+    if (s.cap < n) {
+        const int cap = n < 64 ? 64 : n;
+        if (s.d_recs) HIP_TRY(hipFree(s.d_recs));
+        s.d_recs = nullptr; s.cap = 0;
+        HIP_TRY(hipMalloc((void**)&s.d_recs, (size_t)cap * sizeof(psd_frame_scores)));
+        s.cap = cap;
+    }
+    // the pinned mirror grows with what actually travels: 40 bytes per frame without the histogram, 1064 with it
+    // (page-locking 78 MB for 73 k records took longer than scoring them)
+    const size_t need = (size_t)(n < 64 ? 64 : n) * (heads_only ? sizeof(psd_frame_sums) : sizeof(psd_frame_scores));
+    if (s.h_bytes < need) {
+        if (s.h_recs) HIP_TRY(hipHostFree(s.h_recs));
+        s.h_recs = nullptr; s.h_bytes = 0;
+        HIP_TRY(hipHostMalloc((void**)&s.h_recs, need, hipHostMallocDefault));
+        s.h_bytes = need;
+    }
     return PSD_OK;
 }
 
@@ -274,7 +284,7 @@ static int validate(const void* frames, int n, int height, int width, size_t row
 
 // One submission = a record slot of the ring: zeroed records, timing events around the kernels, the copy of the
 // records into the pinned mirror.  submit_begin / submit_end bracket whatever fills the records.
-static int submit_begin(psd_engine* e, int n, hipStream_t stream, psd_slot** out)
+static int submit_begin(psd_engine* e, int n, uint32_t flags, hipStream_t stream, psd_slot** out)
 {
     if (e->pending >= PSD_MAX_INFLIGHT) {
         psd_set_error("too many submissions in flight (max %d); call psd_score_collect", PSD_MAX_INFLIGHT);
@@ -282,8 +292,12 @@ static int submit_begin(psd_engine* e, int n, hipStream_t stream, psd_slot** out
     }
     HIP_TRY(hipSetDevice(e->device));
     psd_slot& s = e->slots[e->head];
-    int rc = ensure_slot(e, s, n);
+    // the luma pass fills the histogram whenever it runs (for the byte sum alone too); without it the histogram stays zero
+    // and only the 40-byte heads of the records go to the host
+    const bool heads_only = !(flags & (PSD_SCORE_LUMA_HIST | PSD_SCORE_BYTE_SUM));
+    int rc = ensure_slot(e, s, n, heads_only);
     if (rc != PSD_OK) return rc;
+    s.heads_only = heads_only;
     s.n = n;
     s.launches = 0;
     s.edge.active = false;
@@ -295,11 +309,23 @@ static int submit_begin(psd_engine* e, int n, hipStream_t stream, psd_slot** out
     return PSD_OK;
 }
 
+// device records -> pinned mirror: whole records, or only their 40-byte heads (one strided copy) when no histogram was asked for
+static int copy_records_to_host(psd_slot& s, hipStream_t stream)
+{
+    if (s.heads_only)
+        HIP_TRY(hipMemcpy2DAsync(s.h_recs, sizeof(psd_frame_sums), s.d_recs, sizeof(psd_frame_scores), sizeof(psd_frame_sums), (size_t)s.n,
+                                 hipMemcpyDeviceToHost, stream));
+    else
+        HIP_TRY(hipMemcpyAsync(s.h_recs, s.d_recs, (size_t)s.n * sizeof(psd_frame_scores), hipMemcpyDeviceToHost, stream));
+    return PSD_OK;
+}
+
 static int submit_end(psd_engine* e, psd_slot& s, hipStream_t stream)
 {
     if (s.n > 0) {
         HIP_TRY(hipEventRecord(s.ev_stop, stream));
-        HIP_TRY(hipMemcpyAsync(s.h_recs, s.d_recs, (size_t)s.n * sizeof(psd_frame_scores), hipMemcpyDeviceToHost, stream));
+        int rc = copy_records_to_host(s, stream);
+        if (rc != PSD_OK) return rc;
     }
     HIP_TRY(hipEventRecord(s.ev_done, stream));
     s.pending = true;
@@ -378,7 +404,7 @@ int psd_score_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int h
     if (rc != PSD_OK) return rc;
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : e->stream;
     psd_slot* s = nullptr;
-    rc = submit_begin(e, n, stream, &s);
+    rc = submit_begin(e, n, flags, stream, &s);
     if (rc != PSD_OK) return rc;
     if (n > 0) {
         rc = score_terms(e, *s, d_frames, n, height, width, row_stride, frame_stride, d_prev, flags, edge_kernel, stream, nullptr, true);
@@ -421,7 +447,7 @@ int psd_score_segments_submit_device(psd_engine* e, const uint8_t* d_frames, int
     }
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : e->stream;
     psd_slot* s = nullptr;
-    rc = submit_begin(e, n, stream, &s);
+    rc = submit_begin(e, n, flags, stream, &s);
     if (rc != PSD_OK) return rc;
     if (n > 0) {
         rc = upload_segments(*s, n, seg_first, n_seg, stream);
@@ -465,7 +491,7 @@ int psd_score_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, i
     if (dst_h <= 0 || dst_w <= 0) { psd_set_error("invalid target size %dx%d", dst_w, dst_h); return PSD_ERR_INVALID; }
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : e->stream;
     psd_slot* s = nullptr;
-    rc = submit_begin(e, n, stream, &s);
+    rc = submit_begin(e, n, flags, stream, &s);
     if (rc != PSD_OK) return rc;
     if (n > 0) {
         bool done = false;
@@ -521,13 +547,14 @@ int psd_score_downscaled_device(psd_engine* e, const uint8_t* d_frames, int n, i
     return psd_score_collect(e, out, n);
 }
 
-int psd_score_collect(psd_engine* e, psd_frame_scores* out, int n)
+// waits for the oldest submission and retires it; *slot_out = its slot (records in the pinned mirror)
+static int collect_wait(psd_engine* e, const void* out, int n, const char* who, psd_slot** slot_out)
 {
     if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
-    if (e->pending <= 0) { psd_set_error("psd_score_collect: nothing submitted"); return PSD_ERR_INVALID; }
+    if (e->pending <= 0) { psd_set_error("%s: nothing submitted", who); return PSD_ERR_INVALID; }
     psd_slot& s = e->slots[e->tail];
     if (n != s.n || (n > 0 && !out)) {
-        psd_set_error("psd_score_collect: expected n=%d records, caller asked for %d", s.n, n);
+        psd_set_error("%s: expected n=%d records, caller asked for %d", who, s.n, n);
         return PSD_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(e->device));
@@ -547,17 +574,49 @@ int psd_score_collect(psd_engine* e, psd_frame_scores* out, int n)
         int rc = psd::edges_score(e, s.edge.d_frames, s.edge.n, s.edge.height, s.edge.width, s.edge.row_stride, s.edge.frame_stride,
                                   s.edge.d_prev, s.edge.edge_kernel, s.d_recs, s.edge.stream, s.edge.d_seg, nullptr);
         if (rc != PSD_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(s.h_recs, s.d_recs, (size_t)n * sizeof(psd_frame_scores), hipMemcpyDeviceToHost, s.edge.stream));
+        rc = copy_records_to_host(s, s.edge.stream);
+        if (rc != PSD_OK) return rc;
         HIP_TRY(hipStreamSynchronize(s.edge.stream));
     }
     if (n > 0) {
-        memcpy(out, s.h_recs, (size_t)n * sizeof(psd_frame_scores));
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.ev_start, s.ev_stop) == hipSuccess) e->last_ms = ms;
         e->last_launches = s.launches;
     } else {
         e->last_ms = 0.f;
         e->last_launches = 0;
+    }
+    *slot_out = &s;
+    return PSD_OK;
+}
+
+int psd_score_collect(psd_engine* e, psd_frame_scores* out, int n)
+{
+    psd_slot* s = nullptr;
+    int rc = collect_wait(e, out, n, "psd_score_collect", &s);
+    if (rc != PSD_OK || n == 0) return rc;
+    if (!s->heads_only) {
+        memcpy(out, s->h_recs, (size_t)n * sizeof(psd_frame_scores));
+    } else {
+        const psd_frame_sums* heads = (const psd_frame_sums*)s->h_recs;
+        for (int i = 0; i < n; i++) {
+            memset(&out[i], 0, sizeof(psd_frame_scores));
+            memcpy(&out[i], &heads[i], sizeof(psd_frame_sums));
+        }
+    }
+    return PSD_OK;
+}
+
+int psd_score_collect_sums(psd_engine* e, psd_frame_sums* out, int n)
+{
+    psd_slot* s = nullptr;
+    int rc = collect_wait(e, out, n, "psd_score_collect_sums", &s);
+    if (rc != PSD_OK || n == 0) return rc;
+    if (s->heads_only) {
+        memcpy(out, s->h_recs, (size_t)n * sizeof(psd_frame_sums));
+    } else {
+        const psd_frame_scores* recs = (const psd_frame_scores*)s->h_recs;
+        for (int i = 0; i < n; i++) memcpy(&out[i], &recs[i], sizeof(psd_frame_sums));
     }
     return PSD_OK;
 }

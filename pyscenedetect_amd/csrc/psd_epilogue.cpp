@@ -55,13 +55,13 @@ bool check_fps(int64_t num, int64_t den)
 
 extern "C" {
 
-int psd_epilogue_content_scores(const psd_frame_scores* recs, int n, int height, int width,
-                                const double weights[4], int first_has_prev, double* content_val,
-                                double* delta_hue, double* delta_sat, double* delta_lum,
-                                double* delta_edges)
+int psd_epilogue_content_scores_sums(const psd_frame_sums* sums, size_t stride_bytes, int n, int height, int width,
+                                     const double weights[4], int first_has_prev, double* content_val,
+                                     double* delta_hue, double* delta_sat, double* delta_lum,
+                                     double* delta_edges)
 {
-    if (!recs || n < 0 || height <= 0 || width <= 0 || !weights) {
-        psd_set_error("psd_epilogue_content_scores: invalid argument");
+    if (!sums || stride_bytes < sizeof(psd_frame_sums) || n < 0 || height <= 0 || width <= 0 || !weights) {
+        psd_set_error("psd_epilogue_content_scores_sums: invalid argument");
         return PSD_ERR_INVALID;
     }
     const double num_pixels = (double)((int64_t)height * (int64_t)width);
@@ -69,10 +69,11 @@ int psd_epilogue_content_scores(const psd_frame_scores* recs, int n, int height,
     for (int t = 0; t < n; t++) {
         double dh = 0, ds = 0, dl = 0, de = 0, score = 0;
         if (t > 0 || first_has_prev) {
-            dh = (double)recs[t].sad_h / num_pixels;
-            ds = (double)recs[t].sad_s / num_pixels;
-            dl = (double)recs[t].sad_v / num_pixels;
-            de = (double)(255 * recs[t].edge_xor) / num_pixels;
+            const psd_frame_sums& r = *(const psd_frame_sums*)((const char*)sums + (size_t)t * stride_bytes);
+            dh = (double)r.sad_h / num_pixels;
+            ds = (double)r.sad_s / num_pixels;
+            dl = (double)r.sad_v / num_pixels;
+            de = (double)(255 * r.edge_xor) / num_pixels;
             // sum(component*weight ...) starts from int 0 and adds left to right.
             score = (((0.0 + dh * weights[0]) + ds * weights[1]) + dl * weights[2]) + de * weights[3];
             score /= wsum;
@@ -84,6 +85,16 @@ int psd_epilogue_content_scores(const psd_frame_scores* recs, int n, int height,
         if (delta_edges) delta_edges[t] = de;
     }
     return PSD_OK;
+}
+
+int psd_epilogue_content_scores(const psd_frame_scores* recs, int n, int height, int width,
+                                const double weights[4], int first_has_prev, double* content_val,
+                                double* delta_hue, double* delta_sat, double* delta_lum,
+                                double* delta_edges)
+{
+    if (!recs) { psd_set_error("psd_epilogue_content_scores: invalid argument"); return PSD_ERR_INVALID; }
+    return psd_epilogue_content_scores_sums((const psd_frame_sums*)recs, sizeof(psd_frame_scores), n, height, width, weights, first_has_prev,
+                                            content_val, delta_hue, delta_sat, delta_lum, delta_edges);
 }
 
 int psd_epilogue_content_cuts(const double* content_val, int n, int64_t first_frame, int64_t fps_num,
@@ -279,13 +290,13 @@ int psd_epilogue_hist_correl(const float* h1, const float* h2, int bins, double*
     return PSD_OK;
 }
 
-int psd_epilogue_threshold_cuts(const psd_frame_scores* recs, int n, int height, int width,
-                                int64_t first_frame, int64_t fps_num, int64_t fps_den,
-                                const psd_threshold_params* p, double* average_rgb, int64_t* cuts,
-                                int* n_cuts)
+int psd_epilogue_threshold_cuts_sums(const psd_frame_sums* sums, size_t stride_bytes, int n, int height, int width,
+                                     int64_t first_frame, int64_t fps_num, int64_t fps_den,
+                                     const psd_threshold_params* p, double* average_rgb, int64_t* cuts,
+                                     int* n_cuts)
 {
-    if (!recs || n < 0 || height <= 0 || width <= 0 || !p || !cuts || !n_cuts || !check_fps(fps_num, fps_den)) {
-        psd_set_error("psd_epilogue_threshold_cuts: invalid argument");
+    if (!sums || stride_bytes < sizeof(psd_frame_sums) || n < 0 || height <= 0 || width <= 0 || !p || !cuts || !n_cuts || !check_fps(fps_num, fps_den)) {
+        psd_set_error("psd_epilogue_threshold_cuts_sums: invalid argument");
         return PSD_ERR_INVALID;
     }
     const double fps = fps_of(fps_num, fps_den);
@@ -298,7 +309,7 @@ int psd_epilogue_threshold_cuts(const psd_frame_scores* recs, int n, int height,
     int64_t fade_frame = 0, last_scene_cut = first_frame;
     for (int t = 0; t < n; t++) {
         const int64_t tc = first_frame + t;
-        const double avg = (double)recs[t].byte_sum / count;  // numpy.mean: exact sum, one divide
+        const double avg = (double)((const psd_frame_sums*)((const char*)sums + (size_t)t * stride_bytes))->byte_sum / count;  // numpy.mean: exact sum, one divide
         if (average_rgb) average_rgb[t] = avg;
         const bool below = avg < thr;
         if (processed) {
@@ -327,6 +338,16 @@ int psd_epilogue_threshold_cuts(const psd_frame_scores* recs, int n, int height,
     }
     *n_cuts = nc;
     return PSD_OK;
+}
+
+int psd_epilogue_threshold_cuts(const psd_frame_scores* recs, int n, int height, int width,
+                                int64_t first_frame, int64_t fps_num, int64_t fps_den,
+                                const psd_threshold_params* p, double* average_rgb, int64_t* cuts,
+                                int* n_cuts)
+{
+    if (!recs) { psd_set_error("psd_epilogue_threshold_cuts: invalid argument"); return PSD_ERR_INVALID; }
+    return psd_epilogue_threshold_cuts_sums((const psd_frame_sums*)recs, sizeof(psd_frame_scores), n, height, width, first_frame, fps_num,
+                                            fps_den, p, average_rgb, cuts, n_cuts);
 }
 
 int psd_epilogue_hash_bits(const uint8_t* thumbs, int n, int size, int hash_size, uint8_t* bits)

@@ -11,7 +11,7 @@ count.
 
 import numpy as np
 
-from pyscenedetect_amd._native import RECORD_DTYPE
+from pyscenedetect_amd._native import RECORD_DTYPE, SUMS_DTYPE
 
 
 def shard_range(n_items: int, world_size: int, rank: int) -> tuple[int, int]:
@@ -58,7 +58,8 @@ def all_gather_records(local: np.ndarray, group=None, device_records: tuple[int,
     import torch.distributed as dist
 
     local = np.ascontiguousarray(local)
-    assert local.dtype == RECORD_DTYPE
+    dtype = local.dtype     # RECORD_DTYPE, or SUMS_DTYPE (records without the histogram: 40 B/frame); the same on every rank
+    assert dtype in (RECORD_DTYPE, SUMS_DTYPE)
     world = dist.get_world_size(group)
     on_gpu = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
@@ -66,10 +67,11 @@ def all_gather_records(local: np.ndarray, group=None, device_records: tuple[int,
     mine = torch.tensor([len(local)], dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(counts, mine, group=group)
     counts = counts.cpu().tolist()
-    cap = max(max(counts), 1) * RECORD_DTYPE.itemsize
+    cap = max(max(counts), 1) * dtype.itemsize
     if on_gpu and device_records is not None and device_records[1] == len(local) and len(local):
         send = torch.zeros(cap, dtype=torch.uint8, device=dev)
-        send[: local.nbytes] = device_records_tensor(device_records[0], len(local), dev).reshape(-1)
+        # (the device records are always 1064 bytes apart; sums are their first 40)
+        send[: local.nbytes] = device_records_tensor(device_records[0], len(local), dev)[:, : dtype.itemsize].reshape(-1)
     else:
         send = torch.zeros(cap, dtype=torch.uint8)
         if len(local):
@@ -78,7 +80,7 @@ def all_gather_records(local: np.ndarray, group=None, device_records: tuple[int,
     recv = torch.empty(world * cap, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.cpu().numpy().reshape(world, cap)
-    return [recv[r, : counts[r] * RECORD_DTYPE.itemsize].copy().view(RECORD_DTYPE) for r in range(world)]
+    return [recv[r, : counts[r] * dtype.itemsize].copy().view(dtype) for r in range(world)]
 
 
 def score_clip_sharded(engine, get_frames, n_frames: int, flags: int, edge_kernel: int = 0, group=None) -> np.ndarray:
@@ -113,7 +115,9 @@ def score_clips_distributed(engine, clips, flags: int, edge_kernel: int = 0, gro
 
     # this rank's clips, packed by resolution into shared device batches where the engine can (one launch per batch)
     mine = score_clips(engine, [clips[i] for i in plan[rank]], flags, edge_kernel)
-    local = np.concatenate(mine) if mine else np.zeros(0, RECORD_DTYPE)
+    # (a rank without clips must still send the dtype the others send: what score_clips would have returned)
+    sums = hasattr(engine, "score_clips") and not (flags & 2)
+    local = np.concatenate(mine) if mine else np.zeros(0, SUMS_DTYPE if sums else RECORD_DTYPE)
     parts = all_gather_records(local, group)
     out: list = [None] * len(clips)
     for r in range(world):

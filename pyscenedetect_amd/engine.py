@@ -12,6 +12,7 @@ import numpy as np
 from pyscenedetect_amd import _native
 from pyscenedetect_amd._native import (  # noqa: F401  (re-exported)
     RECORD_DTYPE,
+    SUMS_DTYPE,
     SCORE_ALL,
     SCORE_BYTE_SUM,
     SCORE_EDGES,
@@ -345,10 +346,11 @@ class ScoringEngine:
     # -- device frames ---------------------------------------------------------------------
     def score_device(self, d_frames: int, n: int, height: int, width: int, row_stride: int | None = None,
                      frame_stride: int | None = None, d_prev: int | None = None,
-                     flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0, stream: int | None = None) -> np.ndarray:
+                     flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0, stream: int | None = None,
+                     sums_only: bool = False) -> np.ndarray:
         """Score ``n`` frames resident in HBM at device address ``d_frames`` (synchronous)."""
         self.submit_device(d_frames, n, height, width, row_stride, frame_stride, d_prev, flags, edge_kernel, stream)
-        return self.collect(n)
+        return self.collect(n, sums_only)
 
     def submit_device(self, d_frames: int, n: int, height: int, width: int, row_stride: int | None = None,
                       frame_stride: int | None = None, d_prev: int | None = None,
@@ -362,49 +364,68 @@ class ScoringEngine:
 
     def score_device_segments(self, d_frames: int, n: int, height: int, width: int, seg_first, row_stride: int | None = None,
                               frame_stride: int | None = None, flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0,
-                              stream: int | None = None) -> np.ndarray:
+                              stream: int | None = None, sums_only: bool = False) -> np.ndarray:
         """Score ``n`` resident frames that are SEVERAL clips packed back to back: ``seg_first`` holds the batch index of
         every clip's first frame (such a frame has no predecessor).  One launch per term for all clips."""
+        self.submit_device_segments(d_frames, n, height, width, seg_first, row_stride, frame_stride, flags, edge_kernel, stream)
+        return self.collect(n, sums_only)
+
+    def submit_device_segments(self, d_frames: int, n: int, height: int, width: int, seg_first, row_stride: int | None = None,
+                               frame_stride: int | None = None, flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0,
+                               stream: int | None = None) -> None:
+        """Asynchronous half of :meth:`score_device_segments`; pair with :meth:`collect` (at most ``MAX_INFLIGHT`` pending)."""
         row_stride = width * 3 if row_stride is None else row_stride
         frame_stride = height * row_stride if frame_stride is None else frame_stride
         seg = np.ascontiguousarray(seg_first, dtype=np.int32)
         _native.check(self._lib.psd_score_segments_submit_device(self._h, d_frames, int(n), int(height), int(width), row_stride,
                                                                  frame_stride, seg.ctypes.data if len(seg) else None, len(seg),
                                                                  int(flags), int(edge_kernel), stream))
-        return self.collect(n)
 
     def score_clips(self, clips, flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0,
-                    max_batch_bytes: int = 4 << 30) -> list[np.ndarray]:
+                    max_batch_bytes: int = 4 << 30, sums_only: bool = False) -> list[np.ndarray]:
         """Records of many clips (host ``uint8[n,H,W,3]`` arrays, or device tensors with ``data_ptr()``): clips of one
         resolution share device batches of up to ``max_batch_bytes``, scored with ONE launch per term per batch
         (``psd_score_segments_device``) instead of one per clip -- thousands of short clips are launch-bound otherwise.
-        The result equals ``[score_host(c) for c in clips]``."""
+        Batches of resident clips are all submitted before the first is collected (up to ``MAX_INFLIGHT`` at a time), so
+        the host-side copy of one batch's records overlaps the kernels of the next.
+        The result equals ``[score_host(c) for c in clips]`` (``sums_only``: without the histogram, ``SUMS_DTYPE``)."""
         out: list = [None] * len(clips)
+        dtype = SUMS_DTYPE if sums_only else RECORD_DTYPE
         groups: dict[tuple[int, int], list[int]] = {}
         for i, c in enumerate(clips):
             if len(c.shape) != 4 or c.shape[3] != 3:
                 raise ValueError("clips must be uint8[n,H,W,3]")
             if c.shape[0] == 0:
-                out[i] = np.zeros(0, RECORD_DTYPE)
+                out[i] = np.zeros(0, dtype)
                 continue
             groups.setdefault((int(c.shape[1]), int(c.shape[2])), []).append(i)
+        # device clips that already sit back to back in HBM are scored in place: one job per contiguous run
+        jobs: list[tuple[list[int], int, int]] = []
         for (h, w), idxs in groups.items():
             stride = h * w * 3
-            per_batch = max(1, max_batch_bytes // stride)
-            # device clips that already sit back to back in HBM are scored in place
-            dev = [i for i in idxs if hasattr(clips[i], "data_ptr")]
             run: list[int] = []
-            for i in dev + [None]:
+            for i in [i for i in idxs if hasattr(clips[i], "data_ptr")] + [None]:
                 if i is not None and run and clips[run[-1]].data_ptr() + clips[run[-1]].shape[0] * stride == clips[i].data_ptr():
                     run.append(i)
                     continue
                 if run:
-                    first = np.cumsum([0] + [clips[j].shape[0] for j in run[:-1]])
-                    total = int(sum(clips[j].shape[0] for j in run))
-                    recs = self.score_device_segments(clips[run[0]].data_ptr(), total, h, w, first, flags=flags, edge_kernel=edge_kernel)
-                    for j, f0 in zip(run, first):
-                        out[j] = recs[f0:f0 + clips[j].shape[0]]
+                    jobs.append((run, h, w))
                 run = [i] if i is not None else []
+        for k0 in range(0, len(jobs), _native.MAX_INFLIGHT):
+            window = jobs[k0:k0 + _native.MAX_INFLIGHT]
+            meta = []
+            for run, h, w in window:
+                first = np.cumsum([0] + [clips[j].shape[0] for j in run[:-1]])
+                total = int(sum(clips[j].shape[0] for j in run))
+                self.submit_device_segments(clips[run[0]].data_ptr(), total, h, w, first, flags=flags, edge_kernel=edge_kernel)
+                meta.append((run, first, total))
+            for run, first, total in meta:
+                recs = self.collect(total, sums_only)
+                for j, f0 in zip(run, first):
+                    out[j] = recs[f0:f0 + clips[j].shape[0]]
+        for (h, w), idxs in groups.items():
+            stride = h * w * 3
+            per_batch = max(1, max_batch_bytes // stride)
             host = [i for i in idxs if not hasattr(clips[i], "data_ptr")]
             k = 0
             while k < len(host):
@@ -414,7 +435,8 @@ class ScoringEngine:
                     frames += clips[host[k]].shape[0]
                     k += 1
                 if len(batch) == 1 and frames > per_batch:      # one clip larger than a batch: the chunked host path
-                    out[batch[0]] = self.score_host(np.asarray(clips[batch[0]]), flags=flags, edge_kernel=edge_kernel)
+                    recs = self.score_host(np.asarray(clips[batch[0]]), flags=flags, edge_kernel=edge_kernel)
+                    out[batch[0]] = _sums_of(recs) if sums_only else recs
                     continue
                 buf = self._scratch("clips", frames * stride)
                 first, off = [], 0
@@ -423,7 +445,7 @@ class ScoringEngine:
                     buf.upload(c.reshape(-1), off * stride)
                     first.append(off)
                     off += c.shape[0]
-                recs = self.score_device_segments(buf.ptr, frames, h, w, first, flags=flags, edge_kernel=edge_kernel)
+                recs = self.score_device_segments(buf.ptr, frames, h, w, first, flags=flags, edge_kernel=edge_kernel, sums_only=sums_only)
                 for j, f0 in zip(batch, first):
                     out[j] = recs[f0:f0 + clips[j].shape[0]].copy()
         return out
@@ -447,9 +469,16 @@ class ScoringEngine:
                                       interpolation, stream)
         return self.collect(n)
 
-    def collect(self, n: int) -> np.ndarray:
-        out = np.zeros(n, RECORD_DTYPE)
-        _native.check(self._lib.psd_score_collect(self._h, out.ctypes.data if n else None, int(n)))
+    def collect(self, n: int, sums_only: bool = False) -> np.ndarray:
+        """Records of the oldest pending submission.  ``sums_only``: ``SUMS_DTYPE`` (the five sums, 40 bytes per frame)
+        instead of ``RECORD_DTYPE`` (1064 with the luma histogram) -- all that ContentDetector, AdaptiveDetector and
+        ThresholdDetector decide from, and all a submission without the luma terms moves to the host anyway."""
+        if sums_only:
+            out = np.empty(n, SUMS_DTYPE)
+            _native.check(self._lib.psd_score_collect_sums(self._h, out.ctypes.data if n else None, int(n)))
+        else:
+            out = np.empty(n, RECORD_DTYPE)
+            _native.check(self._lib.psd_score_collect(self._h, out.ctypes.data if n else None, int(n)))
         self.kernel_ms_acc += self.last_kernel_ms()[0]      # callers that time a flow of several submissions reset and read this
         return out
 
@@ -473,6 +502,14 @@ class ScoringEngine:
         _native.check(self._lib.psd_edge_map_device(self._h, d_frame, height, width, width * 3 if row_stride is None else row_stride,
                                                     int(edge_kernel), out.ctypes.data))
         return out
+
+
+def _sums_of(records: np.ndarray) -> np.ndarray:
+    """``SUMS_DTYPE`` copy of full records."""
+    out = np.empty(len(records), SUMS_DTYPE)
+    for name in SUMS_DTYPE.names:
+        out[name] = records[name]
+    return out
 
 
 def _locked(fn):

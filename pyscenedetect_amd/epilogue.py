@@ -44,14 +44,25 @@ def _recs(records: np.ndarray) -> np.ndarray:
     return records
 
 
+def _sums(records: np.ndarray) -> tuple[np.ndarray, int]:
+    """(array, stride in bytes) for the epilogues that only read the five sums: full records (``RECORD_DTYPE``) are read in
+    place, records without the histogram (``SUMS_DTYPE``, ``ScoringEngine.collect(sums_only=True)``) likewise."""
+    records = np.asarray(records)
+    if records.dtype != _native.RECORD_DTYPE and records.dtype != _native.SUMS_DTYPE:
+        raise ValueError("records must have dtype RECORD_DTYPE or SUMS_DTYPE")
+    if records.ndim != 1 or (len(records) > 1 and records.strides[0] < records.dtype.itemsize):
+        records = np.ascontiguousarray(records).reshape(-1)
+    return records, (records.strides[0] if len(records) > 1 else records.dtype.itemsize)
+
+
 def content_scores(records, height: int, width: int, weights=(1.0, 1.0, 1.0, 0.0), first_has_prev: bool = False):
     """dict of float64 arrays: content_val, delta_hue, delta_sat, delta_lum, delta_edges."""
-    records = _recs(records)
+    records, stride = _sums(records)
     n = len(records)
     out = {k: np.zeros(n, np.float64) for k in ("content_val", "delta_hue", "delta_sat", "delta_lum", "delta_edges")}
     w = (ctypes.c_double * 4)(*[float(x) for x in weights])
-    _native.check(_native.load().psd_epilogue_content_scores(
-        records.ctypes.data, n, height, width, ctypes.cast(w, ctypes.c_void_p), int(first_has_prev),
+    _native.check(_native.load().psd_epilogue_content_scores_sums(
+        records.ctypes.data, stride, n, height, width, ctypes.cast(w, ctypes.c_void_p), int(first_has_prev),
         *[out[k].ctypes.data for k in ("content_val", "delta_hue", "delta_sat", "delta_lum", "delta_edges")]))
     return out
 
@@ -113,7 +124,7 @@ def threshold_cuts(records, height: int, width: int, fps, threshold: float = 12,
                    fade_bias: float = 0.0, add_final_scene: bool = False, method: int = 0, first_frame: int = 0):
     """(cuts, average_rgb[n])."""
     rate = _fps(fps)
-    records = _recs(records)
+    records, stride = _sums(records)
     p = ThresholdParams()
     p.threshold = int(threshold)
     p.method = int(method)
@@ -123,8 +134,8 @@ def threshold_cuts(records, height: int, width: int, fps, threshold: float = 12,
     avg = np.zeros(len(records), np.float64)
     cuts = np.zeros(len(records) + 1, np.int64)
     nc = ctypes.c_int(0)
-    _native.check(_native.load().psd_epilogue_threshold_cuts(records.ctypes.data, len(records), height, width,
-                                                            first_frame, rate.numerator, rate.denominator,
+    _native.check(_native.load().psd_epilogue_threshold_cuts_sums(records.ctypes.data, stride, len(records), height, width,
+                                                                 first_frame, rate.numerator, rate.denominator,
                                                             ctypes.byref(p), avg.ctypes.data, cuts.ctypes.data,
                                                             ctypes.byref(nc)))
     return cuts[: nc.value].tolist(), avg

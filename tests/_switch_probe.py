@@ -1,0 +1,69 @@
+"""Run by tests/test_gpu_switches.py in a subprocess (the library reads its PSD_* environment switches once per process):
+every entry point a switch can reroute, on small inputs, against the oracle.  Prints "ok" or dies on the first mismatch."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.append(os.path.join(ROOT, "oracle", "cv2_shim"))
+
+import cv2  # noqa: E402  (the oracle's shim)
+
+from oracle import lib as orc  # noqa: E402
+from oracle.detectors_np import score_batch as oracle_score  # noqa: E402
+from pyscenedetect_amd import engine as E  # noqa: E402
+from pyscenedetect_amd.synth import make_clip  # noqa: E402
+
+FIELDS = ("sad_h", "sad_s", "sad_v", "byte_sum", "edge_xor")
+
+
+def same(got, want, fields, tag):
+    for f in fields:
+        assert np.array_equal(got[f], want[f]), (tag, f, np.flatnonzero(np.asarray(got[f]) != np.asarray(want[f]))[:8])
+
+
+def main():
+    eng = E.ScoringEngine(0)
+    # 256 x 144 (16-byte aligned frames: the staged kernels), long enough for several time chunks and flushes
+    frames, _ = make_clip(77, 150, 144, 256, shot_len=(20, 40))
+    want = oracle_score(frames, edges=True)
+    got = eng.score_host(frames, flags=E.SCORE_ALL)
+    same(got, want, FIELDS, "all")
+    assert np.array_equal(got["hist"], want["hist"]), "all: hist"
+    for flags, fields, hist in ((E.SCORE_HSV_SAD, FIELDS[:3], False), (E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM, ("byte_sum",), True),
+                                (E.SCORE_HSV_SAD | E.SCORE_EDGES, FIELDS[:3] + ("edge_xor",), False), (E.SCORE_EDGES, ("edge_xor",), False),
+                                (E.SCORE_HSV_SAD | E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM, FIELDS[:4], True)):
+        got = eng.score_host(frames[1:], prev=frames[0], flags=flags)
+        same(got, want[1:], fields, flags)
+        if hist:
+            assert np.array_equal(got["hist"], want["hist"][1:]), (flags, "hist")
+    # a weak-edge chain across dozens of 64x64 tiles: more hysteresis launches than the speculative path enqueues
+    from tests.test_gpu_fullsize import serpentine
+
+    pair = np.stack([serpentine(300, 700, seed=False)[0], serpentine(300, 700)[0]])
+    ws = oracle_score(pair, edges=True, kernel_size=3)
+    assert ws["edge_xor"][1] > 1000, "the chain must be there"
+    same(eng.score_host(pair, flags=E.SCORE_EDGES, edge_kernel=3), ws, ("edge_xor",), "serpentine")
+    same(eng.score_host(pair, flags=E.SCORE_EDGES | E.SCORE_HSV_SAD, edge_kernel=3), ws, FIELDS[:3] + ("edge_xor",), "serpentine + hsv")
+    # HashDetector thumbnails
+    big, _ = make_clip(5, 6, 360, 640, shot_len=(2, 3))
+    assert np.array_equal(eng.hash_thumbs_host(big, 16), orc.hash_thumbs(big, 16)), "hash thumbnails"
+    assert np.array_equal(eng.hash_thumbs_host(frames[:5], 32), orc.hash_thumbs(frames[:5], 32)), "hash thumbnails (144 x 256)"
+    # the default pipeline: downscale fused with the HSV term, and downscale into a buffer + the other terms
+    buf = eng.alloc(big.nbytes)
+    buf.upload(big.reshape(-1))
+    small = np.stack([cv2.resize(f, (256, 144)) for f in big])
+    w2 = orc.score_batch(small)
+    same(eng.score_device_downscaled(buf.ptr, len(big), 360, 640, 144, 256, flags=E.SCORE_HSV_SAD), w2, FIELDS[:3], "downscaled hsv")
+    got = eng.score_device_downscaled(buf.ptr, len(big), 360, 640, 144, 256, flags=E.SCORE_ALL & ~E.SCORE_EDGES)
+    same(got, w2, FIELDS[:4], "downscaled all")
+    assert np.array_equal(got["hist"], w2["hist"]), "downscaled hist"
+    buf.free()
+    eng.close()
+    print("ok")
+
+
+if __name__ == "__main__":
+    main()

@@ -33,6 +33,26 @@ CORPUS = [(70, 36, 64), (50, 54, 96), (33, 24, 40), (90, 36, 64), (41, 48, 80)]
 ALL_FOUR = {"content": {"min_scene_len": 8}, "adaptive": {"min_scene_len": 8}, "hist": {}, "threshold": {"threshold": 40}}
 
 
+NO_HIST = {"content": {"min_scene_len": 8}, "adaptive": {"min_scene_len": 8}, "threshold": {"threshold": 40}}
+
+
+class PackingOracle:
+    """The oracle behind the interface of ScoringEngine.score_clips (sums_only: records without the histogram)."""
+
+    def __init__(self):
+        from oracle.detectors_np import OracleEngine
+
+        self.eng = OracleEngine()
+        self.asked_for_sums = []
+
+    def score_clips(self, clips, flags, edge_kernel=0, sums_only=False):
+        from pyscenedetect_amd.engine import _sums_of
+
+        self.asked_for_sums.append(sums_only)
+        recs = [self.eng.score_host(c, flags=flags, edge_kernel=edge_kernel) for c in clips]
+        return [_sums_of(r) for r in recs] if sums_only else recs
+
+
 def _worker(rank, world, port, tmp):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -57,6 +77,20 @@ def _worker(rank, world, port, tmp):
     corpus = [make_clip(60 + i, n, h, w, shot_len=(16, 24))[0] for i, (n, h, w) in enumerate(CORPUS)]
     res = detect_corpus(eng, corpus, 25.0, ALL_FOUR)
     with open(os.path.join(tmp, f"corpus{rank}.json"), "w") as f:
+        json.dump(res, f)
+    # records without the histogram (ABI 3): ragged all-gather of 40-byte sums, one rank empty; and the clip flow over an
+    # engine that packs clips and returns sums (what ScoringEngine.score_clips does when no detector reads the histogram)
+    from pyscenedetect_amd._native import SUMS_DTYPE
+
+    mine = np.zeros(0 if rank == 0 else 7, SUMS_DTYPE)
+    mine["sad_v"] = np.arange(len(mine)) + 100 * rank
+    parts = D.all_gather_records(mine)
+    assert [len(x) for x in parts] == [0, 7] and parts[1].dtype == SUMS_DTYPE and parts[1]["sad_v"].tolist() == list(range(100, 107))
+    res = detect_corpus(PackingOracle(), corpus, 25.0, NO_HIST)
+    with open(os.path.join(tmp, f"nohist{rank}.json"), "w") as f:
+        json.dump(res, f)
+    res = detect_corpus(PackingOracle(), corpus[:1], 25.0, NO_HIST)     # fewer clips than ranks: rank 1 sends nothing
+    with open(os.path.join(tmp, f"nohist_one{rank}.json"), "w") as f:
         json.dump(res, f)
     np.save(os.path.join(tmp, f"recs{rank}.npy"), recs)
     np.save(os.path.join(tmp, f"cuts{rank}.npy"), np.array(cuts))
@@ -101,6 +135,13 @@ def test_two_ranks_equal_one(tmp_path):
     assert any(any(v for v in clip.values()) for clip in single)
     for r in range(world):
         assert json.load(open(tmp_path / f"corpus{r}.json")) == single
+    packing = PackingOracle()
+    nohist = detect_corpus(packing, corpus, 25.0, NO_HIST)
+    assert packing.asked_for_sums == [True]
+    assert nohist == [{k: v for k, v in clip.items() if k != "hist"} for clip in single]
+    for r in range(world):
+        assert json.load(open(tmp_path / f"nohist{r}.json")) == nohist
+        assert json.load(open(tmp_path / f"nohist_one{r}.json")) == nohist[:1]
     for clip, res in zip(corpus, single):
         sm = psd.SceneManager(engine=eng)
         sm.auto_downscale = False

@@ -122,3 +122,36 @@ def test_per_frame_histogram_steps_native_equals_numpy():
             for y in normed:
                 p, q = hd.compare_hist_correl(x, y), hd._native_correl(x, y)
                 assert p == q or (p != p and q != q), (bins, p, q)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_epilogues_read_sums_and_full_records_alike(seed):
+    """ABI 3: ContentDetector / AdaptiveDetector / ThresholdDetector decide from the five sums of a record; the epilogues
+    take them as full records (1064 B apart), as packed psd_frame_sums (40 B) or as a strided view, with one result."""
+    from pyscenedetect_amd._native import SUMS_DTYPE
+
+    rng = np.random.default_rng(300 + seed)
+    n = int(rng.integers(1, 300))
+    h, w = 36, 64
+    full = np.zeros(n, RECORD_DTYPE)
+    for name in ("sad_h", "sad_s", "sad_v", "edge_xor"):
+        full[name] = rng.integers(0, 255 * h * w, n)
+    full["byte_sum"] = rng.integers(0, 255 * 3 * h * w, n)
+    full["hist"] = rng.integers(0, 1000, (n, 256))
+    sums = np.empty(n, SUMS_DTYPE)
+    for name in SUMS_DTYPE.names:
+        sums[name] = full[name]
+    every_other = np.repeat(sums, 2)[::2]          # a view with twice the stride
+    weights = (1.0, 0.5, 2.0, 0.25)
+    want = epilogue.content_scores(full, h, w, weights)
+    for recs in (sums, every_other):
+        got = epilogue.content_scores(recs, h, w, weights)
+        assert all(np.array_equal(got[k], want[k]) for k in want)
+    cuts, avg = epilogue.threshold_cuts(full, h, w, 25.0, threshold=100, min_scene_len=3)
+    for recs in (sums, every_other):
+        c2, a2 = epilogue.threshold_cuts(recs, h, w, 25.0, threshold=100, min_scene_len=3)
+        assert c2 == cuts and np.array_equal(a2, avg)
+    with pytest.raises(ValueError):
+        epilogue.content_scores(np.zeros(4, np.uint64), h, w)
+    with pytest.raises(ValueError):
+        epilogue.hist_cuts(sums, 25.0)             # the histogram detector needs the histogram

@@ -458,3 +458,74 @@ def test_a_scene_manager_outlives_the_thread_that_built_it(golden):
     sm2.add_detector(psd.ContentDetector(engine=box["engine"]))
     sm2.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
     assert [c.frame_num for c in sm2.get_cut_list()] == want
+
+
+# ---- ABI 3: records without the histogram (psd_frame_sums, psd_score_collect_sums) ------------------------------------------
+
+
+def test_collect_sums_equals_the_heads_of_full_records(hip_engine):
+    """Submissions without the luma terms move only 40 bytes per frame to the host (one strided device -> host copy);
+    whatever was submitted, collect(sums_only=True) is the head of what collect() returns, and the full form keeps its
+    zero histogram."""
+    import torch
+    from pyscenedetect_amd._native import SUMS_DTYPE
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(31)
+    x = torch.randint(0, 256, (70, 144, 256, 3), dtype=torch.uint8, device="cuda", generator=g)
+    torch.cuda.synchronize()
+    want = oracle_score(x.cpu().numpy(), edges=True)
+    for flags in (E.SCORE_HSV_SAD, E.SCORE_HSV_SAD | E.SCORE_EDGES, E.SCORE_EDGES, E.SCORE_BYTE_SUM, E.SCORE_ALL, NOEDGE):
+        fields = ([f for f in ("sad_h", "sad_s", "sad_v") if flags & E.SCORE_HSV_SAD] + (["edge_xor"] if flags & E.SCORE_EDGES else []) +
+                  (["byte_sum"] if flags & (E.SCORE_BYTE_SUM | E.SCORE_LUMA_HIST) else []))
+        full = hip_engine.score_device(x.data_ptr(), 70, 144, 256, flags=flags)
+        sums = hip_engine.score_device(x.data_ptr(), 70, 144, 256, flags=flags, sums_only=True)
+        assert full.dtype == E.RECORD_DTYPE and sums.dtype == SUMS_DTYPE
+        for f in SUMS_DTYPE.names:
+            assert np.array_equal(full[f], sums[f]), (flags, f)
+        same(sums, want, fields)
+        if flags & (E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM):
+            assert np.array_equal(full["hist"], want["hist"]), flags
+        else:
+            assert not full["hist"].any(), flags
+    # both forms through the pipelined API, interleaved, sizes differing (the pinned mirror of a slot is reused)
+    for n, so in ((70, True), (3, False), (64, True), (70, False)):
+        hip_engine.submit_device(x.data_ptr(), n, 144, 256, flags=E.SCORE_HSV_SAD if n != 3 else NOEDGE)
+    for n, so in ((70, True), (3, False), (64, True), (70, False)):
+        r = hip_engine.collect(n, sums_only=so)
+        same(r, want[:n], ("sad_h", "sad_s", "sad_v"))
+    with pytest.raises(ValueError):
+        hip_engine.collect(5, sums_only=True)      # nothing pending
+
+
+def test_score_clips_pipelines_more_jobs_than_slots(hip_engine):
+    """Six runs of resident clips (alternating resolutions, so no two neighbours are contiguous): more submissions than
+    PSD_MAX_INFLIGHT, collected in windows; with and without the histogram."""
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    shapes = [(9, 72, 128), (4, 90, 160), (17, 72, 128), (6, 90, 160), (30, 72, 128), (1, 90, 160), (12, 36, 64)]
+    pool = {}
+    clips = []
+    for n, h, w in shapes:
+        # separate allocations with a gap: runs stay apart
+        t = torch.randint(0, 256, (n + 1, h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
+        pool[len(clips)] = t
+        clips.append(t[:n])
+    # ... and one run of three clips back to back
+    big = torch.randint(0, 256, (20, 72, 128, 3), dtype=torch.uint8, device="cuda", generator=g)
+    clips += [big[:5], big[5:6], big[6:]]
+    torch.cuda.synchronize()
+    want = [orc.score_batch(c.cpu().numpy()) for c in clips]
+    got = hip_engine.score_clips(clips, flags=NOEDGE)
+    for gr, wv in zip(got, want):
+        same(gr, wv)
+    sums = hip_engine.score_clips(clips, flags=E.SCORE_HSV_SAD, sums_only=True)
+    for gr, wv in zip(sums, want):
+        assert gr.dtype.itemsize == 40 and len(gr) == len(wv)
+        same(gr, wv, ("sad_h", "sad_s", "sad_v"))
+    host = [c.cpu().numpy() for c in clips[:3]]
+    for gr, wv in zip(hip_engine.score_clips(host, flags=E.SCORE_HSV_SAD | E.SCORE_BYTE_SUM, sums_only=True), want):
+        assert gr.dtype.itemsize == 40
+        same(gr, wv, ("sad_h", "sad_s", "sad_v", "byte_sum"))

@@ -1,0 +1,39 @@
+"""Every environment switch of libpsd_hip.so that reroutes work to another kernel, launch shape or host loop
+("untested alternative code paths"): each setting runs tests/_switch_probe.py -- all entry points the
+switch can touch, against the oracle -- in its own process, because the library reads the switches once per process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SWITCHES = [
+    {},                                   # the defaults, through the same probe
+    {"PSD_SCORE_DIRECT": "1"},            # register-staged loads instead of LDS-DMA on the fast path (psd_score_kernels.hip)
+    {"PSD_SCORE_G": "2"},                 # two 16-pixel groups per lane in the small-workgroup HSV pass
+    {"PSD_SCORE_G": "1"},                 # ... one group per lane everywhere (also the 16-wave fused pass)
+    {"PSD_HSV_BLOCKS": "64"},             # few, long time walks
+    {"PSD_HSV_BLOCKS": "1000000"},        # as many walks as frames allow
+    {"PSD_LUMA_WALK": "1"},               # luma histogram on the time-walking kernel instead of luma_hist_kernel
+    {"PSD_EDGE_SPECULATIVE": "0"},        # host-driven hysteresis loop (psd_engine.cpp)
+    {"PSD_EDGE_FUSE_HSV": "0"},           # two reads of the frames for HSV + edges
+    {"PSD_EDGE_VHIST_FUSED": "0"},        # V plane from the HSV-only kernel + v_hist_kernel
+    {"PSD_EDGE_WS_MB": "1"},              # edge workspace of a few frames: many chunks
+    {"PSD_EDGE_WS_MB": "1", "PSD_EDGE_VHIST_FUSED": "0"},
+    {"PSD_HASH_DIRECT": "1"},             # HashDetector thumbnails without LDS-DMA (psd_hash_kernels.hip)
+    {"PSD_RESIZE_DEPTH": "3"},            # downscale kernel with two frames in flight
+    {"PSD_RESIZE_ROWS": "1"},             # ... one destination row per workgroup
+    {"PSD_RESIZE_ROWS": "5", "PSD_RESIZE_DEPTH": "3"},
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", SWITCHES, ids=lambda s: ",".join(f"{k}={v}" for k, v in s.items()) or "defaults")
+def test_switch_matches_the_oracle(switch):
+    env = {k: v for k, v in os.environ.items() if not (k.startswith("PSD_") and k != "PSD_LIB_PATH")}
+    env.update(switch)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_switch_probe.py")], capture_output=True, text=True, env=env,
+                         timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (switch, out.stdout[-400:], out.stderr[-1500:])

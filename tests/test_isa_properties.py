@@ -3,7 +3,7 @@ double-digit percentages when they were lost:
 
 * the staged scoring kernels must not wait for the NEXT frame's LDS-DMA inside a step: hipcc puts `s_waitcnt vmcnt(0)` in
   front of LDS reads whose address it cannot tell apart from the staging slots, and in front of every LDS store / atomic;
-* the Sobel tile kernel must issue its six tile loads before the first LDS write: a load behind a branch is waited for
+* the Sobel / NMS bit-plane kernel must issue its six tile loads before the first LDS write: a load behind a branch is waited for
   before the next one goes out.
 """
 import os
@@ -74,7 +74,7 @@ def test_staged_kernels_do_not_wait_for_the_prefetch_inside_a_step(tmp_path):
 
 def test_sobel_tile_kernel_issues_its_loads_together(tmp_path):
     bodies = kernel_bodies(device_asm("psd_edge_kernels", tmp_path))
-    lines = next(v for k, v in bodies.items() if "sobel_nms_tile_kernel" in k)
+    lines = next(v for k, v in bodies.items() if "sobel_nms_bits_kernel" in k)
     first_write = next(i for i, l in enumerate(lines) if "ds_write_b32" in l)
     loads = [i for i, l in enumerate(lines) if "global_load_dword " in l or "global_load_dword\t" in l]
     assert len([i for i in loads if i < first_write]) >= 6, (loads[:8], first_write)
