@@ -67,14 +67,29 @@ def score_clip(engine, clip, flags: int, edge_kernel: int = 0) -> np.ndarray:
     return engine.score_host(clip[0:len(clip)], flags=flags, edge_kernel=edge_kernel)
 
 
-def score_clips(engine, clips, flags: int, edge_kernel: int = 0) -> list[np.ndarray]:
+def score_clips(engine, clips, flags: int, edge_kernel: int = 0, on_ready=None) -> list[np.ndarray]:
     """Records of every clip; engines that can pack clips of one resolution into shared batches (``ScoringEngine.score_clips``:
-    one launch per term per batch, SAD chain broken at clip starts) do so, others score clip by clip."""
+    one launch per term per batch, SAD chain broken at clip starts) do so, others score clip by clip.
+    ``on_ready(i, records)``: called per clip as its records arrive (see ``ScoringEngine.score_clips``)."""
     if hasattr(engine, "score_clips"):
         # without a HistogramDetector nobody reads the 1 KiB luma histogram of a record: fetch the five sums only
         # (40 instead of 1064 bytes per frame from the device, through the host and over the all-gather)
-        return engine.score_clips(clips, flags=flags, edge_kernel=edge_kernel, sums_only=not (flags & _native.SCORE_LUMA_HIST))
-    return [score_clip(engine, c, flags, edge_kernel) for c in clips]
+        import inspect
+
+        sums_only = not (flags & _native.SCORE_LUMA_HIST)
+        if on_ready is None or "on_ready" in inspect.signature(engine.score_clips).parameters:
+            kw = {"on_ready": on_ready} if on_ready is not None else {}
+            return engine.score_clips(clips, flags=flags, edge_kernel=edge_kernel, sums_only=sums_only, **kw)
+        out = engine.score_clips(clips, flags=flags, edge_kernel=edge_kernel, sums_only=sums_only)
+        for i, r in enumerate(out):
+            on_ready(i, r)
+        return out
+    out = []
+    for i, c in enumerate(clips):
+        out.append(score_clip(engine, c, flags, edge_kernel))
+        if on_ready is not None:
+            on_ready(i, out[-1])
+    return out
 
 
 def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: int = 0) -> list[dict]:
@@ -94,7 +109,14 @@ def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: 
         from pyscenedetect_amd.distributed import score_clips_distributed
 
         records = score_clips_distributed(engine, clips, flags, edge_kernel, group)
-    else:
-        records = score_clips(engine, clips, flags, edge_kernel)
     fps_list = fps if isinstance(fps, (list, tuple)) else [fps] * len(clips)
+    if not use_dist:
+        # one process: a clip is decided as soon as its records are on the host, while the batches behind it are still on the GPU
+        result: list = [None] * len(clips)
+
+        def decide_now(i, recs):
+            result[i] = decide(recs, clips[i].shape[1], clips[i].shape[2], fps_list[i], detectors)
+
+        score_clips(engine, clips, flags, edge_kernel, on_ready=decide_now)
+        return result
     return [decide(r, c.shape[1], c.shape[2], f, detectors) for r, c, f in zip(records, clips, fps_list)]

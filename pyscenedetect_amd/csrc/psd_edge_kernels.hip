@@ -482,7 +482,31 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
     const uint8_t* V = vplane + (size_t)j * g.npix;
     const int x0 = tx * N2_W, y0 = ty * N2_H, H = g.height, W = g.width;
     const int2 lohi = thr[j];   // read here: behind the barriers its latency would sit in front of phase 2
-    {
+    const bool inner = x0 >= 4 && x0 + N2_W + 4 <= W && y0 >= 2 && y0 + N2_H + 2 <= H;
+    if (inner) {
+        // Interior tiles (four in five at 1080p): no clamping, so all six addresses are ONE per-lane 32-bit offset on top of
+        // scalar row bases (global_load_dword v, v_off, s[base]) -- a dozen VALU instructions where the clamped 64-bit
+        // addresses of the general form below took a hundred, a quarter of the kernel's arithmetic.
+        const int cw = lane & 31, half = lane >> 5;
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave);                    // (uniform: the row bases stay in SGPRs)
+        const uint8_t* base = V + (size_t)(y0 - 2) * W + (x0 - 4);                  // row y0-2, column x0-4 of the frame
+        const u32 off = (u32)(half * W + 4 * cw);
+        u32 v[5];
+#pragma unroll
+        for (int it = 0; it < 5; it++) {
+            // rows 2 (5 wave + it) + half; the last wave's surplus rows (36..39) re-read row 35 into the scratch rows
+            const int row = min(2 * (wave_s * 5 + it), N2_H + 2);
+            typedef const __attribute__((address_space(1))) uint8_t* gbl_u8_t;
+            gbl_u8_t rb = (gbl_u8_t)(base + (size_t)row * W);
+            asm volatile("" : "+s"(rb));   // (keeps the row base in an SGPR pair: hipcc would fold it into 64-bit VALU adds)
+            v[it] = *reinterpret_cast<const __attribute__((address_space(1))) u32*>(rb + off);
+        }
+        const int tl = min(tid >> 1, N2_H + 3), c2 = 32 + (tid & 1);
+        const u32 vt = *reinterpret_cast<const u32*>(base + (u32)(tl * W + 4 * c2));
+#pragma unroll
+        for (int it = 0; it < 5; it++) *reinterpret_cast<u32*>(&sv[2 * (wave * 5 + it) + half][4 * cw]) = v[it];
+        *reinterpret_cast<u32*>(&sv[tl][4 * c2]) = vt;
+    } else {
         // 36 rows x 34 dwords, BORDER_REPLICATE (cv2.Sobel inside cv2.Canny): two V rows per wave instruction (lanes 0-31 /
         // 32-63 take the first 32 dwords of a row, 72 threads the two dwords left over per row), the row and the dword
         // position clamped into the image and, where the position was clamped, the edge pixel replicated.  All six loads go
@@ -514,7 +538,6 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
         *reinterpret_cast<u32*>(&sv[tl][4 * c2]) = xb >= W ? __builtin_amdgcn_perm(vt, vt, 0x03030303u) : vt;
     }
     __syncthreads();
-    const bool inner = x0 >= 4 && x0 + N2_W + 4 <= W && y0 >= 2 && y0 + N2_H + 2 <= H;
     if (inner) sobel_phase1_quads<true>(sv, smq, tid, x0, y0, H, W);
     else sobel_phase1_quads<false>(sv, smq, tid, x0, y0, H, W);
     __syncthreads();

@@ -382,14 +382,17 @@ class ScoringEngine:
                                                                  int(flags), int(edge_kernel), stream))
 
     def score_clips(self, clips, flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0,
-                    max_batch_bytes: int = 4 << 30, sums_only: bool = False) -> list[np.ndarray]:
+                    max_batch_bytes: int = 4 << 30, sums_only: bool = False, on_ready=None) -> list[np.ndarray]:
         """Records of many clips (host ``uint8[n,H,W,3]`` arrays, or device tensors with ``data_ptr()``): clips of one
         resolution share device batches of up to ``max_batch_bytes``, scored with ONE launch per term per batch
         (``psd_score_segments_device``) instead of one per clip -- thousands of short clips are launch-bound otherwise.
         Batches of resident clips are all submitted before the first is collected (up to ``MAX_INFLIGHT`` at a time), so
         the host-side copy of one batch's records overlaps the kernels of the next.
-        The result equals ``[score_host(c) for c in clips]`` (``sums_only``: without the histogram, ``SUMS_DTYPE``)."""
+        The result equals ``[score_host(c) for c in clips]`` (``sums_only``: without the histogram, ``SUMS_DTYPE``).
+        ``on_ready(i, records)`` is called for every clip as soon as its records are on the host -- while later batches
+        are still being scored -- so the caller's decisions overlap the remaining kernels."""
         out: list = [None] * len(clips)
+        ready = on_ready if on_ready is not None else (lambda i, r: None)
         dtype = SUMS_DTYPE if sums_only else RECORD_DTYPE
         groups: dict[tuple[int, int], list[int]] = {}
         for i, c in enumerate(clips):
@@ -397,6 +400,7 @@ class ScoringEngine:
                 raise ValueError("clips must be uint8[n,H,W,3]")
             if c.shape[0] == 0:
                 out[i] = np.zeros(0, dtype)
+                ready(i, out[i])
                 continue
             groups.setdefault((int(c.shape[1]), int(c.shape[2])), []).append(i)
         # device clips that already sit back to back in HBM are scored in place: one job per contiguous run
@@ -423,6 +427,7 @@ class ScoringEngine:
                 recs = self.collect(total, sums_only)
                 for j, f0 in zip(run, first):
                     out[j] = recs[f0:f0 + clips[j].shape[0]]
+                    ready(j, out[j])
         for (h, w), idxs in groups.items():
             stride = h * w * 3
             per_batch = max(1, max_batch_bytes // stride)
@@ -437,6 +442,7 @@ class ScoringEngine:
                 if len(batch) == 1 and frames > per_batch:      # one clip larger than a batch: the chunked host path
                     recs = self.score_host(np.asarray(clips[batch[0]]), flags=flags, edge_kernel=edge_kernel)
                     out[batch[0]] = _sums_of(recs) if sums_only else recs
+                    ready(batch[0], out[batch[0]])
                     continue
                 buf = self._scratch("clips", frames * stride)
                 first, off = [], 0
@@ -448,6 +454,7 @@ class ScoringEngine:
                 recs = self.score_device_segments(buf.ptr, frames, h, w, first, flags=flags, edge_kernel=edge_kernel, sums_only=sums_only)
                 for j, f0 in zip(batch, first):
                     out[j] = recs[f0:f0 + clips[j].shape[0]].copy()
+                    ready(j, out[j])
         return out
 
     def submit_device_downscaled(self, d_frames: int, n: int, src_h: int, src_w: int, dst_h: int, dst_w: int,
