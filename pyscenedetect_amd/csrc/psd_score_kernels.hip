@@ -873,12 +873,16 @@ __device__ __forceinline__ void dma_issue(const ScoreParams& p, const uint8_t* f
         // 12 real moves per group).  Their luma side effects are predicated instead.
         const long limit = (long)tile_end * 48;
         uint8_t* slot = stage + (size_t)(k * NW + wave) * 3072;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const long off = gfirst * 48 + j * 1024 + lane * 16;
-            if (off + 16 <= limit)
-                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + off), (lds_ptr_t)(slot + j * 1024), 16, 0, AUX);
-        }
+        // One per-lane 32-bit offset (a frame is far below 4 GiB) on top of the uniform frame pointer, the three 1 KiB pieces
+        // told apart by the instruction's immediate offset, which moves the global and the LDS address alike: the frame
+        // pointer advances in SGPRs and no address arithmetic is left on the VALU (it was a 64-bit add per piece and frame).
+        const u32 voff = (u32)(gfirst * 48) + (u32)lane * 16u;
+        typedef const __attribute__((address_space(1))) uint8_t* gbl_u8_t;
+        gbl_u8_t fb = (gbl_u8_t)frame;
+        asm volatile("" : "+s"(fb));   // (pins the frame pointer to an SGPR pair: global_load_lds v_off, s[base] offset:imm)
+        if ((long)voff + 16 <= limit) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(fb + voff), (lds_ptr_t)slot, 16, 0, AUX);
+        if ((long)voff + 1024 + 16 <= limit) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(fb + voff), (lds_ptr_t)slot, 16, 1024, AUX);
+        if ((long)voff + 2048 + 16 <= limit) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(fb + voff), (lds_ptr_t)slot, 16, 2048, AUX);
     }
 }
 
@@ -978,7 +982,7 @@ void score_frames_dma_kernel(const ScoreParams p)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: slot addresses and M0 stay on the scalar unit)
     const int l16 = tid & (LCD - 1);
     const int lacc = tid & (ACD - 1);
     const int tile = blockIdx.x % p.n_tiles;
@@ -1008,7 +1012,7 @@ void score_frames_dma_kernel(const ScoreParams p)
     const u32* my_lut_s = S1 ? lut_s : lut_s + l16;
     const u32* my_lut_h = lut_h + l16;
 
-    Hsv16 prev[G];
+    Hsv16 prev[G], other[G];   // the previous frame's H, S, V planes of this lane's pixels / the frame being converted (they swap)
     bool have_prev = false;
     Group cur[G];
     if (HSV) {
@@ -1029,7 +1033,10 @@ void score_frames_dma_kernel(const ScoreParams p)
     if (t0 < t1) dma_issue<G, NW, DMA_AUX>(p, p.frames + (size_t)t0 * p.frame_stride, wave_group0, g1, wave, lane, stage);
 
     PT_INIT
-    for (int t = t0; t < t1; t++) {
+    // One step of the walk: frame t against the HSV planes in `prv`, its own left in `nxt`.  The loop below calls it twice per
+    // iteration with the two register sets swapped, so "prev = current" is a renaming instead of twelve v_mov_b32 per group
+    // and frame (0.75 of the 28 VALU instructions per pixel of the HSV pass).
+    auto step = [&](const int t, Hsv16 (&prv)[G], Hsv16 (&nxt)[G]) __attribute__((always_inline)) {
         const int slot = (t - t0) % SLOTS;
         u32* my_acc = &acc[slot][0] + lacc;
         // Frame t has been in flight since the previous step; take it out of the staging slot and
@@ -1056,11 +1063,10 @@ void score_frames_dma_kernel(const ScoreParams p)
 #pragma unroll
         for (int k = 0; k < G; k++) {
             if (HSV || live[k]) {
-                Hsv16 c;
+                Hsv16& c = nxt[k];
                 convert_group<HSV, LUMA, LCD, ACD, FPK, S1, VM>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs, live[k] ? 1u : 0u);
                 if (HSV) {
-                    if (chain) sad_group(c, prev[k], sh, ss, sv);
-                    prev[k] = c;
+                    if (chain) sad_group(c, prv[k], sh, ss, sv);
                 }
                 if constexpr (VM) {
                     // 16 V bytes of the group, in pixel order (a group is 16 consecutive pixels: byte offset 16 * group)
@@ -1100,6 +1106,23 @@ void score_frames_dma_kernel(const ScoreParams p)
             PT(4)
         }
 #endif
+    };
+    // (A/B on 4096 x 1080p: HSV pass 5.30 -> 5.18 ms, the V-mode pass of the edge term +0.8 %; the fused HSV + luma pass, whose
+    //  step is 1350 instructions, loses 3 % with two copies of it and keeps the single step and the moves)
+    constexpr bool SWAP = !(HSV && LUMA && !VM);
+    if constexpr (SWAP) {
+        int t = t0;
+        for (; t + 1 < t1; t += 2) {
+            step(t, prev, other);
+            step(t + 1, other, prev);
+        }
+        if (t < t1) step(t, prev, other);
+    } else {
+        for (int t = t0; t < t1; t++) {
+            step(t, prev, other);
+#pragma unroll
+            for (int k = 0; k < G; k++) prev[k] = other[k];
+        }
     }
     PT_DONE
 }

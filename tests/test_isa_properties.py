@@ -66,8 +66,9 @@ def test_staged_kernels_do_not_wait_for_the_prefetch_inside_a_step(tmp_path):
             continue
         before_read, before_add = staged_kernel_wait_signature(lines)
         # table reads never wait for global memory; the only LDS adds the compiler sees are the per-step (or final) sums,
-        # one group per kernel, behind which the wait is harmless (the step is over)
-        assert before_read == 0 and before_add <= 1, (name, before_read, before_add)
+        # one group per copy of the step (the time walk runs two steps per iteration with the register sets of the previous
+        # and the current frame swapped), behind which the wait is harmless (the step is over)
+        assert before_read == 0 and before_add <= 2, (name, before_read, before_add)
         checked += 1
     assert checked >= 6
 
