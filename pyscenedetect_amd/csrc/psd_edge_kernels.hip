@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void value_plane_hist_dma_kernel(ChunkSrc src,
     constexpr int AC = 16;
     __shared__ __attribute__((aligned(16))) u32 lh[256 * AC];
     __shared__ __attribute__((aligned(16))) uint8_t stage[VD_G * VD_NW * 3072];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 256 * AC; i += 256) lh[i] = 0;
     __syncthreads();
     const int j = blockIdx.y;

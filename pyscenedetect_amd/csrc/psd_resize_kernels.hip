@@ -148,11 +148,17 @@ struct RsParams {
     int depth;               // staging buffers: 2 = one frame ahead, 3 = two frames ahead
 };
 
+// 24-bit multiplies (v_mul_lo_u32 issues at a quarter of their rate; hipcc does not pick them for `>> 4`-ed or table operands)
+__device__ __forceinline__ int mul_i24(int a, int b) { int d; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ u32 mul_u24(u32 a, u32 b) { u32 d; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+
 __device__ __forceinline__ u32 interp(u32 p00, u32 p01, u32 p10, u32 p11, int a0, int a1, int b0, int b1)
 {
-    const int h0 = (int)p00 * a0 + (int)p01 * a1;
-    const int h1 = (int)p10 * a0 + (int)p11 * a1;
-    return (u32)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+    // every factor is far below 2^23 (pixels < 2^8, coefficients <= 2^11, h >> 4 < 2^15): 24-bit multiplies, which issue at
+    // four times the rate of v_mul_lo_u32
+    const int h0 = mul_i24((int)p00, a0) + mul_i24((int)p01, a1);
+    const int h1 = mul_i24((int)p10, a0) + mul_i24((int)p11, a1);
+    return (u32)(((mul_i24(b0, h0 >> 4) >> 16) + (mul_i24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xffu;
 }
 
 // OpenCV's 8-bit BGR -> HSV (RGB2HSV_b, hue range 180) for one pixel, tables pre-shifted by 4 (psd_score_kernels.hip)
@@ -161,10 +167,11 @@ __device__ __forceinline__ void hsv_px(u32 b, u32 g, u32 r, const u32* lut_s, co
     v = max(max(b, g), r);
     const u32 vmin = min(min(b, g), r);
     const u32 diff = v - vmin;
-    s = ((diff * lut_s[v] + (2048u << 4)) >> 16) & 0xffu;
+    // (sdiv << 4 <= 255 * 4096 * 16 < 2^24, hdiv << 4 < 2^21, |hraw| <= 1275: 24-bit multiplies, exact)
+    s = ((mul_u24(diff, lut_s[v]) + (2048u << 4)) >> 16) & 0xffu;
     const int d = (int)diff;
     const int hraw = v == r ? (int)g - (int)b : v == g ? (int)b - (int)r + 2 * d : (int)r - (int)g + 4 * d;
-    int hh = (hraw * (int)lut_h[diff] + (2048 << 4)) >> 16;
+    int hh = (mul_i24(hraw, (int)lut_h[diff]) + (2048 << 4)) >> 16;
     if (hh < 0) hh += 180;
     h = (u32)hh;
 }
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     __shared__ u32 lut_s[256], lut_h[256];
     __shared__ u32 sums[RS_SLOTS][4];
     __shared__ int srows[64];           // clamped source rows of this tile: slot 2 * lr + k
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x % p.n_tiles, chunk = blockIdx.x / p.n_tiles;
     const int r0 = tile * p.rows_per_tile;
     const int nrows = min(p.rows_per_tile, p.dh - r0);
@@ -213,9 +220,37 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     __syncthreads();
     const int pieces = (p.row_bytes + 1023) >> 10;                // 1 KiB wave-instructions per source row
     const size_t buf_bytes = (size_t)2 * p.rows_per_tile * p.row_pad;
+    // This wave's LDS-DMA instructions are the same every frame: piece q = wave + 4 i of the tile's 2 nrows source rows.
+    // Where they read and land is worked out ONCE, on the scalar unit (the wave index is uniform): per frame an instruction
+    // costs one 64-bit add for the lane's 16 bytes.  (The loop this replaces divided q by `pieces` and read srows[] for every
+    // instruction of every frame -- more VALU work than the interpolation and the HSV conversion of the tile's pixels.)
+    constexpr int NI = 8;                                          // instructions per wave kept in registers; more take the loop
+    const int total = pieces * 2 * nrows;
+    size_t goff[NI];
+    u32 loff[NI];
+    int rem[NI];                                                   // bytes of the row behind the piece's start (>= 1024: all lanes)
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int q = wave + i * RS_NW;
+        const bool in = q < total;
+        const int slot = in ? q / pieces : 0, piece = in ? q - slot * pieces : 0;
+        const int row = __builtin_amdgcn_readfirstlane(srows[slot]);
+        goff[i] = (size_t)row * p.srow + (size_t)piece * 1024;
+        loff[i] = (u32)slot * (u32)p.row_pad + (u32)piece * 1024u;
+        rem[i] = in ? p.row_bytes - piece * 1024 : 0;
+    }
     auto issue = [&](const uint8_t* frame, int buf) {
         uint8_t* base = rs_stage + (size_t)buf * buf_bytes;
-        for (int q = wave; q < pieces * 2 * nrows; q += RS_NW) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            if (rem[i] >= 1024) {
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + goff[i] + lane * 16), (lds_ptr_t)(base + loff[i]), 16, 0, PSD_DMA_AUX);
+            } else if (rem[i] > 0) {
+                if (lane * 16 + 16 <= rem[i])
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + goff[i] + lane * 16), (lds_ptr_t)(base + loff[i]), 16, 0, PSD_DMA_AUX);
+            }
+        }
+        for (int q = wave + NI * RS_NW; q < total; q += RS_NW) {
             const int slot = q / pieces, piece = q - slot * pieces;
             const int off = piece * 1024 + lane * 16;
             if (off + 16 <= p.row_bytes)

@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(kLumaWG) void luma_hist_kernel(const ScoreParams p)
     constexpr int WG = kLumaWG, NW = WG / 64, AC = 16, STEP = G * NW * 64;
     __shared__ __attribute__((aligned(16))) u32 acc[NACC * AC];
     __shared__ __attribute__((aligned(16))) uint8_t stage[G * NW * 3072];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x, t = blockIdx.y;
     for (int i = tid; i < NACC * AC; i += WG) acc[i] = 0;
     __syncthreads();
