@@ -1153,14 +1153,17 @@ __global__ __launch_bounds__(kLumaWG) void luma_hist_kernel(const ScoreParams p)
     auto issue = [&](int sbase) {
 #pragma unroll
         for (int k = 0; k < G; k++) {
-            const long gfirst = (long)sbase + (long)(k * NW + wave) * 64;
+            // (uniform base pointer pinned to SGPRs + the lane's 16 bytes + immediate piece offsets: see dma_issue)
+            const long first = ((long)sbase + (long)(k * NW + wave) * 64) * 48;
             uint8_t* slot = stage + (size_t)(k * NW + wave) * 3072;
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const long off = gfirst * 48 + j * 1024 + lane * 16;
-                if (off + 16 <= limit)
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(frame + off), (lds_ptr_t)(slot + j * 1024), 16, 0, PSD_DMA_AUX);
-            }
+            typedef const __attribute__((address_space(1))) uint8_t* gbl_u8_t;
+            gbl_u8_t fb = (gbl_u8_t)(frame + first);
+            asm volatile("" : "+s"(fb));
+            const u32 voff = (u32)lane * 16u;
+            const long room = limit - first - (long)voff;      // bytes of the tile from this lane's first byte on
+            if (room >= 16) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(fb + voff), (lds_ptr_t)slot, 16, 0, PSD_DMA_AUX);
+            if (room >= 1024 + 16) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(fb + voff), (lds_ptr_t)slot, 16, 1024, PSD_DMA_AUX);
+            if (room >= 2048 + 16) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(fb + voff), (lds_ptr_t)slot, 16, 2048, PSD_DMA_AUX);
         }
     };
     u32* my_acc = acc + (tid & (AC - 1));
