@@ -173,7 +173,7 @@ class Workload:
         if self.downscale:
             return "psd::resize_walk_kernel"
         return {"content": "psd::score_frames_dma_kernel", "all": "psd::score_frames_dma_kernel", "hist": "psd::luma_hist_kernel",
-                "hash": "psd::gray_area_dma_kernel", "edges": "psd::sobel_nms_tile_kernel (edge pipeline) + psd::score_frames_dma_kernel"}[self.detector]
+                "hash": "psd::gray_area_dma_kernel", "edges": "psd::score_frames_dma_kernel<V mode> + psd::sobel_nms_bits_kernel (edge pipeline)"}[self.detector]
 
     def submit(self):
         if self.downscale:

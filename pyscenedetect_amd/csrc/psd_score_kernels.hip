@@ -844,6 +844,10 @@ constexpr int ACD_MAX = 16;  // accumulator replicas
 #define PSD_FUSED_WG 1024   // threads per workgroup of the fused HSV + luma pass (PSD_FUSED_SMALL overrides with kHsvWG)
 #endif
 constexpr int kFusedWG = PSD_FUSED_WG;
+#ifndef PSD_HSV_WAVES
+#define PSD_HSV_WAVES 6      // waves per SIMD hipcc has to leave room for in the HSV pass (77 instead of 83 VGPRs, no spills: six workgroups
+                            // per CU again after the swapped register sets; A/B +0.3 ... +1.1 %)
+#endif
 #ifndef PSD_FUSED_SMALL
 #define PSD_FUSED_SMALL 0   // 1: the fused HSV+luma variant also runs on kHsvWG-thread workgroups (measured: 4.32-4.43 ms
                             // vs 4.36 ms on 2048 x 1080p with 4 table / 8 histogram replicas -- no gain, off)
@@ -960,7 +964,7 @@ __device__ unsigned long long g_phase[8];
 // stored to p.vout[t], no byte sum.  The frames are then read once for ContentDetector with weights.delta_edges > 0
 // instead of once by this pass and once by value_plane_hist_dma_kernel.
 template <bool HSV, bool LUMA, int G, int WG, bool VM = false>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((HSV && LUMA) ? 4 : 1)))
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((HSV && LUMA) ? 4 : (HSV && G == 1 && WG == kHsvWG && !VM) ? PSD_HSV_WAVES : 1)))
 void score_frames_dma_kernel(const ScoreParams p)
 {
     static_assert(!VM || HSV, "");
