@@ -168,7 +168,9 @@ int psd_allgather_scores(psd_comm* c, const psd_frame_scores* d_local, int n_loc
                          psd_frame_scores* h_all);
 
 /* Device time (ms, HIP events on the launch stream) spent in the scoring kernels of the most
- * recently *collected* submission, and the number of kernel launches it took. */
+ * recently *collected* submission, and the number of kernel launches it took.  If the edge term had to be repeated at
+ * collect (a weak-edge chain longer than the launches enqueued at submit; rare), the time of the second attempt is
+ * included (host clock around it). */
 int psd_last_kernel_ms(psd_engine* e, float* ms, int* launches);
 
 /* Raw device buffer helpers so hosts without their own allocator (plain C, ctypes) can keep
@@ -208,7 +210,9 @@ int psd_edge_map_device(psd_engine* e, const uint8_t* d_frame, int height, int w
 /* cv2.resize(src, (dst_w, dst_h), interpolation) for n device-resident BGR frames (packed rows): the downscale
  * SceneManager applies in front of the detectors (scene_manager.py:666-678).  `interpolation` takes cv2's values
  * as the reference's Interpolation enum does (common.py:148-160): NEAREST, LINEAR (the default) and AREA are
- * implemented, AREA for decimation only; CUBIC / LANCZOS4 return PSD_ERR_UNSUPPORTED. */
+ * implemented (AREA that does not shrink along both axes is, as in OpenCV, bilinear with area-mode coefficients).
+ * CUBIC / LANCZOS4 return PSD_ERR_UNSUPPORTED on purpose: OpenCV's 8-bit vertical pass for them runs in float32 SIMD whose
+ * lane count, scalar tail and use of fused multiply-add depend on the build, so no restatement can be bit-exact. */
 enum psd_interpolation { PSD_INTER_NEAREST = 0, PSD_INTER_LINEAR = 1, PSD_INTER_CUBIC = 2, PSD_INTER_AREA = 3, PSD_INTER_LANCZOS4 = 4 };
 int psd_resize_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w,
                       size_t src_frame_stride, uint8_t* d_dst, int dst_h, int dst_w,

@@ -380,14 +380,18 @@ static short sat_s16_round(float v)
     return (short)r;
 }
 
-void orc_resize_linear_u8(const uint8_t* src, size_t sstep, int sh, int sw, int cn, uint8_t* dst,
-                          size_t dstep, int dh, int dw)
+/* area_mode != 0: cv2.resize(INTER_AREA) when the image is NOT shrunk along both axes.  resize.cpp: "true area
+ * interpolation is only implemented for the case (scale_x >= 1 && scale_y >= 1); in other cases it is emulated using some
+ * variant of bilinear interpolation" -- the bilinear passes below with the coefficients of area_mode:
+ *     sx = cvFloor(dx * scale_x);  fx = (float)((dx + 1) - (sx + 1) * inv_scale_x);  fx = fx <= 0 ? 0.f : fx - cvFloor(fx) */
+static void resize_bilinear_u8(const uint8_t* src, size_t sstep, int sh, int sw, int cn, uint8_t* dst,
+                               size_t dstep, int dh, int dw, int area_mode)
 {
     double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
     double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
     int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
     int is_area_fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
-    if (is_area_fast && iscale_x == 2 && iscale_y == 2) {
+    if (!area_mode && is_area_fast && iscale_x == 2 && iscale_y == 2) {
         for (int y = 0; y < dh; y++)
             for (int x = 0; x < dw; x++)
                 for (int c = 0; c < cn; c++) {
@@ -402,9 +406,17 @@ void orc_resize_linear_u8(const uint8_t* src, size_t sstep, int sh, int sw, int 
     int* yofs = (int*)malloc(sizeof(int) * dh);
     short* ibeta = (short*)malloc(sizeof(short) * dh * 2);
     for (int dx = 0; dx < dw; dx++) {
-        float fx = (float)((dx + 0.5) * scale_x - 0.5);
-        int sx = (int)floorf(fx);
-        fx -= sx;
+        float fx;
+        int sx;
+        if (!area_mode) {
+            fx = (float)((dx + 0.5) * scale_x - 0.5);
+            sx = (int)floorf(fx);
+            fx -= sx;
+        } else {
+            sx = (int)floor(dx * scale_x);
+            fx = (float)((dx + 1) - (sx + 1) * inv_scale_x);
+            fx = fx <= 0 ? 0.f : fx - floorf(fx);
+        }
         if (sx < 0) { fx = 0; sx = 0; }
         if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
         xofs[dx] = sx;
@@ -412,9 +424,17 @@ void orc_resize_linear_u8(const uint8_t* src, size_t sstep, int sh, int sw, int 
         ialpha[dx * 2 + 1] = sat_s16_round(fx * 2048);
     }
     for (int dy = 0; dy < dh; dy++) {
-        float fy = (float)((dy + 0.5) * scale_y - 0.5);
-        int sy = (int)floorf(fy);
-        fy -= sy;
+        float fy;
+        int sy;
+        if (!area_mode) {
+            fy = (float)((dy + 0.5) * scale_y - 0.5);
+            sy = (int)floorf(fy);
+            fy -= sy;
+        } else {
+            sy = (int)floor(dy * scale_y);
+            fy = (float)((dy + 1) - (sy + 1) * inv_scale_y);
+            fy = fy <= 0 ? 0.f : fy - floorf(fy);
+        }
         yofs[dy] = sy;
         ibeta[dy * 2] = sat_s16_round((1.f - fy) * 2048);
         ibeta[dy * 2 + 1] = sat_s16_round(fy * 2048);
@@ -440,6 +460,19 @@ void orc_resize_linear_u8(const uint8_t* src, size_t sstep, int sh, int sw, int 
             D[x] = (uint8_t)((((b0 * (row0[x] >> 4)) >> 16) + ((b1 * (row1[x] >> 4)) >> 16) + 2) >> 2);
     }
     free(row0); free(row1); free(xofs); free(ialpha); free(yofs); free(ibeta);
+}
+
+void orc_resize_linear_u8(const uint8_t* src, size_t sstep, int sh, int sw, int cn, uint8_t* dst,
+                          size_t dstep, int dh, int dw)
+{
+    resize_bilinear_u8(src, sstep, sh, sw, cn, dst, dstep, dh, dw, 0);
+}
+
+/* cv2.resize(INTER_AREA) with dw > sw or dh > sh (see resize_bilinear_u8) */
+void orc_resize_area_upscale_u8(const uint8_t* src, size_t sstep, int sh, int sw, int cn, uint8_t* dst,
+                                size_t dstep, int dh, int dw)
+{
+    resize_bilinear_u8(src, sstep, sh, sw, cn, dst, dstep, dh, dw, 1);
 }
 
 /* ---------------------------------------------------------------------------

@@ -128,8 +128,11 @@ def resize(src, dsize, interpolation=INTER_LINEAR):
     dw, dh = int(dsize[0]), int(dsize[1])
     dst = np.empty((dh, dw) + (() if src.ndim == 2 else (cn,)), np.uint8)
     if interpolation == INTER_AREA:
-        if _orc.lib().orc_resize_area_u8_cn(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw) != 0:
-            raise NotImplementedError("cv2 shim: INTER_AREA only for decimation")
+        if dw > sw or dh > sh:
+            # not shrunk along both axes: OpenCV emulates INTER_AREA with bilinear passes and area-mode coefficients
+            _orc.lib().orc_resize_area_upscale_u8(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw)
+        elif _orc.lib().orc_resize_area_u8_cn(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw) != 0:
+            raise NotImplementedError("cv2 shim: INTER_AREA failed")
         return dst
     if interpolation == INTER_NEAREST:
         _orc.lib().orc_resize_nearest_u8(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw)

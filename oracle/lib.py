@@ -69,6 +69,8 @@ def lib() -> ctypes.CDLL:
         L.orc_canny.argtypes = [vp, sz, i, i, d, d, vp]
         L.orc_dilate_rect.argtypes = [vp, sz, i, i, i, i, vp]
         L.orc_resize_linear_u8.argtypes = [vp, sz, i, i, i, vp, sz, i, i]
+        L.orc_resize_area_upscale_u8.restype = None
+        L.orc_resize_area_upscale_u8.argtypes = [vp, sz, i, i, i, vp, sz, i, i]
         L.orc_bgr2gray.argtypes = [vp, sz, vp, sz, i, i]
         L.orc_resize_area_u8.argtypes = [vp, sz, i, i, vp, sz, i, i]
         L.orc_resize_area_u8_cn.argtypes = [vp, sz, i, i, i, vp, sz, i, i]

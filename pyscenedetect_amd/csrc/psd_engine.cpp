@@ -3,6 +3,7 @@
 // Owns: one HIP device, one stream, the fixed-point HSV tables in device memory, a small ring
 // of record slots (device buffer + pinned host mirror + timing events) so submissions can be
 // pipelined, and a pair of device staging buffers for callers that hand over host frames.
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -45,7 +46,8 @@ void edges_release(psd_engine* e);
 // psd_resize_kernels.hip
 int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_row_stride,
                         size_t src_frame_stride, const uint8_t* d_prev, uint8_t* d_dst, int dst_h, int dst_w,
-                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg);
+                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg,
+                        bool area_mode = false);
 void resize_release(psd_engine* e);
 int resize_other(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
                  int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream);
@@ -475,9 +477,11 @@ int psd_score_segments_device(psd_engine* e, const uint8_t* d_frames, int n, int
 static int resize_any(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst,
                       int dst_h, int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream)
 {
-    if (interpolation == PSD_INTER_LINEAR)
+    // INTER_AREA that does not shrink along both axes is, in OpenCV, the bilinear kernel with other coefficients (resize.cpp)
+    const bool area_up = interpolation == PSD_INTER_AREA && (dst_w > src_w || dst_h > src_h);
+    if (interpolation == PSD_INTER_LINEAR || area_up)
         return psd::resize_linear_score(e, d_src, n, src_h, src_w, (size_t)src_w * 3, src_frame_stride, nullptr, d_dst, dst_h, dst_w,
-                                        dst_frame_stride, nullptr, stream, nullptr, nullptr);
+                                        dst_frame_stride, nullptr, stream, nullptr, nullptr, area_up);
     return psd::resize_other(d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, interpolation, stream);
 }
 
@@ -567,20 +571,24 @@ static int collect_wait(psd_engine* e, const void* out, int n, const char* who, 
         psd_set_error("scoring failed on device: %s", hipGetErrorString(err));
         return PSD_ERR_HIP;
     }
+    float redo_ms = 0.f;
     if (n > 0 && s.edge.active && *s.h_edge_flag) {
         // some frame's weak-edge chains were longer than the fixed number of hysteresis launches: repeat the edge term with
         // the host-driven loop (it overwrites every edge_xor the first attempt wrote)
         s.edge.active = false;
+        const auto redo_t0 = std::chrono::steady_clock::now();
         int rc = psd::edges_score(e, s.edge.d_frames, s.edge.n, s.edge.height, s.edge.width, s.edge.row_stride, s.edge.frame_stride,
                                   s.edge.d_prev, s.edge.edge_kernel, s.d_recs, s.edge.stream, s.edge.d_seg, nullptr);
         if (rc != PSD_OK) return rc;
         rc = copy_records_to_host(s, s.edge.stream);
         if (rc != PSD_OK) return rc;
         HIP_TRY(hipStreamSynchronize(s.edge.stream));
+        // (psd_last_kernel_ms counts the repeated edge term too: host clock around the synchronous second attempt)
+        redo_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - redo_t0).count();
     }
     if (n > 0) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s.ev_start, s.ev_stop) == hipSuccess) e->last_ms = ms;
+        if (hipEventElapsedTime(&ms, s.ev_start, s.ev_stop) == hipSuccess) e->last_ms = ms + redo_ms;
         e->last_launches = s.launches;
     } else {
         e->last_ms = 0.f;

@@ -61,7 +61,7 @@ struct ResizeTabs {
     bool area2 = false;  // exact 2x2 decimation: OpenCV routes INTER_LINEAR to INTER_AREA (rounded box mean)
 };
 
-typedef std::map<std::tuple<int, int, int, int>, ResizeTabs> ResizeCache;
+typedef std::map<std::tuple<int, int, int, int, int>, ResizeTabs> ResizeCache;
 
 static short sat_s16_round(float v)
 {
@@ -70,25 +70,37 @@ static short sat_s16_round(float v)
 }
 
 // OpenCV's coefficient tables (resize.cpp, INTER_LINEAR, 11-bit fixed point), in the same float arithmetic.
-static int get_tabs(psd_engine* e, int sh, int sw, int dh, int dw, hipStream_t stream, ResizeTabs* out)
+// area_mode: cv2.resize(INTER_AREA) that does not shrink along both axes -- OpenCV emulates it with the bilinear passes and
+// other coefficients (resize.cpp: sx = cvFloor(dx * scale_x), fx = (dx + 1) - (sx + 1) * inv_scale_x, 0 if <= 0 else its
+// fractional part); the kernels are the INTER_LINEAR ones.
+static int get_tabs(psd_engine* e, int sh, int sw, int dh, int dw, hipStream_t stream, ResizeTabs* out, bool area_mode = false)
 {
     void** slot = engine_resize_cache(e);
     if (!*slot) *slot = new ResizeCache();
     ResizeCache& cache = *static_cast<ResizeCache*>(*slot);
-    const auto key = std::make_tuple(sh, sw, dh, dw);
+    const auto key = std::make_tuple(sh, sw, dh, dw, area_mode ? 1 : 0);
     auto it = cache.find(key);
     if (it != cache.end()) { *out = it->second; return PSD_OK; }
-    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
     const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
     ResizeTabs t;
-    t.area2 = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16 &&
+    t.area2 = !area_mode && fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16 &&
               iscale_x == 2 && iscale_y == 2;
     std::vector<XTap> xt(dw);
     std::vector<YTap> yt(dh);
     for (int dx = 0; dx < dw; dx++) {
-        float fx = (float)((dx + 0.5) * scale_x - 0.5);
-        int sx = (int)floorf(fx);
-        fx -= sx;
+        float fx;
+        int sx;
+        if (!area_mode) {
+            fx = (float)((dx + 0.5) * scale_x - 0.5);
+            sx = (int)floorf(fx);
+            fx -= sx;
+        } else {
+            sx = (int)floor(dx * scale_x);
+            fx = (float)((dx + 1) - (sx + 1) * inv_scale_x);
+            fx = fx <= 0 ? 0.f : fx - floorf(fx);
+        }
         if (sx < 0) { fx = 0; sx = 0; }
         if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
         const int sx1 = sx + 1 < sw ? sx + 1 : sw - 1;
@@ -97,9 +109,17 @@ static int get_tabs(psd_engine* e, int sh, int sw, int dh, int dw, hipStream_t s
         xt[dx].a = (int)((u32)(uint16_t)a0 | ((u32)(uint16_t)a1 << 16));
     }
     for (int dy = 0; dy < dh; dy++) {
-        float fy = (float)((dy + 0.5) * scale_y - 0.5);
-        int sy = (int)floorf(fy);
-        fy -= sy;
+        float fy;
+        int sy;
+        if (!area_mode) {
+            fy = (float)((dy + 0.5) * scale_y - 0.5);
+            sy = (int)floorf(fy);
+            fy -= sy;
+        } else {
+            sy = (int)floor(dy * scale_y);
+            fy = (float)((dy + 1) - (sy + 1) * inv_scale_y);
+            fy = fy <= 0 ? 0.f : fy - floorf(fy);
+        }
         const short b0 = sat_s16_round((1.f - fy) * 2048), b1 = sat_s16_round(fy * 2048);
         yt[dy].s0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
         yt[dy].s1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
@@ -403,11 +423,12 @@ static void launch_walk(const RsParams& p, int g, int grid, size_t lds, hipStrea
 //   d_prev  source-size frame preceding frame 0 (HSV carry), or null
 int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_row_stride,
                         size_t src_frame_stride, const uint8_t* d_prev, uint8_t* d_dst, int dst_h, int dst_w,
-                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg)
+                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg,
+                        bool area_mode)
 {
     if (n == 0 || (!d_dst && !d_out)) return PSD_OK;
     ResizeTabs tabs;
-    int rc = get_tabs(e, src_h, src_w, dst_h, dst_w, stream, &tabs);
+    int rc = get_tabs(e, src_h, src_w, dst_h, dst_w, stream, &tabs, area_mode);
     if (rc != PSD_OK) return rc;
     const int row_bytes = src_w * 3;
     const bool fast = (row_bytes % 16 == 0) && (src_row_stride % 16 == 0) && ((uintptr_t)d_src % 16 == 0) &&

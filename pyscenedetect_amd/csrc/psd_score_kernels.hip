@@ -1083,7 +1083,7 @@ void score_frames_dma_kernel(const ScoreParams p)
             }
         }
         constexpr int E0 = LUMA ? 256 : 0;  // index of sad_h among the slot's accumulators
-        if (HSV) {
+        if (HSV && chain) {   // (uniform; without a predecessor the sums are zero: nothing to add, no registers to clear)
             __hip_atomic_fetch_add(&my_acc[(E0 + 0) * ACD], sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&my_acc[(E0 + 1) * ACD], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_fetch_add(&my_acc[(E0 + 2) * ACD], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

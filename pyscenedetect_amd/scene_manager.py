@@ -32,7 +32,9 @@ DEFAULT_BATCH_FRAMES: int = 64
 
 class Interpolation(Enum):
     """Resize filters of the reference (``scenedetect/common.py:148-160``, values = OpenCV's ``INTER_*``).
-    LINEAR (the reference's default), NEAREST and AREA are implemented on the device."""
+    LINEAR (the reference's default), NEAREST and AREA are implemented on the device.  CUBIC and LANCZOS4 are refused:
+    OpenCV's 8-bit vertical pass for them is float32 SIMD whose lane count, scalar tail and fused multiply-add use depend
+    on the build, so a device result could not be bit-identical to "the" reference."""
 
     NEAREST = 0
     LINEAR = 1
@@ -430,10 +432,11 @@ class SceneManager:
 
 class _DeviceFeeder:
     """Three device batch buffers cycling between the decode thread (fills one, frame by frame, with ``psd_upload``) and
-    the scoring thread (``SceneManager.detect_scenes``).  Slot 0 of every buffer is the place of the frame preceding
-    the batch: the last frame of batch k is copied there for batch k + 1 on the engine's stream before buffer k is
-    handed back (the model is the bounded prefetch of the reference's ``_fan_out.py:39-154`` / ``Queue(4)`` of
-    ``scene_manager.py:565-572``, with HBM as the queue's storage)."""
+    the scoring thread (``SceneManager.detect_scenes``).  The frame preceding a batch lives in a small buffer of its own:
+    the last frame of batch k is copied there on the engine's stream before buffer k is handed back (the model is the
+    bounded prefetch of the reference's ``_fan_out.py:39-154`` / ``Queue(4)`` of ``scene_manager.py:565-572``, with HBM as
+    the queue's storage).  The feeder owns its slots: ``close()`` frees every buffer whoever holds the slot at that moment
+    (the queue, the decode thread after an abort, an exception in flight)."""
 
     N_SLOTS = 3
 
@@ -441,12 +444,12 @@ class _DeviceFeeder:
         self._engine = engine
         self._batch = batch_frames
         self._free: queue.Queue = queue.Queue()
-        self._slots: list[dict] = []
+        self._all = [{"id": i, "buf": None, "shape": None} for i in range(self.N_SLOTS)]
         self._halo = None          # (DeviceBuffer, shape): the last frame of the most recent batch
         self._have_halo = False
         self._stopped = False
-        for i in range(self.N_SLOTS):
-            self._free.put({"id": i, "buf": None, "shape": None})
+        for slot in self._all:
+            self._free.put(slot)
 
     def acquire(self, shape):
         """A free buffer shaped for frames of ``shape`` (decode thread; waits for the scoring thread if all are busy)."""
@@ -457,17 +460,18 @@ class _DeviceFeeder:
                 continue
             h, w, _ = shape
             stride = (h * w * 3 + 15) & ~15
-            need = stride * (self._batch + 1)
+            need = stride * self._batch
             if slot["buf"] is None or slot["buf"].nbytes < need:
                 if slot["buf"] is not None:
                     slot["buf"].free()
+                    slot["buf"] = None
                 slot["buf"] = self._engine.alloc(need)
-            slot.update(shape=tuple(shape), h=h, w=w, stride=stride, ptr=slot["buf"].ptr + stride, prev=None)
+            slot.update(shape=tuple(shape), h=h, w=w, stride=stride, ptr=slot["buf"].ptr, prev=None)
             return slot
         return None
 
     def put(self, slot, index: int, frame: np.ndarray) -> None:
-        slot["buf"].upload_unordered(np.ascontiguousarray(frame).reshape(-1), (index + 1) * slot["stride"])
+        slot["buf"].upload_unordered(np.ascontiguousarray(frame).reshape(-1), index * slot["stride"])
 
     def halo_ptr(self, slot):
         """Device address of the frame preceding this batch (None for the first batch or after a size change)."""
@@ -486,27 +490,23 @@ class _DeviceFeeder:
                 self._halo[0].free()
             self._halo = (self._engine.alloc(nbytes), slot["shape"])
         self._halo = (self._halo[0], slot["shape"])
-        self._engine.copy_d2d(self._halo[0].ptr, slot["buf"].ptr + keep_last * slot["stride"], nbytes)
+        self._engine.copy_d2d(self._halo[0].ptr, slot["buf"].ptr + (keep_last - 1) * slot["stride"], nbytes)
         # the batch's results were collected before we got here, so this copy is the only work left on the stream that
         # reads the buffer: wait for it, then the decode thread may overwrite the buffer
         self._engine.synchronize()
         self._have_halo = True
-        self._slots.append(slot)
         self._free.put(slot)
 
     def abort(self) -> None:
         self._stopped = True
 
     def close(self) -> None:
-        seen = set()
-        while True:
-            try:
-                slot = self._free.get_nowait()
-            except queue.Empty:
-                break
-            if slot["buf"] is not None and id(slot["buf"]) not in seen:
-                seen.add(id(slot["buf"]))
+        """Free every buffer (call once the decode thread has stopped)."""
+        self._stopped = True
+        for slot in self._all:
+            if slot["buf"] is not None:
                 slot["buf"].free()
+                slot["buf"] = None
         if self._halo is not None:
             self._halo[0].free()
             self._halo = None

@@ -530,7 +530,30 @@ def test_resize_unsupported_modes(hip_engine):
     with pytest.raises(NotImplementedError):
         hip_engine.resize_device(a.ptr, 1, 64, 64, b.ptr, 32, 32, interpolation=2)     # CUBIC
     with pytest.raises(NotImplementedError):
-        hip_engine.resize_device(a.ptr, 1, 64, 64, b.ptr, 128, 128, interpolation=3)   # AREA is decimation only
+        hip_engine.resize_device(a.ptr, 1, 64, 64, b.ptr, 32, 32, interpolation=4)     # LANCZOS4
+
+
+@pytest.mark.parametrize("shape", [((64, 64), (128, 128)), ((45, 80), (90, 160)), ((37, 53), (55, 80)), ((72, 128), (36, 256)),
+                                   ((72, 128), (100, 64)), ((90, 160), (91, 161)), ((16, 48), (48, 48))])
+def test_resize_area_upscaling_matches_oracle(hip_engine, shape):
+    """cv2.resize(INTER_AREA) that does not shrink along both axes (enlargements, and wider-but-lower / higher-but-narrower
+    targets): OpenCV's bilinear emulation with area-mode coefficients; 16-byte aligned source rows take the staged kernel,
+    the others the generic one."""
+    import cv2  # the oracle shim
+
+    (sh, sw), (dh, dw) = shape
+    rng = np.random.default_rng(sh * 7 + dw)
+    src = rng.integers(0, 256, (3, sh, sw, 3), dtype=np.uint8)
+    a = hip_engine.alloc(src.nbytes)
+    a.upload(src.reshape(-1))
+    b = hip_engine.alloc(3 * dh * dw * 3)
+    hip_engine.resize_device(a.ptr, 3, sh, sw, b.ptr, dh, dw, interpolation=cv2.INTER_AREA)
+    got = b.download().reshape(3, dh, dw, 3)
+    for i in range(3):
+        want = cv2.resize(src[i], (dw, dh), interpolation=cv2.INTER_AREA)
+        assert np.array_equal(got[i], want), f"AREA {sh}x{sw}->{dh}x{dw}: {np.count_nonzero(got[i] != want)} bytes differ"
+    a.free()
+    b.free()
 
 
 def test_downscale_interpolation_modes_golden_through_hip(golden, hip_engine):

@@ -51,10 +51,13 @@ def staged_kernel_wait_signature(lines):
     """(compiler-inserted vmcnt waits directly in front of an LDS table read, ... in front of a compiler-visible LDS add)"""
     ins = _instructions(lines)
     before_read = before_add = 0
-    for a, b in zip(ins, ins[1:]):
+    for i, (a, b) in enumerate(zip(ins, ins[1:])):
         if a.startswith("s_waitcnt") and "vmcnt" in a:
-            before_read += b.startswith("ds_read_b32")
-            before_add += b.startswith("ds_add_u32")
+            # (a read right in front of the step's barrier -- the accumulator the sums were just added to, when a step without
+            #  a predecessor skips the additions -- is the end of the step like the additions themselves: harmless)
+            at_step_end = any(x.startswith("s_barrier") for x in ins[i + 2:i + 6])
+            before_read += b.startswith("ds_read_b32") and not at_step_end
+            before_add += b.startswith("ds_add_u32") or (b.startswith("ds_read_b32") and at_step_end)
     return before_read, before_add
 
 
@@ -68,7 +71,8 @@ def test_staged_kernels_do_not_wait_for_the_prefetch_inside_a_step(tmp_path):
         # table reads never wait for global memory; the only LDS adds the compiler sees are the per-step (or final) sums,
         # one group per copy of the step (the time walk runs two steps per iteration with the register sets of the previous
         # and the current frame swapped), behind which the wait is harmless (the step is over)
-        assert before_read == 0 and before_add <= 2, (name, before_read, before_add)
+        # (per copy of the step: the additions, and the read behind them that a step without a predecessor jumps to)
+        assert before_read == 0 and before_add <= 4, (name, before_read, before_add)
         checked += 1
     assert checked >= 6
 

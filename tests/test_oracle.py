@@ -287,3 +287,26 @@ def test_fp32_formulation_of_the_hsv_pass_is_exact_on_all_triples():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "hsv_fp32_check.py")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all 2^24 triples: 0" in out.stdout
+
+
+def test_inter_area_upscaling_is_bilinear_with_area_coefficients():
+    """cv2.resize(INTER_AREA) that does not shrink along both axes: OpenCV's emulation (resize.cpp) -- for an exact 2x
+    enlargement every source pixel is simply repeated (fx = (dx + 1) - (sx + 1) * 2 <= 0 -> weight 0 on the right tap), a
+    constant image stays constant, and sizes that do shrink go through the true area path as before."""
+    import cv2
+
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (9, 14, 3), dtype=np.uint8)
+    up = cv2.resize(img, (28, 18), interpolation=cv2.INTER_AREA)
+    assert np.array_equal(up, np.repeat(np.repeat(img, 2, axis=0), 2, axis=1))
+    flat = np.full((7, 5, 3), 93, np.uint8)
+    assert (cv2.resize(flat, (13, 9), interpolation=cv2.INTER_AREA) == 93).all()
+    # 1.5x: destination pixel 1 of a row straddles source pixels 0 and 1 (sx = 0, fx = 2 - 1 * 1.5 = 0.5)
+    row = np.array([[[0, 0, 0], [200, 100, 50]]], np.uint8)
+    got = cv2.resize(row, (3, 1), interpolation=cv2.INTER_AREA)[0, :, 0].tolist()
+    assert got == [0, 100, 200]
+    # mixed: wider but lower -- both axes take the emulation
+    mixed = cv2.resize(img, (20, 6), interpolation=cv2.INTER_AREA)
+    assert mixed.shape == (6, 20, 3)
+    down = cv2.resize(img, (7, 3), interpolation=cv2.INTER_AREA)      # shrinks along both: the area path
+    assert down.shape == (3, 7, 3)
