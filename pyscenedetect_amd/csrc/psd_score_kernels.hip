@@ -21,6 +21,8 @@
 //  * Per-frame results leave the workgroup as one global atomic per non-empty bin / sum.
 //    Everything is integer, so the result is independent of scheduling order.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -848,6 +850,9 @@ constexpr int kFusedWG = PSD_FUSED_WG;
 #define PSD_HSV_WAVES 6      // waves per SIMD hipcc has to leave room for in the HSV pass (77 instead of 83 VGPRs, no spills: six workgroups
                             // per CU again after the swapped register sets; A/B +0.3 ... +1.1 %)
 #endif
+#ifndef PSD_FILL_LAST_ROUND
+#define PSD_FILL_LAST_ROUND 1   // launch_range: pick the number of time chunks so that the last round of workgroups is full
+#endif
 #ifndef PSD_FUSED_SMALL
 #define PSD_FUSED_SMALL 0   // 1: the fused HSV+luma variant also runs on kHsvWG-thread workgroups (measured: 4.32-4.43 ms
                             // vs 4.36 ms on 2048 x 1080p with 4 table / 8 histogram replicas -- no gain, off)
@@ -959,6 +964,21 @@ __device__ unsigned long long g_phase[8];
 #define PT_DONE
 #endif
 
+// PSD_WG_TIMELINE (experiments): every workgroup of the staged kernel leaves its start / end on the constant 100 MHz clock
+// and the hardware id of its first wave in g_timeline[3 * blockIdx.x ..] (buffer set with psd_debug_timeline(); tools/wg_timeline.py
+// turns it into a residency curve of the launch: ramp, steady state, tail).
+#ifndef PSD_WG_TIMELINE
+#define PSD_WG_TIMELINE 0
+#endif
+#if PSD_WG_TIMELINE
+__device__ unsigned long long* g_timeline;
+#define TL_BEGIN const unsigned long long tl_t0 = wall_clock64(); const unsigned tl_hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+#define TL_END { const unsigned long long tl_t1 = wall_clock64(); unsigned long long* tl = g_timeline; if (tl && threadIdx.x == 0) { tl[3 * (size_t)blockIdx.x] = tl_t0; tl[3 * (size_t)blockIdx.x + 1] = tl_t1; tl[3 * (size_t)blockIdx.x + 2] = tl_hw; } }
+#else
+#define TL_BEGIN
+#define TL_END
+#endif
+
 // VM ("V mode", only with HSV && LUMA): the front end of the edge term rides on the HSV pass -- the histogram slots count
 // V = max(B, G, R) instead of the luma and go to p.vhist[t], the V plane (which the HSV conversion has packed already) is
 // stored to p.vout[t], no byte sum.  The frames are then read once for ContentDetector with weights.delta_edges > 0
@@ -967,6 +987,7 @@ template <bool HSV, bool LUMA, int G, int WG, bool VM = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((HSV && LUMA) ? 4 : (HSV && G == 1 && WG == kHsvWG && !VM) ? PSD_HSV_WAVES : 1)))
 void score_frames_dma_kernel(const ScoreParams p)
 {
+    TL_BEGIN
     static_assert(!VM || HSV, "");
     constexpr int NW = WG / 64;
     constexpr int ACD = (HSV && LUMA) ? PSD_FUSED_AC : (LUMA ? PSD_LUMA_AC : ACD_MAX);
@@ -1129,6 +1150,7 @@ void score_frames_dma_kernel(const ScoreParams p)
         }
     }
     PT_DONE
+    TL_END
 }
 
 // ---- luma histogram + byte sum without the time walk -------------------------------------------
@@ -1321,6 +1343,23 @@ static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bo
         chunks = (p.n + walk - 1) / walk;
         if (chunks < chunks_lo) chunks = chunks_lo;
         if (chunks > chunks_hi) chunks = chunks_hi;
+#if PSD_FILL_LAST_ROUND
+        // Workgroups of one launch all take about the same time, so the launch runs in rounds of `slots` resident workgroups
+        // and a last round that is 10 % full costs as much as a full one (tools/wg_timeline.py: 21.1 rounds of 230 us at 4096 x
+        // 1080p = 0.2 ms of a 5 ms launch with the chip nearly empty).  Among the chunk counts within 20 % of the target
+        // take the one whose last round is fullest.
+        if (fast && chunks > 1 && slots > 0) {
+            double best = 2.0;
+            int best_c = chunks;
+            for (int c = std::max(1, chunks - chunks / 5); c <= chunks + chunks / 5 && c <= p.n; c++) {
+                const int fpc = (p.n + c - 1) / c, cc = (p.n + fpc - 1) / fpc;
+                const double rounds = (double)p.n_tiles * cc / slots;
+                const double waste = (std::ceil(rounds) - rounds) / std::ceil(rounds);
+                if (waste < best - 1e-9 || (waste < best + 1e-9 && std::abs(cc - chunks) < std::abs(best_c - chunks))) { best = waste; best_c = cc; }
+            }
+            chunks = best_c;
+        }
+#endif
     }
     if (chunks > p.n) chunks = p.n;
     if (chunks < 1) chunks = 1;
@@ -1370,6 +1409,13 @@ hipError_t launch_score_frames(ScoreParams p, bool hsv, bool luma, bool fast, in
 }
 
 }  // namespace psd
+
+#if PSD_WG_TIMELINE
+extern "C" int psd_debug_timeline(unsigned long long* d_buffer)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(psd::g_timeline), &d_buffer, sizeof d_buffer) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #if PSD_PHASE_TIMING
 // phases: 0 wait for the frame's DMA, 1 staging slot -> registers, 2 arithmetic + LDS drain, 3 workgroup barrier, 4 flush,
