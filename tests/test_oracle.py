@@ -270,8 +270,7 @@ def test_nearest_and_multichannel_area_resize():
         area = cv2.resize(img, (dw, dh), interpolation=cv2.INTER_AREA)
         for c in range(3):
             assert np.array_equal(area[..., c], cv2.resize(np.ascontiguousarray(img[..., c]), (dw, dh), interpolation=cv2.INTER_AREA))
-    with pytest.raises(NotImplementedError):
-        cv2.resize(img, (200, 200), interpolation=cv2.INTER_AREA)
+    assert cv2.resize(img, (200, 200), interpolation=cv2.INTER_AREA).shape == (200, 200, 3)   # enlargement: bilinear emulation
     with pytest.raises(NotImplementedError):
         cv2.resize(img, (50, 50), interpolation=cv2.INTER_CUBIC)
 
