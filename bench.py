@@ -296,7 +296,9 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
             lambda: quick_measure(Workload(eng, batch, "hash", None, epilogue, E), steps=3, warmup=1))
     for dist, label in (("S", "shot-like content (64-frame shots, hard cuts)"), ("K", "constant frames (one histogram bin per frame)")):
         def run_dist(dist=dist):
-            b = make_batch(frames_small, dist, 20250921, device, h, w)
+            # shot-like content at the headline's batch length (the fraction of the roofline moves with the length of a
+            # launch, not with the content: like for like), constant frames at the short one
+            b = make_batch(n if dist == "S" else frames_small, dist, 20250921, device, h, w)
             r = quick_measure(Workload(eng, b, "content", None, epilogue, E))
             if dist == "S":
                 r["edges_weights_1111"] = quick_measure(Workload(eng, b, "edges", None, epilogue, E), steps=3, warmup=1)
@@ -305,7 +307,7 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
                 r["histogram_threshold"] = quick_measure(Workload(eng, b, "hist", None, epilogue, E))
             del b
             return r
-        attempt(f"content_1080p_{dist}", f"ContentDetector, {frames_small} x {w}x{h}, {label}", run_dist)
+        attempt(f"content_1080p_{dist}", f"ContentDetector, {n if dist == 'S' else frames_small} x {w}x{h}, {label}", run_dist)
 
     def run_4k():
         b = make_batch(frames_small, "U", 20250921, device, 2160, 3840)
@@ -597,6 +599,11 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
                          "corpus = configs[4] (mixed 1080p/4K clips, four detectors, sharded by clip); bbc = configs[3]")
     ap.add_argument("--corpus-frames", type=int, default=2048, help="frames per 1080p clip of --workload corpus (4K clips: a quarter)")
     ap.add_argument("--bbc-frames", type=int, default=6000, help="frames of the shortest of the 11 clips of --workload bbc")
+    ap.add_argument("--exchange", default="default", choices=["default", "stream", "off"], help=argparse.SUPPRESS)   # diagnosis of the
+    # score-vector all-gather under a launcher: on torch's current stream (default), on a side stream, or skipped.  Measured at
+    # one rank (profiles/r03_y_*): the three small operations of the exchange (slice kernel, all-gather, device -> host copy of
+    # the gathered vectors; 22 us of GPU time, rocprofv3) stretch the concurrently running HSV kernel by 0.12 ms = 2.4 %,
+    # on either stream; without them the run under torch.distributed.run equals the plain one
     ap.add_argument("--height", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--width", type=int, default=0, help=argparse.SUPPRESS)
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -637,6 +644,13 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
 
     kernel_ms: list[float] = []
     state = {"pending_gather": None, "gathered": None}
+    import contextlib
+
+    # (--exchange stream: the exchange on a stream of its own instead of torch's current, legacy default, stream)
+    xstream = torch.cuda.Stream(device) if (on_gpu and use_dist and args.exchange == "stream") else None
+
+    def on_xstream():
+        return torch.cuda.stream(xstream) if xstream is not None else contextlib.nullcontext()
 
     def consume_gather():
         """Finish the score-vector all-gather issued one step earlier (keeps ranks loosely coupled)."""
@@ -644,8 +658,9 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
         if pend is None:
             return
         work, recv, mine = pend
-        work.wait()
-        allv = recv.cpu().numpy().astype(np.uint64).reshape(world, -1, 4)   # every clip's score vectors
+        with on_xstream():
+            work.wait()
+            allv = recv.cpu().numpy().astype(np.uint64).reshape(world, -1, 4)   # every clip's score vectors
         assert np.array_equal(allv[rank, :, 0], mine)
         state["gathered"] = allv
         state["pending_gather"] = None
@@ -672,15 +687,16 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
         ms = wl.finish()
         if collect_timing:
             kernel_ms.append(ms)
-        if use_dist:
+        if use_dist and args.exchange != "off":
             # score vectors only: 4 x u64 per frame, all-gathered from HBM
             import torch.distributed as dist
 
             consume_gather()
             recs = wl.state["recs"]
-            send = score_vectors_on_device(recs)
-            recv = torch.empty((world * send.shape[0], send.shape[1]), dtype=send.dtype, device=device)  # rank-major concat
-            work = dist.all_gather_into_tensor(recv, send, async_op=True)
+            with on_xstream():
+                send = score_vectors_on_device(recs)
+                recv = torch.empty((world * send.shape[0], send.shape[1]), dtype=send.dtype, device=device)  # rank-major concat
+                work = dist.all_gather_into_tensor(recv, send, async_op=True)
             state["pending_gather"] = (work, recv, recs["sad_h"].copy())
 
     def run(steps: int, timing: bool):

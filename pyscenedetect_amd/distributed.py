@@ -11,7 +11,7 @@ count.
 
 import numpy as np
 
-from pyscenedetect_amd._native import RECORD_DTYPE, SUMS_DTYPE
+from pyscenedetect_amd._native import RECORD_DTYPE, SCORE_LUMA_HIST, SUMS_DTYPE
 
 
 def shard_range(n_items: int, world_size: int, rank: int) -> tuple[int, int]:
@@ -116,7 +116,7 @@ def score_clips_distributed(engine, clips, flags: int, edge_kernel: int = 0, gro
     # this rank's clips, packed by resolution into shared device batches where the engine can (one launch per batch)
     mine = score_clips(engine, [clips[i] for i in plan[rank]], flags, edge_kernel)
     # (a rank without clips must still send the dtype the others send: what score_clips would have returned)
-    sums = hasattr(engine, "score_clips") and not (flags & 2)
+    sums = hasattr(engine, "score_clips") and not (flags & SCORE_LUMA_HIST)
     local = np.concatenate(mine) if mine else np.zeros(0, SUMS_DTYPE if sums else RECORD_DTYPE)
     parts = all_gather_records(local, group)
     out: list = [None] * len(clips)

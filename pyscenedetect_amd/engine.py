@@ -418,16 +418,36 @@ class ScoringEngine:
         for k0 in range(0, len(jobs), _native.MAX_INFLIGHT):
             window = jobs[k0:k0 + _native.MAX_INFLIGHT]
             meta = []
-            for run, h, w in window:
-                first = np.cumsum([0] + [clips[j].shape[0] for j in run[:-1]])
-                total = int(sum(clips[j].shape[0] for j in run))
-                self.submit_device_segments(clips[run[0]].data_ptr(), total, h, w, first, flags=flags, edge_kernel=edge_kernel)
-                meta.append((run, first, total))
-            for run, first, total in meta:
-                recs = self.collect(total, sums_only)
-                for j, f0 in zip(run, first):
-                    out[j] = recs[f0:f0 + clips[j].shape[0]]
-                    ready(j, out[j])
+            try:
+                for run, h, w in window:
+                    first = np.cumsum([0] + [clips[j].shape[0] for j in run[:-1]])
+                    total = int(sum(clips[j].shape[0] for j in run))
+                    self.submit_device_segments(clips[run[0]].data_ptr(), total, h, w, first, flags=flags, edge_kernel=edge_kernel)
+                    meta.append((run, first, total))
+            except BaseException:
+                for _, _, total in meta:      # a submission was refused: retire the ones before it
+                    try:
+                        self.collect(total, sums_only)
+                    except Exception:  # noqa: BLE001
+                        pass
+                raise
+            collected = 0
+            try:
+                for run, first, total in meta:
+                    recs = self.collect(total, sums_only)
+                    collected += 1
+                    for j, f0 in zip(run, first):
+                        out[j] = recs[f0:f0 + clips[j].shape[0]]
+                        ready(j, out[j])
+            except BaseException:
+                # (an error in a collect or in the caller's on_ready: retire what is still in flight, so that the engine is
+                #  usable afterwards -- synchronous calls refuse to run over pending submissions)
+                for _, _, total in meta[collected:]:
+                    try:
+                        self.collect(total, sums_only)
+                    except Exception:  # noqa: BLE001
+                        pass
+                raise
         for (h, w), idxs in groups.items():
             stride = h * w * 3
             per_batch = max(1, max_batch_bytes // stride)

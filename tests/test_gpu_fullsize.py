@@ -529,3 +529,28 @@ def test_score_clips_pipelines_more_jobs_than_slots(hip_engine):
     for gr, wv in zip(hip_engine.score_clips(host, flags=E.SCORE_HSV_SAD | E.SCORE_BYTE_SUM, sums_only=True), want):
         assert gr.dtype.itemsize == 40
         same(gr, wv, ("sad_h", "sad_s", "sad_v", "byte_sum"))
+
+
+def test_score_clips_leaves_the_engine_usable_after_an_error(hip_engine):
+    """An exception out of the caller's on_ready (or a refused submission) must not strand submissions in the engine's ring:
+    synchronous calls refuse to run over pending ones."""
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(6)
+    clips = [torch.randint(0, 256, (n, h, w, 3), dtype=torch.uint8, device="cuda", generator=g)
+             for n, h, w in ((5, 72, 128), (4, 90, 160), (6, 36, 64))]
+    torch.cuda.synchronize()
+
+    def boom(i, recs):
+        raise RuntimeError("caller's callback failed")
+
+    with pytest.raises(RuntimeError, match="callback failed"):
+        hip_engine.score_clips(clips, flags=E.SCORE_HSV_SAD, on_ready=boom)
+    # a bad clip among good ones: the submissions before it are retired
+    bad = clips[:2] + [torch.zeros((3, 0, 8, 3), dtype=torch.uint8, device="cuda")]
+    with pytest.raises(ValueError):
+        hip_engine.score_clips(bad, flags=E.SCORE_HSV_SAD)
+    got = hip_engine.score_clips(clips, flags=E.SCORE_HSV_SAD)
+    for gr, c in zip(got, clips):
+        same(gr, orc.score_batch(c.cpu().numpy()), ("sad_h", "sad_s", "sad_v"))
