@@ -310,6 +310,7 @@ struct FpLane {          // per-lane constants of the fp32 formulation
     const u32* obj_s;    // ... and the pointers they came from (provenance for lds_f32_in)
     const u32* obj_h;
     float bias_h;        // LS == 4 only: 2^21 + off_h / 16 (see pixel_fp_front)
+    float bias_rel;      // REL only: 2^(23 - log2 LC) + replica / LC (see pixel_fp_front)
 };
 
 // (compiler builtins rather than inline asm wherever one exists: hipcc pads every use of an asm-defined register with
@@ -369,7 +370,7 @@ __device__ __forceinline__ float channel_fp(const u32 (&d)[3], int c, u32 bias)
 }
 
 // phase 1: unpack, V, diff, table addresses, table reads issued
-template <int LS, int K, bool S1>
+template <int LS, int K, bool S1, bool REL = false>
 __device__ __forceinline__ void pixel_fp_front(const u32 (&d)[3], const FpLane& fl, PxFp& x)
 {
     x.B = channel_fp<K>(d, 0, fl.bias);
@@ -380,6 +381,18 @@ __device__ __forceinline__ void pixel_fp_front(const u32 (&d)[3], const FpLane& 
     // S1: ONE copy of the sdiv table at a 1 KiB-aligned LDS address whose number (address >> 10) sits in byte 1 of the
     // bias, i.e. in bits 8..15 of every channel float: a 16-bit shift of V's bits by 2 IS the table address, no addition.
     // (The copies only spread bank conflicts; the LDS pipe has headroom, the VALU and the power budget do not.)
+    if constexpr (REL) {
+        // The fused passes (any LDS layout, 2^LS / 4 replicas of the hdiv table): both addresses RELATIVE to their table, whose
+        // base -- a link-time constant -- rides in the offset field of the ds_read.  sdiv: ONE copy, 4 v = a 16-bit shift of
+        // V's bits.  hdiv: floats in [2^(23-k), 2^(24-k)) step by 2^-k, so the low bits of diff + (2^(23-k) + replica / 2^k)
+        // are 2^k diff + replica and a 16-bit shift by 2 makes them the byte offset of this lane's replica of entry diff.
+        // One instruction for the first, two for the second, where the absolute forms took two and three.
+        const u32 r_s = lshl16<2>(__float_as_uint(x.V));
+        const u32 r_h = lshl16<2>(__float_as_uint(x.diff + fl.bias_rel));
+        x.sdiv = *(lds_cf32_t)((lds_cc_t)fl.obj_s + r_s);
+        x.hdiv = *(lds_cf32_t)((lds_cc_t)fl.obj_h + r_h);
+        return;
+    }
     const u32 a_s = S1 ? lshl16<2>(__float_as_uint(x.V)) : lshl16_add<LS>(__float_as_uint(x.V), fl.off_s);
     u32 a_h;
     if constexpr (LS == 4) {
@@ -505,7 +518,7 @@ __device__ __forceinline__ void quad_fused(const u32 (&d)[3], u32& hq_out, u32& 
 
 // 8-bit BGR -> HSV exactly as OpenCV's RGB2HSV_b (hsv_shift = 12, hue range 180), plus luma
 // histogram and byte sum.  lut_s/lut_h/hist are already offset by the lane's replica index.
-template <bool HSV, bool LUMA, int LC = COPIES, int AC = COPIES, bool FP = false, bool S1 = false, bool VM = false>
+template <bool HSV, bool LUMA, int LC = COPIES, int AC = COPIES, bool FP = false, bool S1 = false, bool VM = false, bool REL = false>
 __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __restrict__ lut_s,
                                               const u32* __restrict__ lut_h, u32* __restrict__ hist,
                                               u32& byte_sum, u32 inc = 1u)
@@ -532,6 +545,9 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
         fl.obj_s = lut_s;
         fl.obj_h = lut_h;
         fl.bias_h = 2097152.0f + (float)fl.off_h * 0.0625f;   // exact: off_h is a multiple of 4 below 2^16
+        // REL: lut_s / lut_h are the TABLES (no replica offset); this lane reads replica threadIdx.x % LC of the hdiv table
+        static_assert(!REL || !S1, "");
+        fl.bias_rel = (float)(8388608 / LC) + (float)(threadIdx.x & (LC - 1)) * (1.0f / LC);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             if (q > 0)
@@ -542,20 +558,30 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
             continue;
 #endif
             PxFp x0, x1, x2, x3;
-            pixel_fp_front<LS, 0, S1>(d, fl, x0);
-            pixel_fp_front<LS, 1, S1>(d, fl, x1);
-            pixel_fp_front<LS, 2, S1>(d, fl, x2);
-            pixel_fp_front<LS, 3, S1>(d, fl, x3);
+            pixel_fp_front<LS, 0, S1, REL>(d, fl, x0);
+            pixel_fp_front<LS, 1, S1, REL>(d, fl, x1);
+            pixel_fp_front<LS, 2, S1, REL>(d, fl, x2);
+            pixel_fp_front<LS, 3, S1, REL>(d, fl, x3);
             if constexpr (LUMA) __builtin_amdgcn_sched_barrier(0);   // the eight table reads stay in front (see quad_fused)
             const float r0 = pixel_fp_hraw(x0), r1 = pixel_fp_hraw(x1), r2 = pixel_fp_hraw(x2), r3 = pixel_fp_hraw(x3);
             u32 ya[4];
             if constexpr (LUMA) {
                 // V mode (the edge term's front end, psd_edge_kernels.hip): the histogram counts V = max(B, G, R), whose bits'
                 // low byte is v, instead of the luma
+                if constexpr (REL) {
+                    // the bits are 0x4B000000 + y exactly (a float in [2^23, 2^23 + 256)), so (bits << LA) + (base - (0x4B000000 <<
+                    // LA)) is the address modulo 2^32: ONE v_lshl_add_u32 where the 16-bit shift + addition took two
+                    const u32 off_b = off_a - (0x4B000000u << LA);
+                    ya[0] = ((VM ? __float_as_uint(x0.V) : pixel_fp_luma_bits(x0)) << LA) + off_b;
+                    ya[1] = ((VM ? __float_as_uint(x1.V) : pixel_fp_luma_bits(x1)) << LA) + off_b;
+                    ya[2] = ((VM ? __float_as_uint(x2.V) : pixel_fp_luma_bits(x2)) << LA) + off_b;
+                    ya[3] = ((VM ? __float_as_uint(x3.V) : pixel_fp_luma_bits(x3)) << LA) + off_b;
+                } else {
                 ya[0] = lshl16_add<LA>(VM ? __float_as_uint(x0.V) : pixel_fp_luma_bits(x0), off_a);
                 ya[1] = lshl16_add<LA>(VM ? __float_as_uint(x1.V) : pixel_fp_luma_bits(x1), off_a);
                 ya[2] = lshl16_add<LA>(VM ? __float_as_uint(x2.V) : pixel_fp_luma_bits(x2), off_a);
                 ya[3] = lshl16_add<LA>(VM ? __float_as_uint(x3.V) : pixel_fp_luma_bits(x3), off_a);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             u32 hq = 0;
@@ -853,6 +879,9 @@ constexpr int kFusedWG = PSD_FUSED_WG;
 #ifndef PSD_FILL_LAST_ROUND
 #define PSD_FILL_LAST_ROUND 1   // launch_range: pick the number of time chunks so that the last round of workgroups is full
 #endif
+#ifndef PSD_FUSED_REL
+#define PSD_FUSED_REL 1    // fused passes: one sdiv table + table-relative addresses with the base in the ds_read offset field
+#endif
 #ifndef PSD_FUSED_SMALL
 #define PSD_FUSED_SMALL 0   // 1: the fused HSV+luma variant also runs on kHsvWG-thread workgroups (measured: 4.32-4.43 ms
                             // vs 4.36 ms on 2048 x 1080p with 4 table / 8 histogram replicas -- no gain, off)
@@ -1000,8 +1029,11 @@ void score_frames_dma_kernel(const ScoreParams p)
     constexpr int DMA_AUX = (HSV && LUMA) ? 0 : PSD_DMA_AUX;
     constexpr bool FPK = HSV && (LUMA ? PSD_FUSED_FP32 : PSD_HSV_FP32);   // the fp32 formulation and its float tables
     constexpr bool S1 = FPK && !LUMA && PSD_HSV_SINGLE_S && LCD == 4;   // one copy of the sdiv table, addressed without an addition
-    __shared__ __attribute__((aligned(1024))) u32 lut_s[HSV ? (S1 ? 256 : 256 * LCD) : 4];
-    __shared__ __attribute__((aligned(16))) u32 lut_h[HSV ? 256 * LCD : 4];
+    constexpr bool REL = FPK && LUMA && PSD_FUSED_REL;                   // fused passes: table-relative addresses (pixel_fp_front)
+    __shared__ __attribute__((aligned(1024))) u32 lut_s[HSV ? ((S1 || REL) ? 256 : 256 * LCD) : 4];
+    // (512-byte alignment: hipcc lays LDS objects out by descending alignment, so the two tables come first and their bases
+    //  fit the 16-bit offset field of ds_read_b32 -- REL; behind the 96 KiB of staging slots they would not)
+    __shared__ __attribute__((aligned(512))) u32 lut_h[HSV ? 256 * LCD : 4];
     __shared__ __attribute__((aligned(16))) u32 acc[SLOTS][NA * ACD];
     __shared__ __attribute__((aligned(16))) uint8_t stage[G * NW * 3072];
 
@@ -1016,7 +1048,7 @@ void score_frames_dma_kernel(const ScoreParams p)
     if (HSV) {
         const uint32_t* tab = FPK ? p.lutf : p.lut;
         for (int i = tid; i < 256 * LCD; i += WG) {
-            if (!S1) lut_s[i] = tab[i / LCD];
+            if (!S1 && !REL) lut_s[i] = tab[i / LCD];
             else if (i < 256) lut_s[i] = tab[i];
             lut_h[i] = tab[256 + i / LCD];
         }
@@ -1034,8 +1066,8 @@ void score_frames_dma_kernel(const ScoreParams p)
 #pragma unroll
     for (int k = 0; k < G; k++) live[k] = (wave_group0 + k * NW * 64 + lane) < g1;
 
-    const u32* my_lut_s = S1 ? lut_s : lut_s + l16;
-    const u32* my_lut_h = lut_h + l16;
+    const u32* my_lut_s = (S1 || REL) ? lut_s : lut_s + l16;
+    const u32* my_lut_h = REL ? lut_h : lut_h + l16;
 
     Hsv16 prev[G], other[G];   // the previous frame's H, S, V planes of this lane's pixels / the frame being converted (they swap)
     bool have_prev = false;
@@ -1051,7 +1083,7 @@ void score_frames_dma_kernel(const ScoreParams p)
 #pragma unroll
             for (int k = 0; k < G; k++) {
                 u32 dummy = 0;
-                convert_group<true, false, LCD, ACD, FPK, S1>(cur[k], prev[k], my_lut_s, my_lut_h, nullptr, dummy);
+                convert_group<true, false, LCD, ACD, FPK, S1, false, REL>(cur[k], prev[k], my_lut_s, my_lut_h, nullptr, dummy);
             }
         }
     }
@@ -1089,7 +1121,7 @@ void score_frames_dma_kernel(const ScoreParams p)
         for (int k = 0; k < G; k++) {
             if (HSV || live[k]) {
                 Hsv16& c = nxt[k];
-                convert_group<HSV, LUMA, LCD, ACD, FPK, S1, VM>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs, live[k] ? 1u : 0u);
+                convert_group<HSV, LUMA, LCD, ACD, FPK, S1, VM, REL>(cur[k], c, my_lut_s, my_lut_h, my_acc, bs, live[k] ? 1u : 0u);
                 if (HSV) {
                     if (chain) sad_group(c, prv[k], sh, ss, sv);
                 }
