@@ -1164,22 +1164,15 @@ void score_frames_dma_kernel(const ScoreParams p)
         }
 #endif
     };
-    // (A/B on 4096 x 1080p: HSV pass 5.30 -> 5.18 ms, the V-mode pass of the edge term +0.8 %; the fused HSV + luma pass, whose
-    //  step is 1350 instructions, loses 3 % with two copies of it and keeps the single step and the moves)
-    constexpr bool SWAP = !(HSV && LUMA && !VM);
-    if constexpr (SWAP) {
+    // (A/B on 4096 x 1080p: HSV pass 5.30 -> 5.18 ms, the V-mode pass of the edge term +0.8 %; the fused HSV + luma pass lost 3 %
+    //  with two copies of its 1350-instruction step, and gains 1 % since the step has shrunk to 1250: profiles/r03_ad_*)
+    {
         int t = t0;
         for (; t + 1 < t1; t += 2) {
             step(t, prev, other);
             step(t + 1, other, prev);
         }
         if (t < t1) step(t, prev, other);
-    } else {
-        for (int t = t0; t < t1; t++) {
-            step(t, prev, other);
-#pragma unroll
-            for (int k = 0; k < G; k++) prev[k] = other[k];
-        }
     }
     PT_DONE
     TL_END
