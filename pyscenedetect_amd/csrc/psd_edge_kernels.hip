@@ -918,11 +918,12 @@ static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeB
     const bool need_map = !bits_direct(g);
     const size_t per_frame = align_up((size_t)g.npix) * (need_map ? 2 : 1) + align_up(256 * 4) + align_up(sizeof(int2)) +
                              align_up(words * 4) * 2 + align_up(8) + 2 * align_up(tiles);
-    // bound the workspace (default 4 GiB of the 288 GB; PSD_EDGE_WS_MB overrides) unless a single frame needs more
+    // bound the workspace (default 8 GiB of the 288 GB: 2048 x 1080p frames in one chunk, +1.4 % over 4 GiB on such batches;
+    // PSD_EDGE_WS_MB overrides) unless a single frame needs more
     static const size_t ws_cap = [] {
         const char* e = getenv("PSD_EDGE_WS_MB");
-        const long mb = e ? atol(e) : 4096;
-        return (size_t)(mb > 0 ? mb : 4096) << 20;
+        const long mb = e ? atol(e) : 8192;
+        return (size_t)(mb > 0 ? mb : 8192) << 20;
     }();
     int frames = (int)std::max<size_t>(1, std::min<size_t>((size_t)want_frames, ws_cap / per_frame));
     const size_t fixed = 2 * align_up(words * 4) + align_up(64 * sizeof(int)) + align_up(511 * sizeof(int2)) + 16 * 256;
