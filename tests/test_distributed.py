@@ -82,10 +82,11 @@ def _worker(rank, world, port, tmp):
     # engine that packs clips and returns sums (what ScoringEngine.score_clips does when no detector reads the histogram)
     from pyscenedetect_amd._native import SUMS_DTYPE
 
-    mine = np.zeros(0 if rank == 0 else 7, SUMS_DTYPE)
+    mine = np.zeros(0 if rank == 0 else 6 + rank, SUMS_DTYPE)
     mine["sad_v"] = np.arange(len(mine)) + 100 * rank
     parts = D.all_gather_records(mine)
-    assert [len(x) for x in parts] == [0, 7] and parts[1].dtype == SUMS_DTYPE and parts[1]["sad_v"].tolist() == list(range(100, 107))
+    assert [len(x) for x in parts] == [0] + [6 + r for r in range(1, world)] and parts[1].dtype == SUMS_DTYPE
+    assert all(parts[r]["sad_v"].tolist() == list(range(100 * r, 100 * r + 6 + r)) for r in range(1, world))
     res = detect_corpus(PackingOracle(), corpus, 25.0, NO_HIST)
     with open(os.path.join(tmp, f"nohist{rank}.json"), "w") as f:
         json.dump(res, f)
@@ -148,3 +149,29 @@ def test_two_ranks_equal_one(tmp_path):
         sm.add_detector(psd.ContentDetector(min_scene_len=8, engine=eng))
         sm.detect_scenes(psd.ArrayVideoStream(clip, 25.0))
         assert [c.frame_num for c in sm.get_cut_list()] == res["content"]
+
+
+@pytest.mark.timeout(300)
+def test_four_ranks_equal_one(tmp_path):
+    """The same flows over four ranks (more ranks than some shards have clips: the one-clip corpus leaves three ranks
+    without work, the frame-range shards of the 75-frame clip are 19 / 19 / 19 / 18 frames)."""
+    import json
+
+    from oracle.detectors_np import OracleEngine
+    from pyscenedetect_amd.corpus import detect_corpus
+    from pyscenedetect_amd.synth import make_clip
+
+    world = 4
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    eng = OracleEngine()
+    frames, _ = make_clip(31, 75, 36, 64, shot_len=(8, 16))
+    want = eng.score_host(frames, flags=7)
+    corpus = [make_clip(60 + i, n, h, w, shot_len=(16, 24))[0] for i, (n, h, w) in enumerate(CORPUS)]
+    single = detect_corpus(eng, corpus, 25.0, ALL_FOUR)
+    nohist = [{k: v for k, v in clip.items() if k != "hist"} for clip in single]
+    for r in range(world):
+        assert np.load(tmp_path / f"recs{r}.npy").tobytes() == want.tobytes()
+        assert json.load(open(tmp_path / f"corpus{r}.json")) == single
+        assert json.load(open(tmp_path / f"nohist{r}.json")) == nohist
+        assert json.load(open(tmp_path / f"nohist_one{r}.json")) == nohist[:1]
