@@ -177,7 +177,7 @@ class Workload:
 
     def submit(self):
         if self.downscale:
-            self.eng.submit_device_downscaled(self.ptr, self.n, self.h, self.w, self.sh, self.sw, flags=self.flags)
+            self.eng.submit_device_downscaled(self.ptr, self.n, self.h, self.w, self.sh, self.sw, flags=self.flags, stream=self.stream)
         elif self.stream is not None:
             self.eng.submit_device(self.ptr, self.n, self.h, self.w, flags=self.flags, stream=self.stream)
         else:
@@ -599,7 +599,7 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
                          "corpus = configs[4] (mixed 1080p/4K clips, four detectors, sharded by clip); bbc = configs[3]")
     ap.add_argument("--corpus-frames", type=int, default=2048, help="frames per 1080p clip of --workload corpus (4K clips: a quarter)")
     ap.add_argument("--bbc-frames", type=int, default=6000, help="frames of the shortest of the 11 clips of --workload bbc")
-    ap.add_argument("--exchange", default="default", choices=["default", "stream", "off"], help=argparse.SUPPRESS)   # diagnosis of the
+    ap.add_argument("--exchange", default="default", choices=["default", "stream", "inline", "off"], help=argparse.SUPPRESS)   # diagnosis of the
     # score-vector all-gather under a launcher: on torch's current stream (default), on a side stream, or skipped.  Measured at
     # one rank (profiles/r03_y_*): the three small operations of the exchange (slice kernel, all-gather, device -> host copy of
     # the gathered vectors; 22 us of GPU time, rocprofv3) stretch the concurrently running HSV kernel by 0.12 ms = 2.4 %,
@@ -640,30 +640,55 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
         return
     n = args.frames
     batch = make_batch(n, args.dist, 20250921 + rank, device, H, W)
-    wl = Workload(eng, batch, args.detector, args.downscale, epilogue, E)
-
-    kernel_ms: list[float] = []
-    state = {"pending_gather": None, "gathered": None}
     import contextlib
 
-    # (--exchange stream: the exchange on a stream of its own instead of torch's current, legacy default, stream)
-    xstream = torch.cuda.Stream(device) if (on_gpu and use_dist and args.exchange == "stream") else None
+    # --exchange stream: the exchange on a stream of its own instead of torch's current (legacy default) stream.
+    # --exchange inline: scoring AND the exchange's small operations on ONE torch stream (the engine takes any stream), so
+    # that the slice kernel and the device -> host copy of the gathered vectors run between two scoring kernels instead of
+    # beside one (beside one, each of them stretches it by ~40 us: profiles/r03_y_*); only the collective itself still
+    # overlaps the scoring.  The gathered vectors then reach the host through a pinned buffer, checked one step later.
+    # Measured at one rank (profiles/r03_ah_*): kernel 5.00 ms without the exchange, 5.14 ms with it (default), 5.10 ms inline --
+    # not enough to change the default path.
+    inline = on_gpu and use_dist and args.exchange == "inline"
+    xstream = torch.cuda.Stream(device) if (on_gpu and use_dist and args.exchange in ("stream", "inline")) else None
+    wl = Workload(eng, batch, args.detector, args.downscale, epilogue, E, stream=xstream.cuda_stream if inline else None)
+
+    kernel_ms: list[float] = []
+    state = {"pending_gather": None, "gathered": None, "copies": [], "pinned": []}
 
     def on_xstream():
         return torch.cuda.stream(xstream) if xstream is not None else contextlib.nullcontext()
 
-    def consume_gather():
+    def resolve_copies(keep: int):
+        """Host side of the inline exchange: gathered vectors whose copy has been issued at least `keep` steps ago."""
+        while len(state["copies"]) > keep:
+            ev, host, mine = state["copies"].pop(0)
+            ev.synchronize()
+            allv = host.numpy().astype(np.uint64).reshape(world, -1, 4)
+            assert np.array_equal(allv[rank, :, 0], mine)
+            state["gathered"] = allv
+            state["pinned"].append(host)
+
+    def consume_gather(final: bool = False):
         """Finish the score-vector all-gather issued one step earlier (keeps ranks loosely coupled)."""
         pend = state["pending_gather"]
-        if pend is None:
-            return
-        work, recv, mine = pend
-        with on_xstream():
-            work.wait()
-            allv = recv.cpu().numpy().astype(np.uint64).reshape(world, -1, 4)   # every clip's score vectors
-        assert np.array_equal(allv[rank, :, 0], mine)
-        state["gathered"] = allv
-        state["pending_gather"] = None
+        if pend is not None:
+            work, recv, mine = pend
+            with on_xstream():
+                work.wait()
+                if inline:
+                    host = state["pinned"].pop() if state["pinned"] else torch.empty(recv.shape, dtype=recv.dtype, pin_memory=True)
+                    host.copy_(recv, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(xstream)
+                    state["copies"].append((ev, host, mine))
+                else:
+                    allv = recv.cpu().numpy().astype(np.uint64).reshape(world, -1, 4)   # every clip's score vectors
+                    assert np.array_equal(allv[rank, :, 0], mine)
+                    state["gathered"] = allv
+            state["pending_gather"] = None
+        if inline:
+            resolve_copies(0 if final else 1)
 
     def score_vectors_on_device(recs):
         """int64[n, 4] (sad_h, sad_s, sad_v, edge_xor) on the device: a strided view of the records where the kernels
@@ -712,7 +737,7 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
             finish(timing)
         finish(timing)
         if use_dist:
-            consume_gather()   # the last step's exchange completes inside the timed region
+            consume_gather(final=True)   # the last step's exchange completes inside the timed region
 
     def barrier():
         if use_dist:
