@@ -289,9 +289,10 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
 
     n = batch.shape[0]
     attempt("all_four_detectors_fused_1080p", f"Content + Adaptive + Histogram + Threshold from one pass, {n} x {w}x{h}, uniform bytes",
-            lambda: quick_measure(Workload(eng, batch, "all", None, epilogue, E)))
+            lambda: quick_measure(Workload(eng, batch, "all", None, epilogue, E), steps=10, warmup=3))
     attempt("default_pipeline_downscale_auto", f"ContentDetector behind SceneManager's default downscale ({w}x{h} -> 256 wide), {n} frames; "
-            "roofline counts the source rows that carry taps", lambda: quick_measure(Workload(eng, batch, "content", "auto", epilogue, E)))
+            "roofline counts the source rows that carry taps",
+            lambda: quick_measure(Workload(eng, batch, "content", "auto", epilogue, E), steps=20, warmup=5))   # (1.2 ms per step)
     attempt("hash_detector_1080p", f"HashDetector (thumbnail kernel + DCT epilogue), {n} x {w}x{h}",
             lambda: quick_measure(Workload(eng, batch, "hash", None, epilogue, E), steps=3, warmup=1))
     for dist, label in (("S", "shot-like content (64-frame shots, hard cuts)"), ("K", "constant frames (one histogram bin per frame)")):
