@@ -70,6 +70,27 @@ def make_batch(n: int, dist: str, seed: int, device, h: int, w: int) -> torch.Te
             for i in range(s0, min(n, s0 + shot)):
                 noise = torch.randn((h, w, 3), device=device, generator=g) * 2.0
                 x[i] = (base + noise).round().clamp(0, 255).to(torch.uint8)
+    elif dist == "T":  # shots with OBJECTS: the smooth shots of S plus flat rectangles and a bright diagonal band that drift from
+        # frame to frame -- sharp edges for Canny (a few per cent of the pixels), between S (none) and U (every pixel)
+        shot = 64
+        ys = torch.arange(h, device=device).view(h, 1)
+        xs = torch.arange(w, device=device).view(1, w)
+        for s0 in range(0, n, shot):
+            grid = torch.rand((1, 3, 9, 16), device=device, generator=g) * 255.0
+            base = torch.nn.functional.interpolate(grid, size=(h, w), mode="bilinear", align_corners=True)[0].permute(1, 2, 0)
+            rects = torch.rand((12, 4), device=device, generator=g).cpu().tolist()
+            cols = (torch.rand((12, 3), device=device, generator=g) * 255.0)
+            for i in range(s0, min(n, s0 + shot)):
+                k = i - s0
+                img = base + torch.randn((h, w, 3), device=device, generator=g) * 2.0
+                for (ry, rx, rh, rw), col in zip(rects, cols):
+                    y0 = int(ry * (h - h // 4)) + k
+                    x0 = int(rx * (w - w // 4)) + 2 * k
+                    y1, x1 = min(h, y0 + h // 16 + int(rh * h // 6)), min(w, x0 + w // 16 + int(rw * w // 6))
+                    img[y0:y1, x0:x1] = col
+                band = (ys - (xs * h) // w - 3 * k).abs() < max(2, h // 90)
+                img = torch.where(band.unsqueeze(2), img + 80.0, img)
+                x[i] = img.round().clamp(0, 255).to(torch.uint8)
     else:
         raise ValueError(dist)
     if device.type == "cuda":
@@ -303,6 +324,10 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
             r = quick_measure(Workload(eng, b, "content", None, epilogue, E))
             if dist == "S":
                 r["edges_weights_1111"] = quick_measure(Workload(eng, b, "edges", None, epilogue, E), steps=3, warmup=1)
+                # the same with sharp-edged objects in the frames (S holds next to no Canny edges, U nothing else)
+                bt = make_batch(min(frames_small, 1024), "T", 20250921, device, h, w)
+                r["edges_weights_1111_objects"] = quick_measure(Workload(eng, bt, "edges", None, epilogue, E), steps=3, warmup=1)
+                del bt
                 r["all_four_fused"] = quick_measure(Workload(eng, b, "all", None, epilogue, E))
             else:
                 r["histogram_threshold"] = quick_measure(Workload(eng, b, "hist", None, epilogue, E))
@@ -585,7 +610,7 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU batch")
-    ap.add_argument("--dist", default="U", choices=["U", "K", "S"])
+    ap.add_argument("--dist", default="U", choices=["U", "K", "S", "T"])
     ap.add_argument("--detector", default="content", choices=["content", "hist", "all", "hash", "edges"],
                     help="content = ContentDetector (headline); hist = Histogram+Threshold; all = all four fused; "
                          "hash = HashDetector (thumbnail kernel + DCT epilogue); edges = ContentDetector with weights (1,1,1,1)")

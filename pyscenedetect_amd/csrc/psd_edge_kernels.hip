@@ -654,6 +654,81 @@ __device__ __forceinline__ unsigned long long fill_runs_up(unsigned long long se
     return (((seeds + run) ^ run) & run) | seeds;
 }
 
+// strong words: plain loads between launches; inside the per-frame kernel, where ANOTHER wave of the workgroup may have
+// stored them a round ago, loads that go to the L2 (stores are write-through and complete before the round's barrier)
+template <bool COHERENT>
+__device__ __forceinline__ u32 ld_s(const u32* p)
+{
+    if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
+// One 64 x 64 tile (by, bx) of one frame's bit planes S (strong, updated in place) / Wk (weak) to its fix point, by one wave.
+// Returns (uniformly) whether a pixel on the tile's border was promoted: the eight neighbours have to look again.
+template <bool COHERENT>
+__device__ __forceinline__ bool hyst_tile(u32* S, const u32* Wk, const EdgeGeom& g, int by, int bx, int lane)
+{
+    const int H = g.height, nw = g.words_per_row;
+    const int w0 = 2 * bx, y0 = by * HT;
+    // this lane's row, and (lanes 0 / 63) the halo rows above / below; words outside the image read as 0
+    const int y = y0 + lane;
+    const bool row_in = y < H;
+    const int yc = min(y, H - 1);
+    const bool has_hi = w0 + 1 < nw, has_l = w0 > 0, has_r = w0 + 2 < nw;
+    const u32* srow = S + (size_t)yc * nw;
+    const u32* wrow = Wk + (size_t)yc * nw;
+    // unconditional loads on clamped indices (they go out together), masked afterwards
+    u32 s_lo = ld_s<COHERENT>(srow + w0), s_hi = ld_s<COHERENT>(srow + min(w0 + 1, nw - 1)), s_l = ld_s<COHERENT>(srow + max(w0 - 1, 0)),
+        s_r = ld_s<COHERENT>(srow + min(w0 + 2, nw - 1));
+    u32 k_lo = wrow[w0], k_hi = wrow[min(w0 + 1, nw - 1)];
+    const int yh = lane == 0 ? y0 - 1 : y0 + HT;          // halo row of lane 0 (above) / lane 63 (below)
+    const bool halo_lane = lane == 0 || lane == 63;
+    const bool halo_in = halo_lane && yh >= 0 && yh < H;
+    const u32* hrow = S + (size_t)min(max(yh, 0), H - 1) * nw;
+    u32 h_lo = ld_s<COHERENT>(hrow + w0), h_hi = ld_s<COHERENT>(hrow + min(w0 + 1, nw - 1)), h_l = ld_s<COHERENT>(hrow + max(w0 - 1, 0)),
+        h_r = ld_s<COHERENT>(hrow + min(w0 + 2, nw - 1));
+    if (!row_in) { s_lo = s_hi = s_l = s_r = k_lo = k_hi = 0; }
+    if (!has_hi) { s_hi = 0; k_hi = 0; h_hi = 0; }
+    if (!has_l) { s_l = 0; h_l = 0; }
+    if (!has_r) { s_r = 0; h_r = 0; }
+    if (!halo_in) { h_lo = h_hi = h_l = h_r = 0; }
+    unsigned long long Sv = ((unsigned long long)s_hi << 32) | s_lo;
+    const unsigned long long Kv = ((unsigned long long)k_hi << 32) | k_lo;
+    const unsigned long long S0 = Sv;
+    const u32 eL = s_l >> 31, eR = s_r & 1u;              // strong state of the pixels left / right of this row (fixed here)
+    const unsigned long long Hv = ((unsigned long long)h_hi << 32) | h_lo;
+    const u32 hL = h_l >> 31, hR = h_r & 1u;
+    if (__ballot(Kv != 0) == 0) return false;              // no weak pixel in the tile: nothing can change
+    for (;;) {
+        // rows above / below: neighbouring lanes, the halo rows at the ends
+        unsigned long long up = __shfl_up(Sv, 1), dn = __shfl_down(Sv, 1);
+        u32 upL = __shfl_up(eL, 1), upR = __shfl_up(eR, 1), dnL = __shfl_down(eL, 1), dnR = __shfl_down(eR, 1);
+        if (lane == 0) { up = Hv; upL = hL; upR = hR; }
+        if (lane == 63) { dn = Hv; dnL = hL; dnR = hR; }
+        const unsigned long long n = up | Sv | dn;                                   // strong in the three rows, same column
+        const unsigned long long nl = (u64)((upL | eL | dnL) & 1u), nr = (u64)((upR | eR | dnR) & 1u);
+        const unsigned long long near = n | (n << 1) | (n >> 1) | nl | (nr << 63);   // ... or a column next to it
+        unsigned long long grown = Sv | (Kv & near);
+        // horizontal runs of weak pixels in one go: promoted pixels are seeds inside the weak runs
+        const unsigned long long seeds = grown & Kv;
+        grown |= fill_runs_up(seeds, Kv);
+        grown |= __brevll(fill_runs_up(__brevll(seeds), __brevll(Kv)));
+        const bool ch = grown != Sv;
+        Sv = grown;
+        if (__ballot(ch) == 0) break;
+    }
+    const unsigned long long added = Sv & ~S0;
+    const unsigned long long any_added = __ballot(added != 0);
+    if (any_added == 0) return false;
+    if (added != 0 && row_in) {
+        if ((u32)added) S[(size_t)y * nw + w0] = (u32)Sv;
+        if ((u32)(added >> 32) && has_hi) S[(size_t)y * nw + w0 + 1] = (u32)(Sv >> 32);
+    }
+    // promoted pixels on the tile border: the neighbours have to look again
+    const bool border = (added != 0 && (lane == 0 || lane == 63)) || ((added & 0x8000000000000001ull) != 0);
+    return __ballot(border) != 0;
+}
+
 __global__ __launch_bounds__(256) void hysteresis_bits_kernel(u32* strong, const u32* weak, EdgeGeom g, uint8_t* dirty_in, uint8_t* dirty_out,
                                                               int* changed, int tiles_x, int tiles_y, long n_tiles, int tpw)
 {
@@ -681,64 +756,7 @@ __global__ __launch_bounds__(256) void hysteresis_bits_kernel(u32* strong, const
         const long ti = first + bit;
         const int j = (int)(ti / per_frame), rem = (int)(ti - (long)j * per_frame);
         const int by = rem / tiles_x, bx = rem - by * tiles_x;
-        u32* S = strong + (size_t)j * H * nw;
-        const u32* Wk = weak + (size_t)j * H * nw;
-        const int w0 = 2 * bx, y0 = by * HT;
-        // this lane's row, and (lanes 0 / 63) the halo rows above / below; words outside the image read as 0
-        const int y = y0 + lane;
-        const bool row_in = y < H;
-        const int yc = min(y, H - 1);
-        const bool has_hi = w0 + 1 < nw, has_l = w0 > 0, has_r = w0 + 2 < nw;
-        const u32* srow = S + (size_t)yc * nw;
-        const u32* wrow = Wk + (size_t)yc * nw;
-        // unconditional loads on clamped indices (they go out together), masked afterwards
-        u32 s_lo = srow[w0], s_hi = srow[min(w0 + 1, nw - 1)], s_l = srow[max(w0 - 1, 0)], s_r = srow[min(w0 + 2, nw - 1)];
-        u32 k_lo = wrow[w0], k_hi = wrow[min(w0 + 1, nw - 1)];
-        const int yh = lane == 0 ? y0 - 1 : y0 + HT;          // halo row of lane 0 (above) / lane 63 (below)
-        const bool halo_lane = lane == 0 || lane == 63;
-        const bool halo_in = halo_lane && yh >= 0 && yh < H;
-        const u32* hrow = S + (size_t)min(max(yh, 0), H - 1) * nw;
-        u32 h_lo = hrow[w0], h_hi = hrow[min(w0 + 1, nw - 1)], h_l = hrow[max(w0 - 1, 0)], h_r = hrow[min(w0 + 2, nw - 1)];
-        if (!row_in) { s_lo = s_hi = s_l = s_r = k_lo = k_hi = 0; }
-        if (!has_hi) { s_hi = 0; k_hi = 0; h_hi = 0; }
-        if (!has_l) { s_l = 0; h_l = 0; }
-        if (!has_r) { s_r = 0; h_r = 0; }
-        if (!halo_in) { h_lo = h_hi = h_l = h_r = 0; }
-        unsigned long long Sv = ((unsigned long long)s_hi << 32) | s_lo;
-        const unsigned long long Kv = ((unsigned long long)k_hi << 32) | k_lo;
-        const unsigned long long S0 = Sv;
-        const u32 eL = s_l >> 31, eR = s_r & 1u;              // strong state of the pixels left / right of this row (fixed here)
-        const unsigned long long Hv = ((unsigned long long)h_hi << 32) | h_lo;
-        const u32 hL = h_l >> 31, hR = h_r & 1u;
-        if (__ballot(Kv != 0) == 0) continue;                  // no weak pixel in the tile: nothing can change
-        for (;;) {
-            // rows above / below: neighbouring lanes, the halo rows at the ends
-            unsigned long long up = __shfl_up(Sv, 1), dn = __shfl_down(Sv, 1);
-            u32 upL = __shfl_up(eL, 1), upR = __shfl_up(eR, 1), dnL = __shfl_down(eL, 1), dnR = __shfl_down(eR, 1);
-            if (lane == 0) { up = Hv; upL = hL; upR = hR; }
-            if (lane == 63) { dn = Hv; dnL = hL; dnR = hR; }
-            const unsigned long long n = up | Sv | dn;                                   // strong in the three rows, same column
-            const unsigned long long nl = (u64)((upL | eL | dnL) & 1u), nr = (u64)((upR | eR | dnR) & 1u);
-            const unsigned long long near = n | (n << 1) | (n >> 1) | nl | (nr << 63);   // ... or a column next to it
-            unsigned long long grown = Sv | (Kv & near);
-            // horizontal runs of weak pixels in one go: promoted pixels are seeds inside the weak runs
-            const unsigned long long seeds = grown & Kv;
-            grown |= fill_runs_up(seeds, Kv);
-            grown |= __brevll(fill_runs_up(__brevll(seeds), __brevll(Kv)));
-            const bool ch = grown != Sv;
-            Sv = grown;
-            if (__ballot(ch) == 0) break;
-        }
-        const unsigned long long added = Sv & ~S0;
-        const unsigned long long any_added = __ballot(added != 0);
-        if (any_added == 0) continue;
-        if (added != 0 && row_in) {
-            if ((u32)added) S[(size_t)y * nw + w0] = (u32)Sv;
-            if ((u32)(added >> 32) && has_hi) S[(size_t)y * nw + w0 + 1] = (u32)(Sv >> 32);
-        }
-        // promoted pixels on the tile border: the neighbours have to look again
-        const bool border = (added != 0 && (lane == 0 || lane == 63)) || ((added & 0x8000000000000001ull) != 0);
-        if (__ballot(border) != 0) {
+        if (hyst_tile<false>(strong + (size_t)j * H * nw, weak + (size_t)j * H * nw, g, by, bx, lane)) {
             if (lane < 9 && lane != 4) {
                 const int ny = by + lane / 3 - 1, nx = bx + lane % 3 - 1;
                 if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) dirty_out[(size_t)j * per_frame + (size_t)ny * tiles_x + nx] = 1;
@@ -747,6 +765,68 @@ __global__ __launch_bounds__(256) void hysteresis_bits_kernel(u32* strong, const
             //  half a million tiles per launch -- behind the L2's atomic unit)
             if (lane == 0) *changed = 1;
         }
+    }
+}
+
+// The whole hysteresis of ONE FRAME in one workgroup and one launch: chains of weak pixels never leave their frame, so
+// nothing has to be handed from launch to launch -- no convergence flags, no host round trips, no fixed number of
+// speculative launches that a long chain outruns (frames full of straight object edges needed fifty launches of the kernel
+// above: an edge that runs along a tile border crosses it at every wiggle, one launch per crossing; the speculative path
+// then fell back to repeating the whole edge term).  The workgroup keeps two bit maps of the frame's tiles in LDS: the tiles
+// to look at in this round (first round: the flags of the NMS kernel) and the ones woken for the next; sixteen waves take
+// the set bits of this round's map, a barrier, swap, until a round wakes nobody.  A wave that wakes a neighbour has stored
+// its promotions before the round's barrier (write-through L1), and the strong words are read with loads that go to the L2,
+// so the next round sees them whichever wave stored them.  grid = frames.
+constexpr int HF_WAVES = 16, HF_MAXWORDS = 1024;   // up to 32768 tiles per frame (16K x 8K pixels)
+
+__global__ __launch_bounds__(HF_WAVES * 64) void hysteresis_frame_kernel(u32* strong, const u32* weak, EdgeGeom g, const uint8_t* dirty,
+                                                                         int tiles_x, int tiles_y)
+{
+    __shared__ u32 cur[HF_MAXWORDS], nxt[HF_MAXWORDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = blockIdx.x, per_frame = tiles_x * tiles_y, nwords = (per_frame + 31) >> 5;
+    const uint8_t* D = dirty + (size_t)j * per_frame;
+    for (int w = tid; w < nwords; w += HF_WAVES * 64) {
+        u32 m = 0;
+        for (int b = 0; b < 32; b++) {
+            const int t = w * 32 + b;
+            if (t < per_frame && D[t] != 0) m |= 1u << b;
+        }
+        cur[w] = m;
+        nxt[w] = 0;
+    }
+    __syncthreads();
+    u32* S = strong + (size_t)j * g.height * g.words_per_row;
+    const u32* Wk = weak + (size_t)j * g.height * g.words_per_row;
+    for (int round = 0;; round++) {
+        for (int w = wave; w < nwords; w += HF_WAVES) {
+            u32 bits = __builtin_amdgcn_readfirstlane(cur[w]);
+            while (bits) {
+                const int tile = w * 32 + __ffs((int)bits) - 1;
+                bits &= bits - 1;
+                const int by = tile / tiles_x, bx = tile - by * tiles_x;
+                // (the first round -- on noisy frames most of the work -- reads through the L1: nothing of this frame can be
+                //  stale in it yet, and what a neighbouring wave stores meanwhile is picked up in the round that wave triggers)
+                if (round == 0 ? hyst_tile<false>(S, Wk, g, by, bx, lane) : hyst_tile<true>(S, Wk, g, by, bx, lane)) {
+                    if (lane < 9 && lane != 4) {
+                        const int ny = by + lane / 3 - 1, nx = bx + lane % 3 - 1;
+                        if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) {
+                            const int nt = ny * tiles_x + nx;
+                            atomicOr(&nxt[nt >> 5], 1u << (nt & 31));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                       // this round's stores (vmcnt drained) and wake-ups are in
+        u32 any = 0;
+        for (int w = tid; w < nwords; w += HF_WAVES * 64) {
+            const u32 v = nxt[w];
+            cur[w] = v;
+            nxt[w] = 0;
+            any |= v;
+        }
+        if (!__syncthreads_or(any != 0)) break;
     }
 }
 
@@ -1047,11 +1127,15 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, const E
                            b.dirty[0], htx, (int)b.tiles_per_frame);
     }
     HIP_TRY(hipGetLastError());
-    // hysteresis to the fix point: launches ping-pong the two dirty-tile lists (every launch empties the list it read, so the
-    // lists only need the clearing at the top of the chunk), one flag per launch; done when a launch promoted nothing on
-    // any tile border.
+    // hysteresis to the fix point.  Default: one workgroup per frame, one launch (hysteresis_frame_kernel).
+    // PSD_EDGE_HYST_LAUNCHES=1 selects the older scheme: launches of hysteresis_bits_kernel that ping-pong the two dirty-tile
+    // lists (every launch empties the list it read, so the lists only need the clearing at the top of the chunk), one flag per
+    // launch; done when a launch promoted nothing on any tile border.
+    static const bool by_launches = [] { const char* v = getenv("PSD_EDGE_HYST_LAUNCHES"); return v && atoi(v) != 0; }();
     int launch = 0;
-    if (d_unconverged) {
+    if (!by_launches && (long)htx * hty <= (long)HF_MAXWORDS * 32) {
+        hipLaunchKernelGGL(hysteresis_frame_kernel, dim3(count), dim3(HF_WAVES * 64), 0, stream, b.strong, b.weak, g, b.dirty[0], htx, hty);
+    } else if (d_unconverged) {
         for (; launch < HYST_SPEC_LAUNCHES; launch++) {
             hipLaunchKernelGGL(hysteresis_bits_kernel, hyst_grid, dim3(256), 0, stream, b.strong, b.weak, g, b.dirty[launch & 1],
                                b.dirty[(launch + 1) & 1], b.flags + launch, htx, hty, hyst_tiles, HYST_TPW);
