@@ -369,11 +369,11 @@ static int score_terms(psd_engine* e, psd_slot& s, const uint8_t* d_frames, int 
     }
     if (flags & PSD_SCORE_EDGES) {
         int* spec = nullptr;
-        // A fixed number of hysteresis launches and no host round trip inside the submission; psd_score_collect repeats
-        // the term on the exact path if a frame needed more (tests/test_gpu_fullsize.py builds such a chain).  On by default
-        // since the hysteresis launches became cheap (5 us each: tools/edge_time.py on 1080p shot-like content 184 / 252 /
-        // 267 k frames/s at 64 / 256 / 1024 frames per call against 163 / 242 / 261 k with the host-driven loop, uniform noise
-        // 60 k either way); PSD_EDGE_SPECULATIVE=0 selects the host-driven loop.
+        // The hysteresis normally reaches its fix point inside one launch (one workgroup per frame, psd_edge_kernels.hip:
+        // hysteresis_frame_kernel) and nothing below is needed.  With PSD_EDGE_HYST_LAUNCHES=1 it runs as launches of the tile
+        // kernel instead, in one of two forms: a fixed number of launches and no host round trip inside the submission --
+        // psd_score_collect then repeats the term on the exact path if a frame needed more (tests/test_gpu_fullsize.py builds
+        // such a chain; frames full of object edges always do) -- or, with PSD_EDGE_SPECULATIVE=0 as well, the host-driven loop.
         static const bool speculative = [] { const char* v = getenv("PSD_EDGE_SPECULATIVE"); return !v || atoi(v) != 0; }();
         if (frames_outlive_collect && speculative) {
             // the caller keeps the frames until the submission is collected, so a non-converged hysteresis can be
