@@ -777,8 +777,12 @@ __global__ __launch_bounds__(256) void hysteresis_bits_kernel(u32* strong, const
 // the set bits of this round's map, a barrier, swap, until a round wakes nobody.  A wave that wakes a neighbour has stored
 // its promotions before the round's barrier (write-through L1), and the strong words are read with loads that go to the L2,
 // so the next round sees them whichever wave stored them.  grid = frames.
-constexpr int HF_WAVES = 16, HF_MAXWORDS = 1024;   // up to 32768 tiles per frame (16K x 8K pixels)
+// HF_WAVES waves per workgroup: as many as still let every frame of the chunk be resident at once (32 wave slots per CU) --
+// frames whose chains take fifty rounds are bound by the latency of a round, not by throughput, so two waves of workgroups
+// take twice as long as one.
+constexpr int HF_MAXWORDS = 1024;   // up to 32768 tiles per frame (16K x 8K pixels)
 
+template <int HF_WAVES>
 __global__ __launch_bounds__(HF_WAVES * 64) void hysteresis_frame_kernel(u32* strong, const u32* weak, EdgeGeom g, const uint8_t* dirty,
                                                                          int tiles_x, int tiles_y)
 {
@@ -1134,7 +1138,13 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, const E
     static const bool by_launches = [] { const char* v = getenv("PSD_EDGE_HYST_LAUNCHES"); return v && atoi(v) != 0; }();
     int launch = 0;
     if (!by_launches && (long)htx * hty <= (long)HF_MAXWORDS * 32) {
-        hipLaunchKernelGGL(hysteresis_frame_kernel, dim3(count), dim3(HF_WAVES * 64), 0, stream, b.strong, b.weak, g, b.dirty[0], htx, hty);
+        const int slots = 256 * 32;   // wave slots of the chip
+        if ((long)count * 16 <= slots)
+            hipLaunchKernelGGL(hysteresis_frame_kernel<16>, dim3(count), dim3(16 * 64), 0, stream, b.strong, b.weak, g, b.dirty[0], htx, hty);
+        else if ((long)count * 8 <= slots)
+            hipLaunchKernelGGL(hysteresis_frame_kernel<8>, dim3(count), dim3(8 * 64), 0, stream, b.strong, b.weak, g, b.dirty[0], htx, hty);
+        else
+            hipLaunchKernelGGL(hysteresis_frame_kernel<4>, dim3(count), dim3(4 * 64), 0, stream, b.strong, b.weak, g, b.dirty[0], htx, hty);
     } else if (d_unconverged) {
         for (; launch < HYST_SPEC_LAUNCHES; launch++) {
             hipLaunchKernelGGL(hysteresis_bits_kernel, hyst_grid, dim3(256), 0, stream, b.strong, b.weak, g, b.dirty[launch & 1],
