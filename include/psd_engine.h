@@ -40,8 +40,9 @@
 extern "C" {
 #endif
 
-#define PSD_ABI_VERSION 3 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records);
-                            * 3: additive over 2 (psd_frame_sums: records without the histogram, psd_score_collect_sums, psd_epilogue_*_sums) */
+#define PSD_ABI_VERSION 4 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records);
+                            * 3: additive over 2 (psd_frame_sums: records without the histogram, psd_score_collect_sums, psd_epilogue_*_sums);
+                            * 4: additive over 3 (psd_resize_source_rows, psd_upload_rows: a host feeder uploads only the rows a downscale reads) */
 
 typedef enum psd_status {
     PSD_OK = 0,
@@ -194,6 +195,23 @@ int psd_memcpy_d2h(psd_engine* e, void* h_dst, const void* d_src, size_t bytes);
 int psd_host_alloc(psd_engine* e, size_t bytes, void** h_ptr);
 int psd_host_free(psd_engine* e, void* h_ptr);
 int psd_upload(psd_engine* e, void* d_dst, const void* h_src, size_t bytes);
+/* A downscale in front of the detectors (scene_manager.py:110, 123-140, 666-678) reads few of a frame's rows: 2 * dst_h
+ * of src_h for INTER_LINEAR, dst_h for INTER_NEAREST (every row for INTER_AREA and the exact 2x2 case).
+ *   psd_resize_source_rows  the rows the device downscale of this shape and mode reads, ascending (`rows` has room for
+ *                           src_h entries); no engine, no device;
+ *   psd_upload_rows         psd_upload for a frame of which only those rows are needed: rows[0 .. n_rows) (ascending) of the
+ *                           packed host frame (row pitch h_row_stride >= row_bytes) go to the SAME rows of the packed device
+ *                           frame (row pitch row_bytes); the rows in between keep whatever the buffer held.  Runs of equally
+ *                           spaced row groups travel as one strided copy each.  Everything the engine computes from a
+ *                           downscaled frame (records, thumbnails, the small frame itself) is the same as after a full upload. */
+int psd_resize_source_rows(int src_h, int src_w, int dst_h, int dst_w, int interpolation, int* rows, int* n_rows);
+int psd_upload_rows(psd_engine* e, void* d_frame, const void* h_frame, size_t row_bytes, size_t h_row_stride,
+                    const int* rows, int n_rows);
+/* The strided copies psd_upload_rows issues for a row list, for hosts that drive their own copy engine: copy i moves
+ * copies[4i+3] groups of copies[4i+1] consecutive rows, copies[4i+2] rows apart, starting at row copies[4i].  `packed`:
+ * the host frame's rows are contiguous (otherwise every group is one row).  *n_copies is the full count even when it
+ * exceeds max_copies.  No engine, no device. */
+int psd_upload_rows_plan(const int* rows, int n_rows, int packed, int* copies, int max_copies, int* n_copies);
 int psd_upload_async(psd_engine* e, void* d_dst, const void* h_src, size_t bytes);
 int psd_upload_fence(psd_engine* e, int wait_on_host);
 int psd_memcpy_d2d(psd_engine* e, void* d_dst, const void* d_src, size_t bytes);

@@ -132,6 +132,9 @@ SYMBOLS = {
     "psd_host_free": (_i, [_vp, _vp]),
     "psd_upload": (_i, [_vp, _vp, _vp, _sz]),
     "psd_upload_async": (_i, [_vp, _vp, _vp, _sz]),
+    "psd_resize_source_rows": (_i, [_i, _i, _i, _i, _i, _vp, _vp]),
+    "psd_upload_rows": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _i]),
+    "psd_upload_rows_plan": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "psd_upload_fence": (_i, [_vp, _i]),
     "psd_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
     "psd_synchronize": (_i, [_vp]),
@@ -214,8 +217,8 @@ def load() -> ctypes.CDLL:
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from ex
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.psd_abi_version() != 3:
-        raise NativeLibraryError(f"ABI version mismatch: library has {lib.psd_abi_version()}, binding wants 3")
+    if lib.psd_abi_version() != 4:
+        raise NativeLibraryError(f"ABI version mismatch: library has {lib.psd_abi_version()}, binding wants 4")
     _lib = lib
     return lib
 

@@ -1302,150 +1302,4 @@ void edges_release(psd_engine* e)
     *engine_edge_ws_bytes(e) = 0;
 }
 
-// ---- cv2.resize(INTER_NEAREST) and cv2.resize(INTER_AREA), 8-bit, 3 channels ---------------------------
-// The other two `Interpolation` modes SceneManager can be asked to downscale with (reference common.py:148-160,
-// scene_manager.py:670-678).  One destination pixel per thread: correctness paths, not tuned (the default,
-// INTER_LINEAR, lives in psd_resize_kernels.hip).
-
-__global__ __launch_bounds__(64) void resize_nearest_kernel(const uint8_t* src, int sh, int sw, size_t sstride, uint8_t* dst, int dh,
-                                                            int dw, size_t dstride, const int* xofs, const int* yofs)
-{
-    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y;
-    if (dx >= dw) return;
-    const uint8_t* p = src + (size_t)blockIdx.z * sstride + ((size_t)yofs[dy] * sw + xofs[dx]) * 3;
-    uint8_t* D = dst + (size_t)blockIdx.z * dstride + ((size_t)dy * dw + dx) * 3;
-    D[0] = p[0]; D[1] = p[1]; D[2] = p[2];
-}
-
-struct AreaRun3 {   // same run-length form as psd_hash_kernels.hip
-    int first, count, has_head, has_tail;
-    float a_head, a_mid, a_tail;
-    int pad;
-};
-
-// mode 0: float run tables (ResizeArea_<uchar,float> accumulation order: left to right within a source row, rows
-// top to bottom, every product and sum rounded separately); mode 1: integer box * (1.f/area); mode 2: 2x2 rounding shift
-__global__ __launch_bounds__(64) void resize_area_kernel(const uint8_t* src, int sw, size_t sstride, uint8_t* dst, int dh, int dw,
-                                                         size_t dstride, const AreaRun3* xtab, const AreaRun3* ytab, int mode,
-                                                         float inv_area)
-{
-    const int dx = blockIdx.x * 64 + threadIdx.x, dy = blockIdx.y;
-    if (dx >= dw) return;
-    const uint8_t* S = src + (size_t)blockIdx.z * sstride;
-    uint8_t* D = dst + (size_t)blockIdx.z * dstride + ((size_t)dy * dw + dx) * 3;
-    const AreaRun3 xr = xtab[dx], yr = ytab[dy];
-    if (mode == 0) {
-        float sum[3] = {0.f, 0.f, 0.f};
-        for (int j = 0; j < yr.count; j++) {
-            const uint8_t* row = S + ((size_t)(yr.first + j) * sw + xr.first) * 3;
-            const float beta = (j == 0 && yr.has_head) ? yr.a_head : (j == yr.count - 1 && yr.has_tail) ? yr.a_tail : yr.a_mid;
-            float acc[3] = {0.f, 0.f, 0.f};
-            for (int k = 0; k < xr.count; k++) {
-                const float a = (k == 0 && xr.has_head) ? xr.a_head : (k == xr.count - 1 && xr.has_tail) ? xr.a_tail : xr.a_mid;
-#pragma unroll
-                for (int c = 0; c < 3; c++) acc[c] = __fadd_rn(acc[c], __fmul_rn((float)row[3 * k + c], a));
-            }
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float term = __fmul_rn(beta, acc[c]);
-                sum[c] = j == 0 ? term : __fadd_rn(sum[c], term);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++) D[c] = (uint8_t)min(255, max(0, __float2int_rn(sum[c])));
-    } else {
-        int sum[3] = {0, 0, 0};
-        for (int j = 0; j < yr.count; j++) {
-            const uint8_t* row = S + ((size_t)(yr.first + j) * sw + xr.first) * 3;
-            for (int k = 0; k < xr.count; k++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) sum[c] += row[3 * k + c];
-        }
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-            D[c] = mode == 2 ? (uint8_t)((sum[c] + 2) >> 2) : (uint8_t)min(255, max(0, __float2int_rn(__fmul_rn((float)sum[c], inv_area))));
-    }
-}
-
-static void area_table3(int ssize, int dsize, AreaRun3* tab)
-{
-    const double scale = 1. / ((double)dsize / ssize);
-    for (int dx = 0; dx < dsize; dx++) {
-        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
-        const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
-        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
-        if (sx2 > ssize - 1) sx2 = ssize - 1;
-        if (sx1 > sx2) sx1 = sx2;
-        AreaRun3 r;
-        memset(&r, 0, sizeof r);
-        r.first = sx1;
-        if (sx1 - fsx1 > 1e-3) { r.has_head = 1; r.first = sx1 - 1; r.a_head = (float)((sx1 - fsx1) / cell); r.count++; }
-        r.a_mid = (float)(1.0 / cell);
-        r.count += sx2 - sx1;
-        if (fsx2 - sx2 > 1e-3) {
-            double tl = fsx2 - sx2 < 1. ? fsx2 - sx2 : 1.;
-            if (tl > cell) tl = cell;
-            r.has_tail = 1; r.a_tail = (float)(tl / cell); r.count++;
-        }
-        tab[dx] = r;
-    }
-}
-
-// interpolation: 0 = INTER_NEAREST, 3 = INTER_AREA (cv2's values)
-int resize_other(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
-                 int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream)
-{
-    if (n == 0) return PSD_OK;
-    const dim3 grid((dst_w + 63) / 64, dst_h, n);
-    const double scale_x = 1. / ((double)dst_w / src_w), scale_y = 1. / ((double)dst_h / src_h);
-    uint8_t* tabs = nullptr;
-    hipError_t err = hipSuccess;
-    if (interpolation == 0) {
-        std::vector<int> ofs((size_t)dst_w + dst_h);
-        for (int x = 0; x < dst_w; x++) ofs[x] = std::min((int)floor(x * scale_x), src_w - 1);
-        for (int y = 0; y < dst_h; y++) ofs[dst_w + y] = std::min((int)floor(y * scale_y), src_h - 1);
-        HIP_TRY(hipMalloc((void**)&tabs, ofs.size() * sizeof(int)));
-        err = hipMemcpyAsync(tabs, ofs.data(), ofs.size() * sizeof(int), hipMemcpyHostToDevice, stream);
-        if (err == hipSuccess) {
-            hipLaunchKernelGGL(resize_nearest_kernel, grid, dim3(64), 0, stream, d_src, src_h, src_w, src_frame_stride, d_dst, dst_h,
-                               dst_w, dst_frame_stride, (const int*)tabs, (const int*)tabs + dst_w);
-            err = hipGetLastError();
-        }
-        if (err == hipSuccess) err = hipStreamSynchronize(stream);   // `ofs` and `tabs` go away below
-    } else if (interpolation == 3) {
-        if (dst_w > src_w || dst_h > src_h) {
-            psd_set_error("INTER_AREA is implemented for decimation only (%dx%d -> %dx%d)", src_w, src_h, dst_w, dst_h);
-            return PSD_ERR_UNSUPPORTED;
-        }
-        const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
-        const bool area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
-        std::vector<AreaRun3> t((size_t)dst_w + dst_h);
-        int mode = 0;
-        float inv_area = 0.f;
-        if (area_fast) {
-            for (int x = 0; x < dst_w; x++) { AreaRun3 r; memset(&r, 0, sizeof r); r.first = x * iscale_x; r.count = iscale_x; t[x] = r; }
-            for (int y = 0; y < dst_h; y++) { AreaRun3 r; memset(&r, 0, sizeof r); r.first = y * iscale_y; r.count = iscale_y; t[dst_w + y] = r; }
-            mode = (iscale_x == 2 && iscale_y == 2) ? 2 : 1;
-            inv_area = 1.f / (float)(iscale_x * iscale_y);
-        } else {
-            area_table3(src_w, dst_w, t.data());
-            area_table3(src_h, dst_h, t.data() + dst_w);
-        }
-        HIP_TRY(hipMalloc((void**)&tabs, t.size() * sizeof(AreaRun3)));
-        err = hipMemcpyAsync(tabs, t.data(), t.size() * sizeof(AreaRun3), hipMemcpyHostToDevice, stream);
-        if (err == hipSuccess) {
-            hipLaunchKernelGGL(resize_area_kernel, grid, dim3(64), 0, stream, d_src, src_w, src_frame_stride, d_dst, dst_h, dst_w,
-                               dst_frame_stride, (const AreaRun3*)tabs, (const AreaRun3*)tabs + dst_w, mode, inv_area);
-            err = hipGetLastError();
-        }
-        if (err == hipSuccess) err = hipStreamSynchronize(stream);
-    } else {
-        psd_set_error("interpolation %d is not implemented on the device (0 = NEAREST, 1 = LINEAR, 3 = AREA)", interpolation);
-        return PSD_ERR_UNSUPPORTED;
-    }
-    if (tabs) (void)hipFree(tabs);
-    if (err != hipSuccess) { psd_set_error("resize failed: %s", hipGetErrorString(err)); return PSD_ERR_HIP; }
-    return PSD_OK;
-}
-
 }  // namespace psd

@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
+#include <vector>
 
 #include "psd_internal.h"
 
@@ -49,13 +51,12 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
                         size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg,
                         bool area_mode = false);
 void resize_release(psd_engine* e);
-int resize_other(const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
+int resize_other(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
                  int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream);
+int resize_source_rows(int src_h, int src_w, int dst_h, int dst_w, int interpolation, int* rows, int* n_rows);
 // psd_hash_kernels.hip
-struct AreaRun;
-int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
-                int size, AreaRun* d_tabs, uint8_t* d_thumbs, hipStream_t stream, hipEvent_t ev_start);
-size_t hash_tab_bytes(int size);
+int hash_thumbs(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
+                int size, uint8_t* d_thumbs, hipStream_t stream, hipEvent_t ev_start);
 }  // namespace psd
 
 struct psd_slot {
@@ -100,10 +101,10 @@ struct psd_engine {
     size_t stage_bytes = 0;
     void* edge_ws = nullptr;  // owned by psd_edge_kernels.hip
     size_t edge_ws_bytes = 0;
-    uint8_t* d_hash = nullptr;  // thumbnails + run tables of psd_hash_thumbs*
+    uint8_t* d_hash = nullptr;  // thumbnails of psd_hash_thumbs*
     size_t hash_bytes = 0;
     hipEvent_t ev_hash[2] = {nullptr, nullptr};
-    void* resize_cache = nullptr;   // coefficient tables per (src, dst) shape, owned by psd_resize_kernels.hip
+    void* resize_cache = nullptr;   // coefficient tables per (src, dst) shape of every resize mode + the hash thumbnails, owned by psd_resize_kernels.hip
     uint8_t* d_small = nullptr;     // resized frames of psd_score_downscaled_* when the terms need them in memory
     size_t small_bytes = 0;
     hipStream_t copy_stream = nullptr;   // psd_upload_async: host -> device copies that overlap the scoring stream
@@ -482,7 +483,7 @@ static int resize_any(psd_engine* e, const uint8_t* d_src, int n, int src_h, int
     if (interpolation == PSD_INTER_LINEAR || area_up)
         return psd::resize_linear_score(e, d_src, n, src_h, src_w, (size_t)src_w * 3, src_frame_stride, nullptr, d_dst, dst_h, dst_w,
                                         dst_frame_stride, nullptr, stream, nullptr, nullptr, area_up);
-    return psd::resize_other(d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, interpolation, stream);
+    return psd::resize_other(e, d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, interpolation, stream);
 }
 
 int psd_score_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w, size_t frame_stride,
@@ -715,6 +716,47 @@ static int for_each_host_chunk(psd_engine* e, const uint8_t* h_frames, int n, in
     return PSD_OK;
 }
 
+namespace {
+struct RowCopy { int first, len, step, count; };   // `count` groups of `len` consecutive rows, `step` rows apart, from row `first`
+
+// Groups of consecutive rows (one contiguous piece each when the host rows are packed), then strided copies: from a group
+// on, the layout is tried as p interleaved progressions (p = 1 .. 8) of equally long groups at one common distance -- a
+// decimation by 7.5 alternates steps of 7 and 8 rows: two progressions of step 15 -- and the period that covers most
+// groups per copy is taken.  The default 1080p -> 256 x 144 pipeline is two copies per frame.
+std::vector<RowCopy> plan_row_copies(const int* rows, int n_rows, bool packed)
+{
+    std::vector<std::pair<int, int>> groups;   // first row, rows
+    for (int i = 0; i < n_rows; i++) {
+        if (packed && !groups.empty() && rows[i] == groups.back().first + groups.back().second) groups.back().second++;
+        else groups.emplace_back(rows[i], 1);
+    }
+    std::vector<RowCopy> plan;
+    const size_t G = groups.size();
+    for (size_t g = 0; g < G;) {
+        size_t best_p = 1, best_cover = 1;
+        int best_step = 0;
+        for (size_t p = 1; p <= 8 && g + p < G; p++) {
+            const int step = groups[g + p].first - groups[g].first;
+            size_t end = g + p;
+            while (end < G && groups[end].second == groups[end - p].second && groups[end].first - groups[end - p].first == step) end++;
+            const size_t cover = end - g;
+            if (cover > p && cover * best_p > best_cover * p) { best_p = p; best_cover = cover; best_step = step; }
+        }
+        for (size_t j = 0; j < best_p && j < best_cover; j++)
+            plan.push_back(RowCopy{groups[g + j].first, groups[g + j].second, best_step, (int)((best_cover - j + best_p - 1) / best_p)});
+        g += best_cover;
+    }
+    return plan;
+}
+
+bool rows_ascending(const int* rows, int n_rows)
+{
+    for (int i = 0; i < n_rows; i++)
+        if (rows[i] < 0 || (i && rows[i] <= rows[i - 1])) return false;
+    return true;
+}
+}  // namespace
+
 extern "C" {
 
 int psd_score_batch(psd_engine* e, const uint8_t* h_frames, int n, int height, int width,
@@ -752,8 +794,7 @@ int psd_hash_thumbs_device(psd_engine* e, const uint8_t* d_frames, int n, int he
     if (rc != PSD_OK) return rc;
     if (n == 0) return PSD_OK;
     HIP_TRY(hipSetDevice(e->device));
-    const size_t thumbs_bytes = (((size_t)n * size * size) + 255) & ~(size_t)255;
-    const size_t need = thumbs_bytes + psd::hash_tab_bytes(size);
+    const size_t need = (((size_t)n * size * size) + 255) & ~(size_t)255;
     if (e->hash_bytes < need) {
         HIP_TRY(hipStreamSynchronize(e->stream));
         if (e->d_hash) HIP_TRY(hipFree(e->d_hash));
@@ -766,9 +807,8 @@ int psd_hash_thumbs_device(psd_engine* e, const uint8_t* d_frames, int n, int he
         e->hash_bytes = need;
     }
     if (!e->ev_hash[0]) { HIP_TRY(hipEventCreate(&e->ev_hash[0])); HIP_TRY(hipEventCreate(&e->ev_hash[1])); }
-    psd::AreaRun* d_tabs = reinterpret_cast<psd::AreaRun*>(e->d_hash + thumbs_bytes);
-    // ev_hash[0] is recorded inside, after the run tables are on the device
-    rc = psd::hash_thumbs(d_frames, n, height, width, row_stride, frame_stride, size, d_tabs, e->d_hash, e->stream, e->ev_hash[0]);
+    // ev_hash[0] is recorded inside, once the run tables are known to be on the device
+    rc = psd::hash_thumbs(e, d_frames, n, height, width, row_stride, frame_stride, size, e->d_hash, e->stream, e->ev_hash[0]);
     if (rc != PSD_OK) return rc;
     HIP_TRY(hipEventRecord(e->ev_hash[1], e->stream));
     HIP_TRY(hipMemcpyAsync(h_thumbs, e->d_hash, (size_t)n * size * size, hipMemcpyDeviceToHost, e->stream));
@@ -852,6 +892,51 @@ int psd_upload(psd_engine* e, void* d_dst, const void* h_src, size_t bytes)
     // blocking for the CALLER only: no engine state is touched and the engine's stream is not waited for, so a decode
     // thread can fill one device batch while the engine scores another
     HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return PSD_OK;
+}
+
+int psd_resize_source_rows(int src_h, int src_w, int dst_h, int dst_w, int interpolation, int* rows, int* n_rows)
+{
+    if (src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0 || !rows || !n_rows) {
+        psd_set_error("psd_resize_source_rows: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    return psd::resize_source_rows(src_h, src_w, dst_h, dst_w, interpolation, rows, n_rows);
+}
+
+int psd_upload_rows_plan(const int* rows, int n_rows, int packed, int* copies, int max_copies, int* n_copies)
+{
+    if (n_rows < 0 || (n_rows && !rows) || !n_copies || max_copies < 0 || (max_copies && !copies) || !rows_ascending(rows, n_rows)) {
+        psd_set_error("psd_upload_rows_plan: invalid argument (rows must be ascending and >= 0)");
+        return PSD_ERR_INVALID;
+    }
+    const std::vector<RowCopy> plan = plan_row_copies(rows, n_rows, packed != 0);
+    *n_copies = (int)plan.size();
+    for (size_t i = 0; i < plan.size() && i < (size_t)max_copies; i++) {
+        copies[4 * i] = plan[i].first; copies[4 * i + 1] = plan[i].len; copies[4 * i + 2] = plan[i].step; copies[4 * i + 3] = plan[i].count;
+    }
+    return PSD_OK;
+}
+
+int psd_upload_rows(psd_engine* e, void* d_frame, const void* h_frame, size_t row_bytes, size_t h_row_stride,
+                    const int* rows, int n_rows)
+{
+    if (!e || n_rows < 0 || (n_rows && (!d_frame || !h_frame || !rows)) || row_bytes == 0 || h_row_stride < row_bytes) {
+        psd_set_error("psd_upload_rows: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    if (!rows_ascending(rows, n_rows)) { psd_set_error("psd_upload_rows: rows must be ascending and >= 0"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(e->device));
+    const bool packed = h_row_stride == row_bytes;
+    for (const RowCopy& c : plan_row_copies(rows, n_rows, packed)) {
+        const uint8_t* src = static_cast<const uint8_t*>(h_frame) + (size_t)c.first * h_row_stride;
+        uint8_t* dst = static_cast<uint8_t*>(d_frame) + (size_t)c.first * row_bytes;
+        if (c.count == 1)   // packed: one piece; otherwise the group is a single row
+            HIP_TRY(hipMemcpy(dst, src, (size_t)c.len * row_bytes, hipMemcpyHostToDevice));
+        else
+            HIP_TRY(hipMemcpy2D(dst, (size_t)c.step * row_bytes, src, (size_t)c.step * h_row_stride, (size_t)c.len * row_bytes, c.count,
+                                hipMemcpyHostToDevice));
+    }
     return PSD_OK;
 }
 

@@ -42,14 +42,6 @@ namespace psd {
 typedef uint32_t u32;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
-struct AreaRun {
-    int first;       // source index of the first contributing cell
-    int count;       // number of contributing cells (consecutive)
-    int has_head, has_tail;
-    float a_head, a_mid, a_tail;
-    int pad;
-};
-
 struct HashGeom {
     const uint8_t* frames;
     size_t frame_stride, row_stride;
@@ -303,41 +295,10 @@ __global__ __launch_bounds__(kHashWG) void gray_area_dma_kernel(const HashGeom g
 
 constexpr int kHashDmaG = 2;
 
-// computeResizeAreaTab in run-length form (double arithmetic on the host, like OpenCV)
-static void area_table(int ssize, int dsize, AreaRun* tab)
-{
-    const double scale = 1. / ((double)dsize / ssize);
-    for (int dx = 0; dx < dsize; dx++) {
-        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
-        const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
-        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
-        if (sx2 > ssize - 1) sx2 = ssize - 1;
-        if (sx1 > sx2) sx1 = sx2;
-        AreaRun r;
-        memset(&r, 0, sizeof r);
-        r.first = sx1;
-        if (sx1 - fsx1 > 1e-3) {
-            r.has_head = 1;
-            r.first = sx1 - 1;
-            r.a_head = (float)((sx1 - fsx1) / cell);
-            r.count++;
-        }
-        r.a_mid = (float)(1.0 / cell);
-        r.count += sx2 - sx1;
-        if (fsx2 - sx2 > 1e-3) {
-            double tl = fsx2 - sx2 < 1. ? fsx2 - sx2 : 1.;
-            if (tl > cell) tl = cell;
-            r.has_tail = 1;
-            r.a_tail = (float)(tl / cell);
-            r.count++;
-        }
-        tab[dx] = r;
-    }
-}
-
-// d_thumbs: device buffer of n*size*size bytes; d_tabs: device buffer of 2*size AreaRun.
-int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
-                int size, AreaRun* d_tabs, uint8_t* d_thumbs, hipStream_t stream, hipEvent_t ev_start)
+// d_thumbs: device buffer of n*size*size bytes.  The run tables of a (frame shape, size) pair are built once and stay in
+// the engine's table cache.
+int hash_thumbs(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
+                int size, uint8_t* d_thumbs, hipStream_t stream, hipEvent_t ev_start)
 {
     if (size > width || size > height) {
         psd_set_error("hash thumbnails: INTER_AREA is implemented for decimation only (%dx%d -> %dx%d)", width, height, size, size);
@@ -347,28 +308,20 @@ int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t ro
         psd_set_error("hash thumbnails: size*lowpass = %d exceeds %d", size, kHashWG);
         return PSD_ERR_UNSUPPORTED;
     }
-    const double scale_x = 1. / ((double)size / width), scale_y = 1. / ((double)size / height);
-    const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
-    const bool area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
-    std::vector<AreaRun> tabs(2 * (size_t)size);
+    DevTable tab;
+    if (!table_find(e, kTabHashArea, height, width, size, size, &tab)) {
+        std::vector<AreaRun> tabs(2 * (size_t)size);
+        int mode;
+        float inv_area;
+        area_tables(height, width, size, size, tabs.data(), &mode, &inv_area);
+        const int rc = table_store(e, kTabHashArea, height, width, size, size, tabs.data(), tabs.size() * sizeof(AreaRun), mode, inv_area, &tab);
+        if (rc != PSD_OK) return rc;
+    }
+    const AreaRun* d_tabs = static_cast<const AreaRun*>(tab.ptr);
     HashGeom g;
     memset(&g, 0, sizeof g);
-    if (area_fast) {
-        for (int i = 0; i < size; i++) {
-            AreaRun r;
-            memset(&r, 0, sizeof r);
-            r.first = i * iscale_x; r.count = iscale_x;
-            tabs[i] = r;
-            r.first = i * iscale_y; r.count = iscale_y;
-            tabs[size + i] = r;
-        }
-        g.mode = (iscale_x == 2 && iscale_y == 2) ? 2 : 1;
-        g.inv_area = 1.f / (float)(iscale_x * iscale_y);
-    } else {
-        area_table(width, size, tabs.data());
-        area_table(height, size, tabs.data() + size);
-        g.mode = 0;
-    }
+    g.mode = tab.mode;
+    g.inv_area = tab.inv_area;
     g.frames = d_frames; g.frame_stride = frame_stride; g.row_stride = row_stride;
     g.height = height; g.width = width; g.size = size;
     g.wpad = (width + 15) & ~15;
@@ -387,9 +340,6 @@ int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t ro
         return PSD_ERR_UNSUPPORTED;
     }
     g.rows_per_batch = R;
-    hipError_t err = hipMemcpyAsync(d_tabs, tabs.data(), tabs.size() * sizeof(AreaRun), hipMemcpyHostToDevice, stream);
-    if (err == hipSuccess) err = hipStreamSynchronize(stream);  // `tabs` is pageable and goes out of scope
-    if (err != hipSuccess) { psd_set_error("hash tables upload: %s", hipGetErrorString(err)); return PSD_ERR_HIP; }
     if (ev_start) (void)hipEventRecord(ev_start, stream);  // the timed region is the kernel launches only
     // grid.y is limited to 65535: split long batches
     for (int t0 = 0; t0 < n; t0 += 32768) {
@@ -402,11 +352,9 @@ int hash_thumbs(const uint8_t* d_frames, int n, int height, int width, size_t ro
         else if (fast) hipLaunchKernelGGL(gray_area_kernel<true>, grid, dim3(kHashWG), lds, stream, gg, d_tabs, d_tabs + size, out);
         else hipLaunchKernelGGL(gray_area_kernel<false>, grid, dim3(kHashWG), lds, stream, gg, d_tabs, d_tabs + size, out);
     }
-    err = hipGetLastError();
+    const hipError_t err = hipGetLastError();
     if (err != hipSuccess) { psd_set_error("gray_area_kernel launch: %s", hipGetErrorString(err)); return PSD_ERR_HIP; }
     return PSD_OK;
 }
-
-size_t hash_tab_bytes(int size) { return 2 * (size_t)size * sizeof(AreaRun); }
 
 }  // namespace psd

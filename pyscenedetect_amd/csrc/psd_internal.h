@@ -51,6 +51,31 @@ hipError_t launch_score_frames(ScoreParams p, bool hsv, bool luma, bool fast, in
 // V mode (ScoreParams::vout) needs the staged kernel and frames made of whole 16-pixel groups
 bool score_v_mode_available(long npix);
 
+// OpenCV's computeResizeAreaTab for one destination index in run-length form: `count` consecutive source cells from
+// `first`, the first / last of them with their own weight (hash thumbnails and cv2.resize(INTER_AREA) share it).
+struct AreaRun {
+    int first;       // source index of the first contributing cell
+    int count;       // number of contributing cells (consecutive)
+    int has_head, has_tail;
+    float a_head, a_mid, a_tail;
+    int pad;
+};
+void area_table(int ssize, int dsize, AreaRun* tab);   // double arithmetic on the host, like OpenCV
+// fills `tab[0 .. dst_w)` (x) and `tab[dst_w .. dst_w + dst_h)` (y); mode 0 = float run tables, 1 = integer box, 2 = 2x2 box
+void area_tables(int src_h, int src_w, int dst_h, int dst_w, AreaRun* tab, int* mode, float* inv_area);
+
+// Coefficient tables stay on the device for as long as the engine does, one per (kind, src shape, dst shape): built and
+// uploaded on the first call with a shape, found again afterwards (no allocation or synchronisation on the call path).
+enum TableKind { kTabNearest = 2, kTabArea = 3, kTabHashArea = 4 };
+struct DevTable {
+    const void* ptr = nullptr;
+    int mode = 0;
+    float inv_area = 0.f;
+};
+bool table_find(psd_engine* e, int kind, int sh, int sw, int dh, int dw, DevTable* out);
+int table_store(psd_engine* e, int kind, int sh, int sw, int dh, int dw, const void* host, size_t bytes, int mode, float inv_area,
+                DevTable* out);
+
 }  // namespace psd
 
 #endif

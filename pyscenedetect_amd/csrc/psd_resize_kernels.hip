@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <tuple>
 #include <vector>
@@ -61,7 +62,45 @@ struct ResizeTabs {
     bool area2 = false;  // exact 2x2 decimation: OpenCV routes INTER_LINEAR to INTER_AREA (rounded box mean)
 };
 
-typedef std::map<std::tuple<int, int, int, int, int>, ResizeTabs> ResizeCache;
+typedef std::tuple<int, int, int, int, int> ShapeKey;   // src h, w, dst h, w, kind
+struct OtherTab { void* d; int mode; float inv_area; };
+struct ResizeCache {
+    std::map<ShapeKey, ResizeTabs> linear;   // INTER_LINEAR taps (kind 0; 1 = the INTER_AREA enlargement coefficients)
+    std::map<ShapeKey, OtherTab> other;      // TableKind tables: INTER_NEAREST offsets, INTER_AREA runs, hash thumbnail runs
+};
+
+static ResizeCache& cache_of(psd_engine* e)
+{
+    void** slot = engine_resize_cache(e);
+    if (!*slot) *slot = new ResizeCache();
+    return *static_cast<ResizeCache*>(*slot);
+}
+
+bool table_find(psd_engine* e, int kind, int sh, int sw, int dh, int dw, DevTable* out)
+{
+    ResizeCache& c = cache_of(e);
+    auto it = c.other.find(std::make_tuple(sh, sw, dh, dw, kind));
+    if (it == c.other.end()) return false;
+    out->ptr = it->second.d; out->mode = it->second.mode; out->inv_area = it->second.inv_area;
+    return true;
+}
+
+int table_store(psd_engine* e, int kind, int sh, int sw, int dh, int dw, const void* host, size_t bytes, int mode, float inv_area,
+                DevTable* out)
+{
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    // once per shape: a synchronous copy (the host table dies with the caller)
+    hipError_t err = hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        (void)hipFree(d);
+        psd_set_error("coefficient table upload failed: %s", hipGetErrorString(err));
+        return PSD_ERR_HIP;
+    }
+    cache_of(e).other[std::make_tuple(sh, sw, dh, dw, kind)] = OtherTab{d, mode, inv_area};
+    out->ptr = d; out->mode = mode; out->inv_area = inv_area;
+    return PSD_OK;
+}
 
 static short sat_s16_round(float v)
 {
@@ -73,22 +112,15 @@ static short sat_s16_round(float v)
 // area_mode: cv2.resize(INTER_AREA) that does not shrink along both axes -- OpenCV emulates it with the bilinear passes and
 // other coefficients (resize.cpp: sx = cvFloor(dx * scale_x), fx = (dx + 1) - (sx + 1) * inv_scale_x, 0 if <= 0 else its
 // fractional part); the kernels are the INTER_LINEAR ones.
-static int get_tabs(psd_engine* e, int sh, int sw, int dh, int dw, hipStream_t stream, ResizeTabs* out, bool area_mode = false)
+static void linear_tabs_host(int sh, int sw, int dh, int dw, bool area_mode, std::vector<XTap>& xt, std::vector<YTap>& yt, bool* area2)
 {
-    void** slot = engine_resize_cache(e);
-    if (!*slot) *slot = new ResizeCache();
-    ResizeCache& cache = *static_cast<ResizeCache*>(*slot);
-    const auto key = std::make_tuple(sh, sw, dh, dw, area_mode ? 1 : 0);
-    auto it = cache.find(key);
-    if (it != cache.end()) { *out = it->second; return PSD_OK; }
     const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
     const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
     const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
-    ResizeTabs t;
-    t.area2 = !area_mode && fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16 &&
-              iscale_x == 2 && iscale_y == 2;
-    std::vector<XTap> xt(dw);
-    std::vector<YTap> yt(dh);
+    *area2 = !area_mode && fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16 &&
+             iscale_x == 2 && iscale_y == 2;
+    xt.resize(dw);
+    yt.resize(dh);
     for (int dx = 0; dx < dw; dx++) {
         float fx;
         int sx;
@@ -125,6 +157,18 @@ static int get_tabs(psd_engine* e, int sh, int sw, int dh, int dw, hipStream_t s
         yt[dy].s1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
         yt[dy].b = (int)((u32)(uint16_t)b0 | ((u32)(uint16_t)b1 << 16));
     }
+}
+
+static int get_tabs(psd_engine* e, int sh, int sw, int dh, int dw, hipStream_t stream, ResizeTabs* out, bool area_mode = false)
+{
+    std::map<ShapeKey, ResizeTabs>& cache = cache_of(e).linear;
+    const auto key = std::make_tuple(sh, sw, dh, dw, area_mode ? 1 : 0);
+    auto it = cache.find(key);
+    if (it != cache.end()) { *out = it->second; return PSD_OK; }
+    ResizeTabs t;
+    std::vector<XTap> xt;
+    std::vector<YTap> yt;
+    linear_tabs_host(sh, sw, dh, dw, area_mode, xt, yt, &t.area2);
     uint8_t* d = nullptr;
     const size_t xb = (sizeof(XTap) * dw + 255) & ~(size_t)255;
     HIP_TRY(hipMalloc((void**)&d, xb + sizeof(YTap) * dh));
@@ -144,8 +188,10 @@ void resize_release(psd_engine* e)
     void** slot = engine_resize_cache(e);
     if (!*slot) return;
     ResizeCache* cache = static_cast<ResizeCache*>(*slot);
-    for (auto& kv : *cache)
+    for (auto& kv : cache->linear)
         if (kv.second.x) (void)hipFree(kv.second.x);
+    for (auto& kv : cache->other)
+        if (kv.second.d) (void)hipFree(kv.second.d);
     delete cache;
     *slot = nullptr;
 }
@@ -490,6 +536,200 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     else launch_walk<true, false>(p, g, grid, lds, stream);
     HIP_TRY(hipGetLastError());
     if (launches) *launches += 1;
+    return PSD_OK;
+}
+
+// ---- cv2.resize(INTER_NEAREST) and cv2.resize(INTER_AREA), 8-bit, 3 channels ---------------------------------------
+// The other two `Interpolation` modes SceneManager can be asked to downscale with (reference common.py:148-160,
+// scene_manager.py:670-678).  One destination pixel per thread, 256-thread workgroups over the flattened small frame;
+// offsets / run tables per (src, dst) shape come from the engine's table cache like the bilinear taps.
+
+constexpr int kOtherWG = 256;
+
+__global__ __launch_bounds__(kOtherWG) void resize_nearest_kernel(const uint8_t* src, int sw, size_t sstride, uint8_t* dst, int dh, int dw,
+                                                                  size_t dstride, const int* xofs, const int* yofs)
+{
+    const int p = blockIdx.x * kOtherWG + threadIdx.x;
+    if (p >= dh * dw) return;
+    const int dy = p / dw, dx = p - dy * dw;
+    const uint8_t* q = src + (size_t)blockIdx.y * sstride + ((size_t)yofs[dy] * sw + xofs[dx]) * 3;
+    uint8_t* D = dst + (size_t)blockIdx.y * dstride + (size_t)p * 3;
+    D[0] = q[0]; D[1] = q[1]; D[2] = q[2];
+}
+
+// mode 0: float run tables (ResizeArea_<uchar,float> accumulation order: left to right within a source row, rows
+// top to bottom, every product and sum rounded separately); mode 1: integer box * (1.f/area); mode 2: 2x2 rounding shift
+__global__ __launch_bounds__(kOtherWG) void resize_area_kernel(const uint8_t* src, int sw, size_t sstride, uint8_t* dst, int dh, int dw,
+                                                               size_t dstride, const AreaRun* xtab, const AreaRun* ytab, int mode,
+                                                               float inv_area)
+{
+    const int p = blockIdx.x * kOtherWG + threadIdx.x;
+    if (p >= dh * dw) return;
+    const int dy = p / dw, dx = p - dy * dw;
+    const uint8_t* S = src + (size_t)blockIdx.y * sstride;
+    uint8_t* D = dst + (size_t)blockIdx.y * dstride + (size_t)p * 3;
+    const AreaRun xr = xtab[dx], yr = ytab[dy];
+    if (mode == 0) {
+        float sum[3] = {0.f, 0.f, 0.f};
+        for (int j = 0; j < yr.count; j++) {
+            const uint8_t* row = S + ((size_t)(yr.first + j) * sw + xr.first) * 3;
+            const float beta = (j == 0 && yr.has_head) ? yr.a_head : (j == yr.count - 1 && yr.has_tail) ? yr.a_tail : yr.a_mid;
+            float acc[3] = {0.f, 0.f, 0.f};
+            for (int k = 0; k < xr.count; k++) {
+                const float a = (k == 0 && xr.has_head) ? xr.a_head : (k == xr.count - 1 && xr.has_tail) ? xr.a_tail : xr.a_mid;
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc[c] = __fadd_rn(acc[c], __fmul_rn((float)row[3 * k + c], a));
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float term = __fmul_rn(beta, acc[c]);
+                sum[c] = j == 0 ? term : __fadd_rn(sum[c], term);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) D[c] = (uint8_t)min(255, max(0, __float2int_rn(sum[c])));
+    } else {
+        int sum[3] = {0, 0, 0};
+        for (int j = 0; j < yr.count; j++) {
+            const uint8_t* row = S + ((size_t)(yr.first + j) * sw + xr.first) * 3;
+            for (int k = 0; k < xr.count; k++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) sum[c] += row[3 * k + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            D[c] = mode == 2 ? (uint8_t)((sum[c] + 2) >> 2) : (uint8_t)min(255, max(0, __float2int_rn(__fmul_rn((float)sum[c], inv_area))));
+    }
+}
+
+void area_table(int ssize, int dsize, AreaRun* tab)
+{
+    const double scale = 1. / ((double)dsize / ssize);
+    for (int dx = 0; dx < dsize; dx++) {
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        if (sx2 > ssize - 1) sx2 = ssize - 1;
+        if (sx1 > sx2) sx1 = sx2;
+        AreaRun r;
+        memset(&r, 0, sizeof r);
+        r.first = sx1;
+        if (sx1 - fsx1 > 1e-3) { r.has_head = 1; r.first = sx1 - 1; r.a_head = (float)((sx1 - fsx1) / cell); r.count++; }
+        r.a_mid = (float)(1.0 / cell);
+        r.count += sx2 - sx1;
+        if (fsx2 - sx2 > 1e-3) {
+            double tl = fsx2 - sx2 < 1. ? fsx2 - sx2 : 1.;
+            if (tl > cell) tl = cell;
+            r.has_tail = 1; r.a_tail = (float)(tl / cell); r.count++;
+        }
+        tab[dx] = r;
+    }
+}
+
+void area_tables(int src_h, int src_w, int dst_h, int dst_w, AreaRun* tab, int* mode, float* inv_area)
+{
+    const double scale_x = 1. / ((double)dst_w / src_w), scale_y = 1. / ((double)dst_h / src_h);
+    const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);
+    const bool area_fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+    *mode = 0;
+    *inv_area = 0.f;
+    if (area_fast) {   // whole boxes: integer sums (OpenCV's ResizeAreaFast)
+        AreaRun r;
+        memset(&r, 0, sizeof r);
+        for (int x = 0; x < dst_w; x++) { r.first = x * iscale_x; r.count = iscale_x; tab[x] = r; }
+        for (int y = 0; y < dst_h; y++) { r.first = y * iscale_y; r.count = iscale_y; tab[dst_w + y] = r; }
+        *mode = (iscale_x == 2 && iscale_y == 2) ? 2 : 1;
+        *inv_area = 1.f / (float)(iscale_x * iscale_y);
+    } else {
+        area_table(src_w, dst_w, tab);
+        area_table(src_h, dst_h, tab + dst_w);
+    }
+}
+
+static void nearest_offsets(int src_h, int src_w, int dst_h, int dst_w, int* ofs)
+{
+    const double scale_x = 1. / ((double)dst_w / src_w), scale_y = 1. / ((double)dst_h / src_h);
+    for (int x = 0; x < dst_w; x++) ofs[x] = std::min((int)floor(x * scale_x), src_w - 1);
+    for (int y = 0; y < dst_h; y++) ofs[dst_w + y] = std::min((int)floor(y * scale_y), src_h - 1);
+}
+
+// interpolation: 0 = INTER_NEAREST, 3 = INTER_AREA that shrinks along both axes (cv2's values)
+int resize_other(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
+                 int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream)
+{
+    if (n == 0) return PSD_OK;
+    if (interpolation != PSD_INTER_NEAREST && interpolation != PSD_INTER_AREA) {
+        psd_set_error("interpolation %d is not implemented on the device (0 = NEAREST, 1 = LINEAR, 3 = AREA)", interpolation);
+        return PSD_ERR_UNSUPPORTED;
+    }
+    if (interpolation == PSD_INTER_AREA && (dst_w > src_w || dst_h > src_h)) {
+        psd_set_error("INTER_AREA run tables are for decimation (%dx%d -> %dx%d)", src_w, src_h, dst_w, dst_h);
+        return PSD_ERR_UNSUPPORTED;
+    }
+    const int kind = interpolation == PSD_INTER_NEAREST ? kTabNearest : kTabArea;
+    DevTable tab;
+    if (!table_find(e, kind, src_h, src_w, dst_h, dst_w, &tab)) {
+        int rc;
+        if (kind == kTabNearest) {
+            std::vector<int> ofs((size_t)dst_w + dst_h);
+            nearest_offsets(src_h, src_w, dst_h, dst_w, ofs.data());
+            rc = table_store(e, kind, src_h, src_w, dst_h, dst_w, ofs.data(), ofs.size() * sizeof(int), 0, 0.f, &tab);
+        } else {
+            std::vector<AreaRun> t((size_t)dst_w + dst_h);
+            int mode;
+            float inv_area;
+            area_tables(src_h, src_w, dst_h, dst_w, t.data(), &mode, &inv_area);
+            rc = table_store(e, kind, src_h, src_w, dst_h, dst_w, t.data(), t.size() * sizeof(AreaRun), mode, inv_area, &tab);
+        }
+        if (rc != PSD_OK) return rc;
+    }
+    const int blocks = (int)(((long)dst_h * dst_w + kOtherWG - 1) / kOtherWG);
+    for (int t0 = 0; t0 < n; t0 += 32768) {   // grid.y is limited to 65535
+        const int cnt = n - t0 < 32768 ? n - t0 : 32768;
+        const uint8_t* S = d_src + (size_t)t0 * src_frame_stride;
+        uint8_t* D = d_dst + (size_t)t0 * dst_frame_stride;
+        if (kind == kTabNearest)
+            hipLaunchKernelGGL(resize_nearest_kernel, dim3(blocks, cnt), dim3(kOtherWG), 0, stream, S, src_w, src_frame_stride, D, dst_h,
+                               dst_w, dst_frame_stride, (const int*)tab.ptr, (const int*)tab.ptr + dst_w);
+        else
+            hipLaunchKernelGGL(resize_area_kernel, dim3(blocks, cnt), dim3(kOtherWG), 0, stream, S, src_w, src_frame_stride, D, dst_h, dst_w,
+                               dst_frame_stride, (const AreaRun*)tab.ptr, (const AreaRun*)tab.ptr + dst_w, tab.mode, tab.inv_area);
+    }
+    HIP_TRY(hipGetLastError());
+    return PSD_OK;
+}
+
+// The source rows a downscale reads, ascending (psd_resize_source_rows): what a host feeder has to upload.
+int resize_source_rows(int src_h, int src_w, int dst_h, int dst_w, int interpolation, int* rows, int* n_rows)
+{
+    std::vector<uint8_t> used((size_t)src_h, 0);
+    const bool area_up = interpolation == PSD_INTER_AREA && (dst_w > src_w || dst_h > src_h);
+    if (interpolation == PSD_INTER_LINEAR || area_up) {
+        std::vector<XTap> xt;
+        std::vector<YTap> yt;
+        bool area2;
+        linear_tabs_host(src_h, src_w, dst_h, dst_w, area_up, xt, yt, &area2);
+        if (area2) std::fill(used.begin(), used.end(), 1);   // the exact 2x2 decimation averages every row
+        else for (int dy = 0; dy < dst_h; dy++) { used[yt[dy].s0] = 1; used[yt[dy].s1] = 1; }
+    } else if (interpolation == PSD_INTER_NEAREST) {
+        std::vector<int> ofs((size_t)dst_w + dst_h);
+        nearest_offsets(src_h, src_w, dst_h, dst_w, ofs.data());
+        for (int dy = 0; dy < dst_h; dy++) used[ofs[dst_w + dy]] = 1;
+    } else if (interpolation == PSD_INTER_AREA) {
+        std::vector<AreaRun> t((size_t)dst_w + dst_h);
+        int mode;
+        float inv_area;
+        area_tables(src_h, src_w, dst_h, dst_w, t.data(), &mode, &inv_area);
+        for (int dy = 0; dy < dst_h; dy++)
+            for (int j = 0; j < t[dst_w + dy].count; j++) used[std::min(src_h - 1, t[dst_w + dy].first + j)] = 1;
+    } else {
+        psd_set_error("interpolation %d is not implemented on the device (0 = NEAREST, 1 = LINEAR, 3 = AREA)", interpolation);
+        return PSD_ERR_UNSUPPORTED;
+    }
+    int k = 0;
+    for (int y = 0; y < src_h; y++)
+        if (used[y]) rows[k++] = y;
+    *n_rows = k;
     return PSD_OK;
 }
 

@@ -51,6 +51,19 @@ class DeviceBuffer:
             raise ValueError("upload out of range")
         _native.check(self._engine._lib.psd_upload(self._engine._h, self.ptr + offset, host.ctypes.data, host.nbytes))
 
+    def upload_rows(self, frame: np.ndarray, offset: int, rows: np.ndarray) -> None:
+        """``upload_unordered`` for a frame uint8[H,W,3] of which only ``rows`` (ascending int32, from
+        ``ScoringEngine.downscale_source_rows``) are needed: they go to the same rows of the packed frame at ``offset``; the
+        rows in between keep what the buffer held (``psd_upload_rows``)."""
+        if frame.dtype != np.uint8 or frame.ndim != 3 or frame.strides[2] != 1 or frame.strides[1] != frame.shape[2]:
+            frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        h, w, c = frame.shape
+        row_bytes = w * c
+        if offset + h * row_bytes > self.nbytes or (len(rows) and int(rows[-1]) >= h):
+            raise ValueError("upload out of range")
+        _native.check(self._engine._lib.psd_upload_rows(self._engine._h, self.ptr + offset, frame.ctypes.data, row_bytes,
+                                                        frame.strides[0], rows.ctypes.data, len(rows)))
+
     def download(self, nbytes: int | None = None, offset: int = 0) -> np.ndarray:
         nbytes = self.nbytes - offset if nbytes is None else nbytes
         out = np.empty(nbytes, np.uint8)
@@ -248,6 +261,26 @@ class ScoringEngine:
     def synchronize(self) -> None:
         """Wait until the engine's stream is idle."""
         _native.check(self._lib.psd_synchronize(self._h))
+
+    def downscale_source_rows(self, height: int, width: int, dst_h: int, dst_w: int, interpolation: int = 1) -> np.ndarray:
+        """The source rows the device downscale of this shape and mode reads (ascending int32): all a host feeder has to
+        upload when every consumer sees the downscaled frame (``psd_resize_source_rows``)."""
+        rows = np.empty(height, np.int32)
+        n = ctypes.c_int(0)
+        _native.check(self._lib.psd_resize_source_rows(int(height), int(width), int(dst_h), int(dst_w), int(interpolation),
+                                                       rows.ctypes.data, ctypes.addressof(n)))
+        return rows[: n.value].copy()
+
+    def upload_rows_plan(self, rows: np.ndarray, packed: bool = True) -> np.ndarray:
+        """The strided copies ``DeviceBuffer.upload_rows`` issues for ``rows``: int32[k,4] of (first row, rows per group,
+        distance between groups, groups) -- ``psd_upload_rows_plan``."""
+        rows = np.ascontiguousarray(rows, np.int32)
+        n = ctypes.c_int(0)
+        _native.check(self._lib.psd_upload_rows_plan(rows.ctypes.data, len(rows), int(packed), None, 0, ctypes.addressof(n)))
+        plan = np.zeros((n.value, 4), np.int32)
+        _native.check(self._lib.psd_upload_rows_plan(rows.ctypes.data, len(rows), int(packed), plan.ctypes.data, n.value,
+                                                     ctypes.addressof(n)))
+        return plan
 
     def analyze_device(self, d_frames: int, n: int, height: int, width: int, frame_stride: int, d_prev: int | None = None,
                        flags: int = 0, edge_kernels=(0,), downscale: float = 1.0, hash_sizes=(), interpolation: int = 1,

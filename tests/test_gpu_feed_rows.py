@@ -1,0 +1,208 @@
+"""GPU: frames of which only the rows a downscale reads were uploaded (``psd_upload_rows``, ABI 4) give the records,
+thumbnails and small frames of fully uploaded ones -- through the C-ABI, against the oracle on the small shapes and
+against the full upload at 1080p / 4K (reference scene_manager.py:666-678: every consumer sees the resized frame)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import pyscenedetect_amd as psd
+from pyscenedetect_amd import _native
+from pyscenedetect_amd import engine as E
+from tests.conftest import golden_clip
+
+pytestmark = pytest.mark.gpu
+
+NEAREST, LINEAR = 0, 1
+
+
+def _poisoned(engine, nbytes):
+    buf = engine.alloc(nbytes)
+    buf.upload(np.full(nbytes, 0xA5, np.uint8))
+    return buf
+
+
+def _analyze(engine, buf, n, h, w, factor, interp, flags, hash_sizes=()):
+    return engine.analyze_device(buf.ptr, n, h, w, h * w * 3, flags=flags, downscale=factor, interpolation=interp,
+                                 hash_sizes=hash_sizes, want_frames=True)
+
+
+@pytest.mark.parametrize("interp", [LINEAR, NEAREST])
+@pytest.mark.parametrize("h,w,factor,n", [(1080, 1920, 7.5, 6), (1080, 1920, 7.0, 2), (2160, 3840, 15.0, 3), (270, 480, 3.0, 9), (97, 131, 3.0, 5),
+                                          (720, 1280, 5.0, 4)])
+def test_tap_rows_only_equal_the_full_upload(hip_engine, oracle_engine, h, w, factor, n, interp):
+    rng = np.random.default_rng(h + w + interp)
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    frames[n // 2:, : h // 3] //= 4
+    dw, dh = max(1, round(w / factor)), max(1, round(h / factor))
+    rows = hip_engine.downscale_source_rows(h, w, dh, dw, interp)
+    assert len(rows) <= 2 * dh < 0.7 * h
+    stride = h * w * 3
+    sparse, full = _poisoned(hip_engine, n * stride), hip_engine.alloc(n * stride)
+    for t in range(n):
+        sparse.upload_rows(frames[t], t * stride, rows)
+    full.upload(frames.reshape(-1))
+    # the rows in between really were left alone
+    back = sparse.download(stride).reshape(h, w * 3)
+    listed = np.zeros(h, bool)
+    listed[rows] = True
+    assert np.array_equal(back[listed], frames[0].reshape(h, w * 3)[listed]) and np.all(back[~listed] == 0xA5)
+    flags = E.SCORE_HSV_SAD | E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM | (E.SCORE_EDGES if h <= 1080 else 0)
+    a = _analyze(hip_engine, sparse, n, h, w, factor, interp, flags, hash_sizes=(32,) if min(dh, dw) >= 32 else ())
+    b = _analyze(hip_engine, full, n, h, w, factor, interp, flags, hash_sizes=(32,) if min(dh, dw) >= 32 else ())
+    assert a["size"] == b["size"] == (dh, dw)
+    assert a["records"].tobytes() == b["records"].tobytes()
+    assert np.array_equal(a["frames"], b["frames"])
+    for size in b["thumbs"]:
+        assert np.array_equal(a["thumbs"][size], b["thumbs"][size])
+    # the fused downscale + HSV kernel (no small frame in memory) reads the same rows
+    fa = hip_engine.analyze_device(sparse.ptr, n, h, w, stride, flags=E.SCORE_HSV_SAD, downscale=factor, interpolation=interp)
+    fb = hip_engine.analyze_device(full.ptr, n, h, w, stride, flags=E.SCORE_HSV_SAD, downscale=factor, interpolation=interp)
+    assert fa["records"].tobytes() == fb["records"].tobytes()
+    if h * w <= 270 * 480:      # and both are what the oracle computes from the whole frames
+        want = oracle_engine.score_host(frames, flags=flags, downscale=factor, interpolation=interp)
+        for key in ("sad_h", "sad_s", "sad_v", "byte_sum", "edge_xor", "hist"):
+            assert np.array_equal(a["records"][key], want[key]), key
+        assert np.array_equal(a["frames"], oracle_engine.downscale_host(frames, factor, interp))
+    sparse.free()
+    full.free()
+
+
+def test_rows_of_a_strided_host_frame(hip_engine):
+    """A cropped view (row pitch > row bytes) goes row by row; single rows, row pairs and a lone tail row."""
+    h, w = 64, 48
+    rng = np.random.default_rng(5)
+    wide = rng.integers(0, 256, (h, w + 16, 3), dtype=np.uint8)
+    view = wide[:, 8: 8 + w]
+    rows = np.array([0, 1, 5, 6, 10, 11, 12, 30, 63], np.int32)
+    buf = _poisoned(hip_engine, h * w * 3)
+    _native.check(hip_engine._lib.psd_upload_rows(hip_engine._h, buf.ptr, view.ctypes.data, w * 3, view.strides[0],
+                                                  rows.ctypes.data, len(rows)))
+    back = buf.download().reshape(h, w * 3)
+    listed = np.zeros(h, bool)
+    listed[rows] = True
+    assert np.array_equal(back[listed], np.ascontiguousarray(view).reshape(h, w * 3)[listed]) and np.all(back[~listed] == 0xA5)
+    # the same list from a packed frame: consecutive rows travel as one piece, equally spaced groups as one strided copy
+    buf2 = _poisoned(hip_engine, h * w * 3)
+    buf2.upload_rows(np.ascontiguousarray(view), 0, rows)
+    assert np.array_equal(buf2.download(), buf.download())
+    # errors: descending rows, rows beyond the frame (checked by the Python face), a pitch below the row length
+    bad = np.array([3, 2], np.int32)
+    assert hip_engine._lib.psd_upload_rows(hip_engine._h, buf.ptr, view.ctypes.data, w * 3, view.strides[0], bad.ctypes.data, 2) \
+        == _native.PSD_ERR_INVALID
+    assert hip_engine._lib.psd_upload_rows(hip_engine._h, buf.ptr, view.ctypes.data, w * 3, w * 3 - 1, rows.ctypes.data, 2) \
+        == _native.PSD_ERR_INVALID
+    with pytest.raises(ValueError):
+        buf.upload_rows(np.ascontiguousarray(view), 0, np.array([64], np.int32))
+    buf.free()
+    buf2.free()
+
+
+def _run_downscaled(engine, frames, factor, interpolation, detector):
+    stats = psd.StatsManager()
+    sm = psd.SceneManager(stats, engine=engine, batch_frames=16)
+    sm.auto_downscale = False
+    sm.downscale = factor
+    sm.interpolation = interpolation
+    sm.add_detector(detector)
+    shown = []
+    sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), callback=lambda img, pos: shown.append((pos.frame_num, int(img.sum()))))
+    metrics = [[stats.get_metrics(i, [k])[0] if stats.metrics_exist(i, [k]) else None for k in detector.get_metrics()]
+               for i in range(len(frames))]
+    return [c.frame_num for c in sm.get_cut_list()], metrics, shown
+
+
+@pytest.mark.parametrize("interpolation", ["LINEAR", "NEAREST"])
+def test_scene_manager_feeds_tap_rows_and_decides_like_the_oracle(golden, hip_engine, oracle_engine, interpolation):
+    """SceneManager over the device feeder (tap rows only: 36 of 72 rows at factor 4) == the same manager over the oracle
+    engine (whole frames, CPU): cuts, every frame metric, the frames handed to the callback."""
+    from pyscenedetect_amd import scene_manager as smod
+
+    frames = golden_clip(golden, "scenes_a")
+    mode = psd.Interpolation[interpolation]
+    seen = []
+    original = smod._DeviceFeeder.put
+
+    def spy(self, slot, index, frame):
+        seen.append(0 if slot["rows"] is None else len(slot["rows"]))
+        return original(self, slot, index, frame)
+
+    smod._DeviceFeeder.put = spy
+    try:
+        got = _run_downscaled(hip_engine, frames, 4, mode, psd.ContentDetector(engine=hip_engine))
+        got_a = _run_downscaled(hip_engine, frames, 4, mode, psd.AdaptiveDetector(engine=hip_engine))
+    finally:
+        smod._DeviceFeeder.put = original
+    assert seen == [36 if interpolation == "LINEAR" else 18] * (2 * len(frames))
+    want = _run_downscaled(oracle_engine, frames, 4, mode, psd.ContentDetector(engine=oracle_engine))
+    want_a = _run_downscaled(oracle_engine, frames, 4, mode, psd.AdaptiveDetector(engine=oracle_engine))
+    assert got == want and len(got[0]) > 0
+    assert got_a == want_a
+
+
+def test_default_pipeline_at_1080p_takes_the_row_path(hip_engine):
+    """auto_downscale at 1080p: factor 7.5 -> 256 x 144, 288 of 1080 rows in two strided copies per frame; same cuts as with
+    whole-frame uploads."""
+    from pyscenedetect_amd import scene_manager as smod
+    from pyscenedetect_amd.synth import make_clip
+
+    clip, true_cuts = make_clip(11, 48, 1080, 1920, shot_len=(10, 14))
+    rows = hip_engine.downscale_source_rows(1080, 1920, 144, 256, LINEAR)
+    assert len(rows) == 288 and hip_engine.upload_rows_plan(rows).tolist() == [[3, 2, 15, 72], [10, 2, 15, 72]]
+    seen = []
+    original = smod._DeviceFeeder.put
+
+    def spy(self, slot, index, frame):
+        seen.append(0 if slot["rows"] is None else len(slot["rows"]))
+        return original(self, slot, index, frame)
+
+    def run():
+        sm = psd.SceneManager(engine=hip_engine, batch_frames=16)
+        sm.add_detector(psd.ContentDetector(min_scene_len=4, engine=hip_engine))
+        sm.detect_scenes(psd.ArrayVideoStream(clip, 25.0))
+        return [c.frame_num for c in sm.get_cut_list()]
+
+    smod._DeviceFeeder.put = spy
+    keep = smod._DeviceFeeder.ROWS_ONLY_BELOW
+    try:
+        got = run()
+        smod._DeviceFeeder.ROWS_ONLY_BELOW = 0.0      # whole frames
+        full = run()
+    finally:
+        smod._DeviceFeeder.put = original
+        smod._DeviceFeeder.ROWS_ONLY_BELOW = keep
+    assert seen == [288] * 48 + [0] * 48
+    assert got == full and len(got) >= 2 and set(got) <= set(true_cuts)
+
+
+def test_table_cache_across_shapes_modes_and_engines(hip_engine):
+    """NEAREST / AREA / hash-thumbnail tables are built once per (mode, shapes) and kept by the engine: interleaved shapes and
+    a second engine give what a fresh call gives."""
+    import cv2  # the oracle shim
+
+    rng = np.random.default_rng(9)
+    cases = [((90, 120), (30, 40)), ((97, 131), (41, 77)), ((90, 120), (45, 60))]
+    srcs = {c: rng.integers(0, 256, (2, c[0][0], c[0][1], 3), dtype=np.uint8) for c in cases}
+    other = E.ScoringEngine(0)
+    try:
+        for rnd in range(3):
+            for eng in (hip_engine, other):
+                for c in cases:
+                    (sh, sw), (dh, dw) = c
+                    a = eng.alloc(srcs[c].nbytes)
+                    a.upload(srcs[c].reshape(-1))
+                    b = eng.alloc(2 * dh * dw * 3)
+                    for inter in (cv2.INTER_NEAREST, cv2.INTER_AREA):
+                        eng.resize_device(a.ptr, 2, sh, sw, b.ptr, dh, dw, interpolation=inter)
+                        got = b.download().reshape(2, dh, dw, 3)
+                        for i in range(2):
+                            assert np.array_equal(got[i], cv2.resize(srcs[c][i], (dw, dh), interpolation=inter)), (rnd, c, inter)
+                    for size in (16, 24):
+                        thumbs = eng.hash_thumbs_device(a.ptr, 2, sh, sw, size)
+                        for i in range(2):
+                            gray = cv2.cvtColor(srcs[c][i], cv2.COLOR_BGR2GRAY)
+                            assert np.array_equal(thumbs[i], cv2.resize(gray, (size, size), interpolation=cv2.INTER_AREA)), (rnd, c, size)
+                    a.free()
+                    b.free()
+    finally:
+        other.close()

@@ -43,6 +43,20 @@ dt = best_of(up_async)
 out["upload_async_pinned_GBps"] = round(hf.nbytes / dt / 1e9, 2)
 dt = best_of(lambda: buf.upload_unordered(hf.reshape(-1)))
 out["upload_blocking_pageable_GBps"] = round(hf.nbytes / dt / 1e9, 2)
+# the default pipeline's upload: 288 of 1080 rows (1080p -> 256 x 144), two strided copies per frame (psd_upload_rows)
+rows = eng.downscale_source_rows(H, W, 144, 256, 1)
+out["tap_rows_per_frame"] = int(len(rows))
+out["tap_row_copies_per_frame"] = int(len(eng.upload_rows_plan(rows)))
+for src_name, src in (("pageable", hf), ("pinned", pinned)):
+    def up_rows():
+        for t in range(N):
+            buf.upload_rows(src[t], t * H * W * 3, rows)
+    out[f"upload_tap_rows_{src_name}_fps"] = round(N / best_of(up_rows), 1)
+
+    def up_whole():
+        for t in range(N):
+            buf.upload_unordered(src[t].reshape(-1), t * H * W * 3)
+    out[f"upload_whole_frames_{src_name}_fps"] = round(N / best_of(up_whole), 1)
 for src_name, src in (("pageable", hf), ("pinned", pinned)):
     for name, auto in (("full_res", False), ("auto_downscale", True)):
         def run():
@@ -50,5 +64,5 @@ for src_name, src in (("pageable", hf), ("pinned", pinned)):
             sm.auto_downscale = auto
             sm.add_detector(psd.ContentDetector(engine=eng))
             sm.detect_scenes(psd.ArrayVideoStream(src, 25.0))
-        out[f"scene_manager_1080p_{name}_{src_name}_fps"] = round(N / best_of(run, 2), 1)
+        out[f"scene_manager_1080p_{name}_{src_name}_fps"] = round(N / best_of(run, 3), 1)
 print(json.dumps(out))
