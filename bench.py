@@ -355,6 +355,53 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
         torch.cuda.empty_cache()
         return {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "cuts_found", "ground_truth", "parity_sample", "cpu_baseline")} | \
             {"frames_1080p_equivalent_per_s": r["config"]["frames_1080p_equivalent_per_s"], "frames_total": r["config"]["frames_total"]}
+    def run_host_fed():
+        # PCIe-inclusive and never `value`: SceneManager.detect_scenes over frames in pageable host memory, the reference's
+        # default pipeline (auto downscale to 256 wide, ContentDetector).  The decode thread uploads only the rows the
+        # downscale reads (psd_upload_rows) while the previous batch is scored.
+        import pyscenedetect_amd as psd
+        from pyscenedetect_amd.scene_manager import compute_downscale_factor
+
+        b = make_batch(384, "S", 20250921, device, h, w)
+        host = b.cpu().numpy()
+        del b
+        factor = compute_downscale_factor(w)
+        dw, dh = max(1, round(w / factor)), max(1, round(h / factor))
+        rows = eng.downscale_source_rows(h, w, dh, dw, 1)
+
+        def run(engine, frames):
+            stats = psd.StatsManager()
+            sm = psd.SceneManager(stats, engine=engine)
+            sm.add_detector(psd.ContentDetector(engine=engine))
+            sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+            vals = [stats.get_metrics(i, ["content_val"])[0] for i in range(1, len(frames))]
+            return [c.frame_num for c in sm.get_cut_list()], vals
+
+        run(eng, host[:64])
+        best, cuts = 1e9, None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            cuts, _vals = run(eng, host)
+            best = min(best, time.perf_counter() - t0)
+        r = {"value": round(len(host) / best, 1), "unit": "frames/s", "pcie_inclusive": True, "frames": len(host),
+             "source_rows_uploaded_per_frame": int(len(rows)), "source_rows_per_frame": h,
+             "strided_copies_per_frame": int(len(eng.upload_rows_plan(rows))), "cuts_found": len(cuts),
+             "host_to_device_GBps": round(len(rows) * w * 3 * len(host) / best / 1e9, 2)}
+        try:
+            from oracle.detectors_np import OracleEngine
+
+            shim = os.path.join(ROOT, "oracle", "cv2_shim")
+            if shim not in sys.path:
+                sys.path.append(shim)
+            k = 48
+            same = run(eng, host[:k]) == run(OracleEngine(), host[:k])
+            r["parity_sample"] = ("cuts and content_val of the first %d frames identical to the oracle engine behind the same SceneManager" % k
+                                  if same else "MISMATCH vs the oracle engine (first %d frames)" % k)
+        except Exception as ex:  # noqa: BLE001
+            r["parity_sample"] = "not checked: %s: %s" % (type(ex).__name__, ex)
+        return r
+    attempt("host_fed_default_pipeline", f"PCIe-inclusive: SceneManager.detect_scenes (auto downscale, ContentDetector) over 384 x {w}x{h} "
+            "shot-like frames in pageable host memory; only the source rows that carry taps are uploaded", run_host_fed)
     attempt("corpus_mixed_1080p_4k_all_four", "BASELINE configs[4] at reduced length: 3 x 1080p x 512 + 1 x 4K x 128 shot-like frames, all four "
             "detectors, clips packed per resolution (bench.py --workload corpus is the full-length run)", lambda: run_flow_small("corpus"))
     attempt("bbc_standin_adaptive", "BASELINE configs[3] at reduced length: AdaptiveDetector over the 11-clip 640x360 stand-in, 2000+ frames per "
