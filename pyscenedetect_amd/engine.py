@@ -82,7 +82,36 @@ class DeviceBuffer:
             pass
 
 
-class ScoringEngine:
+class TapRowPolicy:
+    """Which rows of a frame a host has to upload when everything is computed from the DOWNSCALED frame
+    (reference scene_manager.py:666-678): a downscale reads 2 * dst_h of src_h rows (INTER_LINEAR; dst_h for NEAREST), and
+    only those cross PCIe, into their own places of the full-size device frame.  Not worth the strided copies when most rows
+    are needed anyway (INTER_AREA, factors below ~3), or when the rows do not fall into a few strided copies
+    (``psd_upload_rows_plan``: two per frame for 1080p -> 256 x 144, dozens for a factor like 4.3).  Needs
+    ``downscale_source_rows`` and ``upload_rows_plan`` of the class it is mixed into."""
+
+    ROWS_ONLY_BELOW = 0.6
+    MAX_ROW_COPIES = 8
+
+    def tap_rows(self, height: int, width: int, downscale: float, interpolation: int = 1):
+        """Ascending int32 rows to upload (``DeviceBuffer.upload_rows``), or None for whole frames."""
+        if downscale <= 1.0:
+            return None
+        cache = self.__dict__.setdefault("_tap_rows", {})
+        key = (height, width, float(downscale), int(interpolation), self.ROWS_ONLY_BELOW, self.MAX_ROW_COPIES)
+        if key not in cache:
+            dst_w, dst_h = max(1, round(width / downscale)), max(1, round(height / downscale))   # as analyze_device
+            try:
+                rows = self.downscale_source_rows(height, width, dst_h, dst_w, interpolation)
+            except Exception:
+                rows = None      # a mode the device refuses: the scoring call reports it
+            if rows is not None and (len(rows) >= self.ROWS_ONLY_BELOW * height or len(self.upload_rows_plan(rows)) > self.MAX_ROW_COPIES):
+                rows = None
+            cache[key] = rows
+        return cache[key]
+
+
+class ScoringEngine(TapRowPolicy):
     """One HIP device + stream.  Not thread-safe per instance; use one engine per thread/GPU."""
 
     def __init__(self, device: int = 0):
@@ -177,14 +206,24 @@ class ScoringEngine:
         src = self._scratch("rs_src", (per_chunk + 1) * sstride)
         dst = self._scratch("rs_dst", (per_chunk + 1) * dstride)
         last = None if prev is None else np.ascontiguousarray(prev, dtype=np.uint8)
+        rows = self.tap_rows(h, w, factor, interpolation)    # only the rows with taps travel (None: whole frames)
         done = 0
         while done < n:
             cnt = min(per_chunk, n - done)
             p = 0
             if last is not None:
-                src.upload(last.reshape(-1), 0)
+                if rows is not None:
+                    src.upload_rows(last, 0, rows)
+                else:
+                    src.upload(last.reshape(-1), 0)
                 p = 1
-            src.upload(frames[done:done + cnt].reshape(-1), p * sstride)
+            if rows is not None:
+                # the chunk as one tall frame of cnt * h rows: where the row pattern continues across frames (1080 rows, steps
+                # of 15) the whole chunk is two strided copies
+                tall = (rows[None, :] + (np.arange(cnt, dtype=np.int32) * h)[:, None]).reshape(-1)
+                src.upload_rows(frames[done:done + cnt].reshape(cnt * h, w, 3), p * sstride, tall)
+            else:
+                src.upload(frames[done:done + cnt].reshape(-1), p * sstride)
             self.resize_device(src.ptr, cnt + p, h, w, dst.ptr, dh, dw, dst_frame_stride=dstride, interpolation=interpolation)
             out[done:done + cnt] = self.score_device(dst.ptr + p * dstride, cnt, dh, dw, dw * 3, dstride,
                                                      d_prev=dst.ptr if p else None, flags=flags, edge_kernel=edge_kernel)
@@ -215,11 +254,15 @@ class ScoringEngine:
         p = 0 if prev is None else 1
         src = self._scratch("fr_src", (n + 1) * sstride)
         items = ([prev] if p else []) + list(frames)
+        rows = self.tap_rows(h, w, downscale, interpolation)     # behind a downscale only the rows with taps travel
         for i, f in enumerate(items):
             f = np.ascontiguousarray(f, dtype=np.uint8)
             if f.shape != (h, w, 3):
                 raise ValueError("all frames of a batch must have the same size")
-            src.upload(f.reshape(-1), i * sstride)
+            if rows is not None:
+                src.upload_rows(f, i * sstride, rows)
+            else:
+                src.upload(f.reshape(-1), i * sstride)
         buf, fh, fw, stride = src, h, w, sstride
         if downscale > 1.0:
             fw, fh = max(1, round(w / downscale)), max(1, round(h / downscale))

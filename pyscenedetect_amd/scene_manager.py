@@ -439,20 +439,15 @@ class _DeviceFeeder:
     (the queue, the decode thread after an abort, an exception in flight)."""
 
     N_SLOTS = 3
-    # A downscale reads 2 * dst_h of a frame's src_h rows (INTER_LINEAR; dst_h for NEAREST): only those cross PCIe, into
-    # their own places of the full-size device frame -- the rows in between are never read (everything the detectors and
-    # callbacks get is computed from the downscaled frame, reference scene_manager.py:666-678).  Not worth the strided
-    # copies when most rows are needed anyway (INTER_AREA, factors below ~3), or when the rows do not fall into a few
-    # strided copies (psd_upload_rows_plan: two per frame for 1080p -> 256 x 144, dozens for a factor like 4.3).
-    ROWS_ONLY_BELOW = 0.6
-    MAX_COPIES = 8
+    # Behind a downscale only the source rows that carry taps cross PCIe (engine.TapRowPolicy / psd_upload_rows), into their
+    # own places of the full-size device frame -- the rows in between are never read: everything the detectors and callbacks
+    # get is computed from the downscaled frame (reference scene_manager.py:666-678).
 
     def __init__(self, engine, batch_frames: int, factor: float = 1.0, interpolation: int = 1):
         self._engine = engine
         self._batch = batch_frames
         self._factor = factor
         self._interpolation = interpolation
-        self._rows: dict = {}
         self._free: queue.Queue = queue.Queue()
         self._all = [{"id": i, "buf": None, "shape": None} for i in range(self.N_SLOTS)]
         self._halo = None          # (DeviceBuffer, shape): the last frame of the most recent batch
@@ -482,20 +477,8 @@ class _DeviceFeeder:
 
     def _rows_of(self, h: int, w: int):
         """The rows of an h x w frame that have to be uploaded, or None for all of them."""
-        if self._factor <= 1.0 or not hasattr(self._engine, "downscale_source_rows"):
-            return None
-        if (h, w) not in self._rows:
-            dst_w, dst_h = max(1, round(w / self._factor)), max(1, round(h / self._factor))   # as analyze_device
-            try:
-                rows = self._engine.downscale_source_rows(h, w, dst_h, dst_w, self._interpolation)
-            except Exception:
-                rows = None      # a mode the device refuses: the scoring call reports it
-            if rows is not None and len(rows) >= self.ROWS_ONLY_BELOW * h:
-                rows = None
-            if rows is not None and hasattr(self._engine, "upload_rows_plan") and len(self._engine.upload_rows_plan(rows)) > self.MAX_COPIES:
-                rows = None
-            self._rows[(h, w)] = rows
-        return self._rows[(h, w)]
+        policy = getattr(self._engine, "tap_rows", None)
+        return policy(h, w, self._factor, self._interpolation) if policy is not None else None
 
     def put(self, slot, index: int, frame: np.ndarray) -> None:
         if slot["rows"] is not None:

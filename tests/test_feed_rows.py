@@ -11,6 +11,7 @@ import pytest
 
 import pyscenedetect_amd as psd
 from pyscenedetect_amd import _native
+from pyscenedetect_amd.engine import TapRowPolicy
 from pyscenedetect_amd.scene_manager import _DeviceFeeder
 from tests.conftest import golden_clip
 
@@ -154,11 +155,9 @@ class _HostDeviceEngine:
     """The part of ScoringEngine the feeder and SceneManager use, over host memory and the oracle: `analyze_device`
     reads the frames back out of the poisoned buffers, so a row the feeder failed to upload shows in the results."""
 
-    def __init__(self, oracle_engine, with_rows=True):
+    def __init__(self, oracle_engine):
         self.oracle = oracle_engine
         self.buffers = []
-        if with_rows:
-            self.downscale_source_rows = lambda h, w, dh, dw, interp=1: source_rows(h, w, dh, dw, interp)
 
     def alloc(self, nbytes):
         self.buffers.append(_HostBuffer(nbytes))
@@ -195,6 +194,16 @@ class _HostDeviceEngine:
         return out
 
 
+class _HostDeviceEngineWithRows(TapRowPolicy, _HostDeviceEngine):
+    """... with the product's row policy over the product's row list and copy plan."""
+
+    def downscale_source_rows(self, h, w, dh, dw, interp=1):
+        return source_rows(h, w, dh, dw, interp)
+
+    def upload_rows_plan(self, rows, packed=True):
+        return copy_plan(rows, packed)
+
+
 def _run(engine, frames, factor, interpolation, detector, callback=None):
     sm = psd.SceneManager(engine=engine, batch_frames=16)
     sm.auto_downscale = False
@@ -210,8 +219,8 @@ def test_scene_manager_over_a_feeder_that_uploads_tap_rows_only(golden, oracle_e
     frames = golden_clip(golden, "scenes_a")
     factor = 4      # 72 x 128 frames: 36 of 72 rows carry bilinear taps
     shown_a, shown_b = [], []
-    by_rows = _HostDeviceEngine(oracle_engine)
-    whole = _HostDeviceEngine(oracle_engine, with_rows=False)
+    by_rows = _HostDeviceEngineWithRows(oracle_engine)
+    whole = _HostDeviceEngine(oracle_engine)
     cuts_a = _run(by_rows, frames, factor, interpolation, psd.ContentDetector(engine=by_rows),
                   callback=lambda img, pos: shown_a.append((pos.frame_num, int(img.sum()))))
     cuts_b = _run(whole, frames, factor, interpolation, psd.ContentDetector(engine=whole),
@@ -225,26 +234,27 @@ def test_scene_manager_over_a_feeder_that_uploads_tap_rows_only(golden, oracle_e
     assert sum(b.row_calls for b in whole.buffers) == 0
 
 
-def test_feeder_row_plan_per_shape():
-    class E:
+def test_row_policy_per_shape():
+    class E(TapRowPolicy):
         calls = 0
 
         def downscale_source_rows(self, h, w, dh, dw, interp=1):
             E.calls += 1
             return source_rows(h, w, dh, dw, interp)
 
-    f = _DeviceFeeder(E(), 4, factor=7.0, interpolation=LINEAR)
-    rows = f._rows_of(1080, 1920)
-    assert rows is not None and len(rows) == 308 and f._rows_of(1080, 1920) is rows and E.calls == 1
-    assert _DeviceFeeder(E(), 4, factor=1.0)._rows_of(1080, 1920) is None          # no downscale: every row is scored
-    assert _DeviceFeeder(E(), 4, factor=1.5, interpolation=LINEAR)._rows_of(270, 481) is None   # most rows carry taps
-    assert _DeviceFeeder(E(), 4, factor=7.0, interpolation=AREA)._rows_of(1080, 1920) is None
-    assert _DeviceFeeder(E(), 4, factor=7.0, interpolation=2)._rows_of(1080, 1920) is None      # CUBIC: the scoring call refuses
-    assert _DeviceFeeder(object(), 4, factor=7.0)._rows_of(1080, 1920) is None     # an engine without the call
-
-    class P(E):
         def upload_rows_plan(self, rows, packed=True):
             return copy_plan(rows, packed)
 
-    assert len(_DeviceFeeder(P(), 4, factor=7.5)._rows_of(1080, 1920)) == 288     # the default pipeline: two copies per frame
-    assert _DeviceFeeder(P(), 4, factor=4.3)._rows_of(1080, 1920) is None          # ~70 copies per frame: not worth it
+    e = E()
+    rows = e.tap_rows(1080, 1920, 7.0, LINEAR)
+    assert rows is not None and len(rows) == 308 and e.tap_rows(1080, 1920, 7.0, LINEAR) is rows and E.calls == 1
+    assert len(e.tap_rows(1080, 1920, 7.5, LINEAR)) == 288       # the default pipeline: two copies per frame
+    assert e.tap_rows(1080, 1920, 1.0, LINEAR) is None            # no downscale: every row is scored
+    assert e.tap_rows(270, 481, 1.5, LINEAR) is None              # most rows carry taps
+    assert e.tap_rows(1080, 1920, 7.0, AREA) is None              # every row carries weight
+    assert e.tap_rows(1080, 1920, 7.0, 2) is None                 # CUBIC: the scoring call refuses
+    assert e.tap_rows(1080, 1920, 4.3, LINEAR) is None            # ~70 copies per frame: not worth it
+    # the feeder asks the engine; an engine without the policy gets whole frames
+    assert len(_DeviceFeeder(e, 4, factor=7.5, interpolation=LINEAR)._rows_of(1080, 1920)) == 288
+    assert _DeviceFeeder(e, 4, factor=1.0)._rows_of(1080, 1920) is None
+    assert _DeviceFeeder(object(), 4, factor=7.0)._rows_of(1080, 1920) is None

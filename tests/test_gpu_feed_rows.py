@@ -163,16 +163,37 @@ def test_default_pipeline_at_1080p_takes_the_row_path(hip_engine):
         return [c.frame_num for c in sm.get_cut_list()]
 
     smod._DeviceFeeder.put = spy
-    keep = smod._DeviceFeeder.ROWS_ONLY_BELOW
+    keep = E.ScoringEngine.ROWS_ONLY_BELOW
     try:
         got = run()
-        smod._DeviceFeeder.ROWS_ONLY_BELOW = 0.0      # whole frames
+        E.ScoringEngine.ROWS_ONLY_BELOW = 0.0      # whole frames
         full = run()
     finally:
         smod._DeviceFeeder.put = original
-        smod._DeviceFeeder.ROWS_ONLY_BELOW = keep
+        E.ScoringEngine.ROWS_ONLY_BELOW = keep
     assert seen == [288] * 48 + [0] * 48
     assert got == full and len(got) >= 2 and set(got) <= set(true_cuts)
+
+
+@pytest.mark.parametrize("interp", [LINEAR, NEAREST])
+def test_host_frame_entry_points_upload_tap_rows(hip_engine, oracle_engine, interp):
+    """score_host(downscale=...) (a stacked array: the chunk travels as one tall frame, two strided copies at 1080p) and
+    score_frames / analyze_frames (separately allocated frames) behind a downscale == the oracle on whole frames."""
+    rng = np.random.default_rng(21 + interp)
+    for h, w, factor, n in ((1080, 1920, 7.5, 5), (270, 480, 4.0, 7), (99, 160, 4.0, 6)):
+        frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+        prev = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert hip_engine.tap_rows(h, w, factor, interp) is not None
+        flags = E.SCORE_HSV_SAD | E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM
+        want = oracle_engine.score_host(frames, prev=prev, flags=flags, downscale=factor, interpolation=interp)
+        got = hip_engine.score_host(frames, prev=prev, flags=flags, downscale=factor, interpolation=interp)
+        got2 = hip_engine.score_frames([f.copy() for f in frames], prev=prev.copy(), flags=flags, downscale=factor, interpolation=interp)
+        for key in ("sad_h", "sad_s", "sad_v", "byte_sum", "hist"):
+            assert np.array_equal(got[key], want[key]), (h, key)
+            assert np.array_equal(got2[key], want[key]), (h, key)
+    rows = hip_engine.tap_rows(1080, 1920, 7.5, LINEAR)
+    tall = (rows[None, :] + (np.arange(5, dtype=np.int32) * 1080)[:, None]).reshape(-1)
+    assert len(hip_engine.upload_rows_plan(tall)) == 2
 
 
 def test_table_cache_across_shapes_modes_and_engines(hip_engine):

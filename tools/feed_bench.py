@@ -31,6 +31,9 @@ def best_of(fn, reps=3):
 
 out["psd_score_batch_pageable_fps"] = round(N / best_of(lambda: eng.score_host(hf, flags=E.SCORE_HSV_SAD)), 1)
 out["psd_score_batch_pinned_fps"] = round(N / best_of(lambda: eng.score_host(pinned, flags=E.SCORE_HSV_SAD)), 1)
+# the same entry point behind the default downscale (1080p -> 256 x 144): the stacked array travels as tap rows only
+out["score_host_downscaled_pageable_fps"] = round(N / best_of(lambda: eng.score_host(hf, flags=E.SCORE_HSV_SAD, downscale=7.5)), 1)
+out["score_host_downscaled_pinned_fps"] = round(N / best_of(lambda: eng.score_host(pinned, flags=E.SCORE_HSV_SAD, downscale=7.5)), 1)
 buf = eng.alloc(hf.nbytes)
 
 
