@@ -151,18 +151,19 @@ def test_two_ranks_equal_one(tmp_path):
         assert [c.frame_num for c in sm.get_cut_list()] == res["content"]
 
 
-@pytest.mark.timeout(300)
-def test_four_ranks_equal_one(tmp_path):
-    """The same flows over four ranks (more ranks than some shards have clips: the one-clip corpus leaves three ranks
-    without work, the frame-range shards of the 75-frame clip are 19 / 19 / 19 / 18 frames)."""
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [4, 8])
+def test_four_and_eight_ranks_equal_one(tmp_path, world):
+    """The same flows over four and eight ranks -- the GPU counts of BASELINE's metric (1 vs 2 vs 4 vs 8 give
+    byte-identical records and cut lists).  More ranks than some shards have clips: the one-clip corpus leaves all ranks
+    but one without work; the frame-range shards of the 75-frame clip are 19 / 19 / 19 / 18 (10 / 10 / 10 / 9 ... ) frames."""
     import json
 
     from oracle.detectors_np import OracleEngine
     from pyscenedetect_amd.corpus import detect_corpus
     from pyscenedetect_amd.synth import make_clip
 
-    world = 4
-    port = 31500 + (os.getpid() % 2000)
+    port = 31500 + world * 16 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     eng = OracleEngine()
     frames, _ = make_clip(31, 75, 36, 64, shot_len=(8, 16))
