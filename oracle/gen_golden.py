@@ -103,6 +103,9 @@ CLIPS = {
 }
 
 
+BIG_CLIP = (15, 56, 540, 960, {"shot_len": (16, 22)})
+
+
 def uniform_clip(seed, n, h, w):
     return np.random.default_rng(seed).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
 
@@ -294,6 +297,19 @@ def main():
             cls_name, kwargs, with_stats = CONFIGS[cname]
             golden["interp"][mode][cname] = run(frames, cls_name, kwargs, with_stats, True, interpolation=mode)
             print("wide_d", mode, cname, golden["interp"][mode][cname]["cuts"])
+    # a frame size where the default downscale skips most source rows (960 x 540 -> 256 x 144, factor 3.75): the host feeder
+    # of the GPU path uploads only the rows that carry taps there (psd_upload_rows) -- the reference sees whole frames
+    seed, n, h, w, kw = BIG_CLIP
+    frames, truth = make_clip(seed, n, h, w, **kw)
+    golden["downscale_rows"] = {"clip": {"seed": seed, "n": n, "h": h, "w": w, "kwargs": kw, "true_cuts": truth,
+                                         "sum_all": int(frames.sum())}, "results": {}}
+    for mode in ("LINEAR", "NEAREST"):
+        golden["downscale_rows"]["results"][mode] = {}
+        for cname in ("content_stats", "content_edges", "adaptive_default", "hist_default", "hash_default", "threshold_default"):
+            cls_name, kwargs, with_stats = CONFIGS[cname]
+            golden["downscale_rows"]["results"][mode][cname] = run(frames, cls_name, kwargs, with_stats, True, interpolation=mode)
+            print("big_e", mode, cname, golden["downscale_rows"]["results"][mode][cname]["cuts"])
+    del frames
     # variable frame rate: PTS-backed positions through the unmodified SceneManager / detectors
     frames, _ = make_clip(*CLIPS["scenes_a"][:4], **CLIPS["scenes_a"][4])
     pts = vfr_pts(len(frames))

@@ -140,6 +140,35 @@ def test_scene_manager_feeds_tap_rows_and_decides_like_the_oracle(golden, hip_en
     assert got_a == want_a
 
 
+def test_reference_runs_on_larger_frames_through_the_row_feeder(golden, hip_engine):
+    """golden["downscale_rows"]: the UNMODIFIED reference over whole 960 x 540 frames (auto downscale to 256 x 144, LINEAR and
+    NEAREST, six detector configurations) against the HIP path whose feeder uploaded 288 (144) of the 540 rows of every frame:
+    same cuts, same per-frame metrics."""
+    from pyscenedetect_amd import scene_manager as smod
+    from tests._helpers import assert_same_run, run_config
+    from tests.test_host_golden import big_clip
+
+    frames = big_clip(golden)
+    seen = []
+    original = smod._DeviceFeeder.put
+
+    def spy(self, slot, index, frame):
+        seen.append(0 if slot["rows"] is None else len(slot["rows"]))
+        return original(self, slot, index, frame)
+
+    smod._DeviceFeeder.put = spy
+    try:
+        for mode, runs in golden["downscale_rows"]["results"].items():
+            for name, want in runs.items():
+                cls_name, kwargs, with_stats = golden["configs"][name]
+                del seen[:]
+                got = run_config(frames, cls_name, kwargs, with_stats, hip_engine, auto_downscale=True, interpolation=mode)
+                assert_same_run(got, want, f"big_e/{mode}/{name}")
+                assert seen == [288 if mode == "LINEAR" else 144] * len(frames), (mode, name, seen[:3])
+    finally:
+        smod._DeviceFeeder.put = original
+
+
 def test_default_pipeline_at_1080p_takes_the_row_path(hip_engine):
     """auto_downscale at 1080p: factor 7.5 -> 256 x 144, 288 of 1080 rows in two strided copies per frame; same cuts as with
     whole-frame uploads."""

@@ -206,6 +206,30 @@ def test_downscale_interpolation_modes_match_reference(golden, oracle_engine):
         sm.interpolation = psd.Interpolation.LANCZOS4
 
 
+def big_clip(golden):
+    """The 960 x 540 clip of golden["downscale_rows"], regenerated from its seed."""
+    from pyscenedetect_amd.synth import make_clip
+
+    c = golden["downscale_rows"]["clip"]
+    kw = dict(c["kwargs"])
+    kw["shot_len"] = tuple(kw["shot_len"])
+    frames, _ = make_clip(c["seed"], c["n"], c["h"], c["w"], **kw)
+    assert int(frames.sum()) == c["sum_all"], "synthetic clip differs from the one the golden run used"
+    return frames
+
+
+def test_default_downscale_of_larger_frames_matches_reference(golden, oracle_engine):
+    """960 x 540 -> 256 x 144 (factor 3.75: two of every 3.75 source rows carry bilinear taps): the reference's runs over whole
+    frames, LINEAR and NEAREST, six detector configurations."""
+    frames = big_clip(golden)
+    for mode, runs in golden["downscale_rows"]["results"].items():
+        for name, want in runs.items():
+            cls_name, kwargs, with_stats = golden["configs"][name]
+            got = run_config(frames, cls_name, kwargs, with_stats, oracle_engine, auto_downscale=True, interpolation=mode)
+            assert_same_run(got, want, f"big_e/{mode}/{name}")
+    assert golden["downscale_rows"]["results"]["LINEAR"]["content_stats"]["cuts"]
+
+
 # ---- plug-in surface: constructor validation, metric keys, look-behind (oracle/gen_api_golden.py) -------------------
 
 def _api_cases():
