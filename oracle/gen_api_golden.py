@@ -101,6 +101,9 @@ def bad_frames():
     return out
 
 
+from manager_cases import manager_cases  # noqa: E402  (shared with tests/test_host_golden.py)
+
+
 def main():
     out = {"ctor": [{"cls": c, "kwargs": k, **outcome(lambda: describe(build(c, k)))} for c, k in CTOR_CASES]}
     out["bad_frames"] = bad_frames()
@@ -160,6 +163,14 @@ def main():
                     emitted.append([i, c.pts])
             return {"emitted": emitted, "max_behind": int(flt.max_behind)}
         out["flash_filter_pts"].append({"length": length, "mode": mode, "above": [int(a) for a in above], "pts": pts, **outcome(drive_pts)})
+    from gen_golden import CLIPS, MemoryStream  # the reference's VideoStream over frames in memory
+    from pyscenedetect_amd.synth import make_clip
+    from scenedetect.stats_manager import StatsManager
+
+    seed, n, h, w, kw = CLIPS["scenes_a"]
+    out["manager_ops"] = manager_cases(lambda: make_clip(seed, n, h, w, **kw)[0],
+                                       lambda with_stats: SceneManager(StatsManager() if with_stats else None),
+                                       lambda frames: MemoryStream(frames, 25.0), lambda: ContentDetector())
     path = os.path.join(os.path.dirname(HERE), "tests", "golden", "api_cases.json")
     with open(path, "w") as fh:
         json.dump(out, fh, separators=(",", ":"))

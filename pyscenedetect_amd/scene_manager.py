@@ -135,7 +135,10 @@ class SceneManager:
             raise ValueError("Downscale factor must be a positive integer >= 1!")
         if self.auto_downscale:
             logger.warning("Downscale factor will be ignored because auto_downscale=True!")
-        self._downscale = int(value)
+        if not isinstance(value, int):
+            logger.warning("Downscale factor will be truncated to integer!")
+            value = int(value)
+        self._downscale = value
 
     @property
     def auto_downscale(self) -> bool:

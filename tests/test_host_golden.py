@@ -278,6 +278,22 @@ def test_rejected_frames_and_manager_properties_match_reference(oracle_engine):
     assert {"ok": sizes} == cases["frame_buffer_sizes"]
 
 
+def test_scene_manager_surface_matches_reference(golden, oracle_engine):
+    """Property setters (downscale, crop), argument checks of detect_scenes, lists before a run, clear(), crop at and beyond
+    the frame border, duration / end_time: every step's value or exception type AND the warnings logged on the way, as the
+    reference's SceneManager produced them (oracle/manager_cases.py, scene_manager.py:278-335, 358-372, 446-530)."""
+    from oracle.manager_cases import manager_cases
+
+    frames = golden_clip(golden, "scenes_a")
+    got = manager_cases(lambda: frames,
+                        lambda with_stats: psd.SceneManager(psd.StatsManager() if with_stats else None, engine=oracle_engine),
+                        lambda fr: psd.ArrayVideoStream(fr, 25.0), lambda: psd.ContentDetector(engine=oracle_engine))
+    want = _api_cases()["manager_ops"]
+    assert set(got) == set(want)
+    for name in want:
+        assert got[name] == want[name], f"{name}: {got[name]} != {want[name]}"
+
+
 def test_variable_frame_rate_positions_match_reference(golden, oracle_engine):
     """PTS-backed positions (what the reference's PyAV backend reports for VFR video) through SceneManager and the
     detectors: cuts and scene boundaries carry the same presentation timestamps as the reference's."""
