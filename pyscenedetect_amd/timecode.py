@@ -321,18 +321,3 @@ def _as_rate(fps) -> Fraction:
     if isinstance(fps, (float, Fraction)):
         return framerate_to_fraction(fps)
     raise TypeError(f"Wrong type for fps: {type(fps)} - expected float, Fraction, or FrameTimecode")
-
-
-def min_len_frames(length, rate: Fraction) -> int:
-    """Frames that ``(a - b) >= length`` compares against for frame-number timecodes."""
-    if isinstance(length, int):
-        return length
-    if isinstance(length, float):
-        return round(length * rate)
-    if isinstance(length, str):
-        if length.strip().isdigit():
-            return int(length.strip())
-        return round(parse_timecode_seconds(length, rate) * rate)
-    if isinstance(length, FrameTimecode):
-        return length.frame_num
-    raise TypeError(f"unsupported min_scene_len type {type(length)}")

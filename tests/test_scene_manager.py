@@ -355,3 +355,45 @@ def test_benchmark_harness_predictions_and_reference_evaluator(tmp_path, golden,
     res = json.loads(out.stdout)["results"]
     assert res[0]["tolerance"] == 0 and res[0]["videos"] == 2 and 0.0 < res[0]["f1"] <= res[1]["f1"] <= 1.0
     assert res[0]["matched"] + res[0]["missed"] == 2 * (len(truth) + 1)
+
+
+def test_array_video_stream_contract():
+    """The part of the reference's VideoStream contract SceneManager relies on (video_stream.py:79-222): frame_number
+    counts the frames read, position is the timecode of the last frame read (frame 0 before any read), read(decode=False)
+    advances without handing out a frame, False at the end, seek / reset move the read position."""
+    from fractions import Fraction
+
+    frames = np.arange(5 * 4 * 6 * 3, dtype=np.uint8).reshape(5, 4, 6, 3)
+    v = psd.ArrayVideoStream(frames, 25.0)
+    assert v.frame_size == (6, 4) and v.frame_rate == 25 and v.base_timecode.frame_num == 0
+    assert v.duration.frame_num == 5 and v.frame_number == 0 and v.position.frame_num == 0
+    f0 = v.read()
+    assert np.array_equal(f0, frames[0]) and v.frame_number == 1 and v.position.frame_num == 0
+    assert v.read(decode=False) is True and v.frame_number == 2 and v.position.frame_num == 1
+    assert np.array_equal(v.read(), frames[2]) and v.position.frame_num == 2
+    v.seek(4)
+    assert np.array_equal(v.read(), frames[4]) and v.frame_number == 5
+    assert v.read() is False and v.read(decode=False) is False and v.frame_number == 5 and v.position.frame_num == 4
+    v.seek(psd.FrameTimecode(1, 25.0))
+    assert np.array_equal(v.read(), frames[1])
+    v.seek(99)
+    assert v.read() is False
+    with pytest.raises(ValueError):
+        v.seek(-1)
+    v.reset()
+    assert v.frame_number == 0 and np.array_equal(v.read(), frames[0])
+    # a list of separately allocated frames works like a stacked array; an empty source reads nothing
+    lst = psd.ArrayVideoStream([f.copy() for f in frames], Fraction(30000, 1001))
+    assert lst.frame_size == (6, 4) and lst.frame_rate == Fraction(30000, 1001) and np.array_equal(lst.read(), frames[0])
+    empty = psd.ArrayVideoStream(frames[:0])
+    assert empty.read() is False and empty.duration.frame_num == 0
+    # presentation timestamps: positions and the duration carry them
+    pts = [0, 40, 100, 140, 220]
+    p = psd.ArrayVideoStream(frames, 25.0, pts=pts, time_base=Fraction(1, 1000))
+    assert p.position.pts == 0
+    p.read(); p.read(); p.read()
+    assert p.position.pts == 100 and abs(p.position.seconds - 0.1) < 1e-12 and p.duration.pts == 220
+    with pytest.raises(ValueError):
+        psd.ArrayVideoStream(frames, 25.0, pts=pts)
+    with pytest.raises(ValueError):
+        psd.ArrayVideoStream(frames, 25.0, pts=pts[:3], time_base=Fraction(1, 1000))
