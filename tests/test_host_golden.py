@@ -365,3 +365,34 @@ def test_min_scene_len_accepts_time_values(golden, oracle_engine, cls_name):
     default_name = {"ContentDetector": "content_default", "AdaptiveDetector": "adaptive_default", "HistogramDetector": "hist_default",
                     "HashDetector": "hash_default", "ThresholdDetector": "threshold_default"}[cls_name]
     assert results[0] == golden["clips"]["scenes_a"]["results"][default_name]["cuts"]
+
+
+def test_static_helpers_match_the_reference_lines(oracle_engine):
+    """``HistogramDetector.calculate_histogram`` (static, histogram_detector.py:122-165: cvtColor(BGR2YUV) + split + calcHist,
+    normalised and flattened or raw counts as a column) and ``_estimated_kernel_size`` (content_detector.py:39-46)."""
+    import math
+
+    import cv2  # the oracle's shim
+
+    from pyscenedetect_amd.detectors.content_detector import estimated_kernel_size
+
+    rng = np.random.default_rng(12)
+    frame = rng.integers(0, 256, (45, 64, 3), dtype=np.uint8)
+    frame[:20] //= 3
+    for bins in (256, 128, 100, 16):
+        y, _, _ = cv2.split(cv2.cvtColor(frame, cv2.COLOR_BGR2YUV))
+        raw = cv2.calcHist([y], [0], None, [bins], [0, 256])
+        got_raw = psd.HistogramDetector.calculate_histogram(frame, bins=bins, normalize=False, engine=oracle_engine)
+        assert got_raw.shape == raw.shape == (bins, 1) and got_raw.dtype == raw.dtype == np.float32
+        assert np.array_equal(got_raw, raw)
+        want = cv2.normalize(raw.copy(), None).flatten()
+        got = psd.HistogramDetector.calculate_histogram(frame, bins=bins, engine=oracle_engine)
+        assert got.shape == want.shape == (bins,) and got.dtype == want.dtype
+        assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        psd.HistogramDetector.calculate_histogram(frame.astype(np.uint16), engine=oracle_engine)
+    with pytest.raises(ValueError):
+        psd.HistogramDetector.calculate_histogram(frame[:, :, :2], engine=oracle_engine)
+    for (w, h), k in (((1920, 1080), 13), ((3840, 2160), 19), ((256, 144), 5), ((320, 180), 5), ((1280, 720), 9), ((7680, 4320), 35)):
+        size = 4 + round(math.sqrt(w * h) / 192)
+        assert estimated_kernel_size(w, h) == (size + 1 if size % 2 == 0 else size) == k
