@@ -201,7 +201,8 @@ int psd_upload(psd_engine* e, void* d_dst, const void* h_src, size_t bytes);
  *                           src_h entries); no engine, no device;
  *   psd_upload_rows         psd_upload for a frame of which only those rows are needed: rows[0 .. n_rows) (ascending) of the
  *                           packed host frame (row pitch h_row_stride >= row_bytes) go to the SAME rows of the packed device
- *                           frame (row pitch row_bytes); the rows in between keep whatever the buffer held.  Runs of equally
+ *                           frame (row pitch row_bytes); the rows in between keep whatever the buffer held (the caller
+ *                           vouches that every listed row lies inside both frames).  Runs of equally
  *                           spaced row groups travel as one strided copy each.  Everything the engine computes from a
  *                           downscaled frame (records, thumbnails, the small frame itself) is the same as after a full upload. */
 int psd_resize_source_rows(int src_h, int src_w, int dst_h, int dst_w, int interpolation, int* rows, int* n_rows);

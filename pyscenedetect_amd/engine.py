@@ -59,6 +59,7 @@ class DeviceBuffer:
             frame = np.ascontiguousarray(frame, dtype=np.uint8)
         h, w, c = frame.shape
         row_bytes = w * c
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
         if offset + h * row_bytes > self.nbytes or (len(rows) and int(rows[-1]) >= h):
             raise ValueError("upload out of range")
         _native.check(self._engine._lib.psd_upload_rows(self._engine._h, self.ptr + offset, frame.ctypes.data, row_bytes,
