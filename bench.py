@@ -106,6 +106,58 @@ def downscaled_size(h: int, w: int, downscale: str) -> tuple[int, int, float]:
     return max(1, round(h / factor)), max(1, round(w / factor)), factor
 
 
+def parity_runs(n: int, k: int, walk: int = 0, frame_bytes: int = 0) -> list[tuple[int, int]]:
+    """Frame ranges [a, b) a parity sample looks at: the first, the middle and the last k frames of the batch, both sides
+    of every boundary between two time walks of the launch (`walk` frames each: psd_last_walk_geometry -- a workgroup starts
+    from a re-read halo frame there) and both sides of the 2^32 / 2^33 / 2^34 / 2^35 byte offsets of the batch.  Merged and
+    sorted."""
+    want = set(range(0, min(n, k))) | set(range(max(0, n - k), n))
+    mid = max(0, n // 2 - k // 2)
+    want |= set(range(mid, min(n, mid + k)))
+    if walk > 0:
+        for b in range(walk, n, walk):
+            want |= {b - 1, b}
+    if frame_bytes > 0:
+        for e in (32, 33, 34, 35):
+            f = (1 << e) // frame_bytes
+            if 1 <= f < n - 1:
+                want |= {f - 1, f, f + 1}
+    idx = sorted(want)
+    runs, a = [], idx[0]
+    for i, j in zip(idx, idx[1:] + [None]):
+        if j != i + 1:
+            runs.append((a, i + 1))
+            a = j
+    return runs
+
+
+def describe_runs(runs: list[tuple[int, int]], walk: int = 0) -> str:
+    total = sum(b - a for a, b in runs)
+    head = ", ".join(f"{a}-{b - 1}" for a, b in runs[:3])
+    tail = ", ".join(f"{a}-{b - 1}" for a, b in runs[-2:]) if len(runs) > 3 else ""
+    s = f"{total} frames in {len(runs)} ranges ({head}" + (f", ..., {tail}" if tail else "") + ")"
+    return s + (f", both sides of every {walk}-frame walk boundary" if walk > 0 else "")
+
+
+def oracle_records_at(batch, runs, flags: int, threads: int, transform=None, edges: bool = False) -> list:
+    """Oracle records of the frames in `runs` (each range scored with the frame in front of it as its predecessor)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import lib as orc
+    from oracle.detectors_np import score_batch as oracle_score
+
+    def work(r):
+        a, b = r
+        host = batch[max(a - 1, 0):b].cpu().numpy()
+        if transform is not None:
+            host = transform(host)
+        prev, frames = (None, host) if a == 0 else (host[0], host[1:])
+        return oracle_score(frames, prev, edges=True) if edges else orc.score_batch(frames, prev, flags=flags & 7)
+
+    with ThreadPoolExecutor(max(1, min(threads, len(runs)))) as ex:
+        return list(ex.map(work, runs))
+
+
 def cpu_baseline(sample: np.ndarray, flags: int, threads: int, repeats: int = 3, model_frames: int = 256) -> dict:
     """The CPU side of the same workload on this box's host cores, bounded samples:
       * value / cores: the C oracle (restatement of the reference's cv2 / numpy pixel path) over all host cores
@@ -180,6 +232,7 @@ class Workload:
         if downscale:
             self.sh, self.sw, self.factor = downscaled_size(self.h, self.w, downscale)
         self.state = {"cuts": [], "recs": None, "thumbs": None}
+        self.walk = 0        # frames per time walk of this workload's launch (0: the kernel does not walk / not known)
 
     # bytes one launch has to read: every BGR byte once; with the edge term 5 B/px; behind the default
     # downscale the source rows that carry taps (two per destination row, never more than all rows)
@@ -203,6 +256,8 @@ class Workload:
             self.eng.submit_device(self.ptr, self.n, self.h, self.w, flags=self.flags, stream=self.stream)
         else:
             self.eng.submit_device(self.ptr, self.n, self.h, self.w, flags=self.flags)
+        if not self.walk and (self.flags & 1) and hasattr(self.eng, "last_walk_geometry"):
+            self.walk = int(self.eng.last_walk_geometry()[0])
 
     def finish(self) -> float:
         """Collect one submission and turn its records into cut lists; returns the kernel time (ms)."""
@@ -235,31 +290,35 @@ class Workload:
 
 
 def parity_sample(wl: Workload, k: int) -> str:
-    """The first k frames of the workload's last step against the CPU oracle (the checker, outside every timed region)."""
+    """The workload's last step against the CPU oracle (the checker, outside every timed region): the first, middle and
+    last k frames of the batch plus both sides of every boundary between two time walks of the launch (`parity_runs`)."""
     from oracle import lib as orc
-    from oracle.detectors_np import score_batch as oracle_score
 
-    k = min(k, wl.n)
-    frames = wl.batch[:k].cpu().numpy()
+    threads = os.cpu_count() or 1
     if wl.detector == "hash":
-        bad = [] if np.array_equal(wl.state["thumbs"][:k], orc.hash_thumbs(frames, 16)) else ["thumbs"]
-        what = "thumbnails"
-    else:
-        if wl.downscale:
-            shim = os.path.join(ROOT, "oracle", "cv2_shim")
-            if shim not in sys.path:
-                sys.path.append(shim)
-            import cv2  # the oracle's shim: cv2.resize restated (scene_manager.py:670-678)
+        k = min(k, wl.n)
+        frames = wl.batch[:k].cpu().numpy()
+        ok = np.array_equal(wl.state["thumbs"][:k], orc.hash_thumbs(frames, 16))
+        return ("thumbnails of the first %d frames identical to the oracle" % k) if ok else "MISMATCH vs oracle in thumbnails (first %d frames)" % k
+    edges = wl.detector == "edges"
+    # (the edge term's oracle is two orders of magnitude slower than the sums: walk boundaries only for the cheap terms)
+    runs = parity_runs(wl.n, k, 0 if edges else wl.walk, 0 if wl.downscale else wl.h * wl.w * 3)
+    transform = None
+    if wl.downscale:
+        shim = os.path.join(ROOT, "oracle", "cv2_shim")
+        if shim not in sys.path:
+            sys.path.append(shim)
+        import cv2  # the oracle's shim: cv2.resize restated (scene_manager.py:670-678)
 
-            frames = np.stack([cv2.resize(f, (wl.sw, wl.sh)) for f in frames])
-        want = oracle_score(frames, edges=wl.detector == "edges")
-        fields = (["sad_h", "sad_s", "sad_v"] if wl.flags & 1 else []) + (["hist"] if wl.flags & 2 else []) + \
-                 (["byte_sum"] if wl.flags & 4 else []) + (["edge_xor"] if wl.flags & 8 else [])
-        got = wl.state["recs"]
-        bad = [f for f in fields if not np.array_equal(got[f][:k], want[f])]
-        what = "records (" + ", ".join(fields) + ")"
-    return ("%s of the first %d frames identical to the oracle" % (what, k)) if not bad else \
-        "MISMATCH vs oracle in %s (first %d frames)" % (bad, k)
+        def transform(host):
+            return np.stack([cv2.resize(f, (wl.sw, wl.sh)) for f in host])
+    wants = oracle_records_at(wl.batch, runs, wl.flags, threads, transform, edges)
+    fields = (["sad_h", "sad_s", "sad_v"] if wl.flags & 1 else []) + (["hist"] if wl.flags & 2 else []) + \
+             (["byte_sum"] if wl.flags & 4 else []) + (["edge_xor"] if wl.flags & 8 else [])
+    got = wl.state["recs"]
+    bad = sorted({f for (a, b), want in zip(runs, wants) for f in fields if f in got.dtype.names and not np.array_equal(got[f][a:b], want[f])})
+    what = "records (" + ", ".join(fields) + ") of " + describe_runs(runs, 0 if edges else wl.walk)
+    return (what + " identical to the oracle") if not bad else "MISMATCH vs oracle in %s: %s" % (bad, what)
 
 
 def quick_measure(wl: Workload, steps: int = 5, warmup: int = 2, parity_frames: int = 16) -> dict:
@@ -400,6 +459,77 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
         except Exception as ex:  # noqa: BLE001
             r["parity_sample"] = "not checked: %s: %s" % (type(ex).__name__, ex)
         return r
+    def run_per_frame():
+        # The per-frame plug-in API north_star keeps (detector.py:48-60: SceneDetector.process_frame(timecode, frame_img)),
+        # one frame per call from pageable host memory, full resolution, beside the reference's own execution model
+        # (`cpu_baseline.reference_model`: the same loop over cv2 / numpy on one core).  PCIe-inclusive, never `value`.
+        import pyscenedetect_amd as psd
+        from pyscenedetect_amd.timecode import FrameTimecode
+
+        b = make_batch(160, "S", 20250921, device, h, w)
+        host = b.cpu().numpy()
+        del b
+        tcs = [FrameTimecode(i, 25.0) for i in range(len(host))]
+
+        def mirror(engine, frames):
+            det = psd.ContentDetector(engine=engine)
+            cuts = []
+            for i, f in enumerate(frames):
+                cuts += det.process_frame(tcs[i], f)
+            return [c.frame_num for c in cuts], det
+
+        mirror(eng, host[:8])
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            cuts, _det = mirror(eng, host)
+            best = min(best, time.perf_counter() - t0)
+        r = {"value": round(len(host) / best, 1), "unit": "frames/s", "pcie_inclusive": True, "frames": len(host), "cuts_found": len(cuts),
+             "api": "pyscenedetect_amd.ContentDetector.process_frame(timecode, frame): one upload (the previous frame stays in HBM), "
+                    "psd_score_batch_device(n=1), decision", "us_per_frame": round(best / len(host) * 1e6, 1)}
+        # the binding a reference maintainer adds calls psd_score_batch(n = 1) with the previous frame from the
+        # reference's own per-frame loop (integration/scenedetect_amd.py: _calculate_frame_score); timed here exactly as that
+        # function issues it (the reference package itself is not on this box)
+        sys.path.insert(0, os.path.join(ROOT, "integration"))
+        import scenedetect_amd as B
+
+        bind = B.Binding(os.path.join(ROOT, "pyscenedetect_amd", "libpsd_hip.so"), device.index or 0)
+
+        def binding_loop(frames):
+            last, sads = None, []
+            for f in frames:
+                rec = bind.score(f, last, B.HSV_SAD)
+                last = np.array(f, copy=True)
+                sads.append((rec.sad_h, rec.sad_s, rec.sad_v))
+            return sads
+
+        binding_loop(host[:4])
+        best_b = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sads = binding_loop(host)
+            best_b = min(best_b, time.perf_counter() - t0)
+        bind.close()
+        r["reference_binding"] = {"value": round(len(host) / best_b, 1), "unit": "frames/s", "pcie_inclusive": True,
+                                  "us_per_frame": round(best_b / len(host) * 1e6, 1),
+                                  "api": "integration/scenedetect_amd.py Binding.score = psd_score_batch(n=1, h_prev): what the patched "
+                                         "reference ContentDetector._calculate_frame_score calls per frame (both frames cross PCIe), plus its "
+                                         "per-frame copy of the frame"}
+        try:
+            from oracle import lib as orc
+            from oracle.detectors_np import OracleEngine
+
+            k = 48
+            want = orc.score_batch(host[:k])
+            same = mirror(eng, host[:k])[0] == mirror(OracleEngine(), host[:k])[0] and \
+                all(tuple(int(want[f][i]) for f in ("sad_h", "sad_s", "sad_v")) == tuple(int(v) for v in sads[i]) for i in range(k))
+            r["parity_sample"] = ("process_frame cuts and the binding's sums of the first %d frames identical to the oracle" % k) if same \
+                else "MISMATCH vs the oracle (first %d frames)" % k
+        except Exception as ex:  # noqa: BLE001
+            r["parity_sample"] = "not checked: %s: %s" % (type(ex).__name__, ex)
+        return r
+    attempt("per_frame_api_1080p", f"PCIe-inclusive: the per-frame plug-in API (SceneDetector.process_frame) and the reference-side "
+            f"binding of INTEGRATION.md B on 160 x {w}x{h} shot-like frames, one frame per call", run_per_frame)
     attempt("host_fed_default_pipeline", f"PCIe-inclusive: SceneManager.detect_scenes (auto downscale, ContentDetector) over 384 x {w}x{h} "
             "shot-like frames in pageable host memory; only the source rows that carry taps are uploaded", run_host_fed)
     attempt("corpus_mixed_1080p_4k_all_four", "BASELINE configs[4] at reduced length: 3 x 1080p x 512 + 1 x 4K x 128 shot-like frames, all four "
@@ -496,9 +626,15 @@ class FlowWorkload:
             t_cpu += time.perf_counter() - t0
             n_cpu += k * (h * w) / (1080 * 1920)
             want = np.concatenate(parts)
-            got = self._records_of(i)[:k]
+            got_all = self._records_of(i)
+            got = got_all[:k]
             if any(not np.array_equal(got[f], want[f]) for f in fields):
                 bad.append(f"records of clip {i}")
+            # ... and deep into the clip (it sits somewhere inside a packed batch): its middle and its last frames
+            deep = [r for r in parity_runs(n, max(2, k // 4)) if r[0] >= k]
+            for (a, b), w_ in zip(deep, oracle_records_at(self.clips[i], deep, flags, threads)):
+                if any(not np.array_equal(got_all[f][a:b], w_[f]) for f in fields):
+                    bad.append(f"records of clip {i}, frames {a}-{b - 1}")
             want_cuts = corpus.decide(want, h, w, 25.0, self.detectors)
             if corpus.decide(got, h, w, 25.0, self.detectors) != want_cuts:
                 bad.append(f"cuts of clip {i}")
@@ -507,7 +643,7 @@ class FlowWorkload:
             for name, cuts in want_cuts.items():
                 if [c for c in self.result[i][name] if c < k - 32] != [c for c in cuts if c < k - 32]:
                     bad.append(f"{name} cuts the flow returned for clip {i}")
-            notes.append(f"clip {i} ({w}x{h}): first {k} frames")
+            notes.append(f"clip {i} ({w}x{h}): first {k} frames" + ("".join(f", frames {a}-{b - 1}" for a, b in deep)))
         msg = ("records and cut lists identical to the oracle: " + "; ".join(notes)) if not bad else "MISMATCH vs oracle: " + ", ".join(bad)
         cpu = {"value": round(n_cpu / t_cpu, 2) if t_cpu > 0 else None, "unit": "1080p-equivalent frames/s", "cores": threads, "kind": "port",
                "sample": "the parity prefixes (" + "; ".join(notes) + f") through oracle/cv2_restate.c, {threads} threads, pixel work only"}
@@ -710,6 +846,11 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
             dist.destroy_process_group()
         if rank == 0:
             print(json.dumps(out))
+            sys.stdout.flush()
+            bad = parity_failures(out)
+            if bad:
+                print("bench: parity sample(s) differ from the oracle: " + "; ".join(bad), file=sys.stderr)
+                sys.exit(3)
         return
     n = args.frames
     batch = make_batch(n, args.dist, 20250921 + rank, device, H, W)
@@ -914,11 +1055,17 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
             sample = batch[: args.cpu_sample].cpu().numpy()
             cb = cpu_baseline(sample, wl.flags & 7, os.cpu_count() or 1)
             ref = cb.pop("_records")
-            got = wl.state["recs"][: args.cpu_sample]
-            same = all(np.array_equal(got[f], ref[f]) for f in ("sad_h", "sad_s", "sad_v", "byte_sum", "hist") if f in got.dtype.names)
+            got = wl.state["recs"]
+            fields = [f for f in ("sad_h", "sad_s", "sad_v", "byte_sum", "hist") if f in got.dtype.names]
+            same = all(np.array_equal(got[f][: args.cpu_sample], ref[f]) for f in fields)
+            # ... and deep into the batch: the middle and the last 64 frames, both sides of every boundary between two time
+            # walks of the launch, both sides of the 2^32 / 2^33 / 2^34 byte offsets (frame pointers beyond 32 bits)
+            runs = [r for r in parity_runs(n, 64, wl.walk, H * W * 3) if r[1] > args.cpu_sample]
+            wants = oracle_records_at(batch, runs, wl.flags, os.cpu_count() or 1)
+            same = same and all(np.array_equal(got[f][a:b], want[f]) for (a, b), want in zip(runs, wants) for f in fields)
             out["cpu_baseline"] = cb
-            out["parity_sample"] = "records of the first %d frames identical to the oracle" % args.cpu_sample if same \
-                else "MISMATCH vs oracle"
+            what = "records of the first %d frames and of %s" % (args.cpu_sample, describe_runs(runs, wl.walk))
+            out["parity_sample"] = (what + " identical to the oracle") if same else "MISMATCH vs oracle: " + what
         else:
             out["cpu_baseline"] = None
         if on_gpu and world == 1 and not use_dist and not args.no_secondary and headline:
@@ -931,6 +1078,24 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
+        bad = parity_failures(out)
+        if bad:
+            print("bench: parity sample(s) differ from the oracle: " + "; ".join(bad), file=sys.stderr)
+            sys.exit(3)
+
+
+def parity_failures(obj, path: str = "") -> list[str]:
+    """Every `parity_sample` anywhere in the result that reports a MISMATCH (the line is printed first, then bench.py exits
+    non-zero: a fast number whose records differ from the reference's is not a result)."""
+    bad = []
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if k == "parity_sample" and isinstance(v, str) and "MISMATCH" in v:
+                bad.append((path or "headline") + ": " + v[:160])
+            else:
+                bad += parity_failures(v, f"{path}.{k}" if path else k)
+    return bad
 
 
 if __name__ == "__main__":

@@ -40,9 +40,11 @@
 extern "C" {
 #endif
 
-#define PSD_ABI_VERSION 4 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records);
+#define PSD_ABI_VERSION 5 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records);
                             * 3: additive over 2 (psd_frame_sums: records without the histogram, psd_score_collect_sums, psd_epilogue_*_sums);
-                            * 4: additive over 3 (psd_resize_source_rows, psd_upload_rows: a host feeder uploads only the rows a downscale reads) */
+                            * 4: additive over 3 (psd_resize_source_rows, psd_upload_rows: a host feeder uploads only the rows a downscale reads);
+                            * 5: additive over 4 (psd_upload_rows_batch: many frames' rows gathered by worker threads into page-locked
+                            *    memory and uploaded asynchronously; psd_last_walk_geometry) */
 
 typedef enum psd_status {
     PSD_OK = 0,
@@ -173,6 +175,12 @@ int psd_allgather_scores(psd_comm* c, const psd_frame_scores* d_local, int n_loc
  * collect (a weak-edge chain longer than the launches enqueued at submit; rare), the time of the second attempt is
  * included (host clock around it). */
 int psd_last_kernel_ms(psd_engine* e, float* ms, int* launches);
+/* How the most recent time-walking launch issued on the CALLING thread (the HSV pass, the fused all-detectors pass, the
+ * V-mode pass of the edge term) cut its batch: every workgroup walked `frames_per_chunk` consecutive frames of one of
+ * `n_tiles` spatial tiles, so frames k * frames_per_chunk are where a walk starts from a re-read halo frame.  Parity
+ * checks sample the oracle at exactly these boundaries (tests/test_gpu_headline_geometry.py, bench.py).  Zeros before the
+ * first such launch. */
+int psd_last_walk_geometry(psd_engine* e, int* frames_per_chunk, int* n_tiles);
 
 /* Raw device buffer helpers so hosts without their own allocator (plain C, ctypes) can keep
  * batches resident in HBM. */
@@ -213,6 +221,16 @@ int psd_upload_rows(psd_engine* e, void* d_frame, const void* h_frame, size_t ro
  * the host frame's rows are contiguous (otherwise every group is one row).  *n_copies is the full count even when it
  * exceeds max_copies.  No engine, no device. */
 int psd_upload_rows_plan(const int* rows, int n_rows, int packed, int* copies, int max_copies, int* n_copies);
+/* psd_upload_rows for n_frames separately allocated host frames at once (what a decoder hands out: backends/pyav.py:322-363
+ * returns a fresh array per frame): frame i's rows go to the packed device frame at d_first_frame + i * d_frame_stride.
+ * The rows are gathered by the engine's worker threads (PSD_FEED_THREADS, default 8) into a ring of page-locked segments,
+ * frame after frame without gaps, and travel from there as asynchronous strided copies on the engine's copy stream --
+ * the call returns once they are enqueued, the host frames may be reused at once, and psd_upload_fence() orders them like
+ * psd_upload_async's.  One call per 8 .. 32 frames keeps PCIe busy where one blocking psd_upload_rows per frame reaches
+ * about 60 % of the link (two ~10 us copy set-ups per 1.7 MB).  Call from ONE thread at a time per engine (the decode
+ * thread); it neither touches the scoring stream nor the record slots. */
+int psd_upload_rows_batch(psd_engine* e, void* d_first_frame, size_t d_frame_stride, const void* const* h_frames, int n_frames,
+                          size_t row_bytes, size_t h_row_stride, const int* rows, int n_rows);
 int psd_upload_async(psd_engine* e, void* d_dst, const void* h_src, size_t bytes);
 int psd_upload_fence(psd_engine* e, int wait_on_host);
 int psd_memcpy_d2d(psd_engine* e, void* d_dst, const void* d_src, size_t bytes);

@@ -27,6 +27,7 @@ SCORE_EDGES = 8
 SCORE_ALL = 15
 
 MAX_INFLIGHT = 4
+ABI_VERSION = 5  # PSD_ABI_VERSION of include/psd_engine.h this binding was written against
 
 #: numpy view of ``psd_frame_scores`` (1064 bytes).
 RECORD_DTYPE = np.dtype(
@@ -135,6 +136,8 @@ SYMBOLS = {
     "psd_resize_source_rows": (_i, [_i, _i, _i, _i, _i, _vp, _vp]),
     "psd_upload_rows": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _i]),
     "psd_upload_rows_plan": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "psd_upload_rows_batch": (_i, [_vp, _vp, _sz, _vp, _i, _sz, _sz, _vp, _i]),
+    "psd_last_walk_geometry": (_i, [_vp, _P(_i), _P(_i)]),
     "psd_upload_fence": (_i, [_vp, _i]),
     "psd_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
     "psd_synchronize": (_i, [_vp]),
@@ -217,8 +220,8 @@ def load() -> ctypes.CDLL:
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from ex
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.psd_abi_version() != 4:
-        raise NativeLibraryError(f"ABI version mismatch: library has {lib.psd_abi_version()}, binding wants 4")
+    if lib.psd_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"ABI version mismatch: library has {lib.psd_abi_version()}, binding wants {ABI_VERSION}")
     _lib = lib
     return lib
 

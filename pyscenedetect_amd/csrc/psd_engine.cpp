@@ -9,7 +9,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -17,6 +21,11 @@
 
 namespace {
 thread_local char g_err[512] = "";
+thread_local int g_walk[2] = {0, 0};   // frames per chunk, spatial tiles of the calling thread's last time-walking launch
+}
+
+namespace psd {
+void note_walk_geometry(int frames_per_chunk, int n_tiles) { g_walk[0] = frames_per_chunk; g_walk[1] = n_tiles; }
 }
 
 extern "C" void psd_set_error(const char* fmt, ...)
@@ -54,10 +63,14 @@ void resize_release(psd_engine* e);
 int resize_other(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
                  int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream);
 int resize_source_rows(int src_h, int src_w, int dst_h, int dst_w, int interpolation, int* rows, int* n_rows);
+// psd_feed.cpp
+void feed_release(psd_engine* e);
 // psd_hash_kernels.hip
 int hash_thumbs(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
                 int size, uint8_t* d_thumbs, hipStream_t stream, hipEvent_t ev_start);
 }  // namespace psd
+
+struct psd_feed;   // psd_feed.cpp
 
 struct psd_slot {
     psd_frame_scores* d_recs = nullptr;
@@ -109,6 +122,7 @@ struct psd_engine {
     size_t small_bytes = 0;
     hipStream_t copy_stream = nullptr;   // psd_upload_async: host -> device copies that overlap the scoring stream
     hipEvent_t ev_copy = nullptr;
+    psd_feed* feed = nullptr;     // psd_upload_rows_batch: gather threads + ring of page-locked / device staging segments
 };
 
 static void fill_tables(int32_t* sdiv, int32_t* hdiv)
@@ -226,6 +240,7 @@ void psd_destroy(psd_engine* e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    psd::feed_release(e);      // (joins the gather threads, waits for the copy stream's last batch)
     psd::edges_release(e);
     psd::resize_release(e);
     if (e->d_small) (void)hipFree(e->d_small);
@@ -653,6 +668,14 @@ int psd_last_records_device(psd_engine* e, const psd_frame_scores** d_recs, int*
     return PSD_OK;
 }
 
+int psd_last_walk_geometry(psd_engine* e, int* frames_per_chunk, int* n_tiles)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    if (frames_per_chunk) *frames_per_chunk = g_walk[0];
+    if (n_tiles) *n_tiles = g_walk[1];
+    return PSD_OK;
+}
+
 int psd_last_kernel_ms(psd_engine* e, float* ms, int* launches)
 {
     if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
@@ -940,14 +963,21 @@ int psd_upload_rows(psd_engine* e, void* d_frame, const void* h_frame, size_t ro
     return PSD_OK;
 }
 
-int psd_upload_async(psd_engine* e, void* d_dst, const void* h_src, size_t bytes)
+static int ensure_copy_stream(psd_engine* e)
 {
-    if (!e || (bytes && (!d_dst || !h_src))) { psd_set_error("psd_upload_async: null argument"); return PSD_ERR_INVALID; }
-    HIP_TRY(hipSetDevice(e->device));
     if (!e->copy_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_copy, hipEventDisableTiming));
     }
+    return PSD_OK;
+}
+
+int psd_upload_async(psd_engine* e, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!e || (bytes && (!d_dst || !h_src))) { psd_set_error("psd_upload_async: null argument"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(e->device));
+    int rc = ensure_copy_stream(e);
+    if (rc != PSD_OK) return rc;
     HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, e->copy_stream));
     return PSD_OK;
 }
@@ -1031,5 +1061,12 @@ int engine_num_cus(psd_engine* e) { return e->num_cus; }
 hipStream_t engine_stream(psd_engine* e) { return e->stream; }
 int engine_device(psd_engine* e) { return e->device; }
 void** engine_resize_cache(psd_engine* e) { return &e->resize_cache; }
+psd_feed** engine_feed_slot(psd_engine* e) { return &e->feed; }
+int engine_copy_stream(psd_engine* e, hipStream_t* out)
+{
+    int rc = ensure_copy_stream(e);
+    *out = e->copy_stream;
+    return rc;
+}
 const uint32_t* engine_lut(psd_engine* e) { return e->d_lut; }
 }  // namespace psd

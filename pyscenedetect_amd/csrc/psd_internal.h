@@ -50,6 +50,8 @@ hipError_t launch_score_frames(ScoreParams p, bool hsv, bool luma, bool fast, in
                                hipStream_t stream, int* launches);
 // V mode (ScoreParams::vout) needs the staged kernel and frames made of whole 16-pixel groups
 bool score_v_mode_available(long npix);
+// every launcher of a time-walking kernel leaves how it cut the batch (psd_last_walk_geometry; thread-local, psd_engine.cpp)
+void note_walk_geometry(int frames_per_chunk, int n_tiles);
 
 // OpenCV's computeResizeAreaTab for one destination index in run-length form: `count` consecutive source cells from
 // `first`, the first / last of them with their own weight (hash thumbnails and cv2.resize(INTER_AREA) share it).

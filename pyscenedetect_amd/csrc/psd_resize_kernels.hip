@@ -531,6 +531,7 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     chunks = (n + p.frames_per_chunk - 1) / p.frames_per_chunk;
     const size_t lds = (size_t)p.depth * 2 * R * p.row_pad;
     const int grid = p.n_tiles * chunks;
+    if (d_out) note_walk_geometry(p.frames_per_chunk, p.n_tiles);
     if (d_dst && d_out) launch_walk<true, true>(p, g, grid, lds, stream);
     else if (d_out) launch_walk<false, true>(p, g, grid, lds, stream);
     else launch_walk<true, false>(p, g, grid, lds, stream);

@@ -1395,6 +1395,7 @@ static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bo
     p.frames_per_chunk = (p.n + chunks - 1) / chunks;
     chunks = (p.n + p.frames_per_chunk - 1) / p.frames_per_chunk;
     const int grid = p.n_tiles * chunks;
+    if (hsv && fast) note_walk_geometry(p.frames_per_chunk, p.n_tiles);
     if (!fast) return launch_flags<false, 1>(p, grid, hsv, luma, stream);
     return gpl == 2 ? launch_flags<true, 2>(p, grid, hsv, luma, stream)
                     : launch_flags<true, 1>(p, grid, hsv, luma, stream);

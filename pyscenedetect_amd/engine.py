@@ -65,6 +65,30 @@ class DeviceBuffer:
         _native.check(self._engine._lib.psd_upload_rows(self._engine._h, self.ptr + offset, frame.ctypes.data, row_bytes,
                                                         frame.strides[0], rows.ctypes.data, len(rows)))
 
+    def upload_rows_batch(self, frames, offset: int, rows: np.ndarray, frame_stride: int) -> None:
+        """``upload_rows`` for a LIST of separately allocated frames uint8[H,W,3] at once (``psd_upload_rows_batch``): frame i's
+        ``rows`` go to the packed device frame at ``offset + i * frame_stride``.  Worker threads of the engine gather the rows
+        into page-locked memory and one asynchronous copy per call moves them; the host frames are free when the call
+        returns, the device side is ordered by ``ScoringEngine.upload_fence``.  Decode thread only, one call at a time."""
+        n = len(frames)
+        if n == 0:
+            return
+        frames = [np.asarray(f) for f in frames]
+        h, w, c = frames[0].shape
+        row_bytes = w * c
+        if any(f.shape != (h, w, c) for f in frames):
+            raise ValueError("all frames of a batch must have the same size")
+        stride0 = frames[0].strides[0]
+        if any(f.dtype != np.uint8 or f.strides[2] != 1 or f.strides[1] != c or f.strides[0] != stride0 for f in frames) or stride0 < row_bytes:
+            frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]     # mixed layouts: all packed
+            stride0 = row_bytes
+        ptrs = (ctypes.c_void_p * n)(*[f.ctypes.data for f in frames])
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        if offset + (n - 1) * frame_stride + h * row_bytes > self.nbytes or (len(rows) and int(rows[-1]) >= h):
+            raise ValueError("upload out of range")
+        _native.check(self._engine._lib.psd_upload_rows_batch(self._engine._h, self.ptr + offset, int(frame_stride), ptrs, n, row_bytes,
+                                                              stride0, rows.ctypes.data, len(rows)))
+
     def download(self, nbytes: int | None = None, offset: int = 0) -> np.ndarray:
         nbytes = self.nbytes - offset if nbytes is None else nbytes
         out = np.empty(nbytes, np.uint8)
@@ -104,8 +128,8 @@ class TapRowPolicy:
             dst_w, dst_h = max(1, round(width / downscale)), max(1, round(height / downscale))   # as analyze_device
             try:
                 rows = self.downscale_source_rows(height, width, dst_h, dst_w, interpolation)
-            except Exception:
-                rows = None      # a mode the device refuses: the scoring call reports it
+            except NotImplementedError:
+                rows = None      # a mode the device refuses (PSD_ERR_UNSUPPORTED): the scoring call reports it
             if rows is not None and (len(rows) >= self.ROWS_ONLY_BELOW * height or len(self.upload_rows_plan(rows)) > self.MAX_ROW_COPIES):
                 rows = None
             cache[key] = rows
@@ -256,13 +280,20 @@ class ScoringEngine(TapRowPolicy):
         src = self._scratch("fr_src", (n + 1) * sstride)
         items = ([prev] if p else []) + list(frames)
         rows = self.tap_rows(h, w, downscale, interpolation)     # behind a downscale only the rows with taps travel
-        for i, f in enumerate(items):
-            f = np.ascontiguousarray(f, dtype=np.uint8)
-            if f.shape != (h, w, 3):
+        if rows is not None:
+            # gathered by the engine's worker threads, one asynchronous copy per 32 frames, ordered in front of the resize
+            self.synchronize()                                   # (nothing queued may still read the buffer)
+            items = [np.asarray(f) for f in items]
+            if any(f.shape != (h, w, 3) for f in items):
                 raise ValueError("all frames of a batch must have the same size")
-            if rows is not None:
-                src.upload_rows(f, i * sstride, rows)
-            else:
+            for a in range(0, len(items), 32):
+                src.upload_rows_batch(items[a:a + 32], a * sstride, rows, sstride)
+            self.upload_fence()
+        else:
+            for i, f in enumerate(items):
+                f = np.ascontiguousarray(f, dtype=np.uint8)
+                if f.shape != (h, w, 3):
+                    raise ValueError("all frames of a batch must have the same size")
                 src.upload(f.reshape(-1), i * sstride)
         buf, fh, fw, stride = src, h, w, sstride
         if downscale > 1.0:
@@ -592,6 +623,13 @@ class ScoringEngine(TapRowPolicy):
         p, n = ctypes.c_void_p(), ctypes.c_int(0)
         _native.check(self._lib.psd_last_records_device(self._h, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
+
+    def last_walk_geometry(self) -> tuple[int, int]:
+        """``(frames_per_chunk, n_tiles)`` of this thread's most recent time-walking launch (``psd_last_walk_geometry``): frames
+        ``k * frames_per_chunk`` of the batch are where a workgroup's walk started from a re-read halo frame."""
+        fpc, tiles = ctypes.c_int(0), ctypes.c_int(0)
+        _native.check(self._lib.psd_last_walk_geometry(self._h, ctypes.byref(fpc), ctypes.byref(tiles)))
+        return fpc.value, tiles.value
 
     def last_kernel_ms(self) -> tuple[float, int]:
         ms, launches = ctypes.c_float(0), ctypes.c_int(0)

@@ -243,12 +243,14 @@ class SceneManager:
         return {"flags": flags, "kernels": kernels or [0], "thumb_sizes": thumb_sizes, "want_frames": want_frames,
                 "device": bool(flags or thumb_sizes), "fallback": fallback}
 
-    def _score_batch(self, engine, plan, frames, factor, last_frame, slot=None):
+    def _score_batch(self, engine, plan, frames, factor, last_frame, slot=None, interp: int | None = None):
         """Device results for one batch: records, per-kernel edge counts, thumbnails (+ hash bits), the frames as the
-        detectors see them."""
+        detectors see them.  ``interp``: the interpolation mode this ``detect_scenes`` call started with (the feeder uploaded
+        the rows THAT mode reads; a setter called from a callback takes effect with the next call)."""
         from pyscenedetect_amd import epilogue
 
-        interp = self._interpolation.value
+        if interp is None:
+            interp = self._interpolation.value
         if slot is not None:
             res = engine.analyze_device(slot["ptr"], len(frames), slot["h"], slot["w"], slot["stride"], d_prev=slot["prev"],
                                         flags=plan["flags"], edge_kernels=plan["kernels"], downscale=factor,
@@ -315,10 +317,11 @@ class SceneManager:
             end_time = (self._base_timecode + duration) + start_frame_num
 
         plan = self._plan(callback, factor)
+        interp = self._interpolation.value          # one mode for the whole call: feeder and scoring must agree on it
         engine = self._engine_or_default() if plan["device"] else None
         # Engines with device batches: the decode thread uploads every frame straight into one of three device batch
         # buffers while this thread scores and decides the previous batch (host -> device copies overlap everything else).
-        feeder = _DeviceFeeder(engine, self._batch_frames, factor, self._interpolation.value) if engine is not None and hasattr(engine, "analyze_device") else None
+        feeder = _DeviceFeeder(engine, self._batch_frames, factor, interp) if engine is not None and hasattr(engine, "analyze_device") else None
 
         batches: queue.Queue = queue.Queue(1 if feeder else 2)
         self._stop.clear()
@@ -340,7 +343,7 @@ class SceneManager:
                             feeder.forget_halo()
                     if slot is not None:
                         slot["prev"] = feeder.halo_ptr(slot)
-                    result = self._score_batch(engine, plan, frames, factor, last_frame, slot)
+                    result = self._score_batch(engine, plan, frames, factor, last_frame, slot, interp)
                     if slot is not None:
                         feeder.release(slot, keep_last=len(frames))
                     last_frame = frames[-1]
@@ -376,6 +379,8 @@ class SceneManager:
         def flush():
             nonlocal frames, positions, slot
             if frames:
+                if feeder is not None and slot is not None:
+                    feeder.seal(slot)        # the batch's last uploads are enqueued and ordered in front of its scoring
                 out_queue.put((frames, positions, slot))
                 frames, positions, slot = [], [], None
 
@@ -442,6 +447,7 @@ class _DeviceFeeder:
     (the queue, the decode thread after an abort, an exception in flight)."""
 
     N_SLOTS = 3
+    FEED_BATCH = 16     # frames per psd_upload_rows_batch call: 16 x 1.66 MB at 1080p -> 256 x 144, about half a millisecond of PCIe
     # Behind a downscale only the source rows that carry taps cross PCIe (engine.TapRowPolicy / psd_upload_rows), into their
     # own places of the full-size device frame -- the rows in between are never read: everything the detectors and callbacks
     # get is computed from the downscaled frame (reference scene_manager.py:666-678).
@@ -474,7 +480,9 @@ class _DeviceFeeder:
                     slot["buf"].free()
                     slot["buf"] = None
                 slot["buf"] = self._engine.alloc(need)
-            slot.update(shape=tuple(shape), h=h, w=w, stride=stride, ptr=slot["buf"].ptr, prev=None, rows=self._rows_of(h, w))
+            slot.update(shape=tuple(shape), h=h, w=w, stride=stride, ptr=slot["buf"].ptr, prev=None, rows=self._rows_of(h, w),
+                        pending=[], pending_first=0)
+            slot["batched"] = slot["rows"] is not None and hasattr(slot["buf"], "upload_rows_batch") and hasattr(self._engine, "upload_fence")
             return slot
         return None
 
@@ -484,10 +492,30 @@ class _DeviceFeeder:
         return policy(h, w, self._factor, self._interpolation) if policy is not None else None
 
     def put(self, slot, index: int, frame: np.ndarray) -> None:
-        if slot["rows"] is not None:
+        if slot["batched"]:
+            # tap rows only, FEED_BATCH frames per call: gathered into page-locked memory by the engine's worker threads and
+            # moved by one asynchronous copy (two blocking strided copies per frame reached 60 % of the link)
+            if not slot["pending"]:
+                slot["pending_first"] = index
+            slot["pending"].append(frame)
+            if len(slot["pending"]) >= self.FEED_BATCH:
+                self._flush_pending(slot)
+        elif slot["rows"] is not None:
             slot["buf"].upload_rows(np.ascontiguousarray(frame), index * slot["stride"], slot["rows"])
         else:
             slot["buf"].upload_unordered(np.ascontiguousarray(frame).reshape(-1), index * slot["stride"])
+
+    def _flush_pending(self, slot) -> None:
+        if slot["pending"]:
+            slot["buf"].upload_rows_batch(slot["pending"], slot["pending_first"] * slot["stride"], slot["rows"], slot["stride"])
+            slot["pending"] = []
+
+    def seal(self, slot) -> None:
+        """The batch is complete (decode thread): enqueue what is still pending and make the engine's stream wait for the
+        copy stream, so that the kernels the scoring thread launches for this batch find every row in place."""
+        if slot["batched"]:
+            self._flush_pending(slot)
+            self._engine.upload_fence()
 
     def halo_ptr(self, slot):
         """Device address of the frame preceding this batch (None for the first batch or after a size change)."""

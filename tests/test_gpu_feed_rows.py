@@ -98,6 +98,58 @@ def test_rows_of_a_strided_host_frame(hip_engine):
     buf2.free()
 
 
+@pytest.mark.parametrize("h,w,n", [(1080, 1920, 40), (97, 131, 7), (64, 48, 1), (270, 480, 33)])
+def test_batched_row_upload_equals_the_per_frame_upload(hip_engine, h, w, n):
+    """``psd_upload_rows_batch`` (ABI 5: rows of many separately allocated frames gathered by the engine's worker threads into
+    page-locked memory, one asynchronous copy + a scatter kernel per call) leaves the device frames exactly as one
+    ``psd_upload_rows`` per frame does: listed rows in place, everything else untouched.  More calls than staging segments, a
+    row length that is not a multiple of 16 bytes, frames that are cropped views, a frame stride with padding."""
+    rng = np.random.default_rng(h * 7 + n)
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(n)]
+    factor = 7.5 if h == 1080 else 3.0
+    dw, dh = max(1, round(w / factor)), max(1, round(h / factor))
+    rows = hip_engine.downscale_source_rows(h, w, dh, dw, LINEAR)
+    stride = (h * w * 3 + 15) & ~15
+    a, b = _poisoned(hip_engine, n * stride), _poisoned(hip_engine, n * stride)
+    for t in range(n):
+        a.upload_rows(frames[t], t * stride, rows)
+    for t0 in range(0, n, 6):                       # 6 frames per call: the ring of three segments wraps around
+        b.upload_rows_batch(frames[t0:t0 + 6], t0 * stride, rows, stride)
+    hip_engine.upload_fence(wait_on_host=True)
+    assert np.array_equal(a.download(), b.download())
+    # cropped views of wider frames (row pitch > row bytes), all in one call
+    wide = [rng.integers(0, 256, (h, w + 16, 3), dtype=np.uint8) for _ in range(min(n, 5))]
+    views = [x[:, 8:8 + w] for x in wide]
+    c, d = _poisoned(hip_engine, len(views) * stride), _poisoned(hip_engine, len(views) * stride)
+    for t, v in enumerate(views):
+        c.upload_rows(np.ascontiguousarray(v), t * stride, rows)
+    d.upload_rows_batch(views, 0, rows, stride)
+    hip_engine.upload_fence(wait_on_host=True)
+    assert np.array_equal(c.download(), d.download())
+    for buf in (a, b, c, d):
+        buf.free()
+
+
+def test_batched_row_upload_argument_errors(hip_engine):
+    h, w = 32, 16
+    f = np.zeros((h, w, 3), np.uint8)
+    buf = hip_engine.alloc(2 * h * w * 3)
+    with pytest.raises(ValueError):
+        buf.upload_rows_batch([f, f, f], 0, np.array([0, 1], np.int32), h * w * 3)          # third frame beyond the buffer
+    with pytest.raises(ValueError):
+        buf.upload_rows_batch([f], 0, np.array([32], np.int32), h * w * 3)                  # row beyond the frame
+    with pytest.raises(ValueError):
+        buf.upload_rows_batch([f, np.zeros((h, w + 1, 3), np.uint8)], 0, np.array([0], np.int32), h * w * 3)
+    lib = hip_engine._lib
+    ptrs = (ctypes.c_void_p * 1)(f.ctypes.data)
+    bad = np.array([3, 2], np.int32)
+    assert lib.psd_upload_rows_batch(hip_engine._h, buf.ptr, h * w * 3, ptrs, 1, w * 3, w * 3, bad.ctypes.data, 2) == _native.PSD_ERR_INVALID
+    assert lib.psd_upload_rows_batch(hip_engine._h, buf.ptr, h * w * 3, ptrs, 1, w * 3, w * 3 - 1, bad.ctypes.data, 1) == _native.PSD_ERR_INVALID
+    assert lib.psd_upload_rows_batch(hip_engine._h, buf.ptr, h * w * 3, None, 1, w * 3, w * 3, bad.ctypes.data, 1) == _native.PSD_ERR_INVALID
+    buf.upload_rows_batch([], 0, np.array([0], np.int32), h * w * 3)                        # nothing to do
+    buf.free()
+
+
 def _run_downscaled(engine, frames, factor, interpolation, detector):
     stats = psd.StatsManager()
     sm = psd.SceneManager(stats, engine=engine, batch_frames=16)

@@ -60,6 +60,16 @@ for src_name, src in (("pageable", hf), ("pinned", pinned)):
         for t in range(N):
             buf.upload_unordered(src[t].reshape(-1), t * H * W * 3)
     out[f"upload_whole_frames_{src_name}_fps"] = round(N / best_of(up_whole), 1)
+# ABI 5: the same rows, 16 frames per call, gathered by the engine's worker threads into page-locked memory + one async copy
+out["feed_threads"] = int(os.environ.get("PSD_FEED_THREADS", "8"))
+for per_call in (8, 16, 32):
+    views = [hf[t] for t in range(N)]
+
+    def up_batched():
+        for a in range(0, N, per_call):
+            buf.upload_rows_batch(views[a:a + per_call], a * H * W * 3, rows, H * W * 3)
+        eng.upload_fence(wait_on_host=True)
+    out[f"upload_tap_rows_batched_{per_call}_pageable_fps"] = round(N / best_of(up_batched), 1)
 for src_name, src in (("pageable", hf), ("pinned", pinned)):
     for name, auto in (("full_res", False), ("auto_downscale", True)):
         def run():
