@@ -223,7 +223,7 @@ int psd_upload_rows(psd_engine* e, void* d_frame, const void* h_frame, size_t ro
 int psd_upload_rows_plan(const int* rows, int n_rows, int packed, int* copies, int max_copies, int* n_copies);
 /* psd_upload_rows for n_frames separately allocated host frames at once (what a decoder hands out: backends/pyav.py:322-363
  * returns a fresh array per frame): frame i's rows go to the packed device frame at d_first_frame + i * d_frame_stride.
- * The rows are gathered by the engine's worker threads (PSD_FEED_THREADS, default 8) into a ring of page-locked segments,
+ * The rows are gathered by the engine's worker threads (PSD_FEED_THREADS, default 16) into a ring of page-locked segments,
  * frame after frame without gaps, and travel from there as asynchronous strided copies on the engine's copy stream --
  * the call returns once they are enqueued, the host frames may be reused at once, and psd_upload_fence() orders them like
  * psd_upload_async's.  One call per 8 .. 32 frames keeps PCIe busy where one blocking psd_upload_rows per frame reaches

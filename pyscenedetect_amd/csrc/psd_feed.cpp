@@ -132,7 +132,7 @@ int feed_threads()
 {
     static const int n = [] {
         const char* v = getenv("PSD_FEED_THREADS");
-        int t = v ? atoi(v) : 8;
+        int t = v ? atoi(v) : 16;
         const unsigned hw = std::thread::hardware_concurrency();
         if (hw && t > (int)hw) t = (int)hw;
         return t < 1 ? 1 : (t > 64 ? 64 : t);

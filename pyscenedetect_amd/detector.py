@@ -14,7 +14,7 @@ from enum import Enum
 
 import numpy as np
 
-from pyscenedetect_amd.timecode import FrameTimecode, parse_timecode_seconds
+from pyscenedetect_amd.timecode import FrameTimecode, Timecode, parse_timecode_seconds
 
 
 class SceneDetector(ABC):
@@ -91,7 +91,7 @@ class FlashFilter:
             self._length_secs = length
         elif isinstance(length, str) and not length.strip().isdigit():
             self._length_secs = parse_timecode_seconds(length, 100)
-        elif isinstance(length, FrameTimecode):
+        elif isinstance(length, (Timecode, FrameTimecode)):      # any TimecodeLike (reference detector.py:136-137)
             self._length_secs = length.seconds
         else:
             self._length_frames = int(length)

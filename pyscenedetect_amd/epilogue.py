@@ -34,6 +34,8 @@ def _min_len(length, rate: Fraction, int_is_frames: bool = True) -> tuple[int, f
             # FlashFilter treats a digit string as frames; FrameTimecode comparisons go through seconds.
             return (int(s), -1.0) if int_is_frames else (0, int(s) / float(rate))
         return 0, float(parse_timecode_seconds(s, rate))
+    if hasattr(length, "seconds") and not isinstance(length, (bytes, bytearray)):   # FrameTimecode / Timecode: a duration
+        return 0, float(length.seconds)
     raise TypeError(f"unsupported min_scene_len type {type(length)}")
 
 

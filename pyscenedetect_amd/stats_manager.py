@@ -67,7 +67,7 @@ class StatsManager:
         if not (force_save or self.is_save_required()):
             return
         close = False
-        if isinstance(csv_file, (str, bytes)):
+        if isinstance(csv_file, (str, bytes, os.PathLike)):      # a path in any spelling (reference stats_manager.py:187)
             csv_file = open(csv_file, "w", newline="")
             close = True
         try:

@@ -18,6 +18,7 @@ Semantics follow the reference for every pair of forms:
 * the hash is the frame number, so an ``int`` can index a stats dictionary (``common.py:783-791``).
 """
 
+import warnings
 from dataclasses import dataclass
 from fractions import Fraction
 
@@ -147,6 +148,31 @@ class FrameTimecode:
         if isinstance(other, FrameTimecode):
             other = other._rate
         return abs(float(self._rate) - float(other)) < MAX_FPS_DELTA
+
+    # -- names the reference still answers to, each with one DeprecationWarning (common.py:292-306, 325-350, 375-383, 396-414)
+    def _legacy(self, old: str, new: str) -> None:
+        warnings.warn(f"{old} is deprecated; use {new} instead.", DeprecationWarning, stacklevel=3)
+
+    @property
+    def framerate(self) -> float:
+        self._legacy("`framerate`", "`frame_rate`")
+        return float(self._rate)
+
+    def get_framerate(self) -> float:
+        self._legacy("get_framerate()", "the `frame_rate` property")
+        return float(self._rate)
+
+    def get_frames(self) -> int:
+        self._legacy("get_frames()", "the `frame_num` property")
+        return self.frame_num
+
+    def get_seconds(self) -> float:
+        self._legacy("get_seconds()", "the `seconds` property")
+        return self.seconds
+
+    def equal_framerate(self, fps) -> bool:
+        self._legacy("`equal_framerate()`", "`equal_frame_rate()`")
+        return self.equal_frame_rate(fps)
 
     def get_timecode(self, precision: int = 3, use_rounding: bool = True, nearest_frame: bool = True) -> str:
         """``HH:MM:SS.nnn``; frame- and seconds-backed values snap to the frame boundary, a PTS already is one

@@ -61,7 +61,7 @@ for src_name, src in (("pageable", hf), ("pinned", pinned)):
             buf.upload_unordered(src[t].reshape(-1), t * H * W * 3)
     out[f"upload_whole_frames_{src_name}_fps"] = round(N / best_of(up_whole), 1)
 # ABI 5: the same rows, 16 frames per call, gathered by the engine's worker threads into page-locked memory + one async copy
-out["feed_threads"] = int(os.environ.get("PSD_FEED_THREADS", "8"))
+out["feed_threads"] = int(os.environ.get("PSD_FEED_THREADS", "16"))
 for per_call in (8, 16, 32):
     views = [hf[t] for t in range(N)]
 
