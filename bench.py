@@ -373,6 +373,9 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
     attempt("default_pipeline_downscale_auto", f"ContentDetector behind SceneManager's default downscale ({w}x{h} -> 256 wide), {n} frames; "
             "roofline counts the source rows that carry taps",
             lambda: quick_measure(Workload(eng, batch, "content", "auto", epilogue, E), steps=20, warmup=5))   # (1.2 ms per step)
+    attempt("default_pipeline_downscale_auto_all_four", f"all four detectors behind SceneManager's default downscale ({w}x{h} -> 256 wide), {n} frames: "
+            "resize + HSV + luma histogram + byte sum in ONE kernel, the small frame never exists in memory; roofline counts the source rows "
+            "that carry taps", lambda: quick_measure(Workload(eng, batch, "all", "auto", epilogue, E), steps=20, warmup=5))
     attempt("hash_detector_1080p", f"HashDetector (thumbnail kernel + DCT epilogue), {n} x {w}x{h}",
             lambda: quick_measure(Workload(eng, batch, "hash", None, epilogue, E), steps=3, warmup=1))
     for dist, label in (("S", "shot-like content (64-frame shots, hard cuts)"), ("K", "constant frames (one histogram bin per frame)")):

@@ -258,9 +258,10 @@ int psd_resize_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int
  * process_frame): cv2.resize(frame, (dst_w, dst_h), interpolation) and then the terms of `flags` on the RESIZED frames.
  * Source frames: packed rows (row stride 3*src_w), frame t at d_frames + t*frame_stride; d_prev is the SOURCE-size
  * frame preceding frame 0 or NULL.  Records are those psd_score_batch_device would return for the resized frames.
- * With INTER_LINEAR and flags == PSD_SCORE_HSV_SAD (ContentDetector / AdaptiveDetector, the reference's default
+ * With INTER_LINEAR and any set of the HSV, luma-histogram and byte-sum terms (Content / Adaptive / Histogram / Threshold
  * detectors) on 16-byte aligned frames the resized frame never exists in memory: one kernel reads the 2*dst_h source
- * rows that carry taps, interpolates and scores.  Every other combination resizes into an engine-owned buffer first.
+ * rows that carry taps, interpolates and scores.  The edge term and the other interpolation modes resize into an
+ * engine-owned buffer first.
  * The submit form pairs with psd_score_collect() like psd_score_submit_device(). */
 int psd_score_downscaled_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w,
                                 size_t frame_stride, const uint8_t* d_prev, int dst_h, int dst_w,

@@ -58,7 +58,7 @@ void edges_release(psd_engine* e);
 int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_row_stride,
                         size_t src_frame_stride, const uint8_t* d_prev, uint8_t* d_dst, int dst_h, int dst_w,
                         size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg,
-                        bool area_mode = false);
+                        bool area_mode = false, uint32_t terms = PSD_SCORE_HSV_SAD);
 void resize_release(psd_engine* e);
 int resize_other(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
                  int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream);
@@ -120,6 +120,8 @@ struct psd_engine {
     void* resize_cache = nullptr;   // coefficient tables per (src, dst) shape of every resize mode + the hash thumbnails, owned by psd_resize_kernels.hip
     uint8_t* d_small = nullptr;     // resized frames of psd_score_downscaled_* when the terms need them in memory
     size_t small_bytes = 0;
+    void* d_hpart = nullptr;        // per (frame, tile) partial luma histograms of the fused downscale + luma pass
+    size_t hpart_bytes = 0;
     hipStream_t copy_stream = nullptr;   // psd_upload_async: host -> device copies that overlap the scoring stream
     hipEvent_t ev_copy = nullptr;
     psd_feed* feed = nullptr;     // psd_upload_rows_batch: gather threads + ring of page-locked / device staging segments
@@ -244,6 +246,7 @@ void psd_destroy(psd_engine* e)
     psd::edges_release(e);
     psd::resize_release(e);
     if (e->d_small) (void)hipFree(e->d_small);
+    if (e->d_hpart) (void)hipFree(e->d_hpart);
     for (auto& s : e->slots) {
         if (s.d_recs) (void)hipFree(s.d_recs);
         if (s.h_recs) (void)hipHostFree(s.h_recs);
@@ -515,10 +518,11 @@ int psd_score_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, i
     if (rc != PSD_OK) return rc;
     if (n > 0) {
         bool done = false;
-        if (interpolation == PSD_INTER_LINEAR && flags == PSD_SCORE_HSV_SAD) {
-            // ContentDetector / AdaptiveDetector behind the default downscale: the resized frame never leaves the CU
+        if (interpolation == PSD_INTER_LINEAR && !(flags & PSD_SCORE_EDGES)) {
+            // Content / Adaptive / Histogram / Threshold detectors, any set of them, behind the default downscale: the resized
+            // frame never leaves the CU (only the edge term needs it in memory)
             rc = psd::resize_linear_score(e, d_frames, n, src_h, src_w, (size_t)src_w * 3, frame_stride, d_prev, nullptr, dst_h, dst_w, 0,
-                                          s->d_recs, stream, &s->launches, nullptr);
+                                          s->d_recs, stream, &s->launches, nullptr, false, flags);
             if (rc == PSD_OK) done = true;
             else if (rc != PSD_ERR_UNSUPPORTED) return rc;
         }
@@ -1062,6 +1066,25 @@ hipStream_t engine_stream(psd_engine* e) { return e->stream; }
 int engine_device(psd_engine* e) { return e->device; }
 void** engine_resize_cache(psd_engine* e) { return &e->resize_cache; }
 psd_feed** engine_feed_slot(psd_engine* e) { return &e->feed; }
+int engine_hist_scratch(psd_engine* e, size_t bytes, hipStream_t stream, void** out)
+{
+    if (e->hpart_bytes < bytes) {
+        // (growing: earlier submissions on either stream may still read the old buffer)
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->d_hpart) HIP_TRY(hipFree(e->d_hpart));
+        e->d_hpart = nullptr; e->hpart_bytes = 0;
+        const size_t cap = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        hipError_t err = hipMalloc(&e->d_hpart, cap);
+        if (err != hipSuccess) {
+            psd_set_error("hipMalloc(%zu) failed: %s", cap, hipGetErrorString(err));
+            return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
+        }
+        e->hpart_bytes = cap;
+    }
+    *out = e->d_hpart;
+    return PSD_OK;
+}
 int engine_copy_stream(psd_engine* e, hipStream_t* out)
 {
     int rc = ensure_copy_stream(e);

@@ -37,6 +37,7 @@ extern "C" void psd_set_error(const char* fmt, ...);
 namespace psd {
 
 void** engine_resize_cache(psd_engine* e);
+int engine_hist_scratch(psd_engine* e, size_t bytes, hipStream_t stream, void** out);   // grows on demand (psd_engine.cpp)
 int engine_num_cus(psd_engine* e);
 const uint32_t* engine_lut(psd_engine* e);
 
@@ -212,6 +213,7 @@ struct RsParams {
     int n, rows_per_tile, n_tiles, frames_per_chunk, row_pad;
     int area2;
     int depth;               // staging buffers: 2 = one frame ahead, 3 = two frames ahead
+    u32* hpart;              // LUMA: per (frame, tile) partial luma histograms, 128 words of two 16-bit counts (bins 2i | 2i+1 << 16)
 };
 
 // 24-bit multiplies (v_mul_lo_u32 issues at a quarter of their rate; hipcc does not pick them for `>> 4`-ed or table operands)
@@ -244,13 +246,29 @@ __device__ __forceinline__ void hsv_px(u32 b, u32 g, u32 r, const u32* lut_s, co
 
 constexpr int RS_WG = 256, RS_NW = 4, RS_SLOTS = 16;
 
+// LDS increment the compiler does not see as an LDS store: hipcc orders every LDS store / atomic behind ALL outstanding LDS-DMA
+// (s_waitcnt vmcnt(0)), i.e. behind the staging of the NEXT frame, which would serialise the prefetch with this frame's
+// arithmetic (psd_score_kernels.hip, lds_add_hidden).  The histogram words never overlap the staging buffers; the barrier of
+// the next frame is preceded by an explicit lgkmcnt(0).
+__device__ __forceinline__ void rs_lds_add(const u32* p, u32 inc)
+{
+    asm volatile("ds_add_u32 %0, %1" ::"v"((u32)(uintptr_t)p), "v"(inc) : "memory");
+}
+
 // grid.x = n_tiles * n_chunks.  Dynamic LDS: 2 buffers x (2 R rows x row_pad bytes).
-template <bool STORE, bool HSV, int G>
+// LUMA: the luma histogram and the byte sum of the RESIZED frame as well (HistogramDetector / ThresholdDetector behind the
+// reference's default downscale, histogram_detector.py:156-159 and threshold_detector.py:127 on what scene_manager.py:666-678
+// hands them).  A workgroup counts its tile's pixels of frame t into one of two 256-bin LDS histograms and, one barrier
+// later, writes it as 128 packed words to hpart[t][tile] with plain coalesced stores; hist_reduce_kernel adds the tiles of a
+// frame up.  (Global atomics instead -- up to 256 per tile and frame, 75 M per 4096-frame launch on one address per bin and
+// frame from every XCD -- would cost more than the pixels.)  The byte sum rides with the three SADs.
+template <bool STORE, bool HSV, int G, bool LUMA = false>
 __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t rs_stage[];
-    __shared__ u32 lut_s[256], lut_h[256];
+    __shared__ u32 lut_s[HSV ? 256 : 1], lut_h[HSV ? 256 : 1];
     __shared__ u32 sums[RS_SLOTS][4];
+    __shared__ u32 lhist[LUMA ? 2 : 1][LUMA ? 256 : 1];
     __shared__ int srows[64];           // clamped source rows of this tile: slot 2 * lr + k
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x % p.n_tiles, chunk = blockIdx.x / p.n_tiles;
@@ -259,7 +277,12 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     const int t0 = chunk * p.frames_per_chunk, t1 = min(p.n, t0 + p.frames_per_chunk);
     if (HSV) {
         for (int i = tid; i < 256; i += RS_WG) { lut_s[i] = p.lut[i]; lut_h[i] = p.lut[256 + i]; }
+    }
+    if (HSV || LUMA) {
         for (int i = tid; i < RS_SLOTS * 4; i += RS_WG) (&sums[0][0])[i] = 0;
+    }
+    if (LUMA) {
+        for (int i = tid; i < 2 * 256; i += RS_WG) (&lhist[0][0])[i] = 0;
     }
     if (tid < 2 * nrows) {
         const YTap y = p.yt[r0 + (tid >> 1)];
@@ -354,20 +377,33 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        if (LUMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's hidden histogram increments of frame t-1
         __syncthreads();                       // every wave's rows of frame t have landed; frame t-1 is fully consumed
         if (t + ahead < t1) issue(frame_ptr(t + ahead), ahead > 1 ? (step + 2) % 3 : (buf ^ 1));
         const int rel = t - t0;                // chunk-relative frame index (-1 for the halo frame)
-        if (HSV && rel >= 8 && (rel & 7) == 0 && tid < 24) {
+        if ((HSV || LUMA) && rel >= 8 && (rel & 7) == 0 && tid < 32) {
             // frames rel-8 .. rel-1 are complete (all waves added them before this frame's barrier)
-            const int f = rel - 8 + tid / 3, q = tid % 3;
+            const int f = rel - 8 + (tid >> 2), q = tid & 3;
             const u32 v = sums[f & (RS_SLOTS - 1)][q];
             sums[f & (RS_SLOTS - 1)][q] = 0;
             psd_frame_scores* rec = p.out + t0 + f;
             if (v) atomicAdd(q == 0 ? (unsigned long long*)&rec->sad_h : q == 1 ? (unsigned long long*)&rec->sad_s
-                                                                            : (unsigned long long*)&rec->sad_v, (unsigned long long)v);
+                             : q == 2 ? (unsigned long long*)&rec->sad_v : (unsigned long long*)&rec->byte_sum, (unsigned long long)v);
+        }
+        if (LUMA && rel >= 1 && tid < 128) {
+            // frame rel-1's histogram of this tile is complete: out as 128 packed words, and the slot is free for frame rel+1
+            u32* hs = lhist[(rel - 1) & 1];
+            const u32 lo = hs[2 * tid], hi = hs[2 * tid + 1];
+            // (cleared with a store the compiler does not see, for the reason given at rs_lds_add: a visible LDS store here would
+            //  make these two waves wait for the NEXT frame's staging, issued a few lines up; the read above is of a different
+            //  object than the staging buffers and is not held back)
+            asm volatile("ds_write_b64 %0, %1" ::"v"((u32)(uintptr_t)&hs[2 * tid]), "v"(0ull) : "memory");
+            p.hpart[((size_t)(t - 1) * p.n_tiles + tile) * 128 + tid] = lo | (hi << 16);
         }
         const uint8_t* base = rs_stage + (size_t)buf * buf_bytes;
-        u32 sh = 0, ss = 0, sv = 0;
+        u32 sh = 0, ss = 0, sv = 0, bsum = 0;
+        const bool count_luma = LUMA && t >= t0;           // (the halo frame only feeds the HSV carry)
+        u32* hcur = lhist[LUMA ? (rel & 1) : 0];
         const bool chain = have_prev && !(HSV && t >= 0 && p.seg != nullptr && p.seg[t] != 0);
 #pragma unroll
         for (int g = 0; g < G; g++) {
@@ -386,6 +422,14 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             if (STORE && t >= t0) {
                 uint8_t* d = p.dst + (size_t)t * p.dstride + ((size_t)(r0 + lrow[g]) * p.dw + (g * RS_WG + tid - lrow[g] * p.dw)) * 3;
                 d[0] = (uint8_t)c[0]; d[1] = (uint8_t)c[1]; d[2] = (uint8_t)c[2];
+            }
+            if (LUMA) {
+                if (count_luma) {
+                    // BT.601 luma in OpenCV's 14-bit fixed point (color_yuv.simd.hpp: 1868 B + 9617 G + 4899 R, + 8192 >> 14)
+                    const u32 y = (mul_u24(c[0], 1868u) + mul_u24(c[1], 9617u) + mul_u24(c[2], 4899u) + 8192u) >> 14;
+                    rs_lds_add(&hcur[y], 1u);
+                    bsum += c[0] + c[1] + c[2];
+                }
             }
             if (HSV) {
                 u32 h, s, v;
@@ -413,19 +457,46 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             }
             have_prev = true;
         }
+        if (LUMA) {
+            if (count_luma) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) bsum += __shfl_xor(bsum, o);
+                if (lane == 0) atomicAdd(&sums[rel & (RS_SLOTS - 1)][3], bsum);
+            }
+        }
     }
-    if (HSV) {
+    if (HSV || LUMA) {
+        if (LUMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
         // the periodic flush took frames [0, 8 * floor((done - 1) / 8)); at most 8 are left
         const int done = t1 - t0;
-        const int f = (done > 0 ? ((done - 1) & ~7) : 0) + tid / 3, q = tid % 3;
-        if (tid < 24 && f < done) {
+        const int f = (done > 0 ? ((done - 1) & ~7) : 0) + (tid >> 2), q = tid & 3;
+        if (tid < 32 && f < done) {
             const u32 v = sums[f & (RS_SLOTS - 1)][q];
             psd_frame_scores* rec = p.out + t0 + f;
             if (v) atomicAdd(q == 0 ? (unsigned long long*)&rec->sad_h : q == 1 ? (unsigned long long*)&rec->sad_s
-                                                                            : (unsigned long long*)&rec->sad_v, (unsigned long long)v);
+                             : q == 2 ? (unsigned long long*)&rec->sad_v : (unsigned long long*)&rec->byte_sum, (unsigned long long)v);
+        }
+        if (LUMA && done > 0 && tid < 128) {   // the chunk's last frame
+            const u32* hs = lhist[(done - 1) & 1];
+            p.hpart[((size_t)(t1 - 1) * p.n_tiles + tile) * 128 + tid] = hs[2 * tid] | (hs[2 * tid + 1] << 16);
         }
     }
+}
+
+// rec[t].hist = sum over the tiles of frame t of their packed partial histograms.  grid = frames, 128 threads.
+__global__ __launch_bounds__(128) void hist_reduce_kernel(const u32* hpart, int n_tiles, psd_frame_scores* out)
+{
+    const int t = blockIdx.x, i = threadIdx.x;
+    const u32* src = hpart + (size_t)t * n_tiles * 128 + i;
+    u32 lo = 0, hi = 0;
+    for (int k = 0; k < n_tiles; k++) {
+        const u32 v = src[(size_t)k * 128];
+        lo += v & 0xffffu;
+        hi += v >> 16;
+    }
+    out[t].hist[2 * i] = lo;
+    out[t].hist[2 * i + 1] = hi;
 }
 
 // Generic cv2.resize(INTER_LINEAR): any alignment / row stride.  grid = (ceil(dw/256), dh, n)
@@ -452,26 +523,31 @@ __global__ __launch_bounds__(256) void resize_linear_generic_kernel(const uint8_
     for (int c = 0; c < 3; c++) D[c] = (uint8_t)interp(ra[x.o0 + c], ra[x.o1 + c], rb[x.o0 + c], rb[x.o1 + c], a0, a1, b0, b1);
 }
 
-template <bool STORE, bool HSV>
+template <bool STORE, bool HSV, bool LUMA = false>
 static void launch_walk(const RsParams& p, int g, int grid, size_t lds, hipStream_t stream)
 {
     switch (g) {
-    case 1: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 1>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
-    case 2: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 2>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
-    case 4: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 4>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
-    default: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 8>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    case 1: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 1, LUMA>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    case 2: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 2, LUMA>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    case 4: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 4, LUMA>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    default: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 8, LUMA>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
     }
 }
 
 // cv2.resize(INTER_LINEAR) of n frames and / or the HSV term of the resized frames.
 //   d_dst   resized frames out (packed rows, dst_frame_stride apart) or null
-//   d_out   zero-initialised records to add sad_h / sad_s / sad_v of the resized frames into, or null
+//   d_out   zero-initialised records to add the terms of the resized frames into, or null
+//   terms   with d_out: PSD_SCORE_HSV_SAD (sad_h / sad_s / sad_v) and / or PSD_SCORE_LUMA_HIST | PSD_SCORE_BYTE_SUM (hist and
+//           byte_sum, always both); the luma terms only without d_dst
 //   d_prev  source-size frame preceding frame 0 (HSV carry), or null
 int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_row_stride,
                         size_t src_frame_stride, const uint8_t* d_prev, uint8_t* d_dst, int dst_h, int dst_w,
                         size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg,
-                        bool area_mode)
+                        bool area_mode, uint32_t terms)
 {
+    const bool want_hsv = d_out && (terms & PSD_SCORE_HSV_SAD), want_luma = d_out && (terms & (PSD_SCORE_LUMA_HIST | PSD_SCORE_BYTE_SUM));
+    if (d_out && !want_hsv && !want_luma) return PSD_OK;
+    if (want_luma && d_dst) { psd_set_error("fused downscale: the luma terms do not combine with storing the resized frames"); return PSD_ERR_UNSUPPORTED; }
     if (n == 0 || (!d_dst && !d_out)) return PSD_OK;
     ResizeTabs tabs;
     int rc = get_tabs(e, src_h, src_w, dst_h, dst_w, stream, &tabs, area_mode);
@@ -524,19 +600,34 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     // time chunks: enough workgroups for every CU several times over, walks long enough that the halo frame stays small
     const int target = engine_num_cus(e) * 12;
     int chunks = (target + p.n_tiles - 1) / p.n_tiles;
-    if (d_out) { const int by_walk = (n + 31) / 32; if (chunks > by_walk) chunks = by_walk; }
+    if (want_hsv) { const int by_walk = (n + 31) / 32; if (chunks > by_walk) chunks = by_walk; }
     if (chunks > n) chunks = n;
     if (chunks < 1) chunks = 1;
     p.frames_per_chunk = (n + chunks - 1) / chunks;
     chunks = (n + p.frames_per_chunk - 1) / p.frames_per_chunk;
     const size_t lds = (size_t)p.depth * 2 * R * p.row_pad;
     const int grid = p.n_tiles * chunks;
-    if (d_out) note_walk_geometry(p.frames_per_chunk, p.n_tiles);
-    if (d_dst && d_out) launch_walk<true, true>(p, g, grid, lds, stream);
-    else if (d_out) launch_walk<false, true>(p, g, grid, lds, stream);
+    if (want_hsv) note_walk_geometry(p.frames_per_chunk, p.n_tiles);
+    if (want_luma) {
+        void* scratch = nullptr;
+        rc = engine_hist_scratch(e, (size_t)n * p.n_tiles * 128 * sizeof(u32), stream, &scratch);
+        if (rc != PSD_OK) return rc;
+        p.hpart = static_cast<u32*>(scratch);
+    }
+    if (d_dst && want_hsv) launch_walk<true, true>(p, g, grid, lds, stream);
+    else if (want_hsv && want_luma) launch_walk<false, true, true>(p, g, grid, lds, stream);
+    else if (want_luma) launch_walk<false, false, true>(p, g, grid, lds, stream);
+    else if (want_hsv) launch_walk<false, true>(p, g, grid, lds, stream);
     else launch_walk<true, false>(p, g, grid, lds, stream);
     HIP_TRY(hipGetLastError());
     if (launches) *launches += 1;
+    if (want_luma) {
+        for (int t0 = 0; t0 < n; t0 += 65535)
+            hipLaunchKernelGGL(hist_reduce_kernel, dim3(std::min(65535, n - t0)), dim3(128), 0, stream, p.hpart + (size_t)t0 * p.n_tiles * 128,
+                               p.n_tiles, d_out + t0);
+        HIP_TRY(hipGetLastError());
+        if (launches) *launches += 1;
+    }
     return PSD_OK;
 }
 

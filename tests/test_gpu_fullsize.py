@@ -211,11 +211,57 @@ def test_downscale_then_score_matches_oracle(hip_engine, case):
         buf.upload(frames[i].reshape(-1), (i + 1) * stride)
     for with_prev in (False, True):
         _, want = oracle_downscaled(frames, prev if with_prev else None, dh, dw)
-        for flags, fields in ((E.SCORE_HSV_SAD, ("sad_h", "sad_s", "sad_v")), (NOEDGE, FIELDS)):
+        # every set of non-edge terms takes ONE fused kernel (round 4: the luma histogram and the byte sum too)
+        for flags, fields in ((E.SCORE_HSV_SAD, ("sad_h", "sad_s", "sad_v")), (NOEDGE, FIELDS),
+                              (E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM, ("hist", "byte_sum")), (E.SCORE_BYTE_SUM, ("byte_sum",)),
+                              (E.SCORE_HSV_SAD | E.SCORE_LUMA_HIST, ("sad_h", "sad_s", "sad_v", "hist"))):
             got = hip_engine.score_device_downscaled(buf.ptr + stride, n, sh, sw, dh, dw, frame_stride=stride,
                                                      d_prev=buf.ptr if with_prev else None, flags=flags)
             same(got, want, fields)
+            assert not got["edge_xor"].any()
+            if not flags & E.SCORE_HSV_SAD:
+                assert not got["sad_h"].any() and not got["sad_v"].any()
     buf.free()
+
+
+def test_downscale_then_all_four_constant_frames_and_headline_size(hip_engine):
+    """The fused downscale + HSV + luma + byte-sum kernel (BASELINE configs[4]'s detector set behind the reference's default
+    downscale, scene_manager.py:666-678): constant frames (every pixel of a tile in ONE histogram bin) against the oracle, and
+    4096 x 1080p -> 256 x 144: chunking invariance (one call == four calls with a predecessor), histograms that sum to the small
+    frame, and the oracle on both sides of walk boundaries deep in the batch."""
+    import torch
+
+    vals = [(0, 0, 0), (255, 255, 255), (128, 128, 128), (255, 0, 0), (0, 255, 0), (0, 0, 255), (17, 200, 99), (128, 128, 128), (90, 10, 200)]
+    frames = np.empty((len(vals), 360, 640, 3), np.uint8)
+    for i, v in enumerate(vals):
+        frames[i] = v
+    buf = device_copy(hip_engine, frames)
+    _, want = oracle_downscaled(frames, None, 144, 256)
+    same(hip_engine.score_device_downscaled(buf.ptr, len(vals), 360, 640, 144, 256, flags=NOEDGE), want)
+    buf.free()
+    n, sh, sw, dh, dw = 4096, 1080, 1920, 144, 256
+    g = torch.Generator(device="cuda")
+    g.manual_seed(78)
+    x = torch.empty((n, sh, sw, 3), dtype=torch.uint8, device="cuda")
+    for i in range(0, n, 64):
+        x[i:i + 64] = torch.randint(0, 256, (64, sh, sw, 3), dtype=torch.uint8, device="cuda", generator=g)
+    x[900:1000] //= 8                        # dark frames: other histogram bins, a fade for ThresholdDetector
+    torch.cuda.synchronize()
+    stride = sh * sw * 3
+    whole = hip_engine.score_device_downscaled(x.data_ptr(), n, sh, sw, dh, dw, flags=NOEDGE)
+    walk, _ = hip_engine.last_walk_geometry()
+    assert (whole["hist"].sum(axis=1) == dh * dw).all() and whole["byte_sum"][950] < whole["byte_sum"][10] // 4
+    hsv_only = hip_engine.score_device_downscaled(x.data_ptr(), n, sh, sw, dh, dw, flags=E.SCORE_HSV_SAD)
+    same(whole, hsv_only, ("sad_h", "sad_s", "sad_v"))
+    luma_only = hip_engine.score_device_downscaled(x.data_ptr(), n, sh, sw, dh, dw, flags=E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM)
+    same(whole, luma_only, ("hist", "byte_sum"))
+    parts = [hip_engine.score_device_downscaled(x.data_ptr() + a * stride, 1024, sh, sw, dh, dw, flags=NOEDGE,
+                                                d_prev=x.data_ptr() + (a - 1) * stride if a else None) for a in range(0, n, 1024)]
+    same(np.concatenate(parts), whole)
+    assert 8 <= walk < n
+    for a in (0, walk - 1, (n // 2 // walk) * walk - 1, n - 3):
+        _, want = oracle_downscaled(x[a:a + 3].cpu().numpy(), x[a - 1].cpu().numpy() if a else None, dh, dw)
+        same(whole[a:a + 3], want)
 
 
 def test_downscale_then_score_other_terms_and_modes(hip_engine):
