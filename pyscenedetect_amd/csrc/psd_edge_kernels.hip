@@ -476,6 +476,9 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
     __shared__ __attribute__((aligned(16))) uint8_t sv[N2_H + 8][N2_SVW];   // rows y0-2 .. y0+33, cols x0-4 .. x0+131 (+ 4 scratch rows)
     __shared__ __attribute__((aligned(16))) uint2 smq[N2_H + 2][N2_NCG];    // rows y0-1 .. y0+32, magnitudes as even / odd pairs
     __shared__ __attribute__((aligned(16))) uint8_t obits[2][N2_H][N2_W / 8]; // [strong | weak][row][8 pixels]
+    __shared__ unsigned short cand[N2_H * N2_W / 4];                        // sparse tiles: the pixels above `low`, row << 7 | column (phase 2)
+    static_assert(N2_H * (N2_W / 8) == 512, "the sparse / dense rule below counts (thread, step) pairs of eight pixels");
+    __shared__ int ncand, npos;   // candidates of the tile; list positions handed out (two words: nobody resets one the others still read)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x, j = blockIdx.y;
     const int ty = tiles_x == 1 ? tile : (int)__umulhi((u32)tile, tiles_x_magic), tx = tile - ty * tiles_x;
@@ -541,55 +544,118 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
     if (inner) sobel_phase1_quads<true>(sv, smq, tid, x0, y0, H, W);
     else sobel_phase1_quads<false>(sv, smq, tid, x0, y0, H, W);
     __syncthreads();
-    // ---- phase 2: non-maximum suppression, eight pixels of a row per thread and step
+    // ---- phase 2: non-maximum suppression.
+    // 2a, eight pixels of a row per thread and step: which of them have a magnitude above `low` at all (the candidates)?
+    // None in most tiles of a natural frame: such a tile is done here.  Where there are some they are usually a few per cent of
+    // the tile, and handled in place -- the pixels of a thread one after the other, each behind its own branch (round 3) -- a
+    // wave runs the whole candidate path for one or two live lanes, sixteen times over: +29 % wave instructions on frames with
+    // objects for 3 % of the pixels.  So a SPARSE tile puts its candidates on a list in LDS (row << 7 | column) and 2b takes
+    // the list densely, one candidate per lane; a DENSE tile (noise: every pixel a candidate, where the list would only add
+    // traffic) keeps the in-place loop, whose lanes are all busy anyway.
+    // Per candidate: dx, dy from the 3 x 3 neighbourhood, the direction in OpenCV's TG22 fixed point, the comparison with the
+    // two neighbours along it.
     const int low = lohi.x, high = lohi.y;
     const u32 lowpk = (u32)low * 0x10001u;
-    bool any_weak = false;
+    reinterpret_cast<u32*>(&obits[0][0][0])[tid] = 0;                       // 2 x 32 x 16 bytes = 256 words
+    if (tid == 0) { ncand = 0; npos = 0; }
+    __syncthreads();
+    constexpr int N_IT = N2_H * (N2_W / 8) / 256;
+    // how many (thread, step) pairs see a candidate at all: at most CAND_CAP / 8 of them -> sparse (the list cannot overflow)
+    constexpr int CAND_CAP = N2_H * N2_W / 4;
+    u32 anyx[N_IT];
 #pragma unroll
-    for (int it = 0; it < N2_H * (N2_W / 8) / 256; it++) {
+    for (int it = 0; it < N_IT; it++) {
         const int i = tid + it * 256;
         const int ly = i >> 4, o = i & 15;
         const uint2 qa = smq[ly + 1][1 + 2 * o], qb = smq[ly + 1][2 + 2 * o];
         // a half above `low` survives the max: (max(m, low) ^ low) != 0   (magnitudes outside the image are 0: never above)
-        const u32 any = (pk_max(qa.x, lowpk) ^ lowpk) | (pk_max(qa.y, lowpk) ^ lowpk) | (pk_max(qb.x, lowpk) ^ lowpk) | (pk_max(qb.y, lowpk) ^ lowpk);
-        u32 sb = 0, wb = 0;
-        if (any) {
-            const u32 w4[4] = {qa.x, qa.y, qb.x, qb.y};
+        anyx[it] = (pk_max(qa.x, lowpk) ^ lowpk) | (pk_max(qa.y, lowpk) ^ lowpk) | (pk_max(qb.x, lowpk) ^ lowpk) | (pk_max(qb.y, lowpk) ^ lowpk);
+        const unsigned long long vote = __ballot(anyx[it] != 0);
+        if (vote && lane == 0) atomicAdd(&ncand, __popcll(vote));
+    }
+    __syncthreads();
+    const int n_any = ncand;
+    // one candidate: is it a local maximum along its gradient, and how strong
+    auto classify = [&](int ly, int cx, int m) -> int {      // m = its magnitude; 0 = nothing, 1 = weak, 2 = strong
+        const int r = ly + 2, c = 4 + cx;                          // centre in sv; magnitude row ly + 1, column c
+        const int tl = sv[r - 1][c - 1], tc = sv[r - 1][c], tr = sv[r - 1][c + 1], ml = sv[r][c - 1], mr = sv[r][c + 1],
+                  bl = sv[r + 1][c - 1], bc = sv[r + 1][c], br = sv[r + 1][c + 1];
+        const int xs = (tr + 2 * mr + br) - (tl + 2 * ml + bl), ys = (bl + 2 * bc + br) - (tl + 2 * tc + tr);
+        const int ax = abs(xs), ay = abs(ys) << 15;
+        const int tg22x = ax * 13573;  // TG22 = round(tan(22.5 deg) * 2^15)
+        bool is_max;
+        if (ay < tg22x) {
+            is_max = m > mag_at(smq, ly + 1, c - 1) && m >= mag_at(smq, ly + 1, c + 1);
+        } else if (ay > tg22x + (ax << 16)) {
+            is_max = m > mag_at(smq, ly, c) && m >= mag_at(smq, ly + 2, c);
+        } else {
+            const int sgn = (xs ^ ys) < 0 ? -1 : 1;
+            is_max = m > mag_at(smq, ly, c - sgn) && m > mag_at(smq, ly + 2, c + sgn);
+        }
+        return is_max ? (m > high ? 2 : 1) : 0;
+    };
+    if (n_any > CAND_CAP / 8) {
+        // dense: in place, a thread's eight pixels one after the other
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int m = (int)((w4[2 * (k >> 2) + (k & 1)] >> (16 * ((k >> 1) & 1))) & 0xffffu);
-                if (m > low) {
-                    const int r = ly + 2, c = 4 + 8 * o + k;       // centre in sv; magnitude row ly + 1, column c
-                    const int tl = sv[r - 1][c - 1], tc = sv[r - 1][c], tr = sv[r - 1][c + 1], ml = sv[r][c - 1], mr = sv[r][c + 1],
-                              bl = sv[r + 1][c - 1], bc = sv[r + 1][c], br = sv[r + 1][c + 1];
-                    const int xs = (tr + 2 * mr + br) - (tl + 2 * ml + bl), ys = (bl + 2 * bc + br) - (tl + 2 * tc + tr);
-                    const int ax = abs(xs), ay = abs(ys) << 15;
-                    const int tg22x = ax * 13573;  // TG22 = round(tan(22.5 deg) * 2^15)
-                    bool is_max;
-                    if (ay < tg22x) {
-                        is_max = m > mag_at(smq, ly + 1, c - 1) && m >= mag_at(smq, ly + 1, c + 1);
-                    } else if (ay > tg22x + (ax << 16)) {
-                        is_max = m > mag_at(smq, ly, c) && m >= mag_at(smq, ly + 2, c);
-                    } else {
-                        const int sgn = (xs ^ ys) < 0 ? -1 : 1;
-                        is_max = m > mag_at(smq, ly, c - sgn) && m > mag_at(smq, ly + 2, c + sgn);
-                    }
-                    if (is_max) {
-                        if (m > high) sb |= 1u << k;
-                        else wb |= 1u << k;
+        for (int it = 0; it < N_IT; it++) {
+            const int i = tid + it * 256;
+            const int ly = i >> 4, o = i & 15;
+            u32 sb = 0, wb = 0;
+            if (anyx[it]) {
+                const uint2 qa = smq[ly + 1][1 + 2 * o], qb = smq[ly + 1][2 + 2 * o];
+                const u32 w4[4] = {qa.x, qa.y, qb.x, qb.y};
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    // pixel k of the eight: quad k >> 2, pair (k & 1), half (k >> 1) & 1
+                    const int m = (int)((w4[2 * (k >> 2) + (k & 1)] >> (16 * ((k >> 1) & 1))) & 0xffffu);
+                    if (m > low) {
+                        const int cls = classify(ly, 8 * o + k, m);
+                        if (cls == 2) sb |= 1u << k;
+                        else if (cls == 1) wb |= 1u << k;
                     }
                 }
             }
+            obits[0][ly][o] = (uint8_t)sb;
+            obits[1][ly][o] = (uint8_t)wb;
+            if (wb) {
+                const int y = y0 + ly, xq = x0 + 8 * o;
+                if (y < H && xq < W) dirty[(size_t)j * htiles_per_frame + (size_t)(y / HT_TILE) * htiles_x + xq / HT_TILE] = 1;
+            }
         }
-        obits[0][ly][o] = (uint8_t)sb;
-        obits[1][ly][o] = (uint8_t)wb;
-        if (wb) {
-            any_weak = true;
-            const int y = y0 + ly, xq = x0 + 8 * o;
-            if (y < H && xq < W) dirty[(size_t)j * htiles_per_frame + (size_t)(y / HT_TILE) * htiles_x + xq / HT_TILE] = 1;
+    } else if (n_any > 0) {
+        // sparse: onto the list (positions claimed per thread with one LDS atomic), then one candidate per lane
+#pragma unroll
+        for (int it = 0; it < N_IT; it++) {
+            if (anyx[it]) {
+                const int i = tid + it * 256;
+                const int ly = i >> 4, o = i & 15;
+                const uint2 qa = smq[ly + 1][1 + 2 * o], qb = smq[ly + 1][2 + 2 * o];
+                const u32 xa = pk_max(qa.x, lowpk) ^ lowpk, xb = pk_max(qa.y, lowpk) ^ lowpk, xc = pk_max(qb.x, lowpk) ^ lowpk, xd = pk_max(qb.y, lowpk) ^ lowpk;
+                u32 cm = 0;
+                cm |= (xa & 0xffffu) ? 1u : 0u;   cm |= (xb & 0xffffu) ? 2u : 0u;   cm |= (xa >> 16) ? 4u : 0u;    cm |= (xb >> 16) ? 8u : 0u;
+                cm |= (xc & 0xffffu) ? 16u : 0u;  cm |= (xd & 0xffffu) ? 32u : 0u;  cm |= (xc >> 16) ? 64u : 0u;   cm |= (xd >> 16) ? 128u : 0u;
+                int at = atomicAdd(&npos, __popc(cm));
+                while (cm) {
+                    const int k = __ffs((int)cm) - 1;
+                    cm &= cm - 1;
+                    cand[at++] = (unsigned short)((ly << 7) | (8 * o + k));
+                }
+            }
+        }
+        __syncthreads();
+        const int n_cand = npos;
+        for (int i = tid; i < n_cand; i += 256) {
+            const int e = cand[i], ly = e >> 7, cx = e & 127;
+            const int cls = classify(ly, cx, mag_at(smq, ly + 1, 4 + cx));
+            if (cls) {
+                atomicOr(reinterpret_cast<u32*>(&obits[cls == 2 ? 0 : 1][ly][0]) + (cx >> 5), 1u << (cx & 31));
+                if (cls == 1) {
+                    const int y = y0 + ly, xq = x0 + cx;
+                    if (y < H && xq < W) dirty[(size_t)j * htiles_per_frame + (size_t)(y / HT_TILE) * htiles_x + xq / HT_TILE] = 1;
+                }
+            }
         }
     }
-    (void)any_weak;
     __syncthreads();
     {
         // 2 planes x 32 rows x 4 words = 256 words, one per thread
@@ -664,9 +730,12 @@ __device__ __forceinline__ u32 ld_s(const u32* p)
 }
 
 // One 64 x 64 tile (by, bx) of one frame's bit planes S (strong, updated in place) / Wk (weak) to its fix point, by one wave.
-// Returns (uniformly) whether a pixel on the tile's border was promoted: the eight neighbours have to look again.
+// Returns (uniformly) WHICH neighbours have to look again, bit (dy + 1) * 3 + (dx + 1) for the tile at (by + dy, bx + dx): only
+// those that touch a promoted pixel -- a promotion in the top row wakes the tile above, in a corner the diagonal one as well.
+// (Round 3 woke all eight on any border promotion: on frames with objects most tile visits of the later rounds were
+// neighbours with nothing new to see, each a round trip to memory.)
 template <bool COHERENT>
-__device__ __forceinline__ bool hyst_tile(u32* S, const u32* Wk, const EdgeGeom& g, int by, int bx, int lane)
+__device__ __forceinline__ u32 hyst_tile(u32* S, const u32* Wk, const EdgeGeom& g, int by, int bx, int lane)
 {
     const int H = g.height, nw = g.words_per_row;
     const int w0 = 2 * bx, y0 = by * HT;
@@ -698,7 +767,7 @@ __device__ __forceinline__ bool hyst_tile(u32* S, const u32* Wk, const EdgeGeom&
     const u32 eL = s_l >> 31, eR = s_r & 1u;              // strong state of the pixels left / right of this row (fixed here)
     const unsigned long long Hv = ((unsigned long long)h_hi << 32) | h_lo;
     const u32 hL = h_l >> 31, hR = h_r & 1u;
-    if (__ballot(Kv != 0) == 0) return false;              // no weak pixel in the tile: nothing can change
+    if (__ballot(Kv != 0) == 0) return 0u;                 // no weak pixel in the tile: nothing can change
     for (;;) {
         // rows above / below: neighbouring lanes, the halo rows at the ends
         unsigned long long up = __shfl_up(Sv, 1), dn = __shfl_down(Sv, 1);
@@ -719,14 +788,24 @@ __device__ __forceinline__ bool hyst_tile(u32* S, const u32* Wk, const EdgeGeom&
     }
     const unsigned long long added = Sv & ~S0;
     const unsigned long long any_added = __ballot(added != 0);
-    if (any_added == 0) return false;
+    if (any_added == 0) return 0u;
     if (added != 0 && row_in) {
         if ((u32)added) S[(size_t)y * nw + w0] = (u32)Sv;
         if ((u32)(added >> 32) && has_hi) S[(size_t)y * nw + w0 + 1] = (u32)(Sv >> 32);
     }
-    // promoted pixels on the tile border: the neighbours have to look again
-    const bool border = (added != 0 && (lane == 0 || lane == 63)) || ((added & 0x8000000000000001ull) != 0);
-    return __ballot(border) != 0;
+    // promoted pixels on the tile border: the neighbours that touch them have to look again
+    const unsigned long long west = __ballot((added & 1ull) != 0), east = __ballot((added >> 63) != 0);
+    const unsigned long long top = __shfl(added, 0), bottom = __shfl(added, 63);   // rows 0 and 63 of the tile
+    u32 wake = 0;
+    if (top) wake |= 1u << 1;
+    if (bottom) wake |= 1u << 7;
+    if (west) wake |= 1u << 3;
+    if (east) wake |= 1u << 5;
+    if (top & 1ull) wake |= 1u << 0;
+    if (top >> 63) wake |= 1u << 2;
+    if (bottom & 1ull) wake |= 1u << 6;
+    if (bottom >> 63) wake |= 1u << 8;
+    return wake;
 }
 
 __global__ __launch_bounds__(256) void hysteresis_bits_kernel(u32* strong, const u32* weak, EdgeGeom g, uint8_t* dirty_in, uint8_t* dirty_out,
@@ -756,8 +835,9 @@ __global__ __launch_bounds__(256) void hysteresis_bits_kernel(u32* strong, const
         const long ti = first + bit;
         const int j = (int)(ti / per_frame), rem = (int)(ti - (long)j * per_frame);
         const int by = rem / tiles_x, bx = rem - by * tiles_x;
-        if (hyst_tile<false>(strong + (size_t)j * H * nw, weak + (size_t)j * H * nw, g, by, bx, lane)) {
-            if (lane < 9 && lane != 4) {
+        const u32 wake = hyst_tile<false>(strong + (size_t)j * H * nw, weak + (size_t)j * H * nw, g, by, bx, lane);
+        if (wake) {
+            if (lane < 9 && ((wake >> lane) & 1u)) {
                 const int ny = by + lane / 3 - 1, nx = bx + lane % 3 - 1;
                 if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) dirty_out[(size_t)j * per_frame + (size_t)ny * tiles_x + nx] = 1;
             }
@@ -811,8 +891,9 @@ __global__ __launch_bounds__(HF_WAVES * 64) void hysteresis_frame_kernel(u32* st
                 const int by = tile / tiles_x, bx = tile - by * tiles_x;
                 // (the first round -- on noisy frames most of the work -- reads through the L1: nothing of this frame can be
                 //  stale in it yet, and what a neighbouring wave stores meanwhile is picked up in the round that wave triggers)
-                if (round == 0 ? hyst_tile<false>(S, Wk, g, by, bx, lane) : hyst_tile<true>(S, Wk, g, by, bx, lane)) {
-                    if (lane < 9 && lane != 4) {
+                const u32 wake = round == 0 ? hyst_tile<false>(S, Wk, g, by, bx, lane) : hyst_tile<true>(S, Wk, g, by, bx, lane);
+                if (wake) {
+                    if (lane < 9 && ((wake >> lane) & 1u)) {
                         const int ny = by + lane / 3 - 1, nx = bx + lane % 3 - 1;
                         if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) {
                             const int nt = ny * tiles_x + nx;
@@ -1248,6 +1329,10 @@ int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
             cp.vout = b.vplane + (src.first_is_prev ? (size_t)g.npix : 0);
             // PSD_EDGE_VHIST_FUSED=0: the HSV-only kernel stores the V plane and v_hist_kernel counts it; default: the 16-wave
             // fused kernel counts the V histogram itself (A/B on 2048 x 1080p shot-like frames: 262-265 k vs 257 k frames/s)
+            // PSD_EDGE_VHIST_FUSED=0: the HSV-only kernel stores the V plane and v_hist_kernel counts it; default: the 16-wave
+            // fused kernel counts the V histogram itself.  (Round 4 also tried counting V in the 4-wave HSV kernel, per-tile partial
+            // histograms in LDS written out with plain stores: 2.03-2.06 ms + 0.1 ms for adding the tiles up against 2.0 ms for the
+            // fused kernel per 1024 x 1080p -- the LDS increments cost as much there; profiles/r04_f_*.)
             static const bool vhist_fused = [] { const char* v = getenv("PSD_EDGE_VHIST_FUSED"); return !v || atoi(v) != 0; }();
             cp.vhist = vhist_fused ? b.hist + (src.first_is_prev ? 256 : 0) : nullptr;
         }
