@@ -171,9 +171,7 @@ int psd_allgather_scores(psd_comm* c, const psd_frame_scores* d_local, int n_loc
                          psd_frame_scores* h_all);
 
 /* Device time (ms, HIP events on the launch stream) spent in the scoring kernels of the most
- * recently *collected* submission, and the number of kernel launches it took.  If the edge term had to be repeated at
- * collect (a weak-edge chain longer than the launches enqueued at submit; rare), the time of the second attempt is
- * included (host clock around it). */
+ * recently *collected* submission, and the number of kernel launches it took. */
 int psd_last_kernel_ms(psd_engine* e, float* ms, int* launches);
 /* How the most recent time-walking launch issued on the CALLING thread (the HSV pass, the fused all-detectors pass, the
  * V-mode pass of the edge term) cut its batch: every workgroup walked `frames_per_chunk` consecutive frames of one of

@@ -67,26 +67,39 @@ def score_clip(engine, clip, flags: int, edge_kernel: int = 0) -> np.ndarray:
     return engine.score_host(clip[0:len(clip)], flags=flags, edge_kernel=edge_kernel)
 
 
-def score_clips(engine, clips, flags: int, edge_kernel: int = 0, on_ready=None) -> list[np.ndarray]:
+def score_clips(engine, clips, flags: int, edge_kernel: int = 0, on_ready=None, sums_only: bool | None = None) -> list[np.ndarray]:
     """Records of every clip; engines that can pack clips of one resolution into shared batches (``ScoringEngine.score_clips``:
     one launch per term per batch, SAD chain broken at clip starts) do so, others score clip by clip.
-    ``on_ready(i, records)``: called per clip as its records arrive (see ``ScoringEngine.score_clips``)."""
+    ``on_ready(i, records)``: called per clip as its records arrive (see ``ScoringEngine.score_clips``).
+
+    Return dtype: ``sums_only=True`` -> ``SUMS_DTYPE`` (the five sums, 40 bytes per frame: all that Content / Adaptive /
+    Threshold decisions read, and all that travels from the device, through the host and over the all-gather);
+    ``sums_only=False`` -> ``RECORD_DTYPE`` (with the 256-bin luma histogram).  The default ``None`` means "sums only unless
+    ``flags`` asks for the luma histogram" -- whatever kind of engine is behind it, so every rank of a process group returns
+    the same dtype for the same flags."""
+    from pyscenedetect_amd.engine import _sums_of
+
+    if sums_only is None:
+        # without a HistogramDetector nobody reads the 1 KiB luma histogram of a record
+        sums_only = not (flags & _native.SCORE_LUMA_HIST)
     if hasattr(engine, "score_clips"):
-        # without a HistogramDetector nobody reads the 1 KiB luma histogram of a record: fetch the five sums only
-        # (40 instead of 1064 bytes per frame from the device, through the host and over the all-gather)
         import inspect
 
-        sums_only = not (flags & _native.SCORE_LUMA_HIST)
-        if on_ready is None or "on_ready" in inspect.signature(engine.score_clips).parameters:
-            kw = {"on_ready": on_ready} if on_ready is not None else {}
-            return engine.score_clips(clips, flags=flags, edge_kernel=edge_kernel, sums_only=sums_only, **kw)
-        out = engine.score_clips(clips, flags=flags, edge_kernel=edge_kernel, sums_only=sums_only)
-        for i, r in enumerate(out):
-            on_ready(i, r)
+        params = inspect.signature(engine.score_clips).parameters
+        kw = {"sums_only": sums_only} if "sums_only" in params else {}
+        if on_ready is not None and "on_ready" in params:
+            kw["on_ready"] = on_ready
+        out = engine.score_clips(clips, flags=flags, edge_kernel=edge_kernel, **kw)
+        if sums_only and "sums_only" not in params:
+            out = [_sums_of(r) for r in out]
+        if on_ready is not None and "on_ready" not in params:
+            for i, r in enumerate(out):
+                on_ready(i, r)
         return out
     out = []
     for i, c in enumerate(clips):
-        out.append(score_clip(engine, c, flags, edge_kernel))
+        recs = score_clip(engine, c, flags, edge_kernel)
+        out.append(_sums_of(recs) if sums_only else recs)
         if on_ready is not None:
             on_ready(i, out[-1])
     return out

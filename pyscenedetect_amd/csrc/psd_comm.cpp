@@ -101,6 +101,7 @@ struct psd_comm {
         hipError_t _e = (expr);                                                                      \
         if (_e != hipSuccess) {                                                                      \
             psd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            (void)hipGetLastError(); /* (the failure is reported here: do not leave it for the next launch check) */ \
             return PSD_ERR_HIP;                                                                      \
         }                                                                                            \
     } while (0)

@@ -10,8 +10,8 @@
 //   K3 sobel_nms_bits     Sobel 3x3 (replicate border), |dx|+|dy|, non-maximum suppression with OpenCV's TG22 fixed point
 //                         -> TWO BIT PLANES, strong (m > high) and weak (low < m <= high); LDS tiles with halo, tiles
 //                         handed out so that neighbours share an XCD's L2
-//   K4 hysteresis_bits    8-connected growth of strong into weak: one wave per 64x64 tile, one row per lane, 64-bit
-//                         word-parallel steps with carry-chain run filling; relaunched until no tile border changes
+//   K4 hysteresis_frame   8-connected growth of strong into weak: one wave per 64x64 tile, one row per lane, 64-bit
+//                         word-parallel steps with carry-chain run filling; one workgroup takes a frame to its fix point
 //   K5 dilate_xor         k x k dilation of the strong bits and XOR count against the previous frame's dilated bits, bands
 //                         of rows walking the time axis; the dilated map stays in LDS
 // Algorithmic traffic is 5 B/px (3 read + edge map write + previous edge map read); the V plane (1 B/px out
@@ -44,6 +44,7 @@ typedef uint64_t u64;
         hipError_t _e = (expr);                                                                      \
         if (_e != hipSuccess) {                                                                      \
             psd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            (void)hipGetLastError(); /* (the failure is reported here: do not leave it for the next launch check) */ \
             return PSD_ERR_HIP;                                                                      \
         }                                                                                            \
     } while (0)
@@ -221,44 +222,6 @@ __global__ __launch_bounds__(256) void value_plane_hist_dma_kernel(ChunkSrc src,
     }
 }
 
-// Histogram of V planes that already exist (written by the HSV pass in V mode): one 4-wave workgroup per (tile, frame),
-// 16-byte loads (16 pixels per lane and load, four in flight), 16x replicated LDS histogram, one flush.  2 B/px of traffic
-// against the 5+ B/px of value_plane_hist_dma_kernel; the HSV pass then needs no per-pixel LDS atomics at all.
-constexpr int VH_UNROLL = 4;
-__global__ __launch_bounds__(256) void v_hist_kernel(const uint8_t* vplane, long npix, int groups_per_tile, u32* hist)
-{
-    constexpr int AC = 16;
-    __shared__ __attribute__((aligned(16))) u32 lh[256 * AC];
-    const int tid = threadIdx.x, j = blockIdx.y;
-    for (int i = tid; i < 256 * AC; i += 256) lh[i] = 0;
-    __syncthreads();
-    const int n_groups = (int)(npix >> 4);
-    const int g0 = blockIdx.x * groups_per_tile, g1 = min(n_groups, g0 + groups_per_tile);
-    const u32x4* V = reinterpret_cast<const u32x4*>(vplane + (size_t)j * npix);
-    u32* my_h = lh + (tid & (AC - 1));
-    for (int gb = g0; gb < g1; gb += 256 * VH_UNROLL) {
-        u32x4 q[VH_UNROLL];
-#pragma unroll
-        for (int u = 0; u < VH_UNROLL; u++)   // unconditional on a clamped index: the loads go out together
-            q[u] = __builtin_nontemporal_load(V + min(gb + u * 256 + tid, g1 - 1));
-#pragma unroll
-        for (int u = 0; u < VH_UNROLL; u++) {
-            if (gb + u * 256 + tid < g1) {
-                const u32 w[4] = {q[u].x, q[u].y, q[u].z, q[u].w};
-#pragma unroll
-                for (int i = 0; i < 16; i++) atomicAdd(&my_h[((w[i >> 2] >> ((i & 3) * 8)) & 0xffu) * AC], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    {
-        u32 sum = 0;
-#pragma unroll
-        for (int r = 0; r < AC; r++) sum += lh[tid * AC + ((r + tid) & (AC - 1))];
-        if (sum) atomicAdd(&hist[(size_t)j * 256 + tid], sum);
-    }
-}
-
 // ---- K2: median -> Canny thresholds ------------------------------------------------------------
 
 // numpy.median of the V plane: for an even count the mean of the two middle order statistics, so
@@ -283,106 +246,9 @@ __global__ __launch_bounds__(256) void median_thresholds_kernel(const u32* hist,
     }
 }
 
-// ---- K3: Sobel + non-maximum suppression -------------------------------------------------------
-
-constexpr int NT_W = 64, NT_H = 32;  // tile of the NMS kernel (256 threads x 8 px)
-
-// grid = (tiles_x, tiles_y, frames)
-__global__ __launch_bounds__(256) void sobel_nms_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, uint8_t* map)
-{
-    constexpr int SVW = NT_W + 8;                       // V rows cover x0-4 .. x0+67 (dword aligned)
-    __shared__ __attribute__((aligned(16))) uint8_t sv[NT_H + 4][SVW];   // rows y0-2 .. y0+NT_H+1
-    __shared__ unsigned short smag[NT_H + 2][NT_W + 2 + 2];              // |dx|+|dy|, 1-px halo, 0 outside the image
-    __shared__ u32 sdxy[NT_H][NT_W];                                     // (dy << 16) | (dx & 0xffff) of interior pixels
-    const int j = blockIdx.z;
-    const uint8_t* V = vplane + (size_t)j * g.npix;
-    const int x0 = blockIdx.x * NT_W, y0 = blockIdx.y * NT_H;
-    const int H = g.height, W = g.width;
-    // Load V with the border replicated.  Interior tiles of frames whose width is a multiple of 4
-    // use aligned dword loads, everything else clamps per byte.
-    const bool inner = (W & 3) == 0 && ((g.npix & 3) == 0) && x0 >= 4 && x0 + NT_W + 4 <= W && y0 >= 2 && y0 + NT_H + 2 <= H;
-    if (inner) {
-        for (int i = threadIdx.x; i < (NT_H + 4) * (SVW / 4); i += 256) {
-            const int ly = i / (SVW / 4), lw = i - ly * (SVW / 4);
-            const u32 v = *reinterpret_cast<const u32*>(V + (size_t)(y0 + ly - 2) * W + x0 - 4 + lw * 4);
-            *reinterpret_cast<u32*>(&sv[ly][lw * 4]) = v;
-        }
-    } else {
-        for (int i = threadIdx.x; i < (NT_H + 4) * SVW; i += 256) {
-            const int ly = i / SVW, lx = i - ly * SVW;
-            const int y = min(max(y0 + ly - 2, 0), H - 1), x = min(max(x0 + lx - 4, 0), W - 1);
-            sv[ly][lx] = V[(size_t)y * W + x];
-        }
-    }
-    __syncthreads();
-    // Separable Sobel down columns: per V row, h1 = right - left and h2 = left + 2*mid + right;
-    // dx = h1[-1] + 2 h1[0] + h1[+1], dy = h2[+1] - h2[-1].  One work item = one column of the
-    // (NT_W+2)-wide magnitude halo region x a third of its rows.
-    // (three row segments: 66 x 3 = 198 work items fit one pass of the 256 threads; four would need a second
-    //  pass for 8 stragglers)
-    constexpr int MW = NT_W + 2, MH = NT_H + 2, NSEG = 3, QR = (MH + NSEG - 1) / NSEG;
-    static_assert(MW * NSEG <= 256, "one pass");
-    for (int item = threadIdx.x; item < MW * NSEG; item += 256) {
-        const int lx = item % MW, q = item / MW;
-        const int r0 = q * QR, r1 = min(MH, r0 + QR);          // magnitude rows [r0, r1)
-        // magnitude (ly, lx) is centred on sv[ly + 1][lx + 3]
-        const int cx = lx + 3;
-        int h1a, h1b, h2a, h2b;
-        {
-            const int a = sv[r0][cx - 1], b = sv[r0][cx], c = sv[r0][cx + 1];
-            h1a = c - a; h2a = a + 2 * b + c;
-            const int a1 = sv[r0 + 1][cx - 1], b1 = sv[r0 + 1][cx], c1 = sv[r0 + 1][cx + 1];
-            h1b = c1 - a1; h2b = a1 + 2 * b1 + c1;
-        }
-        const int x = x0 + lx - 1;
-        for (int ly = r0; ly < r1; ly++) {
-            const int a = sv[ly + 2][cx - 1], b = sv[ly + 2][cx], c = sv[ly + 2][cx + 1];
-            const int h1c = c - a, h2c = a + 2 * b + c;
-            const int dx = h1a + 2 * h1b + h1c, dy = h2c - h2a;
-            const int y = y0 + ly - 1;
-            unsigned short m = 0;
-            if (y >= 0 && y < H && x >= 0 && x < W) {
-                m = (unsigned short)(abs(dx) + abs(dy));
-                if (ly >= 1 && ly <= NT_H && lx >= 1 && lx <= NT_W) sdxy[ly - 1][lx - 1] = ((u32)dy << 16) | ((u32)dx & 0xffffu);
-            }
-            smag[ly][lx] = m;
-            h1a = h1b; h1b = h1c; h2a = h2b; h2b = h2c;
-        }
-    }
-    __syncthreads();
-    const int low = thr[j].x, high = thr[j].y;
-    for (int i = threadIdx.x; i < NT_H * NT_W; i += 256) {
-        const int ly = i / NT_W, lx = i - ly * NT_W;
-        const int y = y0 + ly, x = x0 + lx;
-        if (y >= H || x >= W) continue;
-        const int m = smag[ly + 1][lx + 1];
-        uint8_t out = 0;
-        if (m > low) {
-            const u32 pk = sdxy[ly][lx];
-            const int xs = (int)(short)(pk & 0xffffu), ys = (int)pk >> 16;
-            const int ax = abs(xs), ay = abs(ys) << 15;
-            const int tg22x = ax * 13573;  // TG22 = round(tan(22.5 deg) * 2^15)
-            bool is_max;
-            if (ay < tg22x) {
-                is_max = m > smag[ly + 1][lx] && m >= smag[ly + 1][lx + 2];
-            } else {
-                const int tg67x = tg22x + (ax << 16);
-                if (ay > tg67x) {
-                    is_max = m > smag[ly][lx + 1] && m >= smag[ly + 2][lx + 1];
-                } else {
-                    const int s = (xs ^ ys) < 0 ? -1 : 1;
-                    is_max = m > smag[ly][lx + 1 - s] && m > smag[ly + 2][lx + 1 + s];
-                }
-            }
-            if (is_max) out = m > high ? 2 : 1;
-        }
-        map[(size_t)j * g.npix + (size_t)y * W + x] = out;
-    }
-}
-
-// ---- K3, fast form: Sobel + NMS of 128 x 32 tiles straight into BIT PLANES -------------------------------------------------
-// (frames whose rows are dword aligned: width % 4 == 0 -- 1080p, 4K, 720p, 1440, 640x360, 256x144 ...; anything else goes
-//  through the byte kernel above and map_to_bits_kernel.)
+// ---- K3: Sobel + non-maximum suppression of 128 x 32 tiles straight into BIT PLANES ------------------------------------
+// (Tiles load whole dwords where the frame's rows are dword aligned -- width % 4 == 0: 1080p, 4K, 720p, 640x360, 256x144 ...;
+//  other widths assemble theirs from clamped byte loads.  Round 4 retired the byte-map kernel of round 1 that those took.)
 // The Canny map never exists as bytes: a pixel is "strong" (m > high), "weak" (low < m <= high) or nothing, so the kernel
 // writes two bit rows per image row -- strong[y][x >> 5] bit (x & 31), weak likewise -- 0.25 B/px instead of 1 B/px, and
 // everything behind it (hysteresis, dilation, XOR count) is word-parallel.
@@ -470,6 +336,9 @@ __device__ __forceinline__ void sobel_phase1_quads(const uint8_t (*sv)[N2_SVW], 
 // `dirty` (zeroed by the caller): one flag per 64x64 hysteresis tile, set where this tile leaves a weak pixel -- the first
 // hysteresis launch then only looks at tiles that can change at all (a natural frame has few of them).
 // tiles_x_magic = ceil(2^32 / tiles_x): tile / tiles_x as one multiply-high (exact for tile < 2^20).
+// RAGGED: the instance for frames whose rows are not dword aligned (kept out of the common instance: its byte loads would
+// double the code the interior tiles of every 1080p frame run past).
+template <bool RAGGED>
 __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, u32* strong, u32* weak,
                                                              uint8_t* dirty, int tiles_x, u32 tiles_x_magic, int htiles_x, int htiles_per_frame)
 {
@@ -485,8 +354,26 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
     const uint8_t* V = vplane + (size_t)j * g.npix;
     const int x0 = tx * N2_W, y0 = ty * N2_H, H = g.height, W = g.width;
     const int2 lohi = thr[j];   // read here: behind the barriers its latency would sit in front of phase 2
-    const bool inner = x0 >= 4 && x0 + N2_W + 4 <= W && y0 >= 2 && y0 + N2_H + 2 <= H;
-    if (inner) {
+    const bool inner = !RAGGED && x0 >= 4 && x0 + N2_W + 4 <= W && y0 >= 2 && y0 + N2_H + 2 <= H;
+    if constexpr (RAGGED) {
+        // any width: the 36 x 34 dwords of the tile from four byte loads each, row and column clamped per byte
+        // (BORDER_REPLICATE); slow, exact, and only odd-sized frames come here
+        auto ld4 = [&](int y, int xa) -> u32 {
+            const uint8_t* row = V + (size_t)min(max(y, 0), H - 1) * W;
+            u32 w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) w |= (u32)row[min(max(xa + k, 0), W - 1)] << (8 * k);
+            return w;
+        };
+        const int cw = lane & 31;
+#pragma unroll
+        for (int it = 0; it < 5; it++) {
+            const int ly = 2 * (wave * 5 + it) + (lane >> 5);           // rows 36..39 of sv are scratch
+            *reinterpret_cast<u32*>(&sv[ly][4 * cw]) = ld4(y0 + min(ly, N2_H + 3) - 2, x0 - 4 + 4 * cw);
+        }
+        const int tl = min(tid >> 1, N2_H + 3), c2 = 32 + (tid & 1);
+        *reinterpret_cast<u32*>(&sv[tl][4 * c2]) = ld4(y0 + tl - 2, x0 - 4 + 4 * c2);
+    } else if (inner) {
         // Interior tiles (four in five at 1080p): no clamping, so all six addresses are ONE per-lane 32-bit offset on top of
         // scalar row bases (global_load_dword v, v_off, s[base]) -- a dozen VALU instructions where the clamped 64-bit
         // addresses of the general form below took a hundred, a quarter of the kernel's arithmetic.
@@ -595,13 +482,14 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
         return is_max ? (m > high ? 2 : 1) : 0;
     };
     if (n_any > CAND_CAP / 8) {
-        // dense: in place, a thread's eight pixels one after the other
-#pragma unroll
+        // dense: in place, a thread's eight pixels one after the other (one copy of the eight in the code: the steps loop)
+        static_assert(N_IT == 2, "");
+#pragma unroll 1
         for (int it = 0; it < N_IT; it++) {
             const int i = tid + it * 256;
             const int ly = i >> 4, o = i & 15;
             u32 sb = 0, wb = 0;
-            if (anyx[it]) {
+            if (it == 0 ? anyx[0] : anyx[1]) {
                 const uint2 qa = smq[ly + 1][1 + 2 * o], qb = smq[ly + 1][2 + 2 * o];
                 const u32 w4[4] = {qa.x, qa.y, qb.x, qb.y};
 #pragma unroll
@@ -668,34 +556,6 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
     }
 }
 
-// Byte map (0 none, 1 weak, 2 strong: sobel_nms_kernel, any frame size) -> the bit planes and the dirty-tile flags of the
-// fast form.  One thread per 32-pixel word; grid = (ceil(words_per_frame / 256), frames).
-__global__ __launch_bounds__(256) void map_to_bits_kernel(const uint8_t* map, EdgeGeom g, u32* strong, u32* weak, uint8_t* dirty,
-                                                          int htiles_x, int htiles_per_frame)
-{
-    const int j = blockIdx.y, nw = g.words_per_row;
-    const long words = (long)g.height * nw;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= words) return;
-    const int y = (int)(i / nw), w = (int)(i - (long)y * nw);
-    const uint8_t* M = map + (size_t)j * g.npix + (size_t)y * g.width;
-    u32 sb = 0, wb = 0;
-    for (int b = 0; b < 32; b++) {
-        const int x = w * 32 + b;
-        if (x < g.width) {
-            const uint8_t m = M[x];
-            if (m == 2) sb |= 1u << b;
-            else if (m == 1) wb |= 1u << b;
-        }
-    }
-    strong[(size_t)j * words + i] = sb;
-    weak[(size_t)j * words + i] = wb;
-    if (wb) {
-        // (a 32-pixel word lies inside one 64-pixel tile)
-        dirty[(size_t)j * htiles_per_frame + (size_t)(y / HT_TILE) * htiles_x + (w * 32) / HT_TILE] = 1;
-    }
-}
-
 // ---- K4: hysteresis on the bit planes -------------------------------------------------------------------------------------
 
 constexpr int HT = 64;  // hysteresis tile edge: 64 rows (one per lane of a wave) x 64 columns (two words, one 64-bit value per lane)
@@ -709,11 +569,8 @@ static_assert(HT == HT_TILE, "");
 // for lanes 0 and 63, from the halo rows read with the tile.  One step is a dozen 64-bit operations per lane for all 4096
 // pixels; horizontal runs of weak pixels are filled in ONE step by a carry chain (seed + weak ripples through the run, in
 // both directions via a bit reversal).  No LDS, no barriers.
-// Work list as before: a tile is only looked at when `dirty_in` says so (first launch: flags from the NMS kernel; later: a
-// neighbour promoted a pixel on the shared border in the previous launch); a tile that promotes border pixels marks its
-// neighbours in `dirty_out` and raises *changed.  grid = ceil(tiles / tpw) workgroups of 4 waves, each responsible for
-// tpw <= 64 consecutive tiles of the (frame, tile_y, tile_x) order: one wave reads their flags with one load + ballot and the
-// four waves take the set bits in turn.
+// Work list: a tile is only looked at when its flag says so (first round: the flags of the NMS kernel; later: a neighbour
+// promoted a pixel that touches it); hysteresis_frame_kernel below drives the rounds of one frame.
 __device__ __forceinline__ unsigned long long fill_runs_up(unsigned long long seeds, unsigned long long run)
 {
     // every bit of `run` reachable from a seed bit (seeds subset of run) by walking towards the MSB through set bits of `run`
@@ -808,67 +665,25 @@ __device__ __forceinline__ u32 hyst_tile(u32* S, const u32* Wk, const EdgeGeom& 
     return wake;
 }
 
-__global__ __launch_bounds__(256) void hysteresis_bits_kernel(u32* strong, const u32* weak, EdgeGeom g, uint8_t* dirty_in, uint8_t* dirty_out,
-                                                              int* changed, int tiles_x, int tiles_y, long n_tiles, int tpw)
-{
-    __shared__ unsigned long long todo_mask;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long first = (long)blockIdx.x * tpw;
-    if (threadIdx.x < 64) {
-        const long ti = first + threadIdx.x;
-        const bool mine = (int)threadIdx.x < tpw && ti < n_tiles;
-        const bool set = mine && dirty_in[ti] != 0;
-        const unsigned long long m = __ballot(set);
-        if (threadIdx.x == 0) todo_mask = m;
-        // consumed: leave the list empty, it is the next launch's dirty_out (nobody else touches this range of dirty_in)
-        if (set) dirty_in[ti] = 0;
-    }
-    __syncthreads();
-    unsigned long long todo = todo_mask;
-    const int H = g.height, nw = g.words_per_row;
-    const int per_frame = tiles_x * tiles_y;
-    int turn = 0;
-    while (todo) {
-        const int bit = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        if ((turn++ & 3) != wave) continue;
-        const long ti = first + bit;
-        const int j = (int)(ti / per_frame), rem = (int)(ti - (long)j * per_frame);
-        const int by = rem / tiles_x, bx = rem - by * tiles_x;
-        const u32 wake = hyst_tile<false>(strong + (size_t)j * H * nw, weak + (size_t)j * H * nw, g, by, bx, lane);
-        if (wake) {
-            if (lane < 9 && ((wake >> lane) & 1u)) {
-                const int ny = by + lane / 3 - 1, nx = bx + lane % 3 - 1;
-                if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) dirty_out[(size_t)j * per_frame + (size_t)ny * tiles_x + nx] = 1;
-            }
-            // (a plain store: every writer stores the same 1; one atomic per tile on ONE word serialised uniform-noise frames --
-            //  half a million tiles per launch -- behind the L2's atomic unit)
-            if (lane == 0) *changed = 1;
-        }
-    }
-}
-
 // The whole hysteresis of ONE FRAME in one workgroup and one launch: chains of weak pixels never leave their frame, so
-// nothing has to be handed from launch to launch -- no convergence flags, no host round trips, no fixed number of
-// speculative launches that a long chain outruns (frames full of straight object edges needed fifty launches of the kernel
-// above: an edge that runs along a tile border crosses it at every wiggle, one launch per crossing; the speculative path
-// then fell back to repeating the whole edge term).  The workgroup keeps two bit maps of the frame's tiles in LDS: the tiles
-// to look at in this round (first round: the flags of the NMS kernel) and the ones woken for the next; sixteen waves take
-// the set bits of this round's map, a barrier, swap, until a round wakes nobody.  A wave that wakes a neighbour has stored
-// its promotions before the round's barrier (write-through L1), and the strong words are read with loads that go to the L2,
-// so the next round sees them whichever wave stored them.  grid = frames.
-// HF_WAVES waves per workgroup: as many as still let every frame of the chunk be resident at once (32 wave slots per CU) --
-// frames whose chains take fifty rounds are bound by the latency of a round, not by throughput, so two waves of workgroups
-// take twice as long as one.
-constexpr int HF_MAXWORDS = 1024;   // up to 32768 tiles per frame (16K x 8K pixels)
-
+// nothing has to be handed from launch to launch -- no convergence flags, no host round trips.  (Rounds 2-3 relaunched a
+// tile-parallel kernel over dirty-tile lists: frames full of straight object edges needed fifty launches, an edge that runs
+// along a tile border crosses it at every wiggle.)  The workgroup keeps two bit maps of the frame's tiles in LDS: the tiles to
+// look at in this round (first round: the flags of the NMS kernel) and the ones woken for the next; its waves take the set
+// bits of this round's map, a barrier, swap, until a round wakes nobody.  A wave that wakes a neighbour has stored its
+// promotions before the round's barrier (write-through L1), and the strong words are read with loads that go to the L2, so
+// the next round sees them whichever wave stored them.  grid = frames; dynamic LDS = 2 x ceil(tiles / 32) words.
+// HF_WAVES waves per workgroup: as many as still let every frame of the chunk be resident at once -- frames whose chains
+// take fifty rounds are bound by the latency of a round, not by throughput, so two waves of workgroups take twice as long.
 template <int HF_WAVES>
 __global__ __launch_bounds__(HF_WAVES * 64) void hysteresis_frame_kernel(u32* strong, const u32* weak, EdgeGeom g, const uint8_t* dirty,
                                                                          int tiles_x, int tiles_y)
 {
-    __shared__ u32 cur[HF_MAXWORDS], nxt[HF_MAXWORDS];
+    extern __shared__ u32 hf_maps[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = blockIdx.x, per_frame = tiles_x * tiles_y, nwords = (per_frame + 31) >> 5;
+    u32* cur = hf_maps;
+    u32* nxt = hf_maps + nwords;
     const uint8_t* D = dirty + (size_t)j * per_frame;
     for (int w = tid; w < nwords; w += HF_WAVES * 64) {
         u32 m = 0;
@@ -1064,25 +879,21 @@ static int estimated_kernel_size(int width, int height)
 }
 
 struct EdgeBuffers {
-    uint8_t* vplane; uint8_t* map; u32* strong; u32* weak; u32* hist; int2* thr; u32* carry; u32* dil1;
-    unsigned long long* xr; int* flags; int2* thr_tab; uint8_t* dirty[2];
+    uint8_t* vplane; u32* strong; u32* weak; u32* hist; int2* thr; u32* carry; u32* dil1;
+    unsigned long long* xr; int2* thr_tab; uint8_t* dirty;
     int cap_frames; size_t tiles_per_frame;
-    uint8_t* zero_begin; size_t zero_bytes;   // hist, xr, both tile lists and the flags: cleared by ONE memset per chunk
+    uint8_t* zero_begin; size_t zero_bytes;   // hist, xr and the tile flags: cleared by ONE memset per chunk
     bool fresh;                               // the workspace was (re)allocated by this call
 };
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// frames whose rows are dword aligned take sobel_nms_bits_kernel; the others the byte kernel + map_to_bits_kernel
-static bool bits_direct(const EdgeGeom& g) { return (g.width & 3) == 0; }
-
 static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeBuffers* b)
 {
     const size_t words = (size_t)g.height * g.words_per_row;
     const size_t tiles = (size_t)((g.width + HT - 1) / HT) * ((g.height + HT - 1) / HT);
-    const bool need_map = !bits_direct(g);
-    const size_t per_frame = align_up((size_t)g.npix) * (need_map ? 2 : 1) + align_up(256 * 4) + align_up(sizeof(int2)) +
-                             align_up(words * 4) * 2 + align_up(8) + 2 * align_up(tiles);
+    const size_t per_frame = align_up((size_t)g.npix) + align_up(256 * 4) + align_up(sizeof(int2)) + align_up(words * 4) * 2 + align_up(8) +
+                             align_up(tiles);
     // bound the workspace (default 8 GiB of the 288 GB: 2048 x 1080p frames in one chunk, +1.4 % over 4 GiB on such batches;
     // PSD_EDGE_WS_MB overrides) unless a single frame needs more
     static const size_t ws_cap = [] {
@@ -1091,7 +902,7 @@ static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeB
         return (size_t)(mb > 0 ? mb : 8192) << 20;
     }();
     int frames = (int)std::max<size_t>(1, std::min<size_t>((size_t)want_frames, ws_cap / per_frame));
-    const size_t fixed = 2 * align_up(words * 4) + align_up(64 * sizeof(int)) + align_up(511 * sizeof(int2)) + 16 * 256;
+    const size_t fixed = 2 * align_up(words * 4) + align_up(511 * sizeof(int2)) + 16 * 256;
     const size_t need = per_frame * (size_t)frames + fixed;
     void** ws = engine_edge_ws(e);
     size_t* ws_bytes = engine_edge_ws_bytes(e);
@@ -1107,7 +918,6 @@ static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeB
     auto take = [&](size_t bytes) { uint8_t* r = p; p += align_up(bytes); return r; };
     b->thr_tab = (int2*)take(511 * sizeof(int2));   // first: its place does not depend on the geometry (uploaded once)
     b->vplane = take((size_t)g.npix * frames);
-    b->map = need_map ? take((size_t)g.npix * frames) : nullptr;
     b->thr = (int2*)take((size_t)frames * sizeof(int2));
     b->strong = (u32*)take(words * 4 * frames);
     b->weak = (u32*)take(words * 4 * frames);
@@ -1116,9 +926,7 @@ static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeB
     b->zero_begin = p;
     b->hist = (u32*)take((size_t)frames * 256 * 4);
     b->xr = (unsigned long long*)take((size_t)frames * 8);
-    b->dirty[0] = take(tiles * frames);
-    b->dirty[1] = take(tiles * frames);
-    b->flags = (int*)take(64 * sizeof(int));
+    b->dirty = take(tiles * frames);
     b->zero_bytes = (size_t)(p - b->zero_begin);
     b->tiles_per_frame = tiles;
     b->cap_frames = frames;
@@ -1141,27 +949,14 @@ static void threshold_table(int2* tab)
     }
 }
 
-// after the fixed rounds of the speculative path: did the last launch still pass something on?
-__global__ void note_unconverged_kernel(const int* last_flag, int* unconverged)
-{
-    if (*last_flag) atomicOr(unconverged, 1);
-}
-
-constexpr int HYST_SPEC_LAUNCHES = 6;   // hysteresis launches of the speculative path: chains that cross up to 5 tile borders
-constexpr int HYST_TPW = 16;            // tiles per hysteresis workgroup (one flag load + ballot covers them)
-
 // K1..K4 for `count` virtual frames; on return (stream-ordered) b.strong holds their final Canny edges as bit rows.
-// d_unconverged == nullptr: the hysteresis is relaunched until a launch changes nothing, the host reading the flags
-// after every round (exact, blocks the calling thread).  Otherwise: HYST_SPEC_LAUNCHES launches are enqueued without
-// any host round trip and *d_unconverged is set if the last one still promoted pixels on a tile border -- the caller
-// then repeats the work on the exact path (weak-edge chains that long are rare: tests/test_gpu_fullsize.py builds one).
-// hsv != nullptr: the chunk's real frames get their V plane (and V histogram) from the HSV pass in V mode (one read of the
+// hsv != nullptr: the chunk's real frames get their V plane and V histogram from the HSV pass in V mode (one read of the
 // frames for both terms, psd_score_kernels.hip); only a predecessor frame standing in as virtual frame 0 still goes
 // through the V-plane kernel.
-static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, const EdgeBuffers& b, hipStream_t stream,
-                      int* d_unconverged = nullptr, const ScoreParams* hsv = nullptr, int target_blocks = 0, int* launches = nullptr)
+static int edge_chunk(psd_engine* e, const EdgeGeom& g, const ChunkSrc& src, int count, const EdgeBuffers& b, hipStream_t stream,
+                      const ScoreParams* hsv = nullptr, int target_blocks = 0, int* launches = nullptr)
 {
-    HIP_TRY(hipMemsetAsync(b.zero_begin, 0, b.zero_bytes, stream));   // histograms, XOR counters, both tile lists, flags
+    HIP_TRY(hipMemsetAsync(b.zero_begin, 0, b.zero_bytes, stream));   // histograms, XOR counters, tile flags
     // packed 16-byte aligned frames with a multiple of 16 pixels take the LDS-DMA streaming variant
     const bool vp_dma = g.row_stride == (size_t)g.width * 3 && (g.npix & 15) == 0 && (g.frame_stride & 15) == 0 &&
                         ((uintptr_t)src.frames & 15) == 0 && (!src.first_is_prev || ((uintptr_t)src.prev & 15) == 0);
@@ -1176,82 +971,38 @@ static int edge_chunk(const EdgeGeom& g, const ChunkSrc& src, int count, const E
         hipLaunchKernelGGL(value_plane_hist_kernel, dim3((unsigned)((g.npix + 1024 * VP_ITER - 1) / (1024 * VP_ITER)), vp_count), dim3(256), 0, stream, src, g,
                            b.vplane, b.hist);
     }
-    if (hsv) {
-        HIP_TRY(launch_score_frames(*hsv, true, false, true, target_blocks, stream, launches));
-        if (hsv->vhist == nullptr) {
-            // the HSV-only kernel stored the V planes of the chunk's real frames; their histograms come from the planes
-            const int real = count - src.first_is_prev;
-            const int n_groups = (int)(g.npix >> 4);
-            const int cap = 256 * VH_UNROLL * (real >= 32 ? 4 : 1);
-            const int tiles = (n_groups + cap - 1) / cap;
-            hipLaunchKernelGGL(v_hist_kernel, dim3(tiles, real), dim3(256), 0, stream, b.vplane + (src.first_is_prev ? (size_t)g.npix : 0),
-                               g.npix, (n_groups + tiles - 1) / tiles, b.hist + (src.first_is_prev ? 256 : 0));
-        }
-    }
+    if (hsv) HIP_TRY(launch_score_frames(*hsv, true, false, true, target_blocks, stream, launches));
     hipLaunchKernelGGL(median_thresholds_kernel, dim3(count), dim3(256), 0, stream, b.hist, g.npix, b.thr_tab, b.thr);
     const int htx = (g.width + HT - 1) / HT, hty = (g.height + HT - 1) / HT;
-    const long hyst_tiles = (long)htx * hty * count;
-    const dim3 hyst_grid((unsigned)((hyst_tiles + HYST_TPW - 1) / HYST_TPW));
-    if (bits_direct(g)) {
+    {
         const int tx = (g.width + N2_W - 1) / N2_W, ty = (g.height + N2_H - 1) / N2_H;
         const int per_frame = tx * ty;
         if (per_frame >= (1 << 20)) { psd_set_error("frame too large for the edge term"); return PSD_ERR_UNSUPPORTED; }
         const u32 magic = tx == 1 ? 0u : (u32)((0x100000000ull + (unsigned long long)tx - 1) / (unsigned long long)tx);   // ceil(2^32 / tx)
         for (int f0 = 0; f0 < count; f0 += 32768) {   // grid.y limit
             const int nf = std::min(32768, count - f0);
-            hipLaunchKernelGGL(sobel_nms_bits_kernel, dim3(per_frame, nf), dim3(256), 0, stream,
+            // rows not dword aligned (or narrower than two dwords): the instance that assembles its tiles from byte loads
+            const bool ragged = (g.width & 3) != 0 || g.width < 8;
+            auto kernel = ragged ? sobel_nms_bits_kernel<true> : sobel_nms_bits_kernel<false>;
+            hipLaunchKernelGGL(kernel, dim3(per_frame, nf), dim3(256), 0, stream,
                                b.vplane + (size_t)f0 * g.npix, g, b.thr + f0, b.strong + (size_t)f0 * g.height * g.words_per_row,
-                               b.weak + (size_t)f0 * g.height * g.words_per_row, b.dirty[0] + (size_t)f0 * b.tiles_per_frame, tx,
+                               b.weak + (size_t)f0 * g.height * g.words_per_row, b.dirty + (size_t)f0 * b.tiles_per_frame, tx,
                                magic, htx, (int)b.tiles_per_frame);
         }
-    } else {
-        const size_t words = (size_t)g.height * g.words_per_row;
-        hipLaunchKernelGGL(sobel_nms_kernel, dim3((g.width + NT_W - 1) / NT_W, (g.height + NT_H - 1) / NT_H, count), dim3(256), 0,
-                           stream, b.vplane, g, b.thr, b.map);
-        hipLaunchKernelGGL(map_to_bits_kernel, dim3((unsigned)((words + 255) / 256), count), dim3(256), 0, stream, b.map, g, b.strong, b.weak,
-                           b.dirty[0], htx, (int)b.tiles_per_frame);
     }
     HIP_TRY(hipGetLastError());
-    // hysteresis to the fix point.  Default: one workgroup per frame, one launch (hysteresis_frame_kernel).
-    // PSD_EDGE_HYST_LAUNCHES=1 selects the older scheme: launches of hysteresis_bits_kernel that ping-pong the two dirty-tile
-    // lists (every launch empties the list it read, so the lists only need the clearing at the top of the chunk), one flag per
-    // launch; done when a launch promoted nothing on any tile border.
-    static const bool by_launches = [] { const char* v = getenv("PSD_EDGE_HYST_LAUNCHES"); return v && atoi(v) != 0; }();
-    int launch = 0;
-    if (!by_launches && (long)htx * hty <= (long)HF_MAXWORDS * 32) {
-        const int slots = 256 * 32;   // wave slots of the chip
+    // hysteresis to the fix point: one workgroup per frame, one launch.  As many waves per workgroup as still let every frame
+    // of the chunk be resident at once (wave slots of THIS device: 32 per CU).
+    {
+        const long slots = (long)engine_num_cus(e) * 32;
+        const size_t lds = 2 * (size_t)(((long)htx * hty + 31) / 32) * sizeof(u32);
+        if (lds > 96 * 1024) { psd_set_error("frame too large for the edge term (%d x %d hysteresis tiles)", htx, hty); return PSD_ERR_UNSUPPORTED; }
         if ((long)count * 16 <= slots)
-            hipLaunchKernelGGL(hysteresis_frame_kernel<16>, dim3(count), dim3(16 * 64), 0, stream, b.strong, b.weak, g, b.dirty[0], htx, hty);
+            hipLaunchKernelGGL(hysteresis_frame_kernel<16>, dim3(count), dim3(16 * 64), lds, stream, b.strong, b.weak, g, b.dirty, htx, hty);
         else if ((long)count * 8 <= slots)
-            hipLaunchKernelGGL(hysteresis_frame_kernel<8>, dim3(count), dim3(8 * 64), 0, stream, b.strong, b.weak, g, b.dirty[0], htx, hty);
+            hipLaunchKernelGGL(hysteresis_frame_kernel<8>, dim3(count), dim3(8 * 64), lds, stream, b.strong, b.weak, g, b.dirty, htx, hty);
         else
-            hipLaunchKernelGGL(hysteresis_frame_kernel<4>, dim3(count), dim3(4 * 64), 0, stream, b.strong, b.weak, g, b.dirty[0], htx, hty);
-    } else if (d_unconverged) {
-        for (; launch < HYST_SPEC_LAUNCHES; launch++) {
-            hipLaunchKernelGGL(hysteresis_bits_kernel, hyst_grid, dim3(256), 0, stream, b.strong, b.weak, g, b.dirty[launch & 1],
-                               b.dirty[(launch + 1) & 1], b.flags + launch, htx, hty, hyst_tiles, HYST_TPW);
-        }
-        hipLaunchKernelGGL(note_unconverged_kernel, dim3(1), dim3(1), 0, stream, b.flags + HYST_SPEC_LAUNCHES - 1, d_unconverged);
-    } else {
-        bool converged = false;
-        for (int round = 0; round < 4096 && !converged; round++) {
-            constexpr int R = 3;
-            // a fresh flag per launch out of the 64 cleared at the top of the chunk (re-cleared every 21 rounds)
-            const int fbase = (round % (64 / R)) * R;
-            if (round > 0 && fbase == 0) HIP_TRY(hipMemsetAsync(b.flags, 0, 64 * sizeof(int), stream));
-            for (int i = 0; i < R; i++, launch++) {
-                hipLaunchKernelGGL(hysteresis_bits_kernel, hyst_grid, dim3(256), 0, stream, b.strong, b.weak, g, b.dirty[launch & 1],
-                                   b.dirty[(launch + 1) & 1], b.flags + fbase + i, htx, hty, hyst_tiles, HYST_TPW);
-            }
-            int flags[R];
-            HIP_TRY(hipMemcpyAsync(flags, b.flags + fbase, sizeof(flags), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            for (int i = 0; i < R; i++) converged = converged || !flags[i];   // a launch with nothing to pass on ends it
-        }
-        if (!converged) {
-            psd_set_error("edge hysteresis did not converge within %d launches", launch);
-            return PSD_ERR_HIP;
-        }
+            hipLaunchKernelGGL(hysteresis_frame_kernel<4>, dim3(count), dim3(4 * 64), lds, stream, b.strong, b.weak, g, b.dirty, htx, hty);
     }
     HIP_TRY(hipGetLastError());
     return PSD_OK;
@@ -1289,8 +1040,7 @@ static EdgeGeom make_geom(int height, int width, size_t row_stride, size_t frame
 
 int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
                 size_t frame_stride, const uint8_t* d_prev, int edge_kernel, psd_frame_scores* d_out,
-                hipStream_t stream, const uint8_t* d_seg, int* d_unconverged, const ScoreParams* hsv, int target_blocks,
-                int* launches)
+                hipStream_t stream, const uint8_t* d_seg, const ScoreParams* hsv, int target_blocks, int* launches)
 {
     const EdgeGeom g = make_geom(height, width, row_stride, frame_stride);
     const int k = edge_kernel ? edge_kernel : estimated_kernel_size(width, height);
@@ -1327,16 +1077,13 @@ int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
             cp.out = hsv->out + src.start;
             cp.seg = hsv->seg ? hsv->seg + src.start : nullptr;
             cp.vout = b.vplane + (src.first_is_prev ? (size_t)g.npix : 0);
-            // PSD_EDGE_VHIST_FUSED=0: the HSV-only kernel stores the V plane and v_hist_kernel counts it; default: the 16-wave
-            // fused kernel counts the V histogram itself (A/B on 2048 x 1080p shot-like frames: 262-265 k vs 257 k frames/s)
-            // PSD_EDGE_VHIST_FUSED=0: the HSV-only kernel stores the V plane and v_hist_kernel counts it; default: the 16-wave
-            // fused kernel counts the V histogram itself.  (Round 4 also tried counting V in the 4-wave HSV kernel, per-tile partial
-            // histograms in LDS written out with plain stores: 2.03-2.06 ms + 0.1 ms for adding the tiles up against 2.0 ms for the
-            // fused kernel per 1024 x 1080p -- the LDS increments cost as much there; profiles/r04_f_*.)
-            static const bool vhist_fused = [] { const char* v = getenv("PSD_EDGE_VHIST_FUSED"); return !v || atoi(v) != 0; }();
-            cp.vhist = vhist_fused ? b.hist + (src.first_is_prev ? 256 : 0) : nullptr;
+            // the 16-wave fused kernel counts the V histogram itself.  (Alternatives measured and dropped: the 4-wave HSV kernel
+            // storing V and a separate kernel counting it, round 3, 2.7 % slower; the 4-wave HSV kernel counting V into per-tile
+            // partial histograms, round 4: 2.03-2.06 ms + 0.1 ms for adding the tiles up against 2.0 ms per 1024 x 1080p --
+            // the LDS increments cost the same wherever they sit; profiles/r04_f_vmode_front_end_experiments.txt.)
+            cp.vhist = b.hist + (src.first_is_prev ? 256 : 0);
         }
-        rc = edge_chunk(g, src, count, b, stream, d_unconverged, hsv ? &cp : nullptr, target_blocks, launches);
+        rc = edge_chunk(e, g, src, count, b, stream, hsv ? &cp : nullptr, target_blocks, launches);
         if (rc != PSD_OK) return rc;
         rc = launch_dilate_xor(g, k, count, b, have_carry ? b.carry : nullptr, nullptr, stream);
         if (rc != PSD_OK) return rc;
@@ -1365,7 +1112,7 @@ int edges_map(psd_engine* e, const uint8_t* d_frame, int height, int width, size
     HIP_TRY(hipMemcpyAsync(b.thr_tab, tab, sizeof(tab), hipMemcpyHostToDevice, stream));
     ChunkSrc src;
     src.frames = d_frame; src.prev = nullptr; src.start = 0; src.first_is_prev = 0;
-    rc = edge_chunk(g, src, 1, b, stream);
+    rc = edge_chunk(e, g, src, 1, b, stream);
     if (rc != PSD_OK) return rc;
     rc = launch_dilate_xor(g, k, 1, b, nullptr, b.dil1, stream);
     if (rc != PSD_OK) return rc;

@@ -3,7 +3,6 @@
 // Owns: one HIP device, one stream, the fixed-point HSV tables in device memory, a small ring
 // of record slots (device buffer + pinned host mirror + timing events) so submissions can be
 // pipelined, and a pair of device staging buffers for callers that hand over host frames.
-#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -41,6 +40,7 @@ extern "C" void psd_set_error(const char* fmt, ...)
         hipError_t _e = (expr);                                                                \
         if (_e != hipSuccess) {                                                                \
             psd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            (void)hipGetLastError(); /* (the failure is reported here: do not leave it for the next launch check) */ \
             return PSD_ERR_HIP;                                                                \
         }                                                                                      \
     } while (0)
@@ -49,8 +49,8 @@ namespace psd {
 // psd_edge_kernels.hip
 int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
                 size_t frame_stride, const uint8_t* d_prev, int edge_kernel, psd_frame_scores* d_out,
-                hipStream_t stream, const uint8_t* d_seg, int* d_unconverged, const ScoreParams* hsv = nullptr,
-                int target_blocks = 0, int* launches = nullptr);
+                hipStream_t stream, const uint8_t* d_seg, const ScoreParams* hsv = nullptr, int target_blocks = 0,
+                int* launches = nullptr);
 int edges_map(psd_engine* e, const uint8_t* d_frame, int height, int width, size_t row_stride,
               int edge_kernel, uint8_t* h_edges);
 void edges_release(psd_engine* e);
@@ -85,17 +85,6 @@ struct psd_slot {
     uint8_t* d_seg = nullptr;   // clip-start flags of a segmented submission (device + pinned mirror)
     uint8_t* h_seg = nullptr;
     int seg_cap = 0;
-    // edge term: the hysteresis runs a fixed number of launches without host round trips; if a frame needed more the
-    // flag is set and psd_score_collect repeats the term on the exact (host-driven) path
-    int* d_edge_flag = nullptr;
-    int* h_edge_flag = nullptr;   // pinned
-    struct {
-        bool active = false;
-        const uint8_t* d_frames = nullptr; const uint8_t* d_prev = nullptr; const uint8_t* d_seg = nullptr;
-        int n = 0, height = 0, width = 0, edge_kernel = 0;
-        size_t row_stride = 0, frame_stride = 0;
-        hipStream_t stream = nullptr;
-    } edge;
 };
 
 struct psd_engine {
@@ -255,8 +244,6 @@ void psd_destroy(psd_engine* e)
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
         if (s.d_seg) (void)hipFree(s.d_seg);
         if (s.h_seg) (void)hipHostFree(s.h_seg);
-        if (s.d_edge_flag) (void)hipFree(s.d_edge_flag);
-        if (s.h_edge_flag) (void)hipHostFree(s.h_edge_flag);
     }
     for (auto& d : e->d_stage) if (d) (void)hipFree(d);
     if (e->d_hash) (void)hipFree(e->d_hash);
@@ -321,7 +308,6 @@ static int submit_begin(psd_engine* e, int n, uint32_t flags, hipStream_t stream
     s.heads_only = heads_only;
     s.n = n;
     s.launches = 0;
-    s.edge.active = false;
     if (n > 0) {
         HIP_TRY(hipMemsetAsync(s.d_recs, 0, (size_t)n * sizeof(psd_frame_scores), stream));
         HIP_TRY(hipEventRecord(s.ev_start, stream));
@@ -358,7 +344,7 @@ static int submit_end(psd_engine* e, psd_slot& s, hipStream_t stream)
 // the scoring terms of `flags` for n resident frames, added into the slot's records
 static int score_terms(psd_engine* e, psd_slot& s, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
                        size_t frame_stride, const uint8_t* d_prev, uint32_t flags, int edge_kernel, hipStream_t stream,
-                       const uint8_t* d_seg = nullptr, bool frames_outlive_collect = false)
+                       const uint8_t* d_seg = nullptr)
 {
     const bool hsv = flags & PSD_SCORE_HSV_SAD;
     const bool luma = flags & (PSD_SCORE_LUMA_HIST | PSD_SCORE_BYTE_SUM);
@@ -379,7 +365,7 @@ static int score_terms(psd_engine* e, psd_slot& s, const uint8_t* d_frames, int 
         const bool fast = row_stride == (size_t)width * 3 && ((uintptr_t)d_frames % 16 == 0) &&
                           (frame_stride % 16 == 0 || n == 1) && (!d_prev || (uintptr_t)d_prev % 16 == 0);
         // ContentDetector with weights.delta_edges > 0 (or a StatsManager): the HSV pass also writes the V plane and the V
-        // histogram the edge term starts from (PSD_EDGE_FUSE_HSV=0: two separate reads of the frames, as before)
+        // histogram the edge term starts from (PSD_EDGE_FUSE_HSV=0: two separate reads of the frames)
         static const bool fuse_env = [] { const char* v = getenv("PSD_EDGE_FUSE_HSV"); return !v || atoi(v) != 0; }();
         hsv_with_edges = hsv && (flags & PSD_SCORE_EDGES) && fast && fuse_env && psd::score_v_mode_available(p.npix);
         // ~8 workgroups per CU over the launch keeps the tail short (one 1024-thread WG per CU).
@@ -387,31 +373,10 @@ static int score_terms(psd_engine* e, psd_slot& s, const uint8_t* d_frames, int 
         else if (luma) HIP_TRY(psd::launch_score_frames(p, false, true, fast, e->num_cus * 8, stream, &s.launches));
     }
     if (flags & PSD_SCORE_EDGES) {
-        int* spec = nullptr;
-        // The hysteresis normally reaches its fix point inside one launch (one workgroup per frame, psd_edge_kernels.hip:
-        // hysteresis_frame_kernel) and nothing below is needed.  With PSD_EDGE_HYST_LAUNCHES=1 it runs as launches of the tile
-        // kernel instead, in one of two forms: a fixed number of launches and no host round trip inside the submission --
-        // psd_score_collect then repeats the term on the exact path if a frame needed more (tests/test_gpu_fullsize.py builds
-        // such a chain; frames full of object edges always do) -- or, with PSD_EDGE_SPECULATIVE=0 as well, the host-driven loop.
-        static const bool speculative = [] { const char* v = getenv("PSD_EDGE_SPECULATIVE"); return !v || atoi(v) != 0; }();
-        if (frames_outlive_collect && speculative) {
-            // the caller keeps the frames until the submission is collected, so a non-converged hysteresis can be
-            // repeated there
-            if (!s.d_edge_flag) {
-                HIP_TRY(hipMalloc((void**)&s.d_edge_flag, sizeof(int)));
-                HIP_TRY(hipHostMalloc((void**)&s.h_edge_flag, sizeof(int), hipHostMallocDefault));
-            }
-            HIP_TRY(hipMemsetAsync(s.d_edge_flag, 0, sizeof(int), stream));
-            spec = s.d_edge_flag;
-            s.edge.active = true;
-            s.edge.d_frames = d_frames; s.edge.d_prev = d_prev; s.edge.d_seg = d_seg;
-            s.edge.n = n; s.edge.height = height; s.edge.width = width; s.edge.edge_kernel = edge_kernel;
-            s.edge.row_stride = row_stride; s.edge.frame_stride = frame_stride; s.edge.stream = stream;
-        }
-        int rc = psd::edges_score(e, d_frames, n, height, width, row_stride, frame_stride, d_prev, edge_kernel, s.d_recs, stream, d_seg, spec,
+        // (the hysteresis reaches its fix point inside one launch, one workgroup per frame: nothing to check at collect)
+        int rc = psd::edges_score(e, d_frames, n, height, width, row_stride, frame_stride, d_prev, edge_kernel, s.d_recs, stream, d_seg,
                                   hsv_with_edges ? &p : nullptr, e->num_cus * 8, &s.launches);
         if (rc != PSD_OK) return rc;
-        if (spec) HIP_TRY(hipMemcpyAsync(s.h_edge_flag, s.d_edge_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
     }
     return PSD_OK;
 }
@@ -428,7 +393,7 @@ int psd_score_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int h
     rc = submit_begin(e, n, flags, stream, &s);
     if (rc != PSD_OK) return rc;
     if (n > 0) {
-        rc = score_terms(e, *s, d_frames, n, height, width, row_stride, frame_stride, d_prev, flags, edge_kernel, stream, nullptr, true);
+        rc = score_terms(e, *s, d_frames, n, height, width, row_stride, frame_stride, d_prev, flags, edge_kernel, stream, nullptr);
         if (rc != PSD_OK) return rc;
     }
     return submit_end(e, *s, stream);
@@ -473,7 +438,7 @@ int psd_score_segments_submit_device(psd_engine* e, const uint8_t* d_frames, int
     if (n > 0) {
         rc = upload_segments(*s, n, seg_first, n_seg, stream);
         if (rc != PSD_OK) return rc;
-        rc = score_terms(e, *s, d_frames, n, height, width, row_stride, frame_stride, nullptr, flags, edge_kernel, stream, s->d_seg, true);
+        rc = score_terms(e, *s, d_frames, n, height, width, row_stride, frame_stride, nullptr, flags, edge_kernel, stream, s->d_seg);
         if (rc != PSD_OK) return rc;
     }
     return submit_end(e, *s, stream);
@@ -538,6 +503,7 @@ int psd_score_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, i
                 hipError_t err = hipMalloc((void**)&e->d_small, need);
                 if (err != hipSuccess) {
                     psd_set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(err));
+            (void)hipGetLastError();
                     return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
                 }
                 e->small_bytes = need;
@@ -591,24 +557,9 @@ static int collect_wait(psd_engine* e, const void* out, int n, const char* who, 
         psd_set_error("scoring failed on device: %s", hipGetErrorString(err));
         return PSD_ERR_HIP;
     }
-    float redo_ms = 0.f;
-    if (n > 0 && s.edge.active && *s.h_edge_flag) {
-        // some frame's weak-edge chains were longer than the fixed number of hysteresis launches: repeat the edge term with
-        // the host-driven loop (it overwrites every edge_xor the first attempt wrote)
-        s.edge.active = false;
-        const auto redo_t0 = std::chrono::steady_clock::now();
-        int rc = psd::edges_score(e, s.edge.d_frames, s.edge.n, s.edge.height, s.edge.width, s.edge.row_stride, s.edge.frame_stride,
-                                  s.edge.d_prev, s.edge.edge_kernel, s.d_recs, s.edge.stream, s.edge.d_seg, nullptr);
-        if (rc != PSD_OK) return rc;
-        rc = copy_records_to_host(s, s.edge.stream);
-        if (rc != PSD_OK) return rc;
-        HIP_TRY(hipStreamSynchronize(s.edge.stream));
-        // (psd_last_kernel_ms counts the repeated edge term too: host clock around the synchronous second attempt)
-        redo_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - redo_t0).count();
-    }
     if (n > 0) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s.ev_start, s.ev_stop) == hipSuccess) e->last_ms = ms + redo_ms;
+        if (hipEventElapsedTime(&ms, s.ev_start, s.ev_stop) == hipSuccess) e->last_ms = ms;
         e->last_launches = s.launches;
     } else {
         e->last_ms = 0.f;
@@ -829,6 +780,7 @@ int psd_hash_thumbs_device(psd_engine* e, const uint8_t* d_frames, int n, int he
         hipError_t err = hipMalloc((void**)&e->d_hash, need);
         if (err != hipSuccess) {
             psd_set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(err));
+            (void)hipGetLastError();
             return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
         }
         e->hash_bytes = need;
@@ -869,6 +821,7 @@ int psd_device_alloc(psd_engine* e, size_t bytes, void** d_ptr)
     hipError_t err = hipMalloc(d_ptr, bytes ? bytes : 1);
     if (err != hipSuccess) {
         psd_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+        (void)hipGetLastError();   // (reported: the next kernel launch check must not see it again)
         return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
     }
     return PSD_OK;
@@ -899,6 +852,7 @@ int psd_host_alloc(psd_engine* e, size_t bytes, void** h_ptr)
     hipError_t err = hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault);
     if (err != hipSuccess) {
         psd_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+        (void)hipGetLastError();
         return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
     }
     return PSD_OK;
@@ -1078,6 +1032,7 @@ int engine_hist_scratch(psd_engine* e, size_t bytes, hipStream_t stream, void** 
         hipError_t err = hipMalloc(&e->d_hpart, cap);
         if (err != hipSuccess) {
             psd_set_error("hipMalloc(%zu) failed: %s", cap, hipGetErrorString(err));
+            (void)hipGetLastError();
             return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
         }
         e->hpart_bytes = cap;

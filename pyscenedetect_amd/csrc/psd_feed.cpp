@@ -30,6 +30,7 @@ extern "C" void psd_set_error(const char* fmt, ...);
         hipError_t _e = (expr);                                                                \
         if (_e != hipSuccess) {                                                                \
             psd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            (void)hipGetLastError(); /* (the failure is reported here: do not leave it for the next launch check) */ \
             return PSD_ERR_HIP;                                                                \
         }                                                                                      \
     } while (0)
@@ -175,6 +176,7 @@ int segment_reserve(Segment& s, size_t bytes)
         if (s.h) (void)hipHostFree(s.h);
         s.h = nullptr;
         psd_set_error("psd_upload_rows_batch: staging allocation of %zu bytes failed: %s", cap, hipGetErrorString(err));
+        (void)hipGetLastError();
         return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
     }
     s.bytes = cap;

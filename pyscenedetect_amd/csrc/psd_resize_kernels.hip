@@ -50,6 +50,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
         hipError_t _e = (expr);                                                                      \
         if (_e != hipSuccess) {                                                                      \
             psd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            (void)hipGetLastError(); /* (the failure is reported here: do not leave it for the next launch check) */ \
             return PSD_ERR_HIP;                                                                      \
         }                                                                                            \
     } while (0)
@@ -61,14 +62,33 @@ struct ResizeTabs {
     XTap* x = nullptr;   // device, [dst_w]
     YTap* y = nullptr;   // device, [dst_h]
     bool area2 = false;  // exact 2x2 decimation: OpenCV routes INTER_LINEAR to INTER_AREA (rounded box mean)
+    unsigned long long used = 0;
 };
 
 typedef std::tuple<int, int, int, int, int> ShapeKey;   // src h, w, dst h, w, kind
-struct OtherTab { void* d; int mode; float inv_area; };
+struct OtherTab { void* d; int mode; float inv_area; unsigned long long used; };
 struct ResizeCache {
     std::map<ShapeKey, ResizeTabs> linear;   // INTER_LINEAR taps (kind 0; 1 = the INTER_AREA enlargement coefficients)
     std::map<ShapeKey, OtherTab> other;      // TableKind tables: INTER_NEAREST offsets, INTER_AREA runs, hash thumbnail runs
+    unsigned long long tick = 0;             // use counter: the least recently used table goes when a map is full
 };
+// A long-running service that sees ever new resolutions or crop sizes must not accumulate tables for the life of the engine
+// (a few KiB each, but unbounded): each map keeps the kMaxTables most recently used.
+constexpr size_t kMaxTables = 48;
+
+template <typename Map, typename Free>
+static void evict_lru(Map& m, Free free_entry)
+{
+    while (m.size() >= kMaxTables) {
+        auto victim = m.begin();
+        for (auto it = m.begin(); it != m.end(); ++it)
+            if (it->second.used < victim->second.used) victim = it;
+        // (kernels queued earlier may still read it: a full-device wait on this cold path, once per 49th new shape)
+        (void)hipDeviceSynchronize();
+        free_entry(victim->second);
+        m.erase(victim);
+    }
+}
 
 static ResizeCache& cache_of(psd_engine* e)
 {
@@ -82,6 +102,7 @@ bool table_find(psd_engine* e, int kind, int sh, int sw, int dh, int dw, DevTabl
     ResizeCache& c = cache_of(e);
     auto it = c.other.find(std::make_tuple(sh, sw, dh, dw, kind));
     if (it == c.other.end()) return false;
+    it->second.used = ++c.tick;
     out->ptr = it->second.d; out->mode = it->second.mode; out->inv_area = it->second.inv_area;
     return true;
 }
@@ -98,7 +119,9 @@ int table_store(psd_engine* e, int kind, int sh, int sw, int dh, int dw, const v
         psd_set_error("coefficient table upload failed: %s", hipGetErrorString(err));
         return PSD_ERR_HIP;
     }
-    cache_of(e).other[std::make_tuple(sh, sw, dh, dw, kind)] = OtherTab{d, mode, inv_area};
+    ResizeCache& c = cache_of(e);
+    evict_lru(c.other, [](OtherTab& t) { if (t.d) (void)hipFree(t.d); });
+    c.other[std::make_tuple(sh, sw, dh, dw, kind)] = OtherTab{d, mode, inv_area, ++c.tick};
     out->ptr = d; out->mode = mode; out->inv_area = inv_area;
     return PSD_OK;
 }
@@ -162,10 +185,12 @@ static void linear_tabs_host(int sh, int sw, int dh, int dw, bool area_mode, std
 
 static int get_tabs(psd_engine* e, int sh, int sw, int dh, int dw, hipStream_t stream, ResizeTabs* out, bool area_mode = false)
 {
-    std::map<ShapeKey, ResizeTabs>& cache = cache_of(e).linear;
+    ResizeCache& rc_ = cache_of(e);
+    std::map<ShapeKey, ResizeTabs>& cache = rc_.linear;
     const auto key = std::make_tuple(sh, sw, dh, dw, area_mode ? 1 : 0);
     auto it = cache.find(key);
-    if (it != cache.end()) { *out = it->second; return PSD_OK; }
+    if (it != cache.end()) { it->second.used = ++rc_.tick; *out = it->second; return PSD_OK; }
+    evict_lru(cache, [](ResizeTabs& t) { if (t.x) (void)hipFree(t.x); });
     ResizeTabs t;
     std::vector<XTap> xt;
     std::vector<YTap> yt;
@@ -179,6 +204,7 @@ static int get_tabs(psd_engine* e, int sh, int sw, int dh, int dw, hipStream_t s
     HIP_TRY(hipMemcpy(t.x, xt.data(), sizeof(XTap) * dw, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(t.y, yt.data(), sizeof(YTap) * dh, hipMemcpyHostToDevice));
     (void)stream;
+    t.used = ++rc_.tick;
     cache[key] = t;
     *out = t;
     return PSD_OK;
@@ -484,19 +510,26 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     }
 }
 
-// rec[t].hist = sum over the tiles of frame t of their packed partial histograms.  grid = frames, 128 threads.
-__global__ __launch_bounds__(128) void hist_reduce_kernel(const u32* hpart, int n_tiles, psd_frame_scores* out)
+// rec[t].hist = sum over the tiles of frame t of their packed partial histograms.  grid = frames, 512 threads: four quarters
+// of the tiles side by side, joined in LDS (one thread per word walking all 72 tiles of a 1080p frame was latency-bound:
+// 150 MB per 4096-frame launch at 2 TB/s).
+__global__ __launch_bounds__(512) void hist_reduce_kernel(const u32* hpart, int n_tiles, psd_frame_scores* out)
 {
-    const int t = blockIdx.x, i = threadIdx.x;
+    __shared__ u32 part[3][256];
+    const int t = blockIdx.x, i = threadIdx.x & 127, q = threadIdx.x >> 7;
     const u32* src = hpart + (size_t)t * n_tiles * 128 + i;
     u32 lo = 0, hi = 0;
-    for (int k = 0; k < n_tiles; k++) {
+    for (int k = q; k < n_tiles; k += 4) {
         const u32 v = src[(size_t)k * 128];
         lo += v & 0xffffu;
         hi += v >> 16;
     }
-    out[t].hist[2 * i] = lo;
-    out[t].hist[2 * i + 1] = hi;
+    if (q) { part[q - 1][2 * i] = lo; part[q - 1][2 * i + 1] = hi; }
+    __syncthreads();
+    if (q == 0) {
+        out[t].hist[2 * i] = lo + part[0][2 * i] + part[1][2 * i] + part[2][2 * i];
+        out[t].hist[2 * i + 1] = hi + part[0][2 * i + 1] + part[1][2 * i + 1] + part[2][2 * i + 1];
+    }
 }
 
 // Generic cv2.resize(INTER_LINEAR): any alignment / row stride.  grid = (ceil(dw/256), dh, n)
@@ -623,7 +656,7 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     if (launches) *launches += 1;
     if (want_luma) {
         for (int t0 = 0; t0 < n; t0 += 65535)
-            hipLaunchKernelGGL(hist_reduce_kernel, dim3(std::min(65535, n - t0)), dim3(128), 0, stream, p.hpart + (size_t)t0 * p.n_tiles * 128,
+            hipLaunchKernelGGL(hist_reduce_kernel, dim3(std::min(65535, n - t0)), dim3(512), 0, stream, p.hpart + (size_t)t0 * p.n_tiles * 128,
                                p.n_tiles, d_out + t0);
         HIP_TRY(hipGetLastError());
         if (launches) *launches += 1;

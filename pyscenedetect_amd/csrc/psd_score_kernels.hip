@@ -525,8 +525,7 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
 {
     if constexpr (FP) {
         static_assert(HSV && !(LUMA && S1), "");
-        // VM with LUMA: the histogram slots count V instead of the luma; VM without LUMA: the caller only stores the V bytes
-        // this conversion has packed anyway (o.v)
+        // VM (with LUMA): the histogram slots count V instead of the luma
         constexpr int LA = AC == 4 ? 4 : AC == 8 ? 5 : AC == 16 ? 6 : AC == 32 ? 7 : AC == 2 ? 3 : AC == 1 ? 2 : -1;   // log2(bytes per bin)
         static_assert(!LUMA || LA > 0, "");
         const u32 off_a = LUMA ? (u32)(uintptr_t)hist : 0u;
@@ -1295,12 +1294,6 @@ static hipError_t launch_one(const ScoreParams& p, int grid, hipStream_t stream)
             return hipGetLastError();
         }
     }
-    if constexpr (FAST && HSV && !LUMA) {
-        if (p.vout != nullptr) {   // V mode without the histogram: the HSV-only pass also stores the V plane
-            hipLaunchKernelGGL((score_frames_dma_kernel<true, false, G, kHsvWG, true>), dim3(grid), dim3(kHsvWG), 0, stream, p);
-            return hipGetLastError();
-        }
-    }
     if constexpr (FAST) {
         if (!direct_loads()) {
             constexpr int SWG = (HSV && (!LUMA || PSD_FUSED_SMALL)) ? kHsvWG : (HSV && LUMA) ? kFusedWG : kScoreWG;
@@ -1409,12 +1402,11 @@ hipError_t launch_score_frames(ScoreParams p, bool hsv, bool luma, bool fast, in
     const int total_groups = (int)((p.npix + 15) / 16);
     const int full_groups = (int)(p.npix / 16);
     if (p.vout != nullptr) {
-        // V mode: the HSV term and the edge term's V plane + V histogram from one pass (the staged kernel only, whole groups)
-        // p.vhist set: the fused 16-wave kernel, its histogram slots counting V; not set: the HSV-only kernel plus the V store
-        // (the caller then takes the histogram from the V plane: psd_edge_kernels.hip, v_hist_kernel)
-        if (!hsv || luma || !fast || direct_loads() || total_groups != full_groups) return hipErrorInvalidValue;
+        // V mode: the HSV term and the edge term's V plane + V histogram from one pass (the staged 16-wave fused kernel, its
+        // histogram slots counting V; whole groups only)
+        if (!hsv || luma || !fast || direct_loads() || total_groups != full_groups || p.vhist == nullptr) return hipErrorInvalidValue;
         *launches += 1;
-        return launch_range(p, 0, full_groups, true, p.vhist != nullptr, true, target_blocks, stream);
+        return launch_range(p, 0, full_groups, true, true, true, target_blocks, stream);
     }
     if (!fast) {
         *launches += 1;

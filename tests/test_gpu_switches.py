@@ -17,13 +17,9 @@ SWITCHES = [
     {"PSD_HSV_BLOCKS": "64"},             # few, long time walks
     {"PSD_HSV_BLOCKS": "1000000"},        # as many walks as frames allow
     {"PSD_LUMA_WALK": "1"},               # luma histogram on the time-walking kernel instead of luma_hist_kernel
-    {"PSD_EDGE_HYST_LAUNCHES": "1"},      # hysteresis by launches of the tile kernel instead of one workgroup per frame: the
-                                          # speculative form (six launches, the term repeated at collect if a chain needed more) ...
-    {"PSD_EDGE_HYST_LAUNCHES": "1", "PSD_EDGE_SPECULATIVE": "0"},   # ... and the host-driven loop (psd_engine.cpp)
     {"PSD_EDGE_FUSE_HSV": "0"},           # two reads of the frames for HSV + edges
-    {"PSD_EDGE_VHIST_FUSED": "0"},        # V plane from the HSV-only kernel + v_hist_kernel
     {"PSD_EDGE_WS_MB": "1"},              # edge workspace of a few frames: many chunks
-    {"PSD_EDGE_WS_MB": "1", "PSD_EDGE_VHIST_FUSED": "0"},
+    {"PSD_EDGE_WS_MB": "1", "PSD_EDGE_FUSE_HSV": "0"},
     {"PSD_HASH_DIRECT": "1"},             # HashDetector thumbnails without LDS-DMA (psd_hash_kernels.hip)
     {"PSD_RESIZE_DEPTH": "3"},            # downscale kernel with two frames in flight
     {"PSD_RESIZE_ROWS": "1"},             # ... one destination row per workgroup
