@@ -490,8 +490,8 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
         r = {"value": round(len(host) / best, 1), "unit": "frames/s", "pcie_inclusive": True, "frames": len(host), "cuts_found": len(cuts),
              "api": "pyscenedetect_amd.ContentDetector.process_frame(timecode, frame): one upload (the previous frame stays in HBM), "
                     "psd_score_batch_device(n=1), decision", "us_per_frame": round(best / len(host) * 1e6, 1)}
-        # the binding a reference maintainer adds calls psd_score_batch(n = 1) with the previous frame from the
-        # reference's own per-frame loop (integration/scenedetect_amd.py: _calculate_frame_score); timed here exactly as that
+        # the binding a reference maintainer adds scores one frame per call from the reference's own per-frame
+        # loop (integration/scenedetect_amd.py: _calculate_frame_score -> FramePair.score_next); timed here exactly as that
         # function issues it (the reference package itself is not on this box)
         sys.path.insert(0, os.path.join(ROOT, "integration"))
         import scenedetect_amd as B
@@ -499,11 +499,11 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
         bind = B.Binding(os.path.join(ROOT, "pyscenedetect_amd", "libpsd_hip.so"), device.index or 0)
 
         def binding_loop(frames):
-            last, sads = None, []
+            pair, sads = bind.frame_pair(), []
             for f in frames:
-                rec = bind.score(f, last, B.HSV_SAD)
-                last = np.array(f, copy=True)
+                rec, _had_prev = pair.score_next(f, B.HSV_SAD)
                 sads.append((rec.sad_h, rec.sad_s, rec.sad_v))
+            pair.release()
             return sads
 
         binding_loop(host[:4])
@@ -515,9 +515,9 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
         bind.close()
         r["reference_binding"] = {"value": round(len(host) / best_b, 1), "unit": "frames/s", "pcie_inclusive": True,
                                   "us_per_frame": round(best_b / len(host) * 1e6, 1),
-                                  "api": "integration/scenedetect_amd.py Binding.score = psd_score_batch(n=1, h_prev): what the patched "
-                                         "reference ContentDetector._calculate_frame_score calls per frame (both frames cross PCIe), plus its "
-                                         "per-frame copy of the frame"}
+                                  "api": "integration/scenedetect_amd.py FramePair.score_next = psd_memcpy_h2d + psd_score_batch_device(n=1, d_prev): "
+                                         "what the patched reference ContentDetector._calculate_frame_score calls per frame (the previous frame "
+                                         "stays in HBM: one upload per frame)"}
         try:
             from oracle import lib as orc
             from oracle.detectors_np import OracleEngine

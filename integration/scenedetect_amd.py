@@ -11,8 +11,11 @@
 
 Everything else -- weights, FlashFilter, the adaptive window, the fade state machine, StatsManager, timecodes --
 stays the reference's code.  Only the C-ABI is touched: ``psd_create``, ``psd_score_batch``, ``psd_last_error``,
-``psd_destroy`` on whatever shared library ``lib_path`` names (``pyscenedetect_amd/libpsd_hip.so`` on a machine with
-an MI355X).  Nothing of ``pyscenedetect_amd`` is imported.
+``psd_destroy`` and, for ContentDetector's frame-to-frame term, ``psd_device_alloc`` / ``psd_device_free`` /
+``psd_memcpy_h2d`` / ``psd_score_batch_device`` (the previous frame stays in HBM: one upload per frame instead of two, and no
+host copy of the frame -- the reference keeps three HSV planes per detector for the same purpose, content_detector.py:189)
+on whatever shared library ``lib_path`` names (``pyscenedetect_amd/libpsd_hip.so`` on a machine with an MI355X).
+Nothing of ``pyscenedetect_amd`` is imported.
 """
 
 import ctypes
@@ -38,15 +41,34 @@ class Binding:
         lib.psd_score_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
                                         ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
         lib.psd_last_error.restype = ctypes.c_char_p
+        lib.psd_device_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        lib.psd_device_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.psd_memcpy_h2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        lib.psd_score_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
+                                               ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         self._lib = lib
         self._engine = ctypes.c_void_p()
+        self._pairs = []
         if lib.psd_create(device, ctypes.byref(self._engine)) != 0:
             raise RuntimeError(lib.psd_last_error().decode())
 
     def close(self):
         if self._engine:
+            for pair in self._pairs:
+                pair.release()
+            self._pairs = []
             self._lib.psd_destroy(self._engine)
             self._engine = ctypes.c_void_p()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise (ValueError if rc == -1 else MemoryError if rc == -5 else RuntimeError)(self._lib.psd_last_error().decode())
+
+    def frame_pair(self) -> "FramePair":
+        """State of ONE detector's frame-to-frame comparison: the frame it saw last stays in device memory."""
+        pair = FramePair(self)
+        self._pairs.append(pair)
+        return pair
 
     def score(self, frame: np.ndarray, prev: np.ndarray | None, flags: int, kernel: int = 0) -> FrameScores:
         if frame.dtype != np.uint8 or frame.ndim != 3 or frame.shape[2] != 3:
@@ -61,6 +83,47 @@ class Binding:
         if rc != 0:
             raise (ValueError if rc == -1 else RuntimeError)(self._lib.psd_last_error().decode())
         return rec
+
+
+class FramePair:
+    """Two device buffers that take turns holding "this frame" and "the frame before" of one detector."""
+
+    def __init__(self, binding: Binding):
+        self._b = binding
+        self._bufs = [ctypes.c_void_p(), ctypes.c_void_p()]
+        self._shape = None
+        self._cur = 0
+        self._have_prev = False
+
+    def release(self):
+        b = self._b
+        for buf in self._bufs:
+            if buf and b._engine:
+                b._lib.psd_device_free(b._engine, buf)
+        self._bufs = [ctypes.c_void_p(), ctypes.c_void_p()]
+        self._shape, self._have_prev = None, False
+
+    def score_next(self, frame: np.ndarray, flags: int, kernel: int = 0):
+        """(record of ``frame`` against the frame of the previous call, whether there was one)."""
+        if frame.dtype != np.uint8 or frame.ndim != 3 or frame.shape[2] != 3:
+            raise ValueError("Image must be 8-bit BGR")
+        frame = np.ascontiguousarray(frame)
+        b = self._b
+        if self._shape != frame.shape:
+            self.release()
+            for i in range(2):
+                b._check(b._lib.psd_device_alloc(b._engine, frame.nbytes, ctypes.byref(self._bufs[i])))
+            self._shape = frame.shape
+        cur, other = self._bufs[self._cur], self._bufs[self._cur ^ 1]
+        b._check(b._lib.psd_memcpy_h2d(b._engine, cur, frame.ctypes.data, frame.nbytes))
+        rec = FrameScores()
+        h, w, _ = frame.shape
+        had_prev = self._have_prev
+        b._check(b._lib.psd_score_batch_device(b._engine, cur, 1, h, w, w * 3, frame.nbytes, other if had_prev else None, flags, kernel,
+                                               ctypes.byref(rec), None))
+        self._cur ^= 1
+        self._have_prev = True
+        return rec, had_prev
 
 
 class _NumpyWithDeviceMean:
@@ -90,11 +153,12 @@ def install(binding: Binding):
 
     def _calculate_frame_score(self, timecode, frame_img):
         calculate_edges = (self._weights.delta_edges > 0.0) or self.stats_manager is not None
-        last = getattr(self, "_amd_last_img", None)
+        pair = getattr(self, "_amd_pair", None)
+        if pair is None:
+            pair = self._amd_pair = binding.frame_pair()        # this detector's previous frame lives in HBM
         kernel = int(self._kernel.shape[0]) if self._kernel is not None else 0
-        rec = binding.score(frame_img, last, HSV_SAD | (EDGES if calculate_edges else 0), kernel)
-        self._amd_last_img = np.array(frame_img, copy=True)
-        if last is None:
+        rec, had_prev = pair.score_next(frame_img, HSV_SAD | (EDGES if calculate_edges else 0), kernel)
+        if not had_prev:
             return 0.0
         n = float(frame_img.shape[0] * frame_img.shape[1])
         score_components = ContentDetector.Components(

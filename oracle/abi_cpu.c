@@ -1,6 +1,7 @@
 /*
  * abi_cpu.c -- the entry points of include/psd_engine.h that a per-frame binding touches (psd_create, psd_destroy,
- * psd_score_batch, psd_last_error, psd_abi_version), implemented on the CPU oracle.
+ * psd_score_batch, psd_last_error, psd_abi_version, and for a previous frame kept "on the device": psd_device_alloc,
+ * psd_device_free, psd_memcpy_h2d, psd_score_batch_device -- device memory is host memory here), implemented on the CPU oracle.
  *
  * TEST INFRASTRUCTURE ONLY, like everything under oracle/.  It exists so that the reference-side binding of
  * INTEGRATION.md B (integration/scenedetect_amd.py) can be EXECUTED against the unmodified reference in the build
@@ -110,4 +111,35 @@ int psd_score_batch(psd_engine* e, const uint8_t* h_frames, int n, int height, i
         free(cur); free(last);
     }
     return PSD_OK;
+}
+
+/* "Device" memory of this build is host memory: the binding keeps a detector's previous frame in it. */
+int psd_device_alloc(psd_engine* e, size_t bytes, void** d_ptr)
+{
+    if (!e || !d_ptr) { snprintf(g_err, sizeof g_err, "psd_device_alloc: null argument"); return PSD_ERR_INVALID; }
+    *d_ptr = malloc(bytes ? bytes : 1);
+    if (!*d_ptr) { snprintf(g_err, sizeof g_err, "malloc(%zu) failed", bytes); return PSD_ERR_NOMEM; }
+    return PSD_OK;
+}
+
+int psd_device_free(psd_engine* e, void* d_ptr)
+{
+    if (!e) { snprintf(g_err, sizeof g_err, "null engine"); return PSD_ERR_INVALID; }
+    free(d_ptr);
+    return PSD_OK;
+}
+
+int psd_memcpy_h2d(psd_engine* e, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!e || (bytes && (!d_dst || !h_src))) { snprintf(g_err, sizeof g_err, "psd_memcpy_h2d: null argument"); return PSD_ERR_INVALID; }
+    memcpy(d_dst, h_src, bytes);
+    return PSD_OK;
+}
+
+int psd_score_batch_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
+                           size_t frame_stride, const uint8_t* d_prev, uint32_t flags, int edge_kernel, psd_frame_scores* out,
+                           void* stream)
+{
+    (void)stream;
+    return psd_score_batch(e, d_frames, n, height, width, row_stride, frame_stride, d_prev, flags, edge_kernel, out);
 }

@@ -30,6 +30,15 @@ def test_same_records_through_the_same_binding():
             prev = frames[t - 1] if t else None
             a, b = gpu.score(frames[t], prev, flags, kernel), cpu.score(frames[t], prev, flags, kernel)
             assert bytes(a) == bytes(b), f"flags {flags} kernel {kernel} frame {t}"
+    # ContentDetector's seam: the previous frame stays in device memory (FramePair), one upload per frame
+    for flags, kernel in ((B.HSV_SAD, 0), (B.HSV_SAD | B.EDGES, 0), (B.HSV_SAD | B.EDGES, 5)):
+        pg, pc = gpu.frame_pair(), cpu.frame_pair()
+        for t in range(len(frames)):
+            (a, ha), (b, hb) = pg.score_next(frames[t], flags, kernel), pc.score_next(frames[t], flags, kernel)
+            assert ha == hb == (t > 0) and bytes(a) == bytes(b), f"pair: flags {flags} kernel {kernel} frame {t}"
+            assert bytes(a) == bytes(gpu.score(frames[t], frames[t - 1] if t else None, flags, kernel))
+        other = np.ascontiguousarray(frames[0][:50, :70])            # a size change starts over (no predecessor)
+        assert pg.score_next(other, flags, kernel)[1] is False and pg.score_next(other, flags, kernel)[1] is True
     with pytest.raises(ValueError):
         gpu.score(frames[0], None, B.EDGES, 4)
     with pytest.raises(ValueError):
