@@ -659,19 +659,30 @@ class FlowWorkload:
         return corpus.score_clip(self.eng, self.clips[i], corpus.required_flags(self.detectors))
 
     def truth_f1(self) -> dict | None:
-        """Precision / recall / F1 of this rank's clips against the generator's ground truth (exact frame match)."""
-        tp = npred = ntrue = 0
-        for i, t in self.truth.items():
-            name = "adaptive" if "adaptive" in self.detectors else "content"
-            pred = self.result[i][name]
-            tp += len(set(pred) & set(t))
-            npred += len(pred)
-            ntrue += len(t)
-        if not npred or not ntrue:
+        """Precision / recall / F1 of this rank's clips against the generator's ground truth, scored the way the reference's
+        benchmark scores detectors (benchmark/evaluator.py: greedy 1-to-1 matching within a frame tolerance, counts summed
+        over videos; tools/bbc_scoring.py restates it and passes the reference's own tests for it) at tolerances 0 and 1."""
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from pathlib import Path
+
+        from bbc_scoring import GroundTruth, Prediction, evaluate
+
+        name = "adaptive" if "adaptive" in self.detectors else "content"
+        preds = {Path(f"clip{i}"): Prediction(predicted_cuts=list(self.result[i][name]), ground_truth=GroundTruth(hard_cuts=list(t)), elapsed=0.0)
+                 for i, t in self.truth.items()}
+        if not preds:
             return None
-        p, r = tp / npred, tp / ntrue
-        return {"detector": name, "precision": round(p, 4), "recall": round(r, 4), "f1": round(2 * p * r / (p + r), 4) if p + r else 0.0,
-                "true_cuts": ntrue, "detected": npred, "scope": "clips of rank 0"}
+        out = {"detector": name, "scope": "clips of rank 0", "scorer": "tools/bbc_scoring.py (the reference's benchmark/evaluator.py convention)"}
+        for tol in (0, 1):
+            hc = evaluate(preds, tol).hard_cuts
+            if tol == 0:
+                if not (hc.matched + hc.false_positives) or not (hc.matched + hc.missed):
+                    return None
+                out.update(precision=round(hc.precision, 4), recall=round(hc.recall, 4), f1=round(hc.f1, 4),
+                           true_cuts=hc.matched + hc.missed, detected=hc.matched + hc.false_positives)
+            else:
+                out["f1_tolerance_1"] = round(hc.f1, 4)
+        return out
 
 
 def run_flow(args, eng, device, world, rank, local_rank, use_dist, on_gpu) -> dict | None:

@@ -1,8 +1,8 @@
 """CPU: the REFERENCE'S OWN video-free tests, executed against the mirror.
 
-``/root/reference/tests/test_timecode.py``, ``test_stats_manager.py`` and the video-free cases of ``test_scene_manager.py`` hold
-the reference's assertions for SURVEY.md 8 rows a13 / a14 / a15 (FrameTimecode / Timecode, StatsManager, SceneManager's crop
-and scene-list helpers).  They are run unmodified, from where they lie, in a pytest subprocess whose ``scenedetect`` package is
+``/root/reference/tests/test_timecode.py``, ``test_stats_manager.py``, the video-free cases of ``test_scene_manager.py`` and
+``test_benchmark_evaluator.py`` hold the reference's assertions for SURVEY.md 8 rows a13 / a14 / a15 / f2 (FrameTimecode /
+Timecode, StatsManager, SceneManager's crop and scene-list helpers, the benchmark's TRECVID-style scorer).  They are run unmodified, from where they lie, in a pytest subprocess whose ``scenedetect`` package is
 ``tests/ref_alias/scenedetect`` -- import aliases onto ``pyscenedetect_amd`` -- with ``--noconftest`` (the reference's conftest
 imports cv2 and video fixtures) and importlib import mode (so that the reference checkout never lands on ``sys.path``).
 Cases that open a video file are deselected BY NAME below; everything else must pass.  These are reference-held
@@ -24,8 +24,9 @@ NEEDS_A_VIDEO = {
     "test_scene_manager.py": ["test_scene_list", "test_get_scene_list_start_in_scene", "test_detect_scenes_callback",
                               "test_detect_scenes_callback_adaptive", "test_detect_scenes_crop"],
     "test_timecode.py": [],
+    "test_benchmark_evaluator.py": [],      # (against tools/bbc_scoring.py, the harness's scorer on boxes without the reference)
 }
-EXPECT_AT_LEAST = {"test_timecode.py": 35, "test_stats_manager.py": 5, "test_scene_manager.py": 5}
+EXPECT_AT_LEAST = {"test_timecode.py": 35, "test_stats_manager.py": 5, "test_scene_manager.py": 5, "test_benchmark_evaluator.py": 24}
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_TESTS), reason="the reference checkout is only in the build container")
@@ -44,7 +45,7 @@ def test_reference_test_file_passes_against_the_mirror(name, tmp_path):
     assert m and int(m.group(1)) >= EXPECT_AT_LEAST[name], tail
     assert "failed" not in run.stdout.splitlines()[-1] and "error" not in run.stdout.splitlines()[-1], tail
     # the module under test really was the mirror
-    probe = subprocess.run([sys.executable, "-c", "import scenedetect.common as c, scenedetect.stats_manager as s; "
-                            "print(c.FrameTimecode.__module__, s.StatsManager.__module__)"], cwd=tmp_path, env=env,
+    probe = subprocess.run([sys.executable, "-c", "import scenedetect.common as c, scenedetect.stats_manager as s, benchmark.evaluator as b; "
+                            "print(c.FrameTimecode.__module__, s.StatsManager.__module__, b.score_video.__module__)"], cwd=tmp_path, env=env,
                            capture_output=True, text=True, timeout=120)
-    assert probe.stdout.split() == ["pyscenedetect_amd.timecode", "pyscenedetect_amd.stats_manager"], probe.stdout + probe.stderr
+    assert probe.stdout.split() == ["pyscenedetect_amd.timecode", "pyscenedetect_amd.stats_manager", "bbc_scoring"], probe.stdout + probe.stderr
