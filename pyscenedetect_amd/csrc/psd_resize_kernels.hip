@@ -510,16 +510,15 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     }
 }
 
-// rec[t].hist = sum over the tiles of frame t of their packed partial histograms.  grid = frames, 512 threads: four quarters
-// of the tiles side by side, joined in LDS (one thread per word walking all 72 tiles of a 1080p frame was latency-bound:
-// 150 MB per 4096-frame launch at 2 TB/s).
+// rec[t].hist = sum over the tiles of frame t of their packed partial histograms.  grid = frames; 128 threads (one per packed
+// word) or a multiple: the tiles are split over blockDim / 128 groups of threads and joined in LDS.
 __global__ __launch_bounds__(512) void hist_reduce_kernel(const u32* hpart, int n_tiles, psd_frame_scores* out)
 {
     __shared__ u32 part[3][256];
-    const int t = blockIdx.x, i = threadIdx.x & 127, q = threadIdx.x >> 7;
+    const int t = blockIdx.x, i = threadIdx.x & 127, q = threadIdx.x >> 7, nq = blockDim.x >> 7;
     const u32* src = hpart + (size_t)t * n_tiles * 128 + i;
     u32 lo = 0, hi = 0;
-    for (int k = q; k < n_tiles; k += 4) {
+    for (int k = q; k < n_tiles; k += nq) {
         const u32 v = src[(size_t)k * 128];
         lo += v & 0xffffu;
         hi += v >> 16;
@@ -527,8 +526,9 @@ __global__ __launch_bounds__(512) void hist_reduce_kernel(const u32* hpart, int 
     if (q) { part[q - 1][2 * i] = lo; part[q - 1][2 * i + 1] = hi; }
     __syncthreads();
     if (q == 0) {
-        out[t].hist[2 * i] = lo + part[0][2 * i] + part[1][2 * i] + part[2][2 * i];
-        out[t].hist[2 * i + 1] = hi + part[0][2 * i + 1] + part[1][2 * i + 1] + part[2][2 * i + 1];
+        for (int r = 0; r + 1 < nq; r++) { lo += part[r][2 * i]; hi += part[r][2 * i + 1]; }
+        out[t].hist[2 * i] = lo;
+        out[t].hist[2 * i + 1] = hi;
     }
 }
 
@@ -655,8 +655,10 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     HIP_TRY(hipGetLastError());
     if (launches) *launches += 1;
     if (want_luma) {
+        // (one quarter-less pass of 128 threads per frame: in the pipelined flow the small workgroups slip in beside the next
+        //  submission's kernels -- 1.29-1.30 ms per 4096 frames against 1.31-1.32 with 512 threads, which are faster alone)
         for (int t0 = 0; t0 < n; t0 += 65535)
-            hipLaunchKernelGGL(hist_reduce_kernel, dim3(std::min(65535, n - t0)), dim3(512), 0, stream, p.hpart + (size_t)t0 * p.n_tiles * 128,
+            hipLaunchKernelGGL(hist_reduce_kernel, dim3(std::min(65535, n - t0)), dim3(128), 0, stream, p.hpart + (size_t)t0 * p.n_tiles * 128,
                                p.n_tiles, d_out + t0);
         HIP_TRY(hipGetLastError());
         if (launches) *launches += 1;
