@@ -258,3 +258,73 @@ def test_row_policy_per_shape():
     assert len(_DeviceFeeder(e, 4, factor=7.5, interpolation=LINEAR)._rows_of(1080, 1920)) == 288
     assert _DeviceFeeder(e, 4, factor=1.0)._rows_of(1080, 1920) is None
     assert _DeviceFeeder(object(), 4, factor=7.0)._rows_of(1080, 1920) is None
+
+
+class _AsyncHostBuffer(_HostBuffer):
+    """... whose batched row uploads are ASYNCHRONOUS like psd_upload_rows_batch: the rows reach the buffer only when the
+    engine's fence runs, so a feeder that forgets to flush or to fence a batch scores poisoned rows."""
+
+    def __init__(self, nbytes, engine):
+        super().__init__(nbytes)
+        self._engine = engine
+        self.batch_calls, self.batch_sizes = 0, []
+
+    def upload_rows_batch(self, frames, offset, rows, frame_stride):
+        self.batch_calls += 1
+        self.batch_sizes.append(len(frames))
+        for i, f in enumerate(frames):
+            f = np.array(f, copy=True)                   # (the host frames are free when the call returns)
+            self._engine.in_flight.append((self, offset + i * frame_stride, f, np.array(rows)))
+
+
+class _BatchingEngine(_HostDeviceEngineWithRows):
+    def __init__(self, oracle_engine):
+        super().__init__(oracle_engine)
+        self.in_flight, self.fences = [], 0
+
+    def alloc(self, nbytes):
+        self.buffers.append(_AsyncHostBuffer(nbytes, self))
+        return self.buffers[-1]
+
+    def upload_fence(self, wait_on_host=False):
+        self.fences += 1
+        for buf, off, frame, rows in self.in_flight:
+            h, w, c = frame.shape
+            buf.mem[off: off + h * w * c].reshape(h, w * c)[rows] = frame.reshape(h, w * c)[rows]
+        self.in_flight = []
+
+    def analyze_device(self, d_frames, *a, **k):
+        # (the decode thread may already be filling the NEXT buffer: only this batch's own buffer must be settled)
+        mine = next(b for b in self.buffers if b.ptr <= d_frames < b.ptr + b.nbytes)
+        assert not [x for x in list(self.in_flight) if x[0] is mine], "a batch was scored before its uploads were fenced"
+        return super().analyze_device(d_frames, *a, **k)
+
+
+@pytest.mark.parametrize("batch_frames,feed_batch", [(16, 16), (16, 5), (7, 16), (64, 3)])
+def test_feeder_batches_row_uploads_and_fences_every_batch(golden, oracle_engine, batch_frames, feed_batch):
+    """The feeder's protocol over `upload_rows_batch` (ABI 5): frames are handed over `FEED_BATCH` at a time, what is pending
+    when a batch of the SceneManager closes is flushed, and one fence per batch orders the scoring behind the copies -- same
+    cuts and callback frames as whole-frame uploads."""
+    frames = golden_clip(golden, "scenes_a")
+    keep = _DeviceFeeder.FEED_BATCH
+    _DeviceFeeder.FEED_BATCH = feed_batch
+    try:
+        eng, whole = _BatchingEngine(oracle_engine), _HostDeviceEngine(oracle_engine)
+
+        def run(engine, shown):
+            sm = psd.SceneManager(engine=engine, batch_frames=batch_frames)
+            sm.auto_downscale = False
+            sm.downscale = 4
+            sm.add_detector(psd.ContentDetector(engine=engine))
+            sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), callback=lambda img, pos: shown.append((pos.frame_num, int(img.sum()))))
+            return [c.frame_num for c in sm.get_cut_list()]
+
+        shown_a, shown_b = [], []
+        assert run(eng, shown_a) == run(whole, shown_b) and shown_a == shown_b and len(shown_a) > 0
+    finally:
+        _DeviceFeeder.FEED_BATCH = keep
+    n_batches = -(-len(frames) // batch_frames)
+    assert eng.fences == n_batches and not eng.in_flight
+    sizes = [s for b in eng.buffers for s in getattr(b, "batch_sizes", [])]
+    assert sum(sizes) == len(frames) and max(sizes) <= min(feed_batch, batch_frames)
+    assert sum(b.row_calls + b.full_calls for b in eng.buffers) == 0      # nothing went frame by frame
