@@ -822,11 +822,16 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
                          "corpus = configs[4] (mixed 1080p/4K clips, four detectors, sharded by clip); bbc = configs[3]")
     ap.add_argument("--corpus-frames", type=int, default=2048, help="frames per 1080p clip of --workload corpus (4K clips: a quarter)")
     ap.add_argument("--bbc-frames", type=int, default=6000, help="frames of the shortest of the 11 clips of --workload bbc")
-    ap.add_argument("--exchange", default="default", choices=["default", "stream", "inline", "off"], help=argparse.SUPPRESS)   # diagnosis of the
-    # score-vector all-gather under a launcher: on torch's current stream (default), on a side stream, or skipped.  Measured at
-    # one rank (profiles/r03_y_*): the three small operations of the exchange (slice kernel, all-gather, device -> host copy of
-    # the gathered vectors; 22 us of GPU time, rocprofv3) stretch the concurrently running HSV kernel by 0.12 ms = 2.4 %,
-    # on either stream; without them the run under torch.distributed.run equals the plain one
+    ap.add_argument("--exchange", default="default", choices=["default", "step", "stream", "inline", "off"], help=argparse.SUPPRESS)
+    # The score-vector all-gather under a launcher.  Clips are independent, so the data path has NO collective: every rank
+    # scores and decides its own batch each step (the step ends with that rank's cut list); the ranks' score vectors only have
+    # to meet once so that every rank holds the whole job's result.  default = ONE all-gather of every timed step's vectors at
+    # the end of the run, inside the timed region (32 bytes per frame, taken from the records the engine has copied to the host
+    # anyway: no GPU operation beside the scoring kernels).  step = the round-1..3 form: an all-gather of the device-resident
+    # vectors every step (stream / inline: the same on a side stream / in line with the scoring) -- at one rank its three small
+    # operations (slice kernel, all-gather, device -> host copy; 22 us of GPU time) stretch the concurrently running HSV
+    # kernel by 0.12-0.3 ms = 2.4-5 % whichever stream they run on (profiles/r03_y_*, r04_n_*), which is why it is not the
+    # default any more.  off = no exchange at all (diagnosis).
     ap.add_argument("--height", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--width", type=int, default=0, help=argparse.SUPPRESS)
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -878,11 +883,13 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
     # Measured at one rank (profiles/r03_ah_*): kernel 5.00 ms without the exchange, 5.14 ms with it (default), 5.10 ms inline --
     # not enough to change the default path.
     inline = on_gpu and use_dist and args.exchange == "inline"
+    per_step = use_dist and args.exchange in ("step", "stream", "inline")
+    deferred = use_dist and args.exchange == "default"
     xstream = torch.cuda.Stream(device) if (on_gpu and use_dist and args.exchange in ("stream", "inline")) else None
     wl = Workload(eng, batch, args.detector, args.downscale, epilogue, E, stream=xstream.cuda_stream if inline else None)
 
     kernel_ms: list[float] = []
-    state = {"pending_gather": None, "gathered": None, "copies": [], "pinned": []}
+    state = {"pending_gather": None, "gathered": None, "copies": [], "pinned": [], "held": [], "exchanges": 0}
 
     def on_xstream():
         return torch.cuda.stream(xstream) if xstream is not None else contextlib.nullcontext()
@@ -940,7 +947,11 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
         ms = wl.finish()
         if collect_timing:
             kernel_ms.append(ms)
-        if use_dist and args.exchange != "off":
+        if deferred:
+            # hold this step's score vectors (host records; 32 bytes per frame) for the run's one all-gather
+            recs = wl.state["recs"]
+            state["held"].append(np.stack([recs["sad_h"], recs["sad_s"], recs["sad_v"], recs["edge_xor"]], axis=1).astype(np.int64))
+        if per_step:
             # score vectors only: 4 x u64 per frame, all-gathered from HBM
             import torch.distributed as dist
 
@@ -964,8 +975,26 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
             wl.submit()
             finish(timing)
         finish(timing)
-        if use_dist:
+        if per_step:
             consume_gather(final=True)   # the last step's exchange completes inside the timed region
+        if deferred:
+            exchange_held()              # ... and so does the one all-gather of the deferred form
+
+    def exchange_held():
+        """ONE all-gather of the score vectors of every step since the last call: rank-major [world, steps * n, 4]."""
+        import torch.distributed as dist
+
+        if not state["held"]:
+            return
+        mine = np.concatenate(state["held"], axis=0)
+        state["held"].clear()
+        send = torch.from_numpy(mine).to(device)
+        recv = torch.empty((world * send.shape[0], send.shape[1]), dtype=send.dtype, device=device)
+        dist.all_gather_into_tensor(recv, send)
+        allv = recv.cpu().numpy().astype(np.uint64).reshape(world, -1, 4)
+        assert np.array_equal(allv[rank].astype(np.int64), mine)
+        state["gathered"] = allv
+        state["exchanges"] += 1
 
     def barrier():
         if use_dist:
@@ -1031,11 +1060,15 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
                              f"(BASELINE.json configs[1]); distribution {args.dist}") if headline else
                             f"{what} on {n} x {W}x{H} BGR frames per GPU, device-resident; distribution {args.dist}",
                 "frames_per_gpu": n, "height": H, "width": W, "distribution": args.dist, "ranks_seen": world,
-                "parallelism": f"clips sharded over {world} GPU(s), RCCL all-gather of score vectors (device-resident records)"
+                "parallelism": f"clips sharded over {world} GPU(s), no data-path collective; RCCL all-gather of the score vectors"
                                if use_dist else "1 GPU",
                 "pipeline_depth": 1 if args.detector == "hash" else 2,
-                "exchange": (("host copy of the records (" + state["no_device_view"] + ")") if state.get("no_device_view") else
-                             "score vectors sliced out of the device-resident records (psd_last_records_device)") if use_dist else None,
+                "exchange": None if not use_dist else
+                            ("one all-gather of all %d timed steps' score vectors (32 B/frame) at the end of the timed region; "
+                             "no collective on the data path (clips are independent)" % args.steps) if deferred else
+                            "off" if args.exchange == "off" else
+                            ("every step: host copy of the records (" + state["no_device_view"] + ")") if state.get("no_device_view") else
+                            "every step: score vectors sliced out of the device-resident records (psd_last_records_device)",
             },
             "roofline": {
                 "bound": "hbm",

@@ -45,6 +45,19 @@ def test_two_ranks_over_gloo():
     assert out.returncode == 0, out.stderr[-3000:]
     j = _check(out.stdout, 2)
     assert j["cpu_baseline"] is None and "RCCL all-gather" in j["config"]["parallelism"]
+    assert j["config"]["exchange"].startswith("one all-gather of all 3 timed steps")
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_over_gloo_with_the_exchange_every_step():
+    """--exchange step: the round-1..3 form (an all-gather of the score vectors every step) stays runnable."""
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), DRIVER, "--gpus", "2", "--exchange", "step", *ARGS]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=280)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = _check(out.stdout, 2)
+    assert j["config"]["exchange"].startswith("every step")
 
 
 def _env_without_launcher():
