@@ -565,7 +565,7 @@ static_assert(HT == HT_TILE, "");
 // current state as a read-only halo (OpenCV's stack flood fill computes 8-connected reachability from the strong pixels,
 // which is order independent, so any schedule that reaches the fix point gives the same map).
 // ONE WAVE PER TILE, one image row per lane: the row's 64 strong / weak bits are one 64-bit register each, the halo column
-// left and right one bit each, the rows above / below come from the neighbouring lanes (DPP / ds_bpermute shuffles) and,
+// left and right one bit each, the rows above / below come from the neighbouring lanes (whole-wave DPP shifts) and,
 // for lanes 0 and 63, from the halo rows read with the tile.  One step is a dozen 64-bit operations per lane for all 4096
 // pixels; horizontal runs of weak pixels are filled in ONE step by a carry chain (seed + weak ripples through the run, in
 // both directions via a bit reversal).  No LDS, no barriers.
@@ -620,25 +620,33 @@ __device__ __forceinline__ u32 hyst_tile(u32* S, const u32* Wk, const EdgeGeom& 
     if (!halo_in) { h_lo = h_hi = h_l = h_r = 0; }
     unsigned long long Sv = ((unsigned long long)s_hi << 32) | s_lo;
     const unsigned long long Kv = ((unsigned long long)k_hi << 32) | k_lo;
+    const unsigned long long Kvr = __brevll(Kv);           // (the weak row mirrored, for the runs filled towards the LSB)
     const unsigned long long S0 = Sv;
     const u32 eL = s_l >> 31, eR = s_r & 1u;              // strong state of the pixels left / right of this row (fixed here)
     const unsigned long long Hv = ((unsigned long long)h_hi << 32) | h_lo;
     const u32 hL = h_l >> 31, hR = h_r & 1u;
     if (__ballot(Kv != 0) == 0) return 0u;                 // no weak pixel in the tile: nothing can change
+    // Rows above / below come from the neighbouring lanes with ONE DPP move per 32-bit half (wave_shr:1 / wave_shl:1 shift the
+    // whole wave by a lane; the lane without a source keeps `old`, which is where the halo row goes in: lane 0's row above is
+    // the halo row it loaded, lane 63's row below likewise).  Round 4: these were ds_bpermute_b32 -- eight LDS round trips per
+    // step of the fix point, four of them for the columns left / right of the tile, which do not change inside a visit.
+    auto from_above = [](u32 halo, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)halo, (int)v, 0x138, 0xf, 0xf, false); };   // lane i <- lane i - 1
+    auto from_below = [](u32 halo, u32 v) { return (u32)__builtin_amdgcn_update_dpp((int)halo, (int)v, 0x130, 0xf, 0xf, false); };   // lane i <- lane i + 1
+    const u32 h_lo32 = (u32)Hv, h_hi32 = (u32)(Hv >> 32);
+    // strong in the column left / right of the tile, rows y - 1 .. y + 1: fixed for this visit
+    const unsigned long long nl = (u64)((from_above(hL, eL) | eL | from_below(hL, eL)) & 1u);
+    const unsigned long long nr = (u64)((from_above(hR, eR) | eR | from_below(hR, eR)) & 1u) << 63;
     for (;;) {
-        // rows above / below: neighbouring lanes, the halo rows at the ends
-        unsigned long long up = __shfl_up(Sv, 1), dn = __shfl_down(Sv, 1);
-        u32 upL = __shfl_up(eL, 1), upR = __shfl_up(eR, 1), dnL = __shfl_down(eL, 1), dnR = __shfl_down(eR, 1);
-        if (lane == 0) { up = Hv; upL = hL; upR = hR; }
-        if (lane == 63) { dn = Hv; dnL = hL; dnR = hR; }
+        const u32 s_lo32 = (u32)Sv, s_hi32 = (u32)(Sv >> 32);
+        const unsigned long long up = ((u64)from_above(h_hi32, s_hi32) << 32) | from_above(h_lo32, s_lo32);
+        const unsigned long long dn = ((u64)from_below(h_hi32, s_hi32) << 32) | from_below(h_lo32, s_lo32);
         const unsigned long long n = up | Sv | dn;                                   // strong in the three rows, same column
-        const unsigned long long nl = (u64)((upL | eL | dnL) & 1u), nr = (u64)((upR | eR | dnR) & 1u);
-        const unsigned long long near = n | (n << 1) | (n >> 1) | nl | (nr << 63);   // ... or a column next to it
+        const unsigned long long near = n | (n << 1) | (n >> 1) | nl | nr;           // ... or a column next to it
         unsigned long long grown = Sv | (Kv & near);
         // horizontal runs of weak pixels in one go: promoted pixels are seeds inside the weak runs
         const unsigned long long seeds = grown & Kv;
         grown |= fill_runs_up(seeds, Kv);
-        grown |= __brevll(fill_runs_up(__brevll(seeds), __brevll(Kv)));
+        grown |= __brevll(fill_runs_up(__brevll(seeds), Kvr));
         const bool ch = grown != Sv;
         Sv = grown;
         if (__ballot(ch) == 0) break;
@@ -652,7 +660,10 @@ __device__ __forceinline__ u32 hyst_tile(u32* S, const u32* Wk, const EdgeGeom& 
     }
     // promoted pixels on the tile border: the neighbours that touch them have to look again
     const unsigned long long west = __ballot((added & 1ull) != 0), east = __ballot((added >> 63) != 0);
-    const unsigned long long top = __shfl(added, 0), bottom = __shfl(added, 63);   // rows 0 and 63 of the tile
+    auto row_of = [&](int l) {   // `added` of lane l, into scalar registers
+        return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(added >> 32), l) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)added, l);
+    };
+    const unsigned long long top = row_of(0), bottom = row_of(63);                 // rows 0 and 63 of the tile
     u32 wake = 0;
     if (top) wake |= 1u << 1;
     if (bottom) wake |= 1u << 7;
