@@ -470,15 +470,15 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
         const int xs = (tr + 2 * mr + br) - (tl + 2 * ml + bl), ys = (bl + 2 * bc + br) - (tl + 2 * tc + tr);
         const int ax = abs(xs), ay = abs(ys) << 15;
         const int tg22x = ax * 13573;  // TG22 = round(tan(22.5 deg) * 2^15)
-        bool is_max;
-        if (ay < tg22x) {
-            is_max = m > mag_at(smq, ly + 1, c - 1) && m >= mag_at(smq, ly + 1, c + 1);
-        } else if (ay > tg22x + (ax << 16)) {
-            is_max = m > mag_at(smq, ly, c) && m >= mag_at(smq, ly + 2, c);
-        } else {
-            const int sgn = (xs ^ ys) < 0 ? -1 : 1;
-            is_max = m > mag_at(smq, ly, c - sgn) && m > mag_at(smq, ly + 2, c + sgn);
-        }
+        // the two neighbours along the gradient WITHOUT a branch per direction (round 3 had three arms, and a wave that held
+        // all three directions -- any wave on a busy tile -- ran all three, two magnitude reads each): left / right, above /
+        // below, or the diagonal the signs point along
+        const bool horiz = ay < tg22x, vert = !horiz && ay > tg22x + (ax << 16);
+        const int sgn = (xs ^ ys) < 0 ? -1 : 1;
+        const int dr = horiz ? 0 : 1, dc = horiz ? 1 : vert ? 0 : sgn;
+        const int m1 = mag_at(smq, ly + 1 - dr, c - dc), m2 = mag_at(smq, ly + 1 + dr, c + dc);
+        // horizontal / vertical: m > first && m >= second; diagonal: strictly above both
+        const bool is_max = m > m1 && m + ((horiz || vert) ? 1 : 0) > m2;
         return is_max ? (m > high ? 2 : 1) : 0;
     };
     if (n_any > CAND_CAP / 8) {
@@ -603,16 +603,42 @@ __device__ __forceinline__ u32 hyst_tile(u32* S, const u32* Wk, const EdgeGeom& 
     const bool has_hi = w0 + 1 < nw, has_l = w0 > 0, has_r = w0 + 2 < nw;
     const u32* srow = S + (size_t)yc * nw;
     const u32* wrow = Wk + (size_t)yc * nw;
-    // unconditional loads on clamped indices (they go out together), masked afterwards
-    u32 s_lo = ld_s<COHERENT>(srow + w0), s_hi = ld_s<COHERENT>(srow + min(w0 + 1, nw - 1)), s_l = ld_s<COHERENT>(srow + max(w0 - 1, 0)),
-        s_r = ld_s<COHERENT>(srow + min(w0 + 2, nw - 1));
-    u32 k_lo = wrow[w0], k_hi = wrow[min(w0 + 1, nw - 1)];
     const int yh = lane == 0 ? y0 - 1 : y0 + HT;          // halo row of lane 0 (above) / lane 63 (below)
     const bool halo_lane = lane == 0 || lane == 63;
     const bool halo_in = halo_lane && yh >= 0 && yh < H;
     const u32* hrow = S + (size_t)min(max(yh, 0), H - 1) * nw;
-    u32 h_lo = ld_s<COHERENT>(hrow + w0), h_hi = ld_s<COHERENT>(hrow + min(w0 + 1, nw - 1)), h_l = ld_s<COHERENT>(hrow + max(w0 - 1, 0)),
+    u32 s_lo, s_hi, s_l, s_r, k_lo, k_hi, h_lo, h_hi, h_l, h_r;
+    if (has_l && has_r) {
+        // Interior tile columns (28 of 30 at 1080p): the four strong words w0 - 1 .. w0 + 2 of a row are ONE 16-byte load, the
+        // two weak words one 8-byte load.  Every lane reads its own image row, i.e. its own cache line: the texture path
+        // takes such an instruction lane by lane, and on frames where every tile is looked at (noise: 510 tiles x a few
+        // rounds x 1024 frames) the six dword loads of round 3 were what the kernel waited for (2.6 ms per 1024 frames).
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+        typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+        typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
+        u32x4 s4, h4;
+        const u32x2 k2 = *reinterpret_cast<const u32x2_a4*>(wrow + w0);
+        if (COHERENT) {
+            // (another wave of the workgroup may have stored these words a round ago: loads that go to the L2, like the
+            //  agent-scope atomic loads of the other branch -- which exist for 4 and 8 bytes only)
+            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(s4), "=&v"(h4) : "v"(srow + w0 - 1), "v"(hrow + w0 - 1) : "memory");
+        } else {
+            s4 = *reinterpret_cast<const u32x4_a4*>(srow + w0 - 1);
+            h4 = *reinterpret_cast<const u32x4_a4*>(hrow + w0 - 1);
+        }
+        s_l = s4.x; s_lo = s4.y; s_hi = s4.z; s_r = s4.w;
+        h_l = h4.x; h_lo = h4.y; h_hi = h4.z; h_r = h4.w;
+        k_lo = k2.x; k_hi = k2.y;
+    } else {
+        // unconditional loads on clamped indices (they go out together), masked afterwards
+        s_lo = ld_s<COHERENT>(srow + w0); s_hi = ld_s<COHERENT>(srow + min(w0 + 1, nw - 1)); s_l = ld_s<COHERENT>(srow + max(w0 - 1, 0));
+        s_r = ld_s<COHERENT>(srow + min(w0 + 2, nw - 1));
+        k_lo = wrow[w0]; k_hi = wrow[min(w0 + 1, nw - 1)];
+        h_lo = ld_s<COHERENT>(hrow + w0); h_hi = ld_s<COHERENT>(hrow + min(w0 + 1, nw - 1)); h_l = ld_s<COHERENT>(hrow + max(w0 - 1, 0));
         h_r = ld_s<COHERENT>(hrow + min(w0 + 2, nw - 1));
+    }
     if (!row_in) { s_lo = s_hi = s_l = s_r = k_lo = k_hi = 0; }
     if (!has_hi) { s_hi = 0; k_hi = 0; h_hi = 0; }
     if (!has_l) { s_l = 0; h_l = 0; }
@@ -688,20 +714,25 @@ __device__ __forceinline__ u32 hyst_tile(u32* S, const u32* Wk, const EdgeGeom& 
 // take fifty rounds are bound by the latency of a round, not by throughput, so two waves of workgroups take twice as long.
 template <int HF_WAVES>
 __global__ __launch_bounds__(HF_WAVES * 64) void hysteresis_frame_kernel(u32* strong, const u32* weak, EdgeGeom g, const uint8_t* dirty,
-                                                                         int tiles_x, int tiles_y)
+                                                                         int dirty_stride, int tiles_x, int tiles_y)
 {
     extern __shared__ u32 hf_maps[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = blockIdx.x, per_frame = tiles_x * tiles_y, nwords = (per_frame + 31) >> 5;
     u32* cur = hf_maps;
     u32* nxt = hf_maps + nwords;
-    const uint8_t* D = dirty + (size_t)j * per_frame;
+    // the frame's tile flags (one byte each, the stride a multiple of 32 bytes, the padding zero): 32 of them per map word,
+    // read as two 16-byte loads
+    const uint4* D = reinterpret_cast<const uint4*>(dirty + (size_t)j * dirty_stride);
     for (int w = tid; w < nwords; w += HF_WAVES * 64) {
+        const uint4 a = D[2 * w], b = D[2 * w + 1];
+        const u32 f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         u32 m = 0;
-        for (int b = 0; b < 32; b++) {
-            const int t = w * 32 + b;
-            if (t < per_frame && D[t] != 0) m |= 1u << b;
-        }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((f[q] >> (8 * k)) & 0xffu) m |= 1u << (4 * q + k);
         cur[w] = m;
         nxt[w] = 0;
     }
@@ -902,7 +933,8 @@ static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeBuffers* b)
 {
     const size_t words = (size_t)g.height * g.words_per_row;
-    const size_t tiles = (size_t)((g.width + HT - 1) / HT) * ((g.height + HT - 1) / HT);
+    // (one flag byte per 64 x 64 hysteresis tile; a frame's flags padded to whole 32-byte groups, which the per-frame kernel loads)
+    const size_t tiles = ((size_t)((g.width + HT - 1) / HT) * ((g.height + HT - 1) / HT) + 31) & ~(size_t)31;
     const size_t per_frame = align_up((size_t)g.npix) + align_up(256 * 4) + align_up(sizeof(int2)) + align_up(words * 4) * 2 + align_up(8) +
                              align_up(tiles);
     // bound the workspace (default 8 GiB of the 288 GB: 2048 x 1080p frames in one chunk, +1.4 % over 4 GiB on such batches;
@@ -1009,11 +1041,11 @@ static int edge_chunk(psd_engine* e, const EdgeGeom& g, const ChunkSrc& src, int
         const size_t lds = 2 * (size_t)(((long)htx * hty + 31) / 32) * sizeof(u32);
         if (lds > 96 * 1024) { psd_set_error("frame too large for the edge term (%d x %d hysteresis tiles)", htx, hty); return PSD_ERR_UNSUPPORTED; }
         if ((long)count * 16 <= slots)
-            hipLaunchKernelGGL(hysteresis_frame_kernel<16>, dim3(count), dim3(16 * 64), lds, stream, b.strong, b.weak, g, b.dirty, htx, hty);
+            hipLaunchKernelGGL(hysteresis_frame_kernel<16>, dim3(count), dim3(16 * 64), lds, stream, b.strong, b.weak, g, b.dirty, (int)b.tiles_per_frame, htx, hty);
         else if ((long)count * 8 <= slots)
-            hipLaunchKernelGGL(hysteresis_frame_kernel<8>, dim3(count), dim3(8 * 64), lds, stream, b.strong, b.weak, g, b.dirty, htx, hty);
+            hipLaunchKernelGGL(hysteresis_frame_kernel<8>, dim3(count), dim3(8 * 64), lds, stream, b.strong, b.weak, g, b.dirty, (int)b.tiles_per_frame, htx, hty);
         else
-            hipLaunchKernelGGL(hysteresis_frame_kernel<4>, dim3(count), dim3(4 * 64), lds, stream, b.strong, b.weak, g, b.dirty, htx, hty);
+            hipLaunchKernelGGL(hysteresis_frame_kernel<4>, dim3(count), dim3(4 * 64), lds, stream, b.strong, b.weak, g, b.dirty, (int)b.tiles_per_frame, htx, hty);
     }
     HIP_TRY(hipGetLastError());
     return PSD_OK;
