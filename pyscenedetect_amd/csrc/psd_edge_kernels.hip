@@ -339,8 +339,9 @@ __device__ __forceinline__ void sobel_phase1_quads(const uint8_t (*sv)[N2_SVW], 
 // RAGGED: the instance for frames whose rows are not dword aligned (kept out of the common instance: its byte loads would
 // double the code the interior tiles of every 1080p frame run past).
 template <bool RAGGED>
-__global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, u32* strong, u32* weak,
-                                                             uint8_t* dirty, int tiles_x, u32 tiles_x_magic, int htiles_x, int htiles_per_frame)
+__global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vplane, EdgeGeom g, const int2* thr, u32* strong, u32* strong_t,
+                                                             u32* weak_t, uint8_t* dirty, int tiles_x, u32 tiles_x_magic, int htiles_x,
+                                                             int htiles_per_frame, int ht_frame_words)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sv[N2_H + 8][N2_SVW];   // rows y0-2 .. y0+33, cols x0-4 .. x0+131 (+ 4 scratch rows)
     __shared__ __attribute__((aligned(16))) uint2 smq[N2_H + 2][N2_NCG];    // rows y0-1 .. y0+32, magnitudes as even / odd pairs
@@ -551,7 +552,12 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
         const int y = y0 + ly, w = (x0 >> 5) + wq;
         if (y < H && w < g.words_per_row) {
             const u32 bits = *reinterpret_cast<const u32*>(&obits[plane][ly][4 * wq]);
-            (plane ? weak : strong)[((size_t)j * H + y) * g.words_per_row + w] = bits;
+            // the hysteresis reads TILE-MAJOR copies (a 64 x 64 tile = 128 consecutive words, row r at 2 r: ht_word below); the
+            // strong plane also goes out row-major, which is what the dilation walks.  This tile is two hysteresis tiles wide
+            // and half of one high: 32 rows x 8 bytes, consecutive, per plane and hysteresis tile.
+            const size_t t = (size_t)j * ht_frame_words + ((size_t)(y >> 6) * htiles_x + (w >> 1)) * 128 + (y & 63) * 2 + (w & 1);
+            if (plane) weak_t[t] = bits;
+            else { strong[((size_t)j * H + y) * g.words_per_row + w] = bits; strong_t[t] = bits; }
         }
     }
 }
@@ -585,60 +591,48 @@ __device__ __forceinline__ u32 ld_s(const u32* p)
     if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
 }
+template <bool COHERENT>
+__device__ __forceinline__ unsigned long long ld_s2(const u32* p)   // two words, 8-byte aligned
+{
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    if (COHERENT) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *q;
+}
 
-// One 64 x 64 tile (by, bx) of one frame's bit planes S (strong, updated in place) / Wk (weak) to its fix point, by one wave.
+// One 64 x 64 tile (by, bx) of one frame's bit planes to its fix point, by one wave.  St / Kt: the frame's strong / weak plane
+// TILE-MAJOR (tile t = 128 consecutive words, row r of it at 2 r; written by the NMS kernel, St updated in place here); S: the
+// strong plane row-major, where the promotions are stored as well (the dilation reads that one).
+// Round 4: the visit used to read the row-major planes -- every lane its own image row, i.e. its own cache line: 40 L2
+// requests per load instruction, 14 GB of traffic per 1024 noise frames for 1.4 GB of tile data
+// (profiles/r04_pqr_edge_kernels_ab_and_hysteresis_counters.txt).  Tile-major a visit reads 512 contiguous bytes per plane,
+// one word column of the tiles left and right, and three words of the rows above and below.
 // Returns (uniformly) WHICH neighbours have to look again, bit (dy + 1) * 3 + (dx + 1) for the tile at (by + dy, bx + dx): only
 // those that touch a promoted pixel -- a promotion in the top row wakes the tile above, in a corner the diagonal one as well.
 // (Round 3 woke all eight on any border promotion: on frames with objects most tile visits of the later rounds were
 // neighbours with nothing new to see, each a round trip to memory.)
 template <bool COHERENT>
-__device__ __forceinline__ u32 hyst_tile(u32* S, const u32* Wk, const EdgeGeom& g, int by, int bx, int lane)
+__device__ __forceinline__ u32 hyst_tile(u32* S, u32* St, const u32* Kt, const EdgeGeom& g, int by, int bx, int tiles_x, int tiles_y, int lane)
 {
     const int H = g.height, nw = g.words_per_row;
     const int w0 = 2 * bx, y0 = by * HT;
     // this lane's row, and (lanes 0 / 63) the halo rows above / below; words outside the image read as 0
     const int y = y0 + lane;
     const bool row_in = y < H;
-    const int yc = min(y, H - 1);
     const bool has_hi = w0 + 1 < nw, has_l = w0 > 0, has_r = w0 + 2 < nw;
-    const u32* srow = S + (size_t)yc * nw;
-    const u32* wrow = Wk + (size_t)yc * nw;
-    const int yh = lane == 0 ? y0 - 1 : y0 + HT;          // halo row of lane 0 (above) / lane 63 (below)
-    const bool halo_lane = lane == 0 || lane == 63;
-    const bool halo_in = halo_lane && yh >= 0 && yh < H;
-    const u32* hrow = S + (size_t)min(max(yh, 0), H - 1) * nw;
-    u32 s_lo, s_hi, s_l, s_r, k_lo, k_hi, h_lo, h_hi, h_l, h_r;
-    if (has_l && has_r) {
-        // Interior tile columns (28 of 30 at 1080p): the four strong words w0 - 1 .. w0 + 2 of a row are ONE 16-byte load, the
-        // two weak words one 8-byte load.  Every lane reads its own image row, i.e. its own cache line: the texture path
-        // takes such an instruction lane by lane, and on frames where every tile is looked at (noise: 510 tiles x a few
-        // rounds x 1024 frames) the six dword loads of round 3 were what the kernel waited for (2.6 ms per 1024 frames).
-        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-        typedef u32 u32x2 __attribute__((ext_vector_type(2)));
-        typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
-        typedef u32x2 u32x2_a4 __attribute__((aligned(4)));
-        u32x4 s4, h4;
-        const u32x2 k2 = *reinterpret_cast<const u32x2_a4*>(wrow + w0);
-        if (COHERENT) {
-            // (another wave of the workgroup may have stored these words a round ago: loads that go to the L2, like the
-            //  agent-scope atomic loads of the other branch -- which exist for 4 and 8 bytes only)
-            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(s4), "=&v"(h4) : "v"(srow + w0 - 1), "v"(hrow + w0 - 1) : "memory");
-        } else {
-            s4 = *reinterpret_cast<const u32x4_a4*>(srow + w0 - 1);
-            h4 = *reinterpret_cast<const u32x4_a4*>(hrow + w0 - 1);
-        }
-        s_l = s4.x; s_lo = s4.y; s_hi = s4.z; s_r = s4.w;
-        h_l = h4.x; h_lo = h4.y; h_hi = h4.z; h_r = h4.w;
-        k_lo = k2.x; k_hi = k2.y;
-    } else {
-        // unconditional loads on clamped indices (they go out together), masked afterwards
-        s_lo = ld_s<COHERENT>(srow + w0); s_hi = ld_s<COHERENT>(srow + min(w0 + 1, nw - 1)); s_l = ld_s<COHERENT>(srow + max(w0 - 1, 0));
-        s_r = ld_s<COHERENT>(srow + min(w0 + 2, nw - 1));
-        k_lo = wrow[w0]; k_hi = wrow[min(w0 + 1, nw - 1)];
-        h_lo = ld_s<COHERENT>(hrow + w0); h_hi = ld_s<COHERENT>(hrow + min(w0 + 1, nw - 1)); h_l = ld_s<COHERENT>(hrow + max(w0 - 1, 0));
-        h_r = ld_s<COHERENT>(hrow + min(w0 + 2, nw - 1));
-    }
+    const int tile = by * tiles_x + bx;
+    const u32* own = St + (size_t)tile * 128 + lane * 2;
+    // halo row of lane 0: row 63 of the tile above; of the other lanes (lane 63 uses it): row 0 of the tile below
+    const bool halo_in = lane == 0 ? by > 0 : (lane == 63 && by + 1 < tiles_y);
+    const int hby = lane == 0 ? max(by - 1, 0) : min(by + 1, tiles_y - 1);
+    const u32* hrow = St + (size_t)(hby * tiles_x + bx) * 128 + (lane == 0 ? 126 : 0);
+    // (unconditional loads on clamped tile indices -- they go out together --, masked afterwards)
+    const int dl = has_l ? 128 : 0, dr = has_r ? 128 : 0;
+    unsigned long long s64 = ld_s2<COHERENT>(own);
+    unsigned long long k64 = *reinterpret_cast<const unsigned long long*>(Kt + (size_t)tile * 128 + lane * 2);
+    u32 s_l = ld_s<COHERENT>(own - dl + 1), s_r = ld_s<COHERENT>(own + dr);
+    unsigned long long h64 = ld_s2<COHERENT>(hrow);
+    u32 h_l = ld_s<COHERENT>(hrow - dl + 1), h_r = ld_s<COHERENT>(hrow + dr);
+    u32 s_lo = (u32)s64, s_hi = (u32)(s64 >> 32), k_lo = (u32)k64, k_hi = (u32)(k64 >> 32), h_lo = (u32)h64, h_hi = (u32)(h64 >> 32);
     if (!row_in) { s_lo = s_hi = s_l = s_r = k_lo = k_hi = 0; }
     if (!has_hi) { s_hi = 0; k_hi = 0; h_hi = 0; }
     if (!has_l) { s_l = 0; h_l = 0; }
@@ -681,6 +675,7 @@ __device__ __forceinline__ u32 hyst_tile(u32* S, const u32* Wk, const EdgeGeom& 
     const unsigned long long any_added = __ballot(added != 0);
     if (any_added == 0) return 0u;
     if (added != 0 && row_in) {
+        *reinterpret_cast<unsigned long long*>(St + (size_t)tile * 128 + lane * 2) = Sv;   // (bits beyond the image never get set: Kv is masked)
         if ((u32)added) S[(size_t)y * nw + w0] = (u32)Sv;
         if ((u32)(added >> 32) && has_hi) S[(size_t)y * nw + w0 + 1] = (u32)(Sv >> 32);
     }
@@ -713,8 +708,8 @@ __device__ __forceinline__ u32 hyst_tile(u32* S, const u32* Wk, const EdgeGeom& 
 // HF_WAVES waves per workgroup: as many as still let every frame of the chunk be resident at once -- frames whose chains
 // take fifty rounds are bound by the latency of a round, not by throughput, so two waves of workgroups take twice as long.
 template <int HF_WAVES>
-__global__ __launch_bounds__(HF_WAVES * 64) void hysteresis_frame_kernel(u32* strong, const u32* weak, EdgeGeom g, const uint8_t* dirty,
-                                                                         int dirty_stride, int tiles_x, int tiles_y)
+__global__ __launch_bounds__(HF_WAVES * 64) void hysteresis_frame_kernel(u32* strong, u32* strong_t, const u32* weak_t, EdgeGeom g,
+                                                                         const uint8_t* dirty, int dirty_stride, int tiles_x, int tiles_y)
 {
     extern __shared__ u32 hf_maps[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -738,7 +733,8 @@ __global__ __launch_bounds__(HF_WAVES * 64) void hysteresis_frame_kernel(u32* st
     }
     __syncthreads();
     u32* S = strong + (size_t)j * g.height * g.words_per_row;
-    const u32* Wk = weak + (size_t)j * g.height * g.words_per_row;
+    u32* St = strong_t + (size_t)j * per_frame * 128;
+    const u32* Kt = weak_t + (size_t)j * per_frame * 128;
     for (int round = 0;; round++) {
         for (int w = wave; w < nwords; w += HF_WAVES) {
             u32 bits = __builtin_amdgcn_readfirstlane(cur[w]);
@@ -748,7 +744,8 @@ __global__ __launch_bounds__(HF_WAVES * 64) void hysteresis_frame_kernel(u32* st
                 const int by = tile / tiles_x, bx = tile - by * tiles_x;
                 // (the first round -- on noisy frames most of the work -- reads through the L1: nothing of this frame can be
                 //  stale in it yet, and what a neighbouring wave stores meanwhile is picked up in the round that wave triggers)
-                const u32 wake = round == 0 ? hyst_tile<false>(S, Wk, g, by, bx, lane) : hyst_tile<true>(S, Wk, g, by, bx, lane);
+                const u32 wake = round == 0 ? hyst_tile<false>(S, St, Kt, g, by, bx, tiles_x, tiles_y, lane)
+                                            : hyst_tile<true>(S, St, Kt, g, by, bx, tiles_x, tiles_y, lane);
                 if (wake) {
                     if (lane < 9 && ((wake >> lane) & 1u)) {
                         const int ny = by + lane / 3 - 1, nx = bx + lane % 3 - 1;
@@ -921,9 +918,9 @@ static int estimated_kernel_size(int width, int height)
 }
 
 struct EdgeBuffers {
-    uint8_t* vplane; u32* strong; u32* weak; u32* hist; int2* thr; u32* carry; u32* dil1;
+    uint8_t* vplane; u32* strong; u32* strong_t; u32* weak_t; u32* hist; int2* thr; u32* carry; u32* dil1;
     unsigned long long* xr; int2* thr_tab; uint8_t* dirty;
-    int cap_frames; size_t tiles_per_frame;
+    int cap_frames; size_t tiles_per_frame; size_t ht_frame_words;   // (flags per frame, padded; words of a tile-major plane per frame)
     uint8_t* zero_begin; size_t zero_bytes;   // hist, xr and the tile flags: cleared by ONE memset per chunk
     bool fresh;                               // the workspace was (re)allocated by this call
 };
@@ -934,9 +931,11 @@ static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeB
 {
     const size_t words = (size_t)g.height * g.words_per_row;
     // (one flag byte per 64 x 64 hysteresis tile; a frame's flags padded to whole 32-byte groups, which the per-frame kernel loads)
-    const size_t tiles = ((size_t)((g.width + HT - 1) / HT) * ((g.height + HT - 1) / HT) + 31) & ~(size_t)31;
-    const size_t per_frame = align_up((size_t)g.npix) + align_up(256 * 4) + align_up(sizeof(int2)) + align_up(words * 4) * 2 + align_up(8) +
-                             align_up(tiles);
+    const size_t ht_tiles = (size_t)((g.width + HT - 1) / HT) * ((g.height + HT - 1) / HT);
+    const size_t tiles = (ht_tiles + 31) & ~(size_t)31;
+    const size_t tm_bytes = ht_tiles * 128 * 4;   // one tile-major bit plane of a frame (whole tiles)
+    const size_t per_frame = align_up((size_t)g.npix) + align_up(256 * 4) + align_up(sizeof(int2)) + align_up(words * 4) + align_up(tm_bytes) * 2 +
+                             align_up(8) + align_up(tiles);
     // bound the workspace (default 8 GiB of the 288 GB: 2048 x 1080p frames in one chunk, +1.4 % over 4 GiB on such batches;
     // PSD_EDGE_WS_MB overrides) unless a single frame needs more
     static const size_t ws_cap = [] {
@@ -963,7 +962,9 @@ static int edge_buffers(psd_engine* e, const EdgeGeom& g, int want_frames, EdgeB
     b->vplane = take((size_t)g.npix * frames);
     b->thr = (int2*)take((size_t)frames * sizeof(int2));
     b->strong = (u32*)take(words * 4 * frames);
-    b->weak = (u32*)take(words * 4 * frames);
+    b->strong_t = (u32*)take(tm_bytes * frames);
+    b->weak_t = (u32*)take(tm_bytes * frames);
+    b->ht_frame_words = ht_tiles * 128;
     b->carry = (u32*)take(words * 4);
     b->dil1 = (u32*)take(words * 4);
     b->zero_begin = p;
@@ -1029,8 +1030,8 @@ static int edge_chunk(psd_engine* e, const EdgeGeom& g, const ChunkSrc& src, int
             auto kernel = ragged ? sobel_nms_bits_kernel<true> : sobel_nms_bits_kernel<false>;
             hipLaunchKernelGGL(kernel, dim3(per_frame, nf), dim3(256), 0, stream,
                                b.vplane + (size_t)f0 * g.npix, g, b.thr + f0, b.strong + (size_t)f0 * g.height * g.words_per_row,
-                               b.weak + (size_t)f0 * g.height * g.words_per_row, b.dirty + (size_t)f0 * b.tiles_per_frame, tx,
-                               magic, htx, (int)b.tiles_per_frame);
+                               b.strong_t + (size_t)f0 * b.ht_frame_words, b.weak_t + (size_t)f0 * b.ht_frame_words,
+                               b.dirty + (size_t)f0 * b.tiles_per_frame, tx, magic, htx, (int)b.tiles_per_frame, (int)b.ht_frame_words);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1041,11 +1042,11 @@ static int edge_chunk(psd_engine* e, const EdgeGeom& g, const ChunkSrc& src, int
         const size_t lds = 2 * (size_t)(((long)htx * hty + 31) / 32) * sizeof(u32);
         if (lds > 96 * 1024) { psd_set_error("frame too large for the edge term (%d x %d hysteresis tiles)", htx, hty); return PSD_ERR_UNSUPPORTED; }
         if ((long)count * 16 <= slots)
-            hipLaunchKernelGGL(hysteresis_frame_kernel<16>, dim3(count), dim3(16 * 64), lds, stream, b.strong, b.weak, g, b.dirty, (int)b.tiles_per_frame, htx, hty);
+            hipLaunchKernelGGL(hysteresis_frame_kernel<16>, dim3(count), dim3(16 * 64), lds, stream, b.strong, b.strong_t, b.weak_t, g, b.dirty, (int)b.tiles_per_frame, htx, hty);
         else if ((long)count * 8 <= slots)
-            hipLaunchKernelGGL(hysteresis_frame_kernel<8>, dim3(count), dim3(8 * 64), lds, stream, b.strong, b.weak, g, b.dirty, (int)b.tiles_per_frame, htx, hty);
+            hipLaunchKernelGGL(hysteresis_frame_kernel<8>, dim3(count), dim3(8 * 64), lds, stream, b.strong, b.strong_t, b.weak_t, g, b.dirty, (int)b.tiles_per_frame, htx, hty);
         else
-            hipLaunchKernelGGL(hysteresis_frame_kernel<4>, dim3(count), dim3(4 * 64), lds, stream, b.strong, b.weak, g, b.dirty, (int)b.tiles_per_frame, htx, hty);
+            hipLaunchKernelGGL(hysteresis_frame_kernel<4>, dim3(count), dim3(4 * 64), lds, stream, b.strong, b.strong_t, b.weak_t, g, b.dirty, (int)b.tiles_per_frame, htx, hty);
     }
     HIP_TRY(hipGetLastError());
     return PSD_OK;

@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 4, step s: hysteresis reads tile-major copies of the two bit planes (base = the build of step r)
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r04_s; mkdir -p $O; cd $R; export PYTHONPATH=$R:$R/tools
+B=$R/pyscenedetect_amd/csrc/build/abl/libpsd_base.so
+timeout 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_headline_geometry.py tests/test_gpu_parity.py tests/test_gpu_flows.py -m gpu -q -x --timeout=600 --timeout-method=thread -k "edge or hysteresis or dilation or serpentine or corpus or one_read" > $O/pytest_edges.log 2>&1; echo "pytest rc=$?" >> $O/pytest_edges.log; tail -3 $O/pytest_edges.log
+{ PSD_LIB_PATH=$B python tools/edge_ab.py 2048 STU base; python tools/edge_ab.py 2048 STU new; PSD_LIB_PATH=$B python tools/edge_ab.py 2048 STU base; python tools/edge_ab.py 2048 STU new; } 2>&1 | grep -v amdgpu.ids | tee $O/edge_ab.txt
+bash tools/edge_trace.sh gpurun_out/r04_s "" 2>&1 | grep -v "rocclr\|store_xor\|^$\|^|---" | tee $O/edge_trace_summary.txt
