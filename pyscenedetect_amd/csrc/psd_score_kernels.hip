@@ -856,7 +856,12 @@ constexpr int ACD_MAX = 16;  // accumulator replicas
 #define PSD_FUSED_LC 16
 #endif
 #ifndef PSD_FUSED_AC
-#define PSD_FUSED_AC 8
+// histogram replicas of the two fused 16-wave passes: the lanes of a wave that share a replica serialise when they count the
+// same bin, which uniform noise never shows and every real frame does (equal neighbours).  Round 4, A/B on one box
+// (profiles/r04_w_*): 4 / 8 / 16 replicas -- edge term's front end + pipeline on frames with objects 0.377 / 0.395 / 0.404 of
+// its roofline, constant frames 0.36 / 0.47 / 0.50; all-detectors pass on constant frames 0.31 / 0.46 / 0.51, shot-like 0.432 /
+// 0.446 / 0.451, noise unchanged.  32 do not fit beside the 96 KiB of staging slots (2 x 260 x 32 x 4 bytes).
+#define PSD_FUSED_AC 16
 #endif
 #ifndef PSD_FUSED_F
 #define PSD_FUSED_F 1
