@@ -387,8 +387,10 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
             if dist == "S":
                 r["edges_weights_1111"] = quick_measure(Workload(eng, b, "edges", None, epilogue, E), steps=3, warmup=1)
                 # the same with sharp-edged objects in the frames (S holds next to no Canny edges, U nothing else)
-                bt = make_batch(min(frames_small, 1024), "T", 20250921, device, h, w)
-                r["edges_weights_1111_objects"] = quick_measure(Workload(eng, bt, "edges", None, epilogue, E), steps=3, warmup=1)
+                # (at the secondary batch length, 2048 frames: like the headline, the term's fraction moves with the length of a
+                #  submission -- 1024-frame submissions read 0.02 lower)
+                bt = make_batch(frames_small, "T", 20250921, device, h, w)
+                r["edges_weights_1111_objects"] = quick_measure(Workload(eng, bt, "edges", None, epilogue, E), steps=5, warmup=2)
                 del bt
                 r["all_four_fused"] = quick_measure(Workload(eng, b, "all", None, epilogue, E))
             else:

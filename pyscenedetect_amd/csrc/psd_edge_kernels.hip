@@ -429,6 +429,10 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
         *reinterpret_cast<u32*>(&sv[tl][4 * c2]) = xb >= W ? __builtin_amdgcn_perm(vt, vt, 0x03030303u) : vt;
     }
     __syncthreads();
+    // (the output words and the candidate counters are cleared here, in front of phase 1's barrier: phase 1 does not touch them,
+    //  and a barrier of their own cost every tile of every frame a few per cent)
+    reinterpret_cast<u32*>(&obits[0][0][0])[tid] = 0;                       // 2 x 32 x 16 bytes = 256 words
+    if (tid == 0) { ncand = 0; npos = 0; }
     if (inner) sobel_phase1_quads<true>(sv, smq, tid, x0, y0, H, W);
     else sobel_phase1_quads<false>(sv, smq, tid, x0, y0, H, W);
     __syncthreads();
@@ -444,9 +448,6 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
     // two neighbours along it.
     const int low = lohi.x, high = lohi.y;
     const u32 lowpk = (u32)low * 0x10001u;
-    reinterpret_cast<u32*>(&obits[0][0][0])[tid] = 0;                       // 2 x 32 x 16 bytes = 256 words
-    if (tid == 0) { ncand = 0; npos = 0; }
-    __syncthreads();
     constexpr int N_IT = N2_H * (N2_W / 8) / 256;
     // how many (thread, step) pairs see a candidate at all: at most CAND_CAP / 8 of them -> sparse (the list cannot overflow)
     constexpr int CAND_CAP = N2_H * N2_W / 4;
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
             }
         }
     }
-    __syncthreads();
+    if (n_any > 0) __syncthreads();   // (uniform; a tile without candidates stores the words cleared in front of phase 1's barrier)
     {
         // 2 planes x 32 rows x 4 words = 256 words, one per thread
         const int plane = tid >> 7, ly = (tid >> 2) & 31, wq = tid & 3;
