@@ -492,16 +492,45 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
             const int ly = i >> 4, o = i & 15;
             u32 sb = 0, wb = 0;
             if (it == 0 ? anyx[0] : anyx[1]) {
-                const uint2 qa = smq[ly + 1][1 + 2 * o], qb = smq[ly + 1][2 + 2 * o];
-                const u32 w4[4] = {qa.x, qa.y, qb.x, qb.y};
+                // The magnitudes of the 3 x 10 neighbourhood of the thread's eight pixels come into registers once -- three rows
+                // of four quads (the two of the pixels and one each side) -- and a candidate picks its two neighbours along the
+                // gradient from them with selects: the run-time LDS address of mag_at() cost eight VALU instructions and a read
+                // per neighbour, and on a busy tile every pixel is a candidate.
+                uint2 mq[3][4];
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) mq[r][q] = smq[ly + r][2 * o + q];
+                // magnitude at row r (0 = above), column `col` (-1 .. 8) relative to the thread's first pixel; both constants once
+                // the loop over k is unrolled.  A quad holds {m0 | m2 << 16, m1 | m3 << 16}.
+                auto M = [&](int r, int col) -> int {
+                    const int cc = col + 4;
+                    const uint2 q = mq[r][cc >> 2];
+                    const u32 w = (cc & 1) ? q.y : q.x;
+                    return (int)((cc & 2) ? (w >> 16) : (w & 0xffffu));
+                };
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    // pixel k of the eight: quad k >> 2, pair (k & 1), half (k >> 1) & 1
-                    const int m = (int)((w4[2 * (k >> 2) + (k & 1)] >> (16 * ((k >> 1) & 1))) & 0xffffu);
+                    const int m = M(1, k);
                     if (m > low) {
-                        const int cls = classify(ly, 8 * o + k, m);
-                        if (cls == 2) sb |= 1u << k;
-                        else if (cls == 1) wb |= 1u << k;
+                        const int r = ly + 2, c = 4 + 8 * o + k;                  // centre in sv
+                        const int tl = sv[r - 1][c - 1], tc = sv[r - 1][c], tr = sv[r - 1][c + 1], ml = sv[r][c - 1], mr = sv[r][c + 1],
+                                  bl = sv[r + 1][c - 1], bc = sv[r + 1][c], br = sv[r + 1][c + 1];
+                        const int xs = (tr + 2 * mr + br) - (tl + 2 * ml + bl), ys = (bl + 2 * bc + br) - (tl + 2 * tc + tr);
+                        const int ax = abs(xs), ay = abs(ys) << 15;
+                        const int tg22x = ax * 13573;  // TG22 = round(tan(22.5 deg) * 2^15)
+                        // (bitwise, not short-circuit, logic and plain selects: hipcc turns && / nested ?: here into branches,
+                        //  eight divergent ones per pixel)
+                        const bool horiz = ay < tg22x, vert = (!horiz) & (ay > tg22x + (ax << 16));
+                        const bool pos = (xs ^ ys) >= 0;                         // the diagonal the signs point along
+                        const int d1 = pos ? M(0, k - 1) : M(0, k + 1), d2 = pos ? M(2, k + 1) : M(2, k - 1);
+                        const int v1 = vert ? M(0, k) : d1, v2 = vert ? M(2, k) : d2;
+                        const int m1 = horiz ? M(1, k - 1) : v1, m2 = horiz ? M(1, k + 1) : v2;
+                        // horizontal / vertical: m > first && m >= second; diagonal: strictly above both
+                        const u32 is_max = (u32)(m > m1) & (u32)(m + (int)(horiz | vert) > m2);
+                        const u32 strong_px = (u32)(m > high);
+                        sb |= (is_max & strong_px) << k;
+                        wb |= (is_max & (strong_px ^ 1u)) << k;
                     }
                 }
             }
