@@ -30,7 +30,8 @@
 
 // PSD_ABLATE (build-time, experiments only -- results are WRONG when non-zero):
 //   1 = no LDS table reads, 2 = no per-frame barrier/flush, 4 = no global loads inside the time loop,
-//   8 = no HSV arithmetic (loads + byte SAD only), 16 = no histogram increments in the fused fp32 quad.  tools/ablate.sh builds and times the variants.
+//   8 = no HSV arithmetic (loads + byte SAD only), 16 = no histogram increments in the fused fp32 quad, 32 = no V-plane store (V mode).
+//   tools/ablate.sh builds and times the variants.
 #ifndef PSD_ABLATE
 #define PSD_ABLATE 0
 #endif
@@ -1135,11 +1136,15 @@ void score_frames_dma_kernel(const ScoreParams p)
                 }
                 if constexpr (VM) {
                     // 16 V bytes of the group, in pixel order (a group is 16 consecutive pixels: byte offset 16 * group)
+#if PSD_ABLATE & 32
+                    asm volatile("" :: "v"(c.v[0]), "v"(c.v[1]), "v"(c.v[2]), "v"(c.v[3]));
+#else
                     if (live[k]) {
                         u32x4 pk;
                         pk.x = c.v[0]; pk.y = c.v[1]; pk.z = c.v[2]; pk.w = c.v[3];
                         *reinterpret_cast<u32x4*>(p.vout + (size_t)t * p.npix + (size_t)(wave_group0 + k * NW * 64 + lane) * 16) = pk;
                     }
+#endif
                 }
             }
         }
