@@ -95,3 +95,45 @@ def test_sobel_tile_kernel_issues_its_loads_together(tmp_path):
     if run:
         clusters.append(run)
     assert len(clusters) == 2 and min(clusters) >= 6, clusters
+
+
+def _loops(lines):
+    """(first, last) line index of every backward branch's span"""
+    labels = {l.split(":")[0]: i for i, l in enumerate(lines) if re.match(r"^\.LBB\d+_\d+:", l)}
+    out = []
+    for i, l in enumerate(lines):
+        m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l) or re.search(r"s_branch\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            out.append((labels[m.group(1)], i))
+    return out
+
+
+def test_hysteresis_step_shifts_rows_with_dpp_not_through_the_lds(tmp_path):
+    """Round 4: the fix-point step of a hysteresis tile takes the rows above / below from the neighbouring lanes with whole-wave
+    DPP shifts; as ds_bpermute_b32 (what __shfl_up / __shfl_down compile to) they were eight LDS round trips per step."""
+    bodies = kernel_bodies(device_asm("psd_edge_kernels", tmp_path))
+    checked = 0
+    for name, lines in bodies.items():
+        if "hysteresis_frame_kernel" not in name:
+            continue
+        inner = [span for span in _loops(lines) if any("wave_shr:1" in l for l in lines[span[0]:span[1] + 1])]
+        assert inner, name
+        a, b = min(inner, key=lambda s: s[1] - s[0])          # the fix-point loop itself
+        body = lines[a:b + 1]
+        assert sum("wave_shr:1" in l for l in body) == 2 and sum("wave_shl:1" in l for l in body) == 2, name
+        assert not any("ds_bpermute" in l or "ds_read" in l for l in body), name
+        assert not any("ds_bpermute" in l for l in lines), name   # ... and nowhere else in the kernel
+        checked += 1
+    assert checked == 3
+
+
+def test_busy_sobel_tiles_select_their_neighbours_without_branching(tmp_path):
+    """Round 4: on a busy tile every pixel is a candidate; its two neighbours along the gradient come out of registers by selects.
+    Written with && / nested ?: hipcc made eight divergent branches per pixel of it (69 in the loop over a thread's eight pixels)."""
+    bodies = kernel_bodies(device_asm("psd_edge_kernels", tmp_path))
+    lines = next(v for k, v in bodies.items() if "sobel_nms_bits_kernelILb0E" in k)
+    a, b = max(_loops(lines), key=lambda s: s[1] - s[0])       # the longest loop: the eight pixels of a thread, unrolled
+    body = [l.strip() for l in lines[a:b + 1] if l.startswith("\t") and l.strip() and not l.strip().startswith((";", "."))]
+    branches = sum(1 for l in body if l.startswith(("s_cbranch", "s_branch")))
+    selects = sum(1 for l in body if l.startswith("v_cndmask"))
+    assert len(body) < 650 and branches <= 16 and selects >= 40, (len(body), branches, selects)
