@@ -8,14 +8,16 @@
 //                         the same call the HSV pass writes both (V mode, psd_score_kernels.hip)
 //   K2 median_thresholds  exact numpy.median from the histogram -> (low, high) via a host-built table
 //   K3 sobel_nms_bits     Sobel 3x3 (replicate border), |dx|+|dy|, non-maximum suppression with OpenCV's TG22 fixed point
-//                         -> TWO BIT PLANES, strong (m > high) and weak (low < m <= high); LDS tiles with halo, tiles
-//                         handed out so that neighbours share an XCD's L2
+//                         -> TWO BIT PLANES, strong (m > high) and weak (low < m <= high); LDS tiles with halo.  The weak
+//                         plane is written TILE-MAJOR (a 64x64 hysteresis tile = 128 consecutive words), the strong plane
+//                         both tile-major (for K4) and row-major (for K5)
 //   K4 hysteresis_frame   8-connected growth of strong into weak: one wave per 64x64 tile, one row per lane, 64-bit
-//                         word-parallel steps with carry-chain run filling; one workgroup takes a frame to its fix point
-//   K5 dilate_xor         k x k dilation of the strong bits and XOR count against the previous frame's dilated bits, bands
-//                         of rows walking the time axis; the dilated map stays in LDS
+//                         word-parallel steps with carry-chain run filling, rows exchanged by whole-wave DPP shifts; one
+//                         workgroup takes a frame to its fix point; reads the tile-major planes, stores promotions to both
+//   K5 dilate_xor         k x k dilation of the (row-major) strong bits and XOR count against the previous frame's dilated
+//                         bits, bands of rows walking the time axis in registers
 // Algorithmic traffic is 5 B/px (3 read + edge map write + previous edge map read); the V plane (1 B/px out
-// and in) and the bit planes (0.25 B/px) are implementation overhead.
+// and in) and the bit planes (3 x 0.125 B/px) are implementation overhead.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -250,8 +252,8 @@ __global__ __launch_bounds__(256) void median_thresholds_kernel(const u32* hist,
 // (Tiles load whole dwords where the frame's rows are dword aligned -- width % 4 == 0: 1080p, 4K, 720p, 640x360, 256x144 ...;
 //  other widths assemble theirs from clamped byte loads.  Round 4 retired the byte-map kernel of round 1 that those took.)
 // The Canny map never exists as bytes: a pixel is "strong" (m > high), "weak" (low < m <= high) or nothing, so the kernel
-// writes two bit rows per image row -- strong[y][x >> 5] bit (x & 31), weak likewise -- 0.25 B/px instead of 1 B/px, and
-// everything behind it (hysteresis, dilation, XOR count) is word-parallel.
+// writes two bits per pixel -- strong[y][x >> 5] bit (x & 31) row-major, and strong / weak again in the tile-major layout the
+// hysteresis reads (below) -- instead of a 1 B/px map, and everything behind it (hysteresis, dilation, XOR count) is word-parallel.
 // Phase 1 computes only the magnitude |dx| + |dy| of the tile plus a 1-px ring, four pixels of a row per work item as two
 // packed 16-bit pairs (even / odd columns), rolling down the rows of a 5-row segment; phase 2 suppresses non-maxima: a pixel
 // whose magnitude is not above `low` is done after one read (almost all of a natural frame), the others recompute dx, dy
@@ -735,6 +737,8 @@ __device__ __forceinline__ u32 hyst_tile(u32* S, u32* St, const u32* Kt, const E
 // bits of this round's map, a barrier, swap, until a round wakes nobody.  A wave that wakes a neighbour has stored its
 // promotions before the round's barrier (write-through L1), and the strong words are read with loads that go to the L2, so
 // the next round sees them whichever wave stored them.  grid = frames; dynamic LDS = 2 x ceil(tiles / 32) words.
+// strong = the row-major plane (promotions are stored there too: the dilation reads it), strong_t / weak_t = the tile-major
+// planes the visits read (see hyst_tile); dirty = one flag byte per tile, `dirty_stride` (a multiple of 32) bytes per frame.
 // HF_WAVES waves per workgroup: as many as still let every frame of the chunk be resident at once -- frames whose chains
 // take fifty rounds are bound by the latency of a round, not by throughput, so two waves of workgroups take twice as long.
 template <int HF_WAVES>
