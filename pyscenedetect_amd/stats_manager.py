@@ -22,6 +22,10 @@ class FrameMetricRegistered(Exception):
         self.metric_key = metric_key
 
 
+class FrameMetricNotRegistered(Exception):
+    """Kept for code that still names it: the reference no longer raises it (``stats_manager.py:60-66``, deprecated)."""
+
+
 class StatsFileCorrupt(Exception):
     """The stats file is not one this class wrote (reference ``stats_manager.py:60-70``)."""
 
