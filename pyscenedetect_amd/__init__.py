@@ -13,7 +13,8 @@ from pyscenedetect_amd.detectors import AdaptiveDetector, ContentDetector, HashD
 from pyscenedetect_amd.scene_manager import (Interpolation, SceneManager, compute_downscale_factor, expand_scenes_to_bounds,
                                              get_scenes_from_cuts)
 from pyscenedetect_amd.stats_manager import FrameMetricRegistered, StatsFileCorrupt, StatsManager
-from pyscenedetect_amd.timecode import FrameTimecode, Timecode
+from pyscenedetect_amd.timecode import (CropRegion, CutList, FrameRate, FrameTimecode, SceneList, Timecode, TimecodeLike,
+                                        TimecodePair)
 from pyscenedetect_amd.video_stream import ArrayVideoStream, FrameRateUnavailable, SeekError, VideoOpenFailure, VideoStream
 
 __version__ = "0.1.0"
@@ -39,8 +40,8 @@ def detect(video, detector, stats_file_path=None, show_progress=False, start_tim
     return manager.get_scene_list(start_in_scene=start_in_scene)
 
 __all__ = [
-    "AdaptiveDetector", "ArrayVideoStream", "compute_downscale_factor", "ContentDetector", "detect", "expand_scenes_to_bounds", "FlashFilter",
-    "FrameMetricRegistered", "FrameRateUnavailable", "FrameTimecode", "get_scenes_from_cuts", "HashDetector", "HistogramDetector", "Interpolation",
-    "SceneDetector", "SceneManager", "SeekError", "StatsFileCorrupt", "StatsManager", "ThresholdDetector", "Timecode", "VideoOpenFailure",
-    "VideoStream",
+    "AdaptiveDetector", "ArrayVideoStream", "compute_downscale_factor", "ContentDetector", "CropRegion", "CutList", "detect",
+    "expand_scenes_to_bounds", "FlashFilter", "FrameMetricRegistered", "FrameRate", "FrameRateUnavailable", "FrameTimecode", "get_scenes_from_cuts",
+    "HashDetector", "HistogramDetector", "Interpolation", "SceneDetector", "SceneList", "SceneManager", "SeekError", "StatsFileCorrupt",
+    "StatsManager", "ThresholdDetector", "Timecode", "TimecodeLike", "TimecodePair", "VideoOpenFailure", "VideoStream",
 ]

@@ -25,7 +25,13 @@ from fractions import Fraction
 MAX_FPS_DELTA = 1.0 / 1000000000.0
 _NTSC_TOLERANCE = 1e-3
 
-TimecodeLike = "int | float | str | FrameTimecode"
+# The type names the reference's `scenedetect.common` exports (common.py:77-101), for code that annotates with them:
+TimecodeLike = "int | float | str | Timecode | FrameTimecode"   # whatever FrameTimecode() accepts as a time
+FrameRate = float | Fraction
+CropRegion = tuple[int, int, int, int]                          # (x0, y0, x1, y1)
+CutList = list["FrameTimecode"]
+SceneList = list[tuple["FrameTimecode", "FrameTimecode"]]
+TimecodePair = tuple["FrameTimecode", "FrameTimecode"]
 
 
 @dataclass(frozen=True)
