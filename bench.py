@@ -439,7 +439,7 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
             sm.add_detector(psd.ContentDetector(engine=engine))
             sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
             vals = [stats.get_metrics(i, ["content_val"])[0] for i in range(1, len(frames))]
-            return [c.frame_num for c in sm.get_cut_list()], vals
+            return [c.frame_num for c in sm.get_cut_list(show_warning=False)], vals
 
         run(eng, host[:64])
         best, cuts = 1e9, None

@@ -15,6 +15,7 @@ from enum import Enum
 import sys
 import threading
 import typing as ty
+import warnings
 
 import numpy as np
 
@@ -173,7 +174,10 @@ class SceneManager:
     def _get_cutting_list(self) -> list[FrameTimecode]:
         return sorted(set(self._cutting_list))
 
-    def get_cut_list(self, show_warning: bool = False) -> list[FrameTimecode]:
+    def get_cut_list(self, show_warning: bool = True) -> list[FrameTimecode]:
+        """[DEPRECATED in the reference, scene_manager.py:716-744]  The frames at which a new scene starts."""
+        if show_warning:
+            warnings.warn("get_cut_list() is deprecated and will be removed in a future release.", DeprecationWarning, stacklevel=2)
         return self._get_cutting_list()
 
     def get_scene_list(self, start_in_scene: bool = False):
@@ -284,7 +288,10 @@ class SceneManager:
 
     def detect_scenes(self, video=None, duration=None, end_time=None, frame_skip: int = 0,
                       show_progress: bool = False,
-                      callback: ty.Callable[[np.ndarray, FrameTimecode], None] | None = None) -> int:
+                      callback: ty.Callable[[np.ndarray, FrameTimecode], None] | None = None, frame_source=None) -> int:
+        if frame_source is not None:   # the reference's deprecated spelling of `video` (scene_manager.py:487-494)
+            warnings.warn("The `frame_source` argument is deprecated, use `video` instead.", DeprecationWarning, stacklevel=2)
+            video = frame_source
         if video is None:
             raise TypeError("detect_scenes() missing 1 required positional argument: 'video'")
         if frame_skip > 0 and self.stats_manager is not None:

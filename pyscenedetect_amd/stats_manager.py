@@ -49,24 +49,27 @@ class StatsManager:
             if key not in self._metric_keys:
                 self._metric_keys.append(key)
 
-    def get_metrics(self, frame_number, metric_keys) -> list:
-        row = self._frame_metrics.get(frame_number, {})
+    # (argument names as in the reference, stats_manager.py:126-153: `timecode` is a frame number or a FrameTimecode -- its hash
+    #  and equality are its frame number, common.py:783-791)
+    def get_metrics(self, timecode, metric_keys) -> list:
+        row = self._frame_metrics.get(timecode, {})
         return [row.get(key) for key in metric_keys]
 
-    def set_metrics(self, frame_number, metric_kv_dict: dict) -> None:
+    def set_metrics(self, timecode, metric_kv_dict: dict) -> None:
         self._metrics_updated = True
-        self._frame_metrics.setdefault(frame_number, {}).update(metric_kv_dict)
+        self._frame_metrics.setdefault(timecode, {}).update(metric_kv_dict)
 
-    def metrics_exist(self, frame_number, metric_keys) -> bool:
-        row = self._frame_metrics.get(frame_number)
+    def metrics_exist(self, timecode, metric_keys) -> bool:
+        row = self._frame_metrics.get(timecode)
         return row is not None and all(key in row for key in metric_keys)
 
     def is_save_required(self) -> bool:
         return self._metrics_updated
 
-    def save_to_csv(self, csv_file, base_timecode: FrameTimecode | None = None, force_save: bool = True) -> None:
+    def save_to_csv(self, csv_file, force_save: bool = True, base_timecode: FrameTimecode | None = None) -> None:
         """``Frame Number, Timecode, <sorted metric keys>`` with 1-based frame numbers
-        (reference ``stats_manager.py:164-203``)."""
+        (reference ``stats_manager.py:164-203``: ``save_to_csv(csv_file, force_save=True)``).  ``base_timecode`` (keyword, not in
+        the reference) overrides the time base ``detect_scenes`` left behind, for metrics keyed by plain frame numbers."""
         base = base_timecode or self._base_timecode
         if not (force_save or self.is_save_required()):
             return

@@ -28,7 +28,7 @@ def run_config(frames, cls_name, kwargs, with_stats, engine, auto_downscale=Fals
     sm.add_detector(det)
     video = psd.ArrayVideoStream(frames, fps)
     n = sm.detect_scenes(video)
-    cuts = [c.frame_num for c in sm.get_cut_list()]
+    cuts = [c.frame_num for c in sm.get_cut_list(show_warning=False)]
     scenes = [[a.frame_num, b.frame_num] for a, b in sm.get_scene_list()]
     metrics = {}
     if stats is not None:

@@ -211,7 +211,7 @@ def _run(engine, frames, factor, interpolation, detector, callback=None):
     sm.interpolation = interpolation
     sm.add_detector(detector)
     sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), callback=callback)
-    return [c.frame_num for c in sm.get_cut_list()]
+    return [c.frame_num for c in sm.get_cut_list(show_warning=False)]
 
 
 @pytest.mark.parametrize("interpolation", [psd.Interpolation.LINEAR, psd.Interpolation.NEAREST, psd.Interpolation.AREA])
@@ -317,7 +317,7 @@ def test_feeder_batches_row_uploads_and_fences_every_batch(golden, oracle_engine
             sm.downscale = 4
             sm.add_detector(psd.ContentDetector(engine=engine))
             sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), callback=lambda img, pos: shown.append((pos.frame_num, int(img.sum()))))
-            return [c.frame_num for c in sm.get_cut_list()]
+            return [c.frame_num for c in sm.get_cut_list(show_warning=False)]
 
         shown_a, shown_b = [], []
         assert run(eng, shown_a) == run(whole, shown_b) and shown_a == shown_b and len(shown_a) > 0

@@ -161,7 +161,7 @@ def _run_downscaled(engine, frames, factor, interpolation, detector):
     sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), callback=lambda img, pos: shown.append((pos.frame_num, int(img.sum()))))
     metrics = [[stats.get_metrics(i, [k])[0] if stats.metrics_exist(i, [k]) else None for k in detector.get_metrics()]
                for i in range(len(frames))]
-    return [c.frame_num for c in sm.get_cut_list()], metrics, shown
+    return [c.frame_num for c in sm.get_cut_list(show_warning=False)], metrics, shown
 
 
 @pytest.mark.parametrize("interpolation", ["LINEAR", "NEAREST"])
@@ -241,7 +241,7 @@ def test_default_pipeline_at_1080p_takes_the_row_path(hip_engine):
         sm = psd.SceneManager(engine=hip_engine, batch_frames=16)
         sm.add_detector(psd.ContentDetector(min_scene_len=4, engine=hip_engine))
         sm.detect_scenes(psd.ArrayVideoStream(clip, 25.0))
-        return [c.frame_num for c in sm.get_cut_list()]
+        return [c.frame_num for c in sm.get_cut_list(show_warning=False)]
 
     smod._DeviceFeeder.put = spy
     keep = E.ScoringEngine.ROWS_ONLY_BELOW

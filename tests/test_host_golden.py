@@ -67,7 +67,7 @@ def test_all_detectors_share_one_pass(golden, oracle_engine):
         cls_name, kwargs, _ = golden["configs"][n]
         sm.add_detector(build_detector(cls_name, kwargs, oracle_engine))
     sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
-    assert [c.frame_num for c in sm.get_cut_list()] == sorted(want)
+    assert [c.frame_num for c in sm.get_cut_list(show_warning=False)] == sorted(want)
 
 
 # ---- pure state machines: known-answer traces generated from the reference ----------------------
@@ -313,7 +313,7 @@ def test_variable_frame_rate_positions_match_reference(golden, oracle_engine):
         sm.add_detector(build_detector(cls_name, kwargs, oracle_engine))
         n = sm.detect_scenes(psd.ArrayVideoStream(frames, v["fps"], pts=pts, time_base=Fraction(*v["time_base"])))
         assert n == want["frames_processed"], name
-        cuts = [[c.frame_num, c.pts, c.seconds, c.get_timecode()] for c in sm.get_cut_list()]
+        cuts = [[c.frame_num, c.pts, c.seconds, c.get_timecode()] for c in sm.get_cut_list(show_warning=False)]
         assert cuts == want["cuts"], f"{name}: {cuts} vs {want['cuts']}"
         scenes = [[a.pts, b.pts, a.get_timecode(), b.get_timecode()] for a, b in sm.get_scene_list()]
         assert scenes == want["scenes"], name

@@ -34,7 +34,7 @@ def _run_scenarios(golden, engine):
     sm = _manager(psd.ContentDetector(engine=engine), engine)
     assert sm.detect_scenes(video, end_time=200) == want["window_seek40_end200"]["frames_processed"]
     assert _scenes(sm) == want["window_seek40_end200"]["scenes"]
-    assert [c.frame_num for c in sm.get_cut_list()] == want["window_seek40_end200"]["cuts"]
+    assert [c.frame_num for c in sm.get_cut_list(show_warning=False)] == want["window_seek40_end200"]["cuts"]
     scenes = sm.get_scene_list()
     assert all(a.frame_num < b.frame_num for a, b in scenes) and all(x[1] == y[0] for x, y in zip(scenes, scenes[1:]))
 
@@ -55,18 +55,18 @@ def _run_scenarios(golden, engine):
         sm = _manager(make(), engine)
         sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), callback=lambda img, pos: calls.append([pos.frame_num, int(img.sum())]))
         assert calls == want[f"callback_{name}"]["calls"], name
-        assert [c.frame_num for c in sm.get_cut_list()] == want[f"callback_{name}"]["cuts"]
+        assert [c.frame_num for c in sm.get_cut_list(show_warning=False)] == want[f"callback_{name}"]["cuts"]
 
     sm = _manager(psd.ContentDetector(engine=engine), engine, stats=True, crop=(10, 5, 100, 60))
     assert sm.crop == (10, 5, 100, 60)
     sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
-    assert [c.frame_num for c in sm.get_cut_list()] == want["crop_10_5_100_60"]["cuts"]
+    assert [c.frame_num for c in sm.get_cut_list(show_warning=False)] == want["crop_10_5_100_60"]["cuts"]
     cv = [sm.stats_manager.get_metrics(i, ["content_val"])[0] for i in range(len(frames))]
     assert [None if v is None else float(v) for v in cv] == want["crop_10_5_100_60"]["content_val"]
 
     sm = _manager(psd.ContentDetector(engine=engine), engine)
     assert sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), frame_skip=1) == want["frame_skip_1"]["frames_processed"]
-    assert [c.frame_num for c in sm.get_cut_list()] == want["frame_skip_1"]["cuts"]
+    assert [c.frame_num for c in sm.get_cut_list(show_warning=False)] == want["frame_skip_1"]["cuts"]
     assert _scenes(sm) == want["frame_skip_1"]["scenes"]
 
 
@@ -131,7 +131,7 @@ def test_stats_csv_and_cached_threshold_metric(golden, oracle_engine):
     sm.auto_downscale = False
     sm.add_detector(psd.ThresholdDetector(engine=oracle_engine))
     sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
-    cuts = [c.frame_num for c in sm.get_cut_list()]
+    cuts = [c.frame_num for c in sm.get_cut_list(show_warning=False)]
     assert cuts == golden["clips"]["fades_b"]["results"]["threshold_default"]["cuts"]
     buf = io.StringIO()
     stats.save_to_csv(buf)
@@ -271,7 +271,7 @@ def _independence_checks(golden, engine):
     small = [cv2.resize(f, (256, 144)) for f in frames]
     assert set(probe.shapes) == {(144, 256, 3)} and probe.sums == [int(s.sum()) for s in small]
     assert seen and all(shape == (144, 256, 3) and total == int(small[n].sum()) for n, shape, total in seen)
-    assert [c.frame_num for c in sm.get_cut_list()] == golden["clips"]["wide_d"]["results"]["content_default"]["cuts"]
+    assert [c.frame_num for c in sm.get_cut_list(show_warning=False)] == golden["clips"]["wide_d"]["results"]["content_default"]["cuts"]
 
     # two thumbnail sizes in one pass: each HashDetector's metrics equal its solo run (and the reference's)
     key8, key16 = "hash_dist [size=8 lowpass=2]", "hash_dist [size=16 lowpass=2]"
@@ -397,3 +397,33 @@ def test_array_video_stream_contract():
         psd.ArrayVideoStream(frames, 25.0, pts=pts)
     with pytest.raises(ValueError):
         psd.ArrayVideoStream(frames, 25.0, pts=pts[:3], time_base=Fraction(1, 1000))
+
+
+def test_deprecated_spellings_of_the_reference(golden, oracle_engine):
+    """`get_cut_list()` warns like the reference's (scene_manager.py:716-744) unless told not to; `frame_source=` still names the
+    video (scene_manager.py:487-494); `save_to_csv(csv_file, force_save)` takes `force_save` second (stats_manager.py:164-168) and
+    the StatsManager accessors take `timecode=` (stats_manager.py:126-153)."""
+    frames = golden_clip(golden, "scenes_a")
+    stats = psd.StatsManager()
+    sm = psd.SceneManager(stats, engine=oracle_engine)
+    sm.add_detector(psd.ContentDetector(engine=oracle_engine))
+    with pytest.warns(DeprecationWarning, match="frame_source"):
+        assert sm.detect_scenes(frame_source=psd.ArrayVideoStream(frames, 25.0)) == len(frames)
+    with pytest.warns(DeprecationWarning, match="get_cut_list"):
+        cuts = sm.get_cut_list()
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert sm.get_cut_list(show_warning=False) == cuts and len(cuts) >= 2
+    key = psd.ContentDetector.FRAME_SCORE_KEY
+    assert stats.metrics_exist(timecode=cuts[0], metric_keys=[key]) and stats.metrics_exist(timecode=cuts[0].frame_num, metric_keys=[key])
+    assert stats.get_metrics(timecode=cuts[0], metric_keys=[key]) == stats.get_metrics(cuts[0].frame_num, [key])
+    stats.set_metrics(timecode=3, metric_kv_dict={"custom": 1.5})
+    assert stats.get_metrics(3, ["custom"]) == [1.5]
+    buf = io.StringIO()
+    stats._metrics_updated = False
+    stats.save_to_csv(buf, False)                       # nothing new to write, and the second positional argument is force_save
+    assert buf.getvalue() == ""
+    stats.save_to_csv(buf, True)
+    assert buf.getvalue().startswith("Frame Number,Timecode,")

@@ -92,8 +92,8 @@ def test_a_backend_written_against_the_interface_runs_under_scene_manager(golden
     got.add_detector(psd.ContentDetector(engine=oracle_engine))
     stream = CountingStream(frames)
     assert got.detect_scenes(stream) == len(frames) and stream.frame_number == len(frames)
-    assert [c.frame_num for c in got.get_cut_list()] == [c.frame_num for c in want.get_cut_list()]
-    assert len(got.get_cut_list()) >= 2                                   # (the clip has cuts to find)
+    assert [c.frame_num for c in got.get_cut_list(show_warning=False)] == [c.frame_num for c in want.get_cut_list(show_warning=False)]
+    assert len(got.get_cut_list(show_warning=False)) >= 2                                   # (the clip has cuts to find)
     assert [(a.frame_num, b.frame_num) for a, b in got.get_scene_list()] == [(a.frame_num, b.frame_num) for a, b in want.get_scene_list()]
     assert stream.decode_failures == 0 and stream.base_timecode.frame_rate == Fraction(30000, 1001)
     with pytest.raises(psd.SeekError):
