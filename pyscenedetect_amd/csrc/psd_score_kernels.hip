@@ -55,6 +55,9 @@ __device__ __forceinline__ void lds_add_hidden_at(uint32_t lds_byte_address, uin
     asm volatile("ds_add_u32 %0, %1" ::"v"(lds_byte_address), "v"(inc) : "memory");
 }
 __device__ __forceinline__ void lds_hidden_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#ifndef PSD_VSTORE_MODE
+#define PSD_VSTORE_MODE 0   // how the V mode stores the V plane (1 / 2 / 3: experiments, see the store)
+#endif
 #ifndef PSD_FUSED_PHASED
 #define PSD_FUSED_PHASED 1   // the fused HSV + luma quad in phases (quad_fused); 0 = pixel by pixel as in round 1
 #endif
@@ -1142,7 +1145,18 @@ void score_frames_dma_kernel(const ScoreParams p)
                     if (live[k]) {
                         u32x4 pk;
                         pk.x = c.v[0]; pk.y = c.v[1]; pk.z = c.v[2]; pk.w = c.v[3];
-                        *reinterpret_cast<u32x4*>(p.vout + (size_t)t * p.npix + (size_t)(wave_group0 + k * NW * 64 + lane) * 16) = pk;
+                        u32x4* dst = reinterpret_cast<u32x4*>(p.vout + (size_t)t * p.npix + (size_t)(wave_group0 + k * NW * 64 + lane) * 16);
+#if PSD_VSTORE_MODE == 1      // experiments for the open question of profiles/r04_ag_*: why this store costs more on smooth data
+                        __builtin_nontemporal_store(pk, dst);
+#elif PSD_VSTORE_MODE == 2    // (WRONG results: the bytes scrambled with their position -- does the cost follow the data's entropy?)
+                        const u32 z = (u32)(wave_group0 + k * NW * 64 + lane) * 2654435761u + (u32)t * 40503u;
+                        pk.x ^= z; pk.y ^= z * 3u; pk.z ^= z * 5u; pk.w ^= z * 7u;
+                        *dst = pk;
+#elif PSD_VSTORE_MODE == 3    // system-scope write-through
+                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(pk) : "memory");
+#else
+                        *dst = pk;
+#endif
                     }
 #endif
                 }
