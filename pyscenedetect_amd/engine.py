@@ -5,6 +5,7 @@ device-memory owner (``data_ptr()``), never for arithmetic.
 """
 
 import ctypes
+import os
 import threading
 
 import numpy as np
@@ -523,39 +524,74 @@ class ScoringEngine(TapRowPolicy):
                 if run:
                     jobs.append((run, h, w))
                 run = [i] if i is not None else []
-        for k0 in range(0, len(jobs), _native.MAX_INFLIGHT):
-            window = jobs[k0:k0 + _native.MAX_INFLIGHT]
-            meta = []
-            try:
-                for run, h, w in window:
-                    first = np.cumsum([0] + [clips[j].shape[0] for j in run[:-1]])
-                    total = int(sum(clips[j].shape[0] for j in run))
-                    self.submit_device_segments(clips[run[0]].data_ptr(), total, h, w, first, flags=flags, edge_kernel=edge_kernel)
-                    meta.append((run, first, total))
-            except BaseException:
-                for _, _, total in meta:      # a submission was refused: retire the ones before it
-                    try:
-                        self.collect(total, sums_only)
-                    except Exception:  # noqa: BLE001
-                        pass
-                raise
-            collected = 0
-            try:
-                for run, first, total in meta:
-                    recs = self.collect(total, sums_only)
-                    collected += 1
-                    for j, f0 in zip(run, first):
-                        out[j] = recs[f0:f0 + clips[j].shape[0]]
-                        ready(j, out[j])
-            except BaseException:
-                # (an error in a collect or in the caller's on_ready: retire what is still in flight, so that the engine is
-                #  usable afterwards -- synchronous calls refuse to run over pending submissions)
-                for _, _, total in meta[collected:]:
-                    try:
-                        self.collect(total, sums_only)
-                    except Exception:  # noqa: BLE001
-                        pass
-                raise
+        # Every run is one submission, except the last, which ends in a tail piece of its own (_plan_pieces): the records of
+        # everything in front of the tail reach the host -- and the caller's on_ready decides those clips -- while the tail is
+        # on the GPU, so the host's share of a pass (0.5 - 0.9 ms for the 11 clips of the BBC stand-in) hides behind a kernel
+        # instead of following the last one.  A piece that starts inside a clip starts one frame early: that frame is flagged
+        # as a clip start, gives the piece's first real frame its predecessor, and its own record is dropped.
+        pieces = []          # (run index, device pointer, frames, clip starts inside, first frame of the run it covers, drop_first)
+        runs = []
+        for ji, (run, h, w) in enumerate(jobs):
+            stride = h * w * 3
+            first = np.cumsum([0] + [clips[j].shape[0] for j in run[:-1]]).astype(np.int64)
+            total = int(first[-1] + clips[run[-1]].shape[0])
+            base = clips[run[0]].data_ptr()
+            cuts = _plan_pieces(total, first, stride, last_run=ji == len(jobs) - 1 and on_ready is not None)
+            if len(cuts) == 3 and os.environ.get("PSD_CLIPS_TAIL_MB") is None:
+                # a cut buys the host's time for the clips in front of it (50 - 100 us of decisions each) and costs one more
+                # launch's ramp, tail and halo frames (0.1 - 0.2 ms; more when the tail is a short walk): worth it from about
+                # six clips and a tail of 512 frames on (BBC stand-in, 11 clips: +6 ... +9 %; the mixed corpus, 3 + 1 clips
+                # with a 4K tail of 100 frames: -3 %, profiles/r05_e_*)
+                ahead = sum(len(r["run"]) for r in runs) + int(np.sum(first + [clips[j].shape[0] for j in run] <= cuts[1]))
+                if ahead < 6 or total - cuts[1] < 512:
+                    cuts = [0, total]
+            runs.append({"run": run, "first": first, "total": total, "recs": None, "done": 0, "next_clip": 0})
+            starts = set(first.tolist())
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                inside = a > 0 and a not in starts
+                a0 = a - 1 if inside else a
+                seg = [0] + [int(f - a0) for f in first if a < f < b]
+                pieces.append((len(runs) - 1, base + a0 * stride, b - a0, seg, a, inside, h, w))
+        in_flight: list = []
+        k = 0
+
+        def retire_all():
+            for pc in in_flight:      # something failed: retire what is still in flight, so that the engine stays usable
+                try:
+                    self.collect(pc[2], sums_only)
+                except Exception:  # noqa: BLE001
+                    pass
+            in_flight.clear()
+
+        try:
+            while k < len(pieces) or in_flight:
+                while k < len(pieces) and len(in_flight) < _native.MAX_INFLIGHT:
+                    pc = pieces[k]
+                    self.submit_device_segments(pc[1], pc[2], pc[6], pc[7], pc[3], flags=flags, edge_kernel=edge_kernel)
+                    in_flight.append(pc)
+                    k += 1
+                pc = in_flight.pop(0)
+                ri, _, cnt, _, a, inside, _, _ = pc
+                recs = self.collect(cnt, sums_only)
+                r = runs[ri]
+                if inside:
+                    recs = recs[1:]
+                if r["recs"] is None:
+                    r["recs"] = recs if len(recs) == r["total"] else np.empty(r["total"], recs.dtype)
+                if r["recs"] is not recs:
+                    r["recs"][a:a + len(recs)] = recs
+                r["done"] = a + len(recs)
+                while r["next_clip"] < len(r["run"]):
+                    j = r["run"][r["next_clip"]]
+                    f0 = int(r["first"][r["next_clip"]])
+                    if f0 + clips[j].shape[0] > r["done"]:
+                        break
+                    out[j] = r["recs"][f0:f0 + clips[j].shape[0]]
+                    r["next_clip"] += 1
+                    ready(j, out[j])
+        except BaseException:
+            retire_all()
+            raise
         for (h, w), idxs in groups.items():
             stride = h * w * 3
             per_batch = max(1, max_batch_bytes // stride)
@@ -644,6 +680,34 @@ class ScoringEngine(TapRowPolicy):
         _native.check(self._lib.psd_edge_map_device(self._h, d_frame, height, width, width * 3 if row_stride is None else row_stride,
                                                     int(edge_kernel), out.ctypes.data))
         return out
+
+
+def _plan_pieces(total: int, first, frame_bytes: int, last_run: bool = True) -> list[int]:
+    """Frame indices at which ``score_clips`` cuts a run of ``total`` resident frames (clip starts at ``first``) into
+    submissions: ``[0, total]`` or ``[0, cut, total]``.
+
+    Only the LAST run of a call is cut, and only once: while its tail piece (a fifth of the run, between 1.5 and 6 GiB --
+    0.3 to 1.2 ms of kernel) is on the GPU, the host collects and decides everything in front of it; what is left exposed
+    after the last kernel is the tail's own few clips.  (The host's share of a pass hides behind the next run's kernel for
+    every run but the last.  More, equal pieces were measured too, ``profiles/r05_c_*``: every extra launch costs its ramp
+    and tail -- 4 pieces of the BBC stand-in's 20 GB ran 5 % longer on the GPU than one, which ate what the overlap gave.)
+    The cut snaps to a clip start within a third of the tail.  ``PSD_CLIPS_TAIL_MB`` overrides the tail's size (0: no cut)."""
+    env = os.environ.get("PSD_CLIPS_TAIL_MB")
+    run_bytes = total * frame_bytes
+    if env is not None:
+        tail_bytes = int(env) << 20
+    else:
+        tail_bytes = min(max(run_bytes // 5, 1536 << 20), 6144 << 20)
+    tail = tail_bytes // max(1, frame_bytes)
+    if not last_run or tail_bytes <= 0 or tail < 1 or total < 3 * tail:
+        return [0, total]
+    cut = total - tail
+    starts = np.asarray(first, dtype=np.int64)
+    if len(starts):
+        near = int(starts[np.argmin(np.abs(starts - cut))])
+        if abs(near - cut) <= max(1, tail // 3) and 0 < near < total:
+            cut = near
+    return [0, int(cut), total]
 
 
 def _sums_of(records: np.ndarray) -> np.ndarray:
