@@ -1369,6 +1369,11 @@ static hipError_t launch_range(ScoreParams p, int group_begin, int group_end, bo
     p.groups_per_tile = (n_groups + p.n_tiles - 1) / p.n_tiles;
     // Time chunks: enough workgroups to keep every CU busy for several rounds, but chunks long
     // enough that the re-read halo frame stays a small fraction.
+    if (staged && hsv && luma) {
+        // (experiments: workgroups per launch of the 16-wave fused passes; default 8 per CU)
+        static const int env_fused = [] { const char* e = getenv("PSD_FUSED_BLOCKS"); return e ? atoi(e) : 0; }();
+        if (env_fused > 0) target_blocks = env_fused;
+    }
     if (mid) target_blocks *= kScoreWG / wg;
     else if (wg != kScoreWG) {
         // small workgroups: several share a CU, so ask for proportionally more of them (PSD_HSV_BLOCKS overrides)

@@ -25,6 +25,31 @@ from pyscenedetect_amd.timecode import FrameTimecode
 
 logger = logging.getLogger("pyscenedetect")
 
+PROGRESS_BAR_DESCRIPTION = "  Detected: %d | Progress"
+"""Template of the progress bar's description (reference ``scene_manager.py:119``)."""
+
+
+class _NoProgress:
+    """What ``show_progress=True`` gets where ``tqdm`` is not installed (reference ``platform.py:53-67``)."""
+
+    def __init__(self, **kwargs):
+        pass
+
+    def update(self, n=1):
+        pass
+
+    def close(self):
+        pass
+
+    def set_description(self, desc=None, refresh=True):
+        pass
+
+
+try:
+    from tqdm import tqdm as _tqdm
+except ModuleNotFoundError:      # optional, like in the reference
+    _tqdm = _NoProgress
+
 DEFAULT_MIN_WIDTH: int = 256
 MAX_FRAME_QUEUE_LENGTH: int = 4
 MAX_FRAME_SIZE_ERRORS: int = 16
@@ -323,6 +348,17 @@ class SceneManager:
         elif duration is not None:
             end_time = (self._base_timecode + duration) + start_frame_num
 
+        progress_bar = None
+        if show_progress:          # reference scene_manager.py:549-563 (the total from the stream's duration, 0 if unknown)
+            total_frames = 0
+            if video.duration is not None:
+                if end_time is not None and end_time < video.duration:
+                    total_frames = end_time - start_frame_num
+                else:
+                    total_frames = video.duration.frame_num - start_frame_num
+            progress_bar = _tqdm(total=int(total_frames), unit="frames", desc=PROGRESS_BAR_DESCRIPTION % 0, dynamic_ncols=True)
+        prev_position = None
+
         plan = self._plan(callback, factor)
         interp = self._interpolation.value          # one mode for the whole call: feeder and scoring must agree on it
         engine = self._engine_or_default() if plan["device"] else None
@@ -336,6 +372,7 @@ class SceneManager:
         worker = threading.Thread(target=self._decode_thread, args=(video, frame_skip, end_time, batches, feeder), daemon=True)
         worker.start()
         last_frame = None
+        logger.info("Detecting scenes...")
         try:
             while not self._stop.is_set():
                 batch = batches.get()
@@ -356,8 +393,17 @@ class SceneManager:
                     last_frame = frames[-1]
                 shown = result["frames"] if result is not None and result.get("frames") is not None else frames
                 for i, position in enumerate(positions):
-                    self._dispatch(position, shown[i], result, i, callback)
+                    new_cuts = self._dispatch(position, shown[i], result, i, callback)
+                    if progress_bar is not None:      # reference scene_manager.py:585-596
+                        if new_cuts:
+                            progress_bar.set_description(PROGRESS_BAR_DESCRIPTION % len(self._cutting_list), refresh=False)
+                        # by the position's delta rather than 1: a VFR stream's frame count is an approximation
+                        progress_bar.update(1 if prev_position is None else position.frame_num - prev_position.frame_num)
+                        prev_position = position
         finally:
+            if progress_bar is not None:
+                progress_bar.set_description(PROGRESS_BAR_DESCRIPTION % len(self._cutting_list), refresh=True)
+                progress_bar.close()
             self._stop.set()
             if feeder:
                 feeder.abort()

@@ -427,3 +427,46 @@ def test_deprecated_spellings_of_the_reference(golden, oracle_engine):
     assert buf.getvalue() == ""
     stats.save_to_csv(buf, True)
     assert buf.getvalue().startswith("Frame Number,Timecode,")
+
+
+def test_show_progress_drives_a_tqdm_bar_like_the_reference(oracle_engine, monkeypatch):
+    """``detect_scenes(show_progress=True)``: a bar over the stream's remaining frames (to ``end_time`` if that comes first),
+    advanced once per frame, its description carrying the cut count (reference ``scene_manager.py:549-563, 585-603``)."""
+    import pyscenedetect_amd as psd
+    from pyscenedetect_amd import scene_manager as SM
+    from pyscenedetect_amd.synth import make_clip
+
+    bars = []
+
+    class Bar:
+        def __init__(self, **kw):
+            self.kw, self.n, self.descs, self.closed = kw, 0, [], False
+            bars.append(self)
+
+        def update(self, n=1):
+            self.n += n
+
+        def set_description(self, desc=None, refresh=True):
+            self.descs.append((desc, refresh))
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(SM, "_tqdm", Bar)
+    frames, cuts = make_clip(3, 90, 36, 64, shot_len=(20, 30))
+    for kwargs, total in (({}, 90), ({"end_time": 50}, 50), ({"duration": 40}, 40)):
+        sm = psd.SceneManager(engine=oracle_engine)
+        sm.add_detector(psd.ContentDetector(engine=oracle_engine, min_scene_len=5))
+        n = sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), show_progress=True, **kwargs)
+        bar = bars[-1]
+        found = len(sm.get_cut_list(show_warning=False))
+        assert bar.kw["total"] == total and bar.kw["unit"] == "frames" and bar.kw["desc"] == SM.PROGRESS_BAR_DESCRIPTION % 0
+        assert bar.n == n and bar.closed
+        assert bar.descs[-1] == (SM.PROGRESS_BAR_DESCRIPTION % found, True)
+        assert found and all(not refresh for _, refresh in bar.descs[:-1])
+    # without the flag nothing is created
+    sm = psd.SceneManager(engine=oracle_engine)
+    sm.add_detector(psd.ContentDetector(engine=oracle_engine))
+    before = len(bars)
+    sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+    assert len(bars) == before
