@@ -335,7 +335,11 @@ __global__ __launch_bounds__(256) void gather_heads_kernel(const psd_frame_score
 // of the BBC stand-in -- a blit of 40-byte rows -- on the critical path between the kernel and the decisions; now 3 + 25 us)
 static int copy_records_to_host(psd_slot& s, hipStream_t stream)
 {
-    if (s.heads_only) {
+    if (s.heads_only && s.n < 256) {
+        // (a few records -- the per-frame API submits one: the strided copy is one call, the packed form a launch more)
+        HIP_TRY(hipMemcpy2DAsync(s.h_recs, sizeof(psd_frame_sums), s.d_recs, sizeof(psd_frame_scores), sizeof(psd_frame_sums), (size_t)s.n,
+                                 hipMemcpyDeviceToHost, stream));
+    } else if (s.heads_only) {
         hipLaunchKernelGGL(gather_heads_kernel, dim3((s.n * 5 + 255) / 256), dim3(256), 0, stream, s.d_recs, (unsigned long long*)s.d_heads, s.n);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(s.h_recs, s.d_heads, (size_t)s.n * sizeof(psd_frame_sums), hipMemcpyDeviceToHost, stream));

@@ -26,7 +26,17 @@ import numpy as np  # noqa: E402
 FIELDS = ("sad_h", "sad_s", "sad_v", "edge_xor", "byte_sum", "hist")
 
 
+BIG = False      # --big: video-sized frames (720p ... 8K, also a few pixels off those sizes), one to three frames per case
+
+
 def draw_shape(rng) -> tuple[int, int]:
+    if BIG:
+        h, w = [(720, 1280), (1080, 1920), (1080, 1920), (2160, 3840), (1440, 2560), (576, 720), (4320, 7680), (1088, 1920)][int(rng.integers(0, 8))]
+        if (h, w) == (4320, 7680) and rng.integers(0, 3):
+            h, w = 1080, 1920
+        if rng.integers(0, 3) == 0:
+            h, w = h + int(rng.integers(-3, 4)), w + int(rng.integers(-5, 6))
+        return h, w
     kind = rng.integers(0, 8)
     if kind == 0:      # tiny
         return int(rng.integers(1, 9)), int(rng.integers(1, 9))
@@ -125,7 +135,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-cases", type=int, default=100000)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--big", action="store_true", help="video-sized frames, up to three per case")
     args = ap.parse_args()
+    global BIG
+    BIG = args.big
     out = run(args.seed, args.seconds, args.max_cases, args.verbose)
     print(json.dumps(out))
     return 1 if out["mismatches"] else 0
@@ -149,6 +162,8 @@ def run(seed: int, seconds: float, max_cases: int, verbose: bool = False, engine
         n = int(rng.integers(1, 9)) if rng.integers(0, 4) else int(rng.integers(9, 40))
         if h * w > 40000:
             n = min(n, 6)
+        if BIG:
+            n = int(rng.integers(1, 4)) if h * w < 5_000_000 else 1
         desc = {"seed": seed, "case": case, "entry": entry, "h": h, "w": w, "n": n}
         try:
             if entry in ("score_host", "score_frames", "edges"):
@@ -159,6 +174,8 @@ def run(seed: int, seconds: float, max_cases: int, verbose: bool = False, engine
                     flags = (flags & 9) or 8 if rng.integers(0, 2) else flags | 8
                     kernel = int(rng.choice([0, 0, 3, 5, 7, 13, 21, 63]))
                     n = min(n, 6)
+                    if BIG:
+                        n = min(n, 2 if h * w < 3_000_000 else 1)
                 frames = draw_content(rng, n, h, w)
                 prev = draw_content(rng, 1, h, w)[0] if rng.integers(0, 2) else None
                 desc.update(flags=flags, kernel=kernel, prev=prev is not None)
@@ -191,9 +208,9 @@ def run(seed: int, seconds: float, max_cases: int, verbose: bool = False, engine
                 flags = int(rng.integers(1, 8))
                 sizes = [(h, w)] + ([draw_shape(rng)] if rng.integers(0, 2) else [])
                 clips, wants = [], []
-                for _ in range(int(rng.integers(1, 6))):
+                for _ in range(int(rng.integers(1, 6)) if not BIG else 2):
                     ch, cw = sizes[int(rng.integers(0, len(sizes)))]
-                    cn = int(rng.integers(1, 12))
+                    cn = int(rng.integers(1, 12)) if not BIG else int(rng.integers(1, 3))
                     fr = draw_content(rng, cn, ch, cw)
                     clips.append(fr)
                     wants.append(ora.score_host(fr, None, flags=flags))
