@@ -190,12 +190,32 @@ int psd_epilogue_adaptive_cuts(const double* content_val, int n, int64_t first_f
 // cv2.calcHist LUT + cv2.normalize(NORM_L2) of one record's luma histogram.
 static void normalized_hist(const uint32_t* hist256, int bins, const int* lut, float* out)
 {
-    std::vector<uint64_t> cnt((size_t)bins, 0);
-    for (int j = 0; j < 256; j++) cnt[(size_t)lut[j]] += hist256[j];
-    double ss = 0.0;
+    uint64_t cnt[256];
+    if (bins > 0 && (bins & (bins - 1)) == 0) {
+        // power-of-two bin counts (the reference's default 128): floor(j * bins / 256) = j >> shift, consecutive runs
+        const int per = 256 / bins;
+        for (int i = 0; i < bins; i++) {
+            uint64_t c = 0;
+            for (int k = 0; k < per; k++) c += hist256[i * per + k];
+            cnt[i] = c;
+        }
+    } else {
+        for (int i = 0; i < bins; i++) cnt[i] = 0;
+        for (int j = 0; j < 256; j++) cnt[lut[j]] += hist256[j];
+    }
+    // The squares are integers below 2^48 and their sum stays below 2^53 (a frame has fewer than 2^26 pixels where it matters:
+    // counts are exact in float32 up to 2^24), so the double sum is exact in ANY order: four independent partial sums.
+    double ss4[4] = {0.0, 0.0, 0.0, 0.0};
+    bool exact = true;
     for (int i = 0; i < bins; i++) {
-        out[i] = (float)cnt[(size_t)i];  // exact below 2^24, a single rounding above (as OpenCV's int->f32)
-        ss += (double)out[i] * (double)out[i];
+        out[i] = (float)(int64_t)cnt[i];  // exact below 2^24, a single rounding above (as OpenCV's int->f32); signed: one cvtsi2ss
+        exact &= cnt[i] < (1ull << 24);
+        ss4[i & 3] += (double)out[i] * (double)out[i];
+    }
+    double ss = (ss4[0] + ss4[1]) + (ss4[2] + ss4[3]);
+    if (!exact) {                // (frames beyond 16.7 M pixels in one bin: OpenCV's sequential order)
+        ss = 0.0;
+        for (int i = 0; i < bins; i++) ss += (double)out[i] * (double)out[i];
     }
     const double nrm = std::sqrt(ss);
     const float scale = (float)(nrm > DBL_EPSILON ? 1.0 / nrm : 0.0);
@@ -204,14 +224,16 @@ static void normalized_hist(const uint32_t* hist256, int bins, const int* lut, f
 
 // cv2.compareHist(HISTCMP_CORREL): double sums in the lane order of OpenCV's 2-lane f64 SIMD
 // (x86-64 baseline): even and odd elements accumulate separately over the multiple-of-4 body.
+// (Written over pairs -- lane l of every sum takes the elements of parity l, in order: the same additions in the same order as
+//  OpenCV's loop.)
 static double correl(const float* h1, const float* h2, int n)
 {
     double s1[2] = {0, 0}, s2[2] = {0, 0}, s11[2] = {0, 0}, s12[2] = {0, 0}, s22[2] = {0, 0};
+    const int body = n >= 4 ? (n & ~3) : 0;      // OpenCV's vector body: whole groups of four
     int j = 0;
-    for (; j <= n - 4; j += 4)
-        for (int k = 0; k < 4; k++) {
-            const double a = h1[j + k], b = h2[j + k];
-            const int l = k & 1;
+    for (; j < body; j += 2)
+        for (int l = 0; l < 2; l++) {
+            const double a = h1[j + l], b = h2[j + l];
             s12[l] += a * b; s11[l] += a * a; s22[l] += b * b; s1[l] += a; s2[l] += b;
         }
     double S1 = s1[0] + s1[1], S2 = s2[0] + s2[1], S11 = s11[0] + s11[1], S12 = s12[0] + s12[1],
