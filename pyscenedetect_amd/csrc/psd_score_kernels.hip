@@ -1020,7 +1020,8 @@ __device__ unsigned long long* g_timeline;
 // V = max(B, G, R) instead of the luma and go to p.vhist[t], the V plane (which the HSV conversion has packed already) is
 // stored to p.vout[t], no byte sum.  The frames are then read once for ContentDetector with weights.delta_edges > 0
 // instead of once by this pass and once by value_plane_hist_dma_kernel.
-template <bool HSV, bool LUMA, int G, int WG, bool VM = false>
+// SEG: the instance for batches of packed clips (p.seg != nullptr); the common instance carries no clip-start code at all.
+template <bool HSV, bool LUMA, int G, int WG, bool VM = false, bool SEG = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu((HSV && LUMA) ? 4 : (HSV && G == 1 && WG == kHsvWG && !VM) ? PSD_HSV_WAVES : 1)))
 void score_frames_dma_kernel(const ScoreParams p)
 {
@@ -1079,7 +1080,7 @@ void score_frames_dma_kernel(const ScoreParams p)
 
     Hsv16 prev[G], other[G];   // the previous frame's H, S, V planes of this lane's pixels / the frame being converted (they swap)
     bool have_prev = false;
-    u32 seg_flag = (p.seg != nullptr && t0 < t1) ? p.seg[t0] : 0u;   // clip-start flag of the next frame to be stepped (packed clips)
+    u32 seg_flag = (SEG && t0 < t1) ? p.seg[t0] : 0u;   // clip-start flag of the next frame to be stepped (packed clips)
     Group cur[G];
     if (HSV) {
         const uint8_t* halo = (t0 > 0) ? p.frames + (size_t)(t0 - 1) * p.frame_stride : p.prev;
@@ -1111,17 +1112,31 @@ void score_frames_dma_kernel(const ScoreParams p)
         PT(5)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PT(0)
+        // The first frame of a clip packed into the batch has no predecessor (p.seg, psd_score_segments_device).  Its flag was
+        // requested one step earlier, behind that step's DMA issue, so the wait above covered it and its latency lay under a
+        // whole step (read at the top of its own step it cost every wave a memory round trip per frame: 2 % on packed clips).
+        // It goes into an SGPR HERE, in front of the next frame's DMA issue: hipcc waits for a loaded register where it is first
+        // read and knows nothing of the wait above, so read behind the issue (round 4) its own s_waitcnt vmcnt(0) drained the
+        // prefetch the wave had just issued -- in the 4-wave pass in every step of every launch, packed clips or not (the
+        // register was read whether or not it had been loaded), so the prefetch overlapped nothing inside a wave; the 16-wave
+        // passes turned the loaded flag into an SGPR at once, a bare memory round trip per step on packed clips.  Round 5: the
+        // flag's code only exists in the SEG instances (HSV pass +1.3 ... +2.1 % on plain batches, +2.6 ... +4 % on packed
+        // clips; the fused pass on packed clips +5 %, profiles/r05_h_*, r05_i_*).
+        u32 flag_now = 0;
+        if constexpr (SEG) {
+            flag_now = __builtin_amdgcn_readfirstlane(seg_flag);
+            asm volatile("" ::"s"(flag_now) : "memory");
+        }
         stage_read<G, NW>(stage, wave, lane, cur);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PT(1)
         if (t + 1 < t1) dma_issue<G, NW, DMA_AUX>(p, p.frames + (size_t)(t + 1) * p.frame_stride, wave_group0, g1, wave, lane, stage);
-        // The first frame of a clip packed into the batch has no predecessor (p.seg, psd_score_segments_device).  Its flag was
-        // requested one step earlier, behind that step's DMA issue, so the wait above covered it and its latency lay under a
-        // whole step (read at the top of its own step it cost every wave a memory round trip per frame: 2 % on packed clips).
-        const bool clip_start = seg_flag != 0;
-        if (p.seg != nullptr && t + 1 < t1) seg_flag = p.seg[t + 1];
+        const bool clip_start = SEG && flag_now != 0;
+        if constexpr (SEG) {
+            if (t + 1 < t1) seg_flag = p.seg[t + 1];
+        }
 #else
-        const bool clip_start = p.seg != nullptr && p.seg[t] != 0;
+        const bool clip_start = SEG && p.seg[t] != 0;
 #pragma unroll
         for (int k = 0; k < G; k++)
 #pragma unroll
@@ -1163,13 +1178,15 @@ void score_frames_dma_kernel(const ScoreParams p)
             }
         }
         constexpr int E0 = LUMA ? 256 : 0;  // index of sad_h among the slot's accumulators
+        // (the frame's sums go into the accumulators with LDS adds the compiler does not see, like the histogram increments:
+        //  in front of a visible LDS atomic hipcc waits for the staging of frame t + 1 -- s_waitcnt vmcnt(0) -- at the end of
+        //  every step; lds_hidden_fence() below, in front of the barrier behind which the flush reads them)
         if (HSV && chain) {   // (uniform; without a predecessor the sums are zero: nothing to add, no registers to clear)
-            __hip_atomic_fetch_add(&my_acc[(E0 + 0) * ACD], sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&my_acc[(E0 + 1) * ACD], ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&my_acc[(E0 + 2) * ACD], sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_add_hidden(&my_acc[(E0 + 0) * ACD], sh);
+            lds_add_hidden(&my_acc[(E0 + 1) * ACD], ss);
+            lds_add_hidden(&my_acc[(E0 + 2) * ACD], sv);
         }
-        if (LUMA)
-            __hip_atomic_fetch_add(&my_acc[(E0 + 3) * ACD], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (LUMA) lds_add_hidden(&my_acc[(E0 + 3) * ACD], bs);
         have_prev = true;
         PT(2)
 #if !(PSD_ABLATE & 2)
@@ -1177,7 +1194,7 @@ void score_frames_dma_kernel(const ScoreParams p)
         // are complete in one half of the slot ring: flush that half while the other half fills.
         const int done = t - t0 + 1;
         if (done % F == 0 || t + 1 == t1) {
-            if (LUMA) lds_hidden_fence();
+            lds_hidden_fence();
             __syncthreads();
             PT(3)
             const int nf = (done % F == 0) ? F : done % F;       // frames in this half
@@ -1314,14 +1331,17 @@ static hipError_t launch_one(const ScoreParams& p, int grid, hipStream_t stream)
     constexpr int WG = kScoreWG;
     if constexpr (FAST && HSV && LUMA) {
         if (p.vout != nullptr) {   // V mode (launch_score_frames checked the preconditions)
-            hipLaunchKernelGGL((score_frames_dma_kernel<true, true, G, kFusedWG, true>), dim3(grid), dim3(kFusedWG), 0, stream, p);
+            if (p.seg != nullptr) hipLaunchKernelGGL((score_frames_dma_kernel<true, true, G, kFusedWG, true, true>), dim3(grid), dim3(kFusedWG), 0, stream, p);
+            else hipLaunchKernelGGL((score_frames_dma_kernel<true, true, G, kFusedWG, true, false>), dim3(grid), dim3(kFusedWG), 0, stream, p);
             return hipGetLastError();
         }
     }
     if constexpr (FAST) {
         if (!direct_loads()) {
             constexpr int SWG = (HSV && (!LUMA || PSD_FUSED_SMALL)) ? kHsvWG : (HSV && LUMA) ? kFusedWG : kScoreWG;
-            hipLaunchKernelGGL((score_frames_dma_kernel<HSV, LUMA, G, SWG>), dim3(grid), dim3(SWG), 0, stream, p);
+            // (the clip-start flags only matter to the HSV carry: the luma-only instance has no SEG form)
+            if (HSV && p.seg != nullptr) hipLaunchKernelGGL((score_frames_dma_kernel<HSV, LUMA, G, SWG, false, HSV>), dim3(grid), dim3(SWG), 0, stream, p);
+            else hipLaunchKernelGGL((score_frames_dma_kernel<HSV, LUMA, G, SWG, false, false>), dim3(grid), dim3(SWG), 0, stream, p);
             return hipGetLastError();
         }
     }
