@@ -241,7 +241,8 @@ __global__ __launch_bounds__(kHashWG) void gray_area_dma_kernel(const HashGeom g
                 if (gidx < ngroups) *reinterpret_cast<u32x4*>(rows + (size_t)gidx * 16) = gray16(w[k]);
             }
         }
-        __syncthreads();
+        lds_barrier();      // (not __syncthreads(): its vmcnt(0) would drain the next batch's staging, issued a few lines up -- the
+                            //  stream that is meant to run under phases (B) and (C))
         // (B) one run of one row per item, accumulated left to right
         for (int item = tid; item < nrows * S; item += kHashWG) {
             const int r = item / S, dx = item - r * S;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(kHashWG) void gray_area_dma_kernel(const HashGeom g
                 part[r * S + dx] = __int_as_float(acc);
             }
         }
-        __syncthreads();
+        lds_barrier();
         // (C) fold the batch into the column sums, top to bottom
         if (tid < S) {
             if (g.mode == 0) {
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(kHashWG) void gray_area_dma_kernel(const HashGeom g
                 for (int r = 0; r < nrows; r++) isum += __float_as_int(part[r * S + tid]);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (tid < S) {
         int v;

@@ -17,6 +17,11 @@
 
 namespace psd {
 
+// Workgroup barrier of kernels whose waves share nothing but LDS: it waits for this wave's LDS operations and not for its
+// global ones.  __syncthreads() carries a workgroup-scope fence, for which hipcc also emits s_waitcnt vmcnt(0) -- and that drains
+// the LDS-DMA prefetch (global_load_lds) a wave keeps in flight across the barrier, which is the point of issuing it early.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int kScoreWG = 1024;  // threads per workgroup of the scoring kernels (16 waves) ...
 #ifndef PSD_HSV_WG
 #define PSD_HSV_WG 256

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (LUMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's hidden histogram increments of frame t-1
-        __syncthreads();                       // every wave's rows of frame t have landed; frame t-1 is fully consumed
+        lds_barrier();                         // every wave's rows of frame t have landed; frame t-1 is fully consumed (LDS only: no vmcnt drain)
         if (t + ahead < t1) issue(frame_ptr(t + ahead), ahead > 1 ? (step + 2) % 3 : (buf ^ 1));
         const int rel = t - t0;                // chunk-relative frame index (-1 for the halo frame)
         if ((HSV || LUMA) && rel >= 8 && (rel & 7) == 0 && tid < 32) {

@@ -1194,8 +1194,7 @@ void score_frames_dma_kernel(const ScoreParams p)
         // are complete in one half of the slot ring: flush that half while the other half fills.
         const int done = t - t0 + 1;
         if (done % F == 0 || t + 1 == t1) {
-            lds_hidden_fence();
-            __syncthreads();
+            lds_barrier();      // (lgkmcnt(0) + s_barrier: the waves share LDS only; __syncthreads() would also drain the staging of frame t + 1)
             PT(3)
             const int nf = (done % F == 0) ? F : done % F;       // frames in this half
             const int first = done - nf;                          // chunk-relative index of the first
