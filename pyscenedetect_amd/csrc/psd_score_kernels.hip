@@ -1169,6 +1169,31 @@ void score_frames_dma_kernel(const ScoreParams p)
                         *dst = pk;
 #elif PSD_VSTORE_MODE == 3    // system-scope write-through
                         asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(pk) : "memory");
+#elif PSD_VSTORE_MODE == 4    // (WRONG results: scrambled with the position inside the frame only -- what a reader could undo cheaply)
+                        const u32 z = (u32)(wave_group0 + k * NW * 64 + lane) * 2654435761u;
+                        pk.x ^= z; pk.y ^= z; pk.z ^= z; pk.w ^= z;
+                        *dst = pk;
+#elif PSD_VSTORE_MODE == 6    // (WRONG edges) per-dword Weyl key: z = (dword index inside the frame) * K
+                        const u32 z = (u32)(wave_group0 + k * NW * 64 + lane) * 4u * 2654435761u;
+                        pk.x ^= z; pk.y ^= z + 2654435761u; pk.z ^= z + 2u * 2654435761u; pk.w ^= z + 3u * 2654435761u;
+                        *dst = pk;
+#elif PSD_VSTORE_MODE == 7    // (WRONG edges) one key per 128-byte line
+                        const u32 z = ((u32)(wave_group0 + k * NW * 64 + lane) >> 3) * 2654435761u;
+                        pk.x ^= z; pk.y ^= z; pk.z ^= z; pk.w ^= z;
+                        *dst = pk;
+#elif PSD_VSTORE_MODE == 8    // (WRONG edges) one constant key
+                        pk.x ^= 2654435761u; pk.y ^= 2654435761u; pk.z ^= 2654435761u; pk.w ^= 2654435761u;
+                        *dst = pk;
+#elif PSD_VSTORE_MODE == 9    // (WRONG edges) Weyl key on the low byte of every dword only
+                        const u32 z = (u32)(wave_group0 + k * NW * 64 + lane) * 4u * 2654435761u;
+                        pk.x ^= (z >> 24); pk.y ^= ((z + 2654435761u) >> 24); pk.z ^= ((z + 2u * 2654435761u) >> 24); pk.w ^= ((z + 3u * 2654435761u) >> 24);
+                        *dst = pk;
+#elif PSD_VSTORE_MODE == 10   // (WRONG edges) constant keys per dword of the 16 bytes: -DPSD_VSTORE_K0=... K1 K2 K3
+                        pk.x ^= (u32)(PSD_VSTORE_K0); pk.y ^= (u32)(PSD_VSTORE_K1); pk.z ^= (u32)(PSD_VSTORE_K2); pk.w ^= (u32)(PSD_VSTORE_K3);
+                        *dst = pk;
+#elif PSD_VSTORE_MODE == 5    // (WRONG plane, RIGHT edges: 255 - V; Sobel magnitudes, directions and the NMS do not see the difference)
+                        pk.x = ~pk.x; pk.y = ~pk.y; pk.z = ~pk.z; pk.w = ~pk.w;
+                        *dst = pk;
 #else
                         *dst = pk;
 #endif

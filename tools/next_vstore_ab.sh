@@ -6,10 +6,10 @@
 # Build here (no GPU needed):  bash tools/next_vstore_ab.sh build      On the GPU box:  bash tools/next_vstore_ab.sh
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; export PYTHONPATH=$R:$R/tools
 if [ "$1" = build ]; then
-  for m in 1 2 3; do bash tools/ablate.sh -f vs$m "-DPSD_VSTORE_MODE=$m"; done; exit 0
+  for m in 1 2 3 4 5; do bash tools/ablate.sh -f vs$m "-DPSD_VSTORE_MODE=$m"; done; exit 0
 fi
 O=$R/gpurun_out/next_vstore; mkdir -p $O; A=$R/pyscenedetect_amd/csrc/build/abl
 for rep in 1 2; do
   timeout 120 python tools/edge_ab.py 2048 STU default
-  for m in 1 2 3; do [ -f $A/libpsd_vs$m.so ] && PSD_LIB_PATH=$A/libpsd_vs$m.so timeout 120 python tools/edge_ab.py 2048 STU vs$m; done
+  for m in 1 2 3 4 5; do [ -f $A/libpsd_vs$m.so ] && PSD_LIB_PATH=$A/libpsd_vs$m.so timeout 120 python tools/edge_ab.py 2048 STU vs$m; done
 done 2>&1 | grep -v amdgpu.ids | tee $O/vstore_ab.txt
