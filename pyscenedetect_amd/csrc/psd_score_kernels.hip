@@ -55,9 +55,6 @@ __device__ __forceinline__ void lds_add_hidden_at(uint32_t lds_byte_address, uin
     asm volatile("ds_add_u32 %0, %1" ::"v"(lds_byte_address), "v"(inc) : "memory");
 }
 __device__ __forceinline__ void lds_hidden_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#ifndef PSD_VSTORE_MODE
-#define PSD_VSTORE_MODE 0   // how the V mode stores the V plane (1 / 2 / 3: experiments, see the store)
-#endif
 #ifndef PSD_FUSED_PHASED
 #define PSD_FUSED_PHASED 1   // the fused HSV + luma quad in phases (quad_fused); 0 = pixel by pixel as in round 1
 #endif
@@ -1161,42 +1158,12 @@ void score_frames_dma_kernel(const ScoreParams p)
                         u32x4 pk;
                         pk.x = c.v[0]; pk.y = c.v[1]; pk.z = c.v[2]; pk.w = c.v[3];
                         u32x4* dst = reinterpret_cast<u32x4*>(p.vout + (size_t)t * p.npix + (size_t)(wave_group0 + k * NW * 64 + lane) * 16);
-#if PSD_VSTORE_MODE == 1      // experiments for the open question of profiles/r04_ag_*: why this store costs more on smooth data
-                        __builtin_nontemporal_store(pk, dst);
-#elif PSD_VSTORE_MODE == 2    // (WRONG results: the bytes scrambled with their position -- does the cost follow the data's entropy?)
-                        const u32 z = (u32)(wave_group0 + k * NW * 64 + lane) * 2654435761u + (u32)t * 40503u;
-                        pk.x ^= z; pk.y ^= z * 3u; pk.z ^= z * 5u; pk.w ^= z * 7u;
+                        // (Rounds 4-5 chased a "content dependence" of this store -- 0.17 ms per 1024 shot-like frames, 0.04 ms on
+                        //  noise -- through non-temporal / write-through forms and a dozen XOR keys on the stored bytes.  It is not
+                        //  the store: keyed planes that the Sobel kernel un-keys changed nothing, and the variants that "helped" were
+                        //  the ones that fed the kernels BEHIND this one garbage -- their long, low-power runs bank package power
+                        //  that this pass then spends as clock.  profiles/r05_klm_*, r05_no_*.)
                         *dst = pk;
-#elif PSD_VSTORE_MODE == 3    // system-scope write-through
-                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(pk) : "memory");
-#elif PSD_VSTORE_MODE == 4    // (WRONG results: scrambled with the position inside the frame only -- what a reader could undo cheaply)
-                        const u32 z = (u32)(wave_group0 + k * NW * 64 + lane) * 2654435761u;
-                        pk.x ^= z; pk.y ^= z; pk.z ^= z; pk.w ^= z;
-                        *dst = pk;
-#elif PSD_VSTORE_MODE == 6    // (WRONG edges) per-dword Weyl key: z = (dword index inside the frame) * K
-                        const u32 z = (u32)(wave_group0 + k * NW * 64 + lane) * 4u * 2654435761u;
-                        pk.x ^= z; pk.y ^= z + 2654435761u; pk.z ^= z + 2u * 2654435761u; pk.w ^= z + 3u * 2654435761u;
-                        *dst = pk;
-#elif PSD_VSTORE_MODE == 7    // (WRONG edges) one key per 128-byte line
-                        const u32 z = ((u32)(wave_group0 + k * NW * 64 + lane) >> 3) * 2654435761u;
-                        pk.x ^= z; pk.y ^= z; pk.z ^= z; pk.w ^= z;
-                        *dst = pk;
-#elif PSD_VSTORE_MODE == 8    // (WRONG edges) one constant key
-                        pk.x ^= 2654435761u; pk.y ^= 2654435761u; pk.z ^= 2654435761u; pk.w ^= 2654435761u;
-                        *dst = pk;
-#elif PSD_VSTORE_MODE == 9    // (WRONG edges) Weyl key on the low byte of every dword only
-                        const u32 z = (u32)(wave_group0 + k * NW * 64 + lane) * 4u * 2654435761u;
-                        pk.x ^= (z >> 24); pk.y ^= ((z + 2654435761u) >> 24); pk.z ^= ((z + 2u * 2654435761u) >> 24); pk.w ^= ((z + 3u * 2654435761u) >> 24);
-                        *dst = pk;
-#elif PSD_VSTORE_MODE == 10   // (WRONG edges) constant keys per dword of the 16 bytes: -DPSD_VSTORE_K0=... K1 K2 K3
-                        pk.x ^= (u32)(PSD_VSTORE_K0); pk.y ^= (u32)(PSD_VSTORE_K1); pk.z ^= (u32)(PSD_VSTORE_K2); pk.w ^= (u32)(PSD_VSTORE_K3);
-                        *dst = pk;
-#elif PSD_VSTORE_MODE == 5    // (WRONG plane, RIGHT edges: 255 - V; Sobel magnitudes, directions and the NMS do not see the difference)
-                        pk.x = ~pk.x; pk.y = ~pk.y; pk.z = ~pk.z; pk.w = ~pk.w;
-                        *dst = pk;
-#else
-                        *dst = pk;
-#endif
                     }
 #endif
                 }
