@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -330,19 +331,37 @@ __global__ __launch_bounds__(256) void gather_heads_kernel(const psd_frame_score
     heads[i] = reinterpret_cast<const unsigned long long*>(recs + t)[k];
 }
 
+// whole records of a small submission, word by word (the destination is the pinned mirror: see copy_records_to_host)
+__global__ __launch_bounds__(256) void copy_words_kernel(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, int n_words)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_words) dst[i] = src[i];
+}
+
 // device records -> pinned mirror: whole records, or only their 40-byte heads when no histogram was asked for (packed on the
 // device first and moved by ONE contiguous copy: the strided hipMemcpy2DAsync this replaces took 134 us for the 29.5 k records
 // of the BBC stand-in -- a blit of 40-byte rows -- on the critical path between the kernel and the decisions; now 3 + 25 us)
 static int copy_records_to_host(psd_slot& s, hipStream_t stream)
 {
-    if (s.heads_only && s.n < 256) {
-        // (a few records -- the per-frame API submits one: the strided copy is one call, the packed form a launch more)
+    // A few records (the per-frame API submits ONE): PSD_SMALL_COPY = 0 the kernel that packs the heads stores them straight into
+    // the pinned mirror (page-locked host memory is device-addressable: no copy engine, no second call; default), 1 one strided
+    // hipMemcpy2DAsync (rounds 4-5), 2 the packed form of large submissions.
+    static const int small_copy = [] { const char* v = getenv("PSD_SMALL_COPY"); return v ? atoi(v) : 0; }();
+    if (s.heads_only && s.n < 256 && small_copy == 0) {
+        hipLaunchKernelGGL(gather_heads_kernel, dim3((s.n * 5 + 255) / 256), dim3(256), 0, stream, s.d_recs, (unsigned long long*)s.h_recs, s.n);
+        HIP_TRY(hipGetLastError());
+    } else if (s.heads_only && s.n < 256 && small_copy == 1) {
         HIP_TRY(hipMemcpy2DAsync(s.h_recs, sizeof(psd_frame_sums), s.d_recs, sizeof(psd_frame_scores), sizeof(psd_frame_sums), (size_t)s.n,
                                  hipMemcpyDeviceToHost, stream));
     } else if (s.heads_only) {
         hipLaunchKernelGGL(gather_heads_kernel, dim3((s.n * 5 + 255) / 256), dim3(256), 0, stream, s.d_recs, (unsigned long long*)s.d_heads, s.n);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(s.h_recs, s.d_heads, (size_t)s.n * sizeof(psd_frame_sums), hipMemcpyDeviceToHost, stream));
+    } else if (s.n < 256 && small_copy == 0) {
+        const int words = s.n * (int)(sizeof(psd_frame_scores) / 8);
+        hipLaunchKernelGGL(copy_words_kernel, dim3((words + 255) / 256), dim3(256), 0, stream, (const unsigned long long*)s.d_recs,
+                           (unsigned long long*)s.h_recs, words);
+        HIP_TRY(hipGetLastError());
     } else
         HIP_TRY(hipMemcpyAsync(s.h_recs, s.d_recs, (size_t)s.n * sizeof(psd_frame_scores), hipMemcpyDeviceToHost, stream));
     return PSD_OK;
@@ -558,6 +577,25 @@ int psd_score_downscaled_device(psd_engine* e, const uint8_t* d_frames, int n, i
     return psd_score_collect(e, out, n);
 }
 
+// Completion of a SMALL submission (the per-frame plug-in API scores one frame per call): hipEventSynchronize spins only
+// briefly and then sleeps on an interrupt, which on some hosts costs 80-90 us per call -- score_device(n = 1) read 46 us on
+// one box and 134 us on the next, process_frame() 170 vs 253 us (profiles/r05_q_*).  Poll the event instead for as long as
+// such a submission can plausibly take, then fall back to the runtime's wait.  PSD_SPIN_US overrides the budget (0: never poll).
+static hipError_t wait_done(hipEvent_t ev, int n)
+{
+    static const int spin_us = [] { const char* v = getenv("PSD_SPIN_US"); return v ? atoi(v) : 400; }();
+    if (n <= 16 && spin_us > 0) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
+        do {
+            const hipError_t q = hipEventQuery(ev);
+            // (hipErrorNotReady lands in HIP's last-error slot like any failure: clear it, or the next launch check reports it)
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); return q; }
+        } while (std::chrono::steady_clock::now() < until);
+        (void)hipGetLastError();
+    }
+    return hipEventSynchronize(ev);
+}
+
 // waits for the oldest submission and retires it; *slot_out = its slot (records in the pinned mirror)
 static int collect_wait(psd_engine* e, const void* out, int n, const char* who, psd_slot** slot_out)
 {
@@ -569,7 +607,7 @@ static int collect_wait(psd_engine* e, const void* out, int n, const char* who, 
         return PSD_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(e->device));
-    hipError_t err = hipEventSynchronize(s.ev_done);
+    hipError_t err = wait_done(s.ev_done, s.n);
     s.pending = false;
     e->last_slot = e->tail;
     e->tail = (e->tail + 1) % PSD_MAX_INFLIGHT;

@@ -20,6 +20,8 @@ SWITCHES = [
     {"PSD_EDGE_FUSE_HSV": "0"},           # two reads of the frames for HSV + edges
     {"PSD_EDGE_WS_MB": "1"},              # edge workspace of a few frames: many chunks
     {"PSD_EDGE_WS_MB": "1", "PSD_EDGE_FUSE_HSV": "0"},
+    {"PSD_SMALL_COPY": "1"},              # records of a small submission by one strided 2-D copy instead of a kernel's stores into the mirror
+    {"PSD_SMALL_COPY": "2", "PSD_SPIN_US": "0"},   # ... packed + contiguous copy; completion by the runtime's wait instead of polling
     {"PSD_HASH_DIRECT": "1"},             # HashDetector thumbnails without LDS-DMA (psd_hash_kernels.hip)
     {"PSD_RESIZE_DEPTH": "3"},            # downscale kernel with two frames in flight
     {"PSD_RESIZE_ROWS": "1"},             # ... one destination row per workgroup
