@@ -40,11 +40,13 @@
 extern "C" {
 #endif
 
-#define PSD_ABI_VERSION 5 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records);
+#define PSD_ABI_VERSION 6 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records);
                             * 3: additive over 2 (psd_frame_sums: records without the histogram, psd_score_collect_sums, psd_epilogue_*_sums);
                             * 4: additive over 3 (psd_resize_source_rows, psd_upload_rows: a host feeder uploads only the rows a downscale reads);
                             * 5: additive over 4 (psd_upload_rows_batch: many frames' rows gathered by worker threads into page-locked
-                            *    memory and uploaded asynchronously; psd_last_walk_geometry) */
+                            *    memory and uploaded asynchronously; psd_last_walk_geometry);
+                            * 6: additive over 5 (psd_cpus_near_device: the CPUs of the GPU's NUMA node, for hosts that place their decode
+                            *    threads and frame buffers themselves) */
 
 typedef enum psd_status {
     PSD_OK = 0,
@@ -229,6 +231,14 @@ int psd_upload_rows_plan(const int* rows, int n_rows, int packed, int* copies, i
  * thread); it neither touches the scoring stream nor the record slots. */
 int psd_upload_rows_batch(psd_engine* e, void* d_first_frame, size_t d_frame_stride, const void* const* h_frames, int n_frames,
                           size_t row_bytes, size_t h_row_stride, const int* rows, int n_rows);
+/* The CPUs of the NUMA node the engine's GPU hangs off (/sys/bus/pci/devices/<bdf>/numa_node), restricted to the calling
+ * thread's affinity mask: cpus[0 .. min(*n_cpus, capacity)) in ascending order, *n_cpus the full count -- 0 when the host has
+ * one node, the node is unknown, the mask already lies inside it, or PSD_FEED_NUMA=0.  This is where psd_upload_rows_batch
+ * puts its page-locked segments and worker threads; a host that decodes on threads of its own (the reference's decode thread,
+ * scene_manager.py:565-572, 625-710) gets the same effect for the frames it allocates by running those threads here: with
+ * the frames on the other socket the same feed moves 21 k instead of 31 k 1080p frames/s (profiles/r04_l_feed_numa.txt).
+ * The engine itself never changes the affinity of a thread it did not create.  No device work. */
+int psd_cpus_near_device(psd_engine* e, int* cpus, int capacity, int* n_cpus);
 int psd_upload_async(psd_engine* e, void* d_dst, const void* h_src, size_t bytes);
 int psd_upload_fence(psd_engine* e, int wait_on_host);
 int psd_memcpy_d2d(psd_engine* e, void* d_dst, const void* d_src, size_t bytes);

@@ -27,7 +27,7 @@ SCORE_EDGES = 8
 SCORE_ALL = 15
 
 MAX_INFLIGHT = 4
-ABI_VERSION = 5  # PSD_ABI_VERSION of include/psd_engine.h this binding was written against
+ABI_VERSION = 6  # PSD_ABI_VERSION of include/psd_engine.h this binding was written against
 
 #: numpy view of ``psd_frame_scores`` (1064 bytes).
 RECORD_DTYPE = np.dtype(
@@ -137,6 +137,7 @@ SYMBOLS = {
     "psd_upload_rows": (_i, [_vp, _vp, _vp, _sz, _sz, _vp, _i]),
     "psd_upload_rows_plan": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "psd_upload_rows_batch": (_i, [_vp, _vp, _sz, _vp, _i, _sz, _sz, _vp, _i]),
+    "psd_cpus_near_device": (_i, [_vp, _vp, _i, _vp]),
     "psd_last_walk_geometry": (_i, [_vp, _P(_i), _P(_i)]),
     "psd_upload_fence": (_i, [_vp, _i]),
     "psd_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),

@@ -338,3 +338,20 @@ extern "C" int psd_upload_rows_batch(psd_engine* e, void* d_first_frame, size_t 
     s.busy = true;
     return PSD_OK;
 }
+
+extern "C" int psd_cpus_near_device(psd_engine* e, int* cpus, int capacity, int* n_cpus)
+{
+    if (!e || !n_cpus || capacity < 0 || (capacity > 0 && !cpus)) { psd_set_error("psd_cpus_near_device: invalid argument"); return PSD_ERR_INVALID; }
+    *n_cpus = 0;
+    cpu_set_t near;
+    CPU_ZERO(&near);
+    if (!cpus_near_gpu(psd::engine_device(e), &near)) return PSD_OK;
+    int n = 0;
+    for (int c = 0; c < CPU_SETSIZE; c++)
+        if (CPU_ISSET(c, &near)) {
+            if (n < capacity) cpus[n] = c;
+            n++;
+        }
+    *n_cpus = n;
+    return PSD_OK;
+}

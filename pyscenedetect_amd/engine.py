@@ -338,6 +338,16 @@ class ScoringEngine(TapRowPolicy):
         """Wait until the engine's stream is idle."""
         _native.check(self._lib.psd_synchronize(self._h))
 
+    def cpus_near_gpu(self) -> list[int]:
+        """CPUs of the NUMA node this engine's GPU hangs off, within the calling thread's affinity mask (``psd_cpus_near_device``);
+        empty when there is nothing to steer (one node, unknown, already inside it, ``PSD_FEED_NUMA=0``).  A host that decodes on
+        its own threads runs them here -- ``os.sched_setaffinity(0, engine.cpus_near_gpu())`` in the decode thread -- so that the
+        frames it allocates sit next to the GPU; the engine never moves a thread it did not create."""
+        buf = (ctypes.c_int * 4096)()
+        n = ctypes.c_int(0)
+        _native.check(self._lib.psd_cpus_near_device(self._h, buf, 4096, ctypes.byref(n)))
+        return [int(buf[i]) for i in range(min(n.value, 4096))]
+
     def downscale_source_rows(self, height: int, width: int, dst_h: int, dst_w: int, interpolation: int = 1) -> np.ndarray:
         """The source rows the device downscale of this shape and mode reads (ascending int32): all a host feeder has to
         upload when every consumer sees the downscaled frame (``psd_resize_source_rows``)."""

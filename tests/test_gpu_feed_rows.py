@@ -308,3 +308,24 @@ def test_table_cache_across_shapes_modes_and_engines(hip_engine):
                     b.free()
     finally:
         other.close()
+
+
+@pytest.mark.gpu
+def test_cpus_near_the_device(hip_engine):
+    """``psd_cpus_near_device`` (ABI 6): ascending CPUs inside this thread's affinity mask, a proper subset of it or nothing;
+    the count comes back whole when the caller's array is short; argument errors are reported."""
+    import os
+
+    mine = os.sched_getaffinity(0)
+    cpus = hip_engine.cpus_near_gpu()
+    assert cpus == sorted(set(cpus)) and set(cpus) <= mine
+    assert len(cpus) == 0 or len(cpus) < len(mine)
+    lib, h = hip_engine._lib, hip_engine._h
+    n = ctypes.c_int(-1)
+    short = (ctypes.c_int * 2)()
+    assert lib.psd_cpus_near_device(h, short, 2, ctypes.byref(n)) == 0 and n.value == len(cpus)
+    assert list(short)[:min(2, len(cpus))] == cpus[:2]
+    assert lib.psd_cpus_near_device(h, None, 0, ctypes.byref(n)) == 0 and n.value == len(cpus)
+    assert lib.psd_cpus_near_device(h, None, 4, ctypes.byref(n)) == _native.PSD_ERR_INVALID
+    assert lib.psd_cpus_near_device(h, short, 2, None) < 0
+    assert os.sched_getaffinity(0) == mine           # asking moves nobody

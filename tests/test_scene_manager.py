@@ -470,3 +470,42 @@ def test_show_progress_drives_a_tqdm_bar_like_the_reference(oracle_engine, monke
     before = len(bars)
     sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
     assert len(bars) == before
+
+
+def test_decode_thread_moves_onto_the_cpus_the_engine_names_and_nobody_else_does():
+    """``_run_near_gpu`` (the first thing SceneManager's own decode thread does when a device feeder is attached) applies
+    ``ScoringEngine.cpus_near_gpu()`` to the CALLING thread only; an engine without the method, an empty answer or a refused
+    call leave it where it was."""
+    import os
+    import threading
+
+    from pyscenedetect_amd.scene_manager import _run_near_gpu
+
+    mine = os.sched_getaffinity(0)
+    one = {min(mine)}
+
+    class Near:
+        def cpus_near_gpu(self):
+            return sorted(one)
+
+    class Nothing:
+        def cpus_near_gpu(self):
+            return []
+
+    class Refused:
+        def cpus_near_gpu(self):
+            return [10 ** 6]          # no such CPU: sched_setaffinity raises, the thread stays
+
+    seen = {}
+
+    def body(name, engine):
+        _run_near_gpu(engine)
+        seen[name] = os.sched_getaffinity(0)
+
+    for name, engine in (("near", Near()), ("nothing", Nothing()), ("refused", Refused()), ("plain", object())):
+        t = threading.Thread(target=body, args=(name, engine))
+        t.start()
+        t.join()
+    assert seen["near"] == one
+    assert seen["nothing"] == mine and seen["refused"] == mine and seen["plain"] == mine
+    assert os.sched_getaffinity(0) == mine
