@@ -283,10 +283,31 @@ class Workload:
         # HashDetector: grey INTER_AREA thumbnails on the device, DCT / median / Hamming distance / decision on the host
         thumbs = self.eng.hash_thumbs_device(self.ptr, self.n, self.h, self.w, 16)
         ms = self.eng.last_kernel_ms()[0]
+        self.hash_decide(thumbs)
+        return ms
+
+    def hash_decide(self, thumbs) -> None:
         bits = self.ep.hash_bits(thumbs, 8)
         self.state["cuts"] = self.ep.hash_cuts(bits, 25.0, threshold=0.35, min_scene_len=15)[0]
         self.state["thumbs"] = thumbs
-        return ms
+
+    def run_hash_steps(self, k: int, sink: list) -> None:
+        """k HashDetector steps with two in flight, like every other workload: the thumbnail call is synchronous, so the host
+        epilogue of step i (a DCT per frame: 1.1 ms for 4096 frames on 16 threads) runs on a second thread while the device
+        makes the thumbnails of step i + 1 (both are native calls that release the GIL).  Serial, the GPU idled a fifth of
+        the step: 744 k frames/s whole-step against 941 k for the kernel alone."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(1) as ex:
+            pending = None
+            for _ in range(k):
+                thumbs = self.eng.hash_thumbs_device(self.ptr, self.n, self.h, self.w, 16)
+                sink.append(self.eng.last_kernel_ms()[0])
+                if pending is not None:
+                    pending.result()
+                pending = ex.submit(self.hash_decide, thumbs)
+            if pending is not None:
+                pending.result()
 
 
 def parity_sample(wl: Workload, k: int) -> str:
@@ -325,8 +346,7 @@ def quick_measure(wl: Workload, steps: int = 5, warmup: int = 2, parity_frames: 
     """Short single-GPU measurement of a secondary workload: same step definition, two steps in flight."""
     def run(k, sink):
         if wl.detector == "hash":
-            for _ in range(k):
-                sink.append(wl.run_hash_step())
+            wl.run_hash_steps(k, sink)
             return
         wl.submit()
         for _ in range(k - 1):
@@ -334,8 +354,16 @@ def quick_measure(wl: Workload, steps: int = 5, warmup: int = 2, parity_frames: 
             sink.append(wl.finish())
         sink.append(wl.finish())
 
+    # Warm up by TIME as well as by count: every secondary follows seconds of CPU work (the previous line's parity sample) with the
+    # GPU idle, and a GPU that wakes up reclocks under load some tens of milliseconds in -- one stall of 5 ... 37 ms
+    # (tools/experiments_r05/probe21.py: steps of 1.15 ms, the fourth ten of them took 48.9 ms).  Inside a 20-step window of a 1 ms
+    # kernel that read as 1.36 ms per step in this list against 1.195 ms for the same workload run on its own.
+    t_warm = time.perf_counter()
     run(warmup, [])
     torch.cuda.synchronize()
+    while time.perf_counter() - t_warm < 0.12:
+        run(max(2, warmup), [])
+        torch.cuda.synchronize()
     ms: list[float] = []
     t0 = time.perf_counter()
     run(steps, ms)
@@ -1011,10 +1039,7 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
 
     def run(steps: int, timing: bool):
         if args.detector == "hash":
-            for _ in range(steps):
-                ms = wl.run_hash_step()
-                if timing:
-                    kernel_ms.append(ms)
+            wl.run_hash_steps(steps, kernel_ms if timing else [])
             return
         wl.submit()
         for _ in range(steps - 1):

@@ -584,7 +584,8 @@ int psd_score_downscaled_device(psd_engine* e, const uint8_t* d_frames, int n, i
 static hipError_t wait_done(hipEvent_t ev, int n)
 {
     static const int spin_us = [] { const char* v = getenv("PSD_SPIN_US"); return v ? atoi(v) : 400; }();
-    if (n <= 16 && spin_us > 0) {
+    static const int spin_n = [] { const char* v = getenv("PSD_SPIN_N"); return v ? atoi(v) : 16; }();
+    if (n <= spin_n && spin_us > 0) {
         const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
         do {
             const hipError_t q = hipEventQuery(ev);
