@@ -61,6 +61,22 @@ def main():
     same(got, w2, FIELDS[:4], "downscaled all")
     assert np.array_equal(got["hist"], w2["hist"]), "downscaled hist"
     buf.free()
+    # submissions with LARGE record sets, two in flight (the packed-heads form of >= 256 records, the whole-record copy): 320
+    # records with histograms (340 KB), 7000 without (280 KB of heads)
+    many = np.random.default_rng(3).integers(0, 256, (7000, 16, 32, 3), dtype=np.uint8)
+    many[3000:] //= 3
+    wm = orc.score_batch(many)
+    dbuf = eng.alloc(many.nbytes)
+    dbuf.upload(many.reshape(-1))
+    for n, flags, sums in ((320, E.SCORE_ALL & ~E.SCORE_EDGES, False), (7000, E.SCORE_HSV_SAD, True)):
+        eng.submit_device(dbuf.ptr, n, 16, 32, flags=flags)
+        eng.submit_device(dbuf.ptr, n, 16, 32, flags=flags)
+        for rep in range(2):
+            got = eng.collect(n, sums_only=sums)
+            same(got, wm[:n], FIELDS[:3] + (() if sums else ("byte_sum",)), ("large records", n, rep))
+            if not sums:
+                assert np.array_equal(got["hist"], wm["hist"][:n]), ("large records: hist", rep)
+    dbuf.free()
     eng.close()
     print("ok")
 
