@@ -123,7 +123,10 @@ def hash_thumbs(frames: np.ndarray, size: int) -> np.ndarray:
     out = np.empty((n, size, size), np.uint8)
     for t in range(n):
         L.orc_bgr2gray(_p(frames[t]), w * 3, _p(gray), w, h, w)
-        if L.orc_resize_area_u8(_p(gray), w, h, w, _p(out[t]), size, size, size) != 0:
+        if size > w or size > h:
+            # not shrunk along both axes: OpenCV's bilinear emulation with area-mode coefficients (resize.cpp), as in the shim
+            L.orc_resize_area_upscale_u8(_p(gray), w, h, w, 1, _p(out[t]), size, size, size)
+        elif L.orc_resize_area_u8(_p(gray), w, h, w, _p(out[t]), size, size, size) != 0:
             raise NotImplementedError("INTER_AREA restated for decimation only")
     return out
 

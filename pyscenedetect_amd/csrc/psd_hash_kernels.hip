@@ -296,15 +296,77 @@ __global__ __launch_bounds__(kHashWG) void gray_area_dma_kernel(const HashGeom g
 
 constexpr int kHashDmaG = 2;
 
+// ---- frames SMALLER than the thumbnail along an axis (a 24-row frame, 32 x 32 thumbnails) -----------------------------------
+// cv2.resize(INTER_AREA) that does not shrink along both axes is OpenCV's bilinear kernel with area-mode coefficients
+// (resize.cpp), which the engine's cv2.resize path implements for BGR frames (psd_resize_kernels.hip, `area_mode`).  A grey
+// image resized on its own equals any channel of the frame (grey, grey, grey) resized, so: grey into all three channels of a
+// scratch frame, that resize, channel 0 out.  Three tiny kernels on frames of a few kilobytes; no video has them, the reference
+// accepts them.
+int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_row_stride,
+                        size_t src_frame_stride, const uint8_t* d_prev, uint8_t* d_dst, int dst_h, int dst_w,
+                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg,
+                        bool area_mode, uint32_t terms);
+
+__global__ __launch_bounds__(256) void gray3_kernel(const uint8_t* __restrict__ frames, size_t frame_stride, size_t row_stride, int h, int w,
+                                                    uint8_t* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
+    if (i >= h * w) return;
+    const int y = i / w, x = i - y * w;
+    const uint8_t* s = frames + (size_t)t * frame_stride + (size_t)y * row_stride + (size_t)x * 3;
+    const uint8_t g = (uint8_t)gray_of(s[0], s[1], s[2]);
+    uint8_t* d = out + ((size_t)t * h * w + i) * 3;
+    d[0] = g; d[1] = g; d[2] = g;
+}
+
+__global__ __launch_bounds__(256) void first_channel_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long total)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) out[i] = in[i * 3];
+}
+
+static int hash_thumbs_enlarging(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
+                                 size_t frame_stride, int size, uint8_t* d_thumbs, hipStream_t stream, hipEvent_t ev_start)
+{
+    uint8_t *grey3 = nullptr, *small3 = nullptr;
+    const size_t a = (size_t)n * height * width * 3, b = (size_t)n * size * size * 3;
+    hipError_t err = hipMalloc((void**)&grey3, a);
+    if (err == hipSuccess) err = hipMalloc((void**)&small3, b);
+    if (err != hipSuccess) {
+        if (grey3) (void)hipFree(grey3);
+        psd_set_error("hash thumbnails: scratch of %zu bytes: %s", a + b, hipGetErrorString(err));
+        (void)hipGetLastError();
+        return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
+    }
+    if (ev_start) (void)hipEventRecord(ev_start, stream);
+    int rc = PSD_OK;
+    for (int t0 = 0; t0 < n && rc == PSD_OK; t0 += 32768) {
+        const int cnt = n - t0 < 32768 ? n - t0 : 32768;
+        hipLaunchKernelGGL(gray3_kernel, dim3((height * width + 255) / 256, cnt), dim3(256), 0, stream, d_frames + (size_t)t0 * frame_stride,
+                           frame_stride, row_stride, height, width, grey3 + (size_t)t0 * height * width * 3);
+    }
+    if (hipGetLastError() != hipSuccess) { psd_set_error("gray3_kernel launch failed"); rc = PSD_ERR_HIP; }
+    if (rc == PSD_OK)
+        rc = resize_linear_score(e, grey3, n, height, width, (size_t)width * 3, (size_t)height * width * 3, nullptr, small3, size, size,
+                                 (size_t)size * size * 3, nullptr, stream, nullptr, nullptr, true, 0);
+    if (rc == PSD_OK) {
+        const long total = (long)n * size * size;
+        hipLaunchKernelGGL(first_channel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, small3, d_thumbs, total);
+        if (hipGetLastError() != hipSuccess) { psd_set_error("first_channel_kernel launch failed"); rc = PSD_ERR_HIP; }
+    }
+    (void)hipStreamSynchronize(stream);     // (the scratch goes away here: a path for toy frames, not a hot one)
+    (void)hipFree(grey3);
+    (void)hipFree(small3);
+    return rc;
+}
+
 // d_thumbs: device buffer of n*size*size bytes.  The run tables of a (frame shape, size) pair are built once and stay in
 // the engine's table cache.
 int hash_thumbs(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
                 int size, uint8_t* d_thumbs, hipStream_t stream, hipEvent_t ev_start)
 {
-    if (size > width || size > height) {
-        psd_set_error("hash thumbnails: INTER_AREA is implemented for decimation only (%dx%d -> %dx%d)", width, height, size, size);
-        return PSD_ERR_UNSUPPORTED;
-    }
+    if (size > width || size > height)
+        return hash_thumbs_enlarging(e, d_frames, n, height, width, row_stride, frame_stride, size, d_thumbs, stream, ev_start);
     if (size > kHashWG) {
         psd_set_error("hash thumbnails: size*lowpass = %d exceeds %d", size, kHashWG);
         return PSD_ERR_UNSUPPORTED;

@@ -335,9 +335,13 @@ class SceneManager:
             frame_width, frame_height = video.frame_size
             if x0 >= frame_width or y0 >= frame_height:
                 raise ValueError("crop starts outside video boundary")
-            if x1 > frame_width or y1 > frame_height:
+            # (the reference's arithmetic, scene_manager.py:513-525, on the STORED crop, whose far corner is already exclusive:
+            #  its warning fires for a crop that ends exactly at the border, and the size the auto-downscale factor is taken from
+            #  is one more than the crop's per axis.  Kept as it is -- the factor decides the size of the frames that are scored;
+            #  found by tools/fuzz_host_vs_reference.py, round 5.)
+            if x1 >= frame_width or y1 >= frame_height:
                 logger.warning("Warning: crop ends outside of video boundary.")
-            effective_frame_size = (min(x1, frame_width) - x0, min(y1, frame_height) - y0)
+            effective_frame_size = (1 + min(x1, frame_width) - x0, 1 + min(y1, frame_height) - y0)
         factor = compute_downscale_factor(max(effective_frame_size)) if self.auto_downscale else self.downscale
 
         self._base_timecode = video.base_timecode

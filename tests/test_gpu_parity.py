@@ -424,10 +424,29 @@ def test_hash_thumbs_padded_rows_and_smooth_content(hip_engine):
     assert np.array_equal(got, orc.hash_thumbs(np.ascontiguousarray(frames), 16))
 
 
+@pytest.mark.parametrize("case", [(3, 24, 520, 32), (3, 24, 80, 32), (2, 54, 32, 16 + 32), (4, 20, 20, 32), (2, 37, 53, 64), (1, 20, 40, 32),
+                                  (2, 16, 16, 16 + 1)])
+def test_hash_thumbs_of_frames_smaller_than_the_thumbnail(hip_engine, case):
+    """``cv2.resize(INTER_AREA)`` that does not shrink along both axes is OpenCV's bilinear emulation with area-mode coefficients:
+    the reference accepts such frames (a 24-row frame, 32 x 32 thumbnails), rounds 1-4 refused them (round 5,
+    tools/fuzz_host_vs_reference.py)."""
+    n, h, w, size = case
+    rng = np.random.default_rng(h * 11 + w + size)
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    frames[0, : h // 2] = 255
+    want = orc.hash_thumbs(frames, size)
+    assert np.array_equal(hip_engine.hash_thumbs_host(frames, size), want)
+    pad = np.zeros((n, h, w + 5, 3), np.uint8)            # padded rows (a decoder's stride)
+    pad[:, :, 2:2 + w] = frames
+    assert np.array_equal(hip_engine.hash_thumbs_host(pad[:, :, 2:2 + w], size), want)
+    import cv2  # the oracle's shim: the reference's own two calls
+
+    for t in range(n):
+        assert np.array_equal(want[t], cv2.resize(cv2.cvtColor(frames[t], cv2.COLOR_BGR2GRAY), (size, size), interpolation=cv2.INTER_AREA))
+
+
 def test_hash_thumbs_invalid_arguments(hip_engine):
     frames = np.zeros((1, 20, 40, 3), np.uint8)
-    with pytest.raises(NotImplementedError):
-        hip_engine.hash_thumbs_host(frames, 32)  # would need upscaling vertically
     with pytest.raises(ValueError):
         hip_engine.hash_thumbs_host(frames, 0)
     with pytest.raises(ValueError):

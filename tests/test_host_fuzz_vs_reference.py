@@ -1,0 +1,78 @@
+"""CPU, build container only: a fixed-seed slice of ``tools/fuzz_host_vs_reference.py`` -- the unmodified reference over the cv2
+shim against the mirror over the oracle engine on random clips, detector sets, parameters and SceneManager settings (crop,
+downscales, interpolations, frame_skip, end_time / duration, presentation timestamps, things both sides must refuse) -- and the
+cases the full campaigns of round 5 found (20 k cases over seeds 1-3 after the fixes):
+
+* crop + auto-downscale: the reference takes the factor from ``1 + (stored crop size)`` per axis, one more than the crop
+  (``scene_manager.py:513-525`` works on the crop as STORED, whose far corner is already exclusive); the mirror took it from the
+  crop size itself, and a 394-pixel crop was scored at another size;
+* HashDetector on frames smaller than its thumbnail along an axis (24 rows, 32 x 32 thumbnails): ``cv2.resize(INTER_AREA)`` then
+  enlarges (OpenCV's bilinear emulation); oracle and engine refused such frames."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/scenedetect"), reason="the reference checkout is only in the build container")
+
+
+@pytest.fixture(scope="module")
+def fuzz():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import logging
+    import warnings
+
+    import fuzz_host_vs_reference as F
+
+    warnings.simplefilter("ignore")
+    level = logging.root.manager.disable
+    logging.disable(logging.CRITICAL)
+    yield F
+    logging.disable(level)
+
+
+def _same(F, seed, case, engine):
+    rng = np.random.default_rng([seed, case])
+    frames, fps, dets, cfg = F.draw_case(rng)
+    cfg["batch_frames"] = int(rng.choice([1, 7, 64]))
+    a = F.outcome(lambda: F.run_side("ref", frames, fps, dets, cfg, None))
+    b = F.outcome(lambda: F.run_side("mirror", frames, fps, dets, cfg, engine))
+    return F.differ(a, b), (seed, case, list(frames.shape), dets, cfg)
+
+
+def test_a_slice_of_the_campaign(fuzz, oracle_engine):
+    raised = 0
+    for case in range(160):
+        rng = np.random.default_rng([20250922, case])
+        frames, fps, dets, cfg = fuzz.draw_case(rng)
+        cfg["batch_frames"] = int(rng.choice([1, 7, 64]))
+        a = fuzz.outcome(lambda: fuzz.run_side("ref", frames, fps, dets, cfg, None))
+        b = fuzz.outcome(lambda: fuzz.run_side("mirror", frames, fps, dets, cfg, oracle_engine))
+        assert fuzz.differ(a, b) is None, (case, fuzz.differ(a, b), list(frames.shape), dets, cfg)
+        raised += "raises" in a
+    assert raised >= 3          # the slice holds cases both sides refuse
+
+
+def test_crop_with_auto_downscale_takes_the_references_factor(fuzz, oracle_engine):
+    frames = np.random.default_rng(4).integers(0, 256, (12, 48, 520, 3), dtype=np.uint8)
+    cfg = {"stats": True, "auto_downscale": True, "crop": (103, 6, 497, 41), "start_in_scene": False, "batch_frames": 64}
+    dets = [("ContentDetector", {}), ("HistogramDetector", {})]
+    a = fuzz.run_side("ref", frames, 25.0, dets, cfg, None)
+    b = fuzz.run_side("mirror", frames, 25.0, dets, cfg, oracle_engine)
+    assert fuzz.differ(a, b) is None, fuzz.differ(a, b)
+    # and a crop that ends exactly at the border, which the reference warns about but accepts
+    cfg["crop"] = (0, 0, 519, 47)
+    assert fuzz.differ(fuzz.run_side("ref", frames, 25.0, dets, cfg, None), fuzz.run_side("mirror", frames, 25.0, dets, cfg, oracle_engine)) is None
+
+
+@pytest.mark.parametrize("shape,kw", [((24, 520), {}), ((24, 80), {"size": 8, "lowpass": 4}), ((54, 32), {"size": 16}), ((20, 20), {"size": 16, "lowpass": 2})])
+def test_hash_detector_on_frames_smaller_than_its_thumbnail(fuzz, oracle_engine, shape, kw):
+    frames = np.random.default_rng(5).integers(0, 256, (30,) + shape + (3,), dtype=np.uint8)
+    frames[15:] //= 3
+    cfg = {"stats": True, "auto_downscale": False, "start_in_scene": False, "batch_frames": 7}
+    dets = [("HashDetector", kw)]
+    a = fuzz.run_side("ref", frames, 25.0, dets, cfg, None)
+    b = fuzz.run_side("mirror", frames, 25.0, dets, cfg, oracle_engine)
+    assert fuzz.differ(a, b) is None, fuzz.differ(a, b)

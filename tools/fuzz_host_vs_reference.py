@@ -1,0 +1,301 @@
+"""Differential fuzz of the HOST side: the unmodified reference (``/root/reference/scenedetect`` over the cv2 shim) against
+the mirror (``pyscenedetect_amd`` over the CPU oracle engine), on random clips, detector sets, detector parameters and
+SceneManager settings.  Build container only (the reference is not on the GPU box); no GPU involved.
+
+    python tools/fuzz_host_vs_reference.py [--seconds 120] [--seed 1] [--max-cases 100000] [--verbose]
+
+Every case draws a small synthetic clip (``pyscenedetect_amd.synth.make_clip``, sometimes with fades to black, sometimes uniform
+noise), a frame rate, one to three detectors with random constructor arguments (thresholds, ``min_scene_len`` as frames / seconds /
+a timecode string, weights with and without the edge term, ``luma_only``, ``kernel_size``, filter modes, window widths, bins,
+fade bias, FLOOR / CEILING, ``add_final_scene``, hash sizes), a StatsManager or none, and SceneManager settings (auto / manual
+downscale with each interpolation the mirror supports, crop, ``frame_skip``, ``end_time`` / ``duration`` as frames or seconds,
+``start_in_scene``), runs both sides and requires the SAME outcome: frames processed, cut list, scene list, every per-frame metric
+bit for bit -- or the same exception type.  Prints one JSON line: cases, by detector, the first mismatches with the seed and
+case number that reproduce them."""
+import argparse
+import json
+import os
+import sys
+import time
+from fractions import Fraction
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path[:0] = [os.path.join(ROOT, "oracle", "cv2_shim"), ROOT, "/root/reference"]
+
+import numpy as np  # noqa: E402
+
+import scenedetect as ref  # noqa: E402  (the reference, unmodified)
+from scenedetect.common import Interpolation as RefInterpolation  # noqa: E402
+from scenedetect.detector import FlashFilter as RefFlashFilter  # noqa: E402
+from scenedetect.detectors import (AdaptiveDetector as RefAdaptive, ContentDetector as RefContent, HashDetector as RefHash,  # noqa: E402
+                                   HistogramDetector as RefHistogram, ThresholdDetector as RefThreshold)
+from scenedetect.scene_manager import SceneManager as RefSceneManager  # noqa: E402
+from scenedetect.stats_manager import StatsManager as RefStatsManager  # noqa: E402
+
+import pyscenedetect_amd as psd  # noqa: E402
+from oracle.detectors_np import OracleEngine  # noqa: E402
+from oracle.gen_golden import MemoryStream, VfrMemoryStream  # noqa: E402
+from pyscenedetect_amd.synth import make_clip  # noqa: E402
+
+REF_CLASSES = {"ContentDetector": RefContent, "AdaptiveDetector": RefAdaptive, "HistogramDetector": RefHistogram,
+               "ThresholdDetector": RefThreshold, "HashDetector": RefHash}
+
+
+def draw_min_scene_len(rng):
+    k = int(rng.integers(0, 5))
+    if k == 0:
+        return int(rng.integers(0, 30))
+    if k == 1:
+        return float(round(rng.uniform(0.05, 1.5), 3))
+    if k == 2:
+        return "%.3fs" % rng.uniform(0.05, 1.2)
+    if k == 3:
+        return "00:00:%06.3f" % rng.uniform(0.04, 1.5)
+    return 15
+
+
+def draw_detector(rng):
+    name = ["ContentDetector", "AdaptiveDetector", "HistogramDetector", "ThresholdDetector", "HashDetector"][int(rng.integers(0, 5))]
+    kw = {}
+    if rng.integers(0, 4):
+        kw["min_scene_len"] = draw_min_scene_len(rng)
+    if name in ("ContentDetector", "AdaptiveDetector"):
+        if rng.integers(0, 2):
+            w = [float(rng.integers(0, 3)) for _ in range(3)] + [float(rng.integers(0, 2))]
+            if sum(abs(x) for x in w) == 0:
+                w[2] = 1.0
+            kw["weights"] = w
+        if rng.integers(0, 4) == 0:
+            kw["luma_only"] = True
+        if rng.integers(0, 3) == 0:
+            kw["kernel_size"] = int(rng.choice([3, 5, 7, 9]))
+    if name == "ContentDetector":
+        if rng.integers(0, 3):
+            kw["threshold"] = float(round(rng.uniform(4.0, 70.0), 2))
+        if rng.integers(0, 3) == 0:
+            kw["filter_mode"] = ["MERGE", "SUPPRESS"][int(rng.integers(0, 2))]
+    elif name == "AdaptiveDetector":
+        if rng.integers(0, 2):
+            kw["adaptive_threshold"] = float(round(rng.uniform(1.2, 6.0), 2))
+        if rng.integers(0, 2):
+            kw["window_width"] = int(rng.integers(1, 5))
+        if rng.integers(0, 2):
+            kw["min_content_val"] = float(round(rng.uniform(2.0, 30.0), 2))
+    elif name == "HistogramDetector":
+        if rng.integers(0, 2):
+            kw["threshold"] = float(round(rng.uniform(0.01, 0.6), 3))
+        if rng.integers(0, 2):
+            kw["bins"] = int(rng.choice([16, 32, 64, 100, 128, 200, 256]))
+    elif name == "ThresholdDetector":
+        if rng.integers(0, 2):
+            kw["threshold"] = float(rng.integers(3, 120)) if rng.integers(0, 2) else int(rng.integers(3, 120))
+        if rng.integers(0, 2):
+            kw["fade_bias"] = float(round(rng.uniform(-1.0, 1.0), 2))
+        if rng.integers(0, 2):
+            kw["add_final_scene"] = True
+        if rng.integers(0, 3) == 0:
+            kw["method"] = ["FLOOR", "CEILING"][int(rng.integers(0, 2))]
+    else:
+        if rng.integers(0, 2):
+            kw["threshold"] = float(round(rng.uniform(0.1, 0.6), 3))
+        if rng.integers(0, 2):
+            kw["size"] = int(rng.choice([8, 16]))
+        if rng.integers(0, 2):
+            kw["lowpass"] = int(rng.choice([1, 2, 4]))
+    return name, kw
+
+
+def build(side, name, kw, engine):
+    kw = dict(kw)
+    if side == "ref":
+        cls = REF_CLASSES[name]
+        if "weights" in kw:
+            kw["weights"] = RefContent.Components(*kw["weights"])
+        if "filter_mode" in kw:
+            kw["filter_mode"] = RefFlashFilter.Mode[kw["filter_mode"]]
+        if "method" in kw:
+            kw["method"] = RefThreshold.Method[kw["method"]]
+        return cls(**kw)
+    cls = getattr(psd, name)
+    if "weights" in kw:
+        kw["weights"] = psd.ContentDetector.Components(*kw["weights"])
+    if "filter_mode" in kw:
+        kw["filter_mode"] = psd.FlashFilter.Mode[kw["filter_mode"]]
+    if "method" in kw:
+        kw["method"] = psd.ThresholdDetector.Method[kw["method"]]
+    return cls(engine=engine, **kw)
+
+
+def draw_clip(rng):
+    h = int(rng.choice([24, 36, 37, 48, 54, 72]))
+    w = int(rng.choice([32, 53, 64, 80, 96, 128, 160, 300, 520]))
+    n = int(rng.integers(12, 110))
+    kind = int(rng.integers(0, 5))
+    seed = int(rng.integers(0, 1 << 30))
+    if kind == 0:
+        frames = np.random.default_rng(seed).integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    else:
+        lo = int(rng.integers(3, 12))
+        kw = {"shot_len": (lo, lo + int(rng.integers(2, 25)))}
+        if kind == 1:
+            kw["fade_every"] = int(rng.integers(1, 4))
+        frames, _ = make_clip(seed, n, h, w, **kw)
+        if kind == 2:      # a dark stretch for the fade detector
+            a = int(rng.integers(0, n))
+            frames[a:a + int(rng.integers(2, 20))] //= int(rng.choice([8, 32, 255]))
+    return frames
+
+
+def draw_case(rng):
+    frames = draw_clip(rng)
+    n, h, w = frames.shape[:3]
+    fps = [25.0, 30.0, 24.0, 29.97, 23.976, 60.0, 12.5][int(rng.integers(0, 7))]
+    dets = [draw_detector(rng) for _ in range(int(rng.choice([1, 1, 1, 2, 3])))]
+    sm = {"stats": bool(rng.integers(0, 3)), "auto_downscale": bool(rng.integers(0, 2))}
+    if not sm["auto_downscale"] and rng.integers(0, 3) == 0:
+        sm["downscale"] = int(rng.integers(1, 4))
+    if rng.integers(0, 3) == 0:
+        sm["interpolation"] = ["LINEAR", "NEAREST", "AREA"][int(rng.integers(0, 3))]
+    if rng.integers(0, 5) == 0 and w > 40 and h > 30:
+        x0, y0 = int(rng.integers(0, w // 3)), int(rng.integers(0, h // 3))
+        sm["crop"] = (x0, y0, int(rng.integers(x0 + 17, w)), int(rng.integers(y0 + 17, h)))
+    if rng.integers(0, 5) == 0:
+        sm["frame_skip"] = int(rng.integers(1, 3))
+        sm["stats"] = False           # (the reference refuses frame_skip with a StatsManager)
+    k = int(rng.integers(0, 8))
+    if k == 0:
+        sm["end_time"] = int(rng.integers(1, n + 10))
+    elif k == 1:
+        sm["end_time"] = float(round(rng.uniform(0.1, (n + 5) / fps), 3))
+    elif k == 2:
+        sm["duration"] = int(rng.integers(1, n + 10))
+    elif k == 3:
+        sm["duration"] = float(round(rng.uniform(0.1, (n + 5) / fps), 3))
+    sm["start_in_scene"] = bool(rng.integers(0, 2))
+    if rng.integers(0, 7) == 0:      # presentation timestamps instead of a constant frame rate (the reference's PyAV backend)
+        steps = rng.choice([20, 40, 40, 40, 40, 60, 80], size=n - 1)
+        sm["pts"] = [0] + [int(x) for x in np.cumsum(steps)]
+    if rng.integers(0, 12) == 0:     # things both sides must refuse (or accept) alike
+        k = int(rng.integers(0, 8))
+        if k == 0:
+            sm["crop"] = (w + 3, 0, w + 20, h - 1)                 # starts outside the frame
+        elif k == 1:
+            sm["end_time"], sm["duration"] = 10, 10                # both
+        elif k == 2:
+            sm["end_time"] = -1
+        elif k == 3:
+            sm["frame_skip"], sm["stats"] = 1, True                # the reference refuses this combination
+        elif k == 4:
+            dets[0] = ("ContentDetector", {"kernel_size": int(rng.choice([2, 4, 1, 0]))})
+        elif k == 5:
+            dets[0] = ("AdaptiveDetector", {"window_width": int(rng.choice([0, -1]))})
+        elif k == 6:
+            sm["crop"] = (5, 5, 2, 2) if w > 8 and h > 8 else (0, 0, 0, 0)          # corners swapped
+        else:
+            sm["crop"] = (0, 0, w - 1, h - 1)                      # ends exactly at the border
+    return frames, fps, dets, sm
+
+
+def run_side(side, frames, fps, dets, cfg, engine):
+    if side == "ref":
+        stats = RefStatsManager() if cfg["stats"] else None
+        sm = RefSceneManager(stats)
+        video = VfrMemoryStream(frames, fps, cfg["pts"], Fraction(1, 1000)) if "pts" in cfg else MemoryStream(frames, fps)
+        interp = RefInterpolation
+    else:
+        stats = psd.StatsManager() if cfg["stats"] else None
+        sm = psd.SceneManager(stats, engine=engine, batch_frames=int(cfg.get("batch_frames", 64)))
+        video = (psd.ArrayVideoStream(frames, fps, pts=cfg["pts"], time_base=Fraction(1, 1000)) if "pts" in cfg
+                 else psd.ArrayVideoStream(frames, fps))
+        interp = psd.Interpolation
+    sm.auto_downscale = cfg["auto_downscale"]
+    if "downscale" in cfg:
+        sm.downscale = cfg["downscale"]
+    if "interpolation" in cfg:
+        sm.interpolation = interp[cfg["interpolation"]]
+    if "crop" in cfg:
+        sm.crop = cfg["crop"]
+    built = [build(side, name, kw, engine) for name, kw in dets]
+    for d in built:
+        sm.add_detector(d)
+    kwargs = {k: cfg[k] for k in ("frame_skip", "end_time", "duration") if k in cfg}
+    n = sm.detect_scenes(video, **kwargs)
+    cuts = [c.frame_num for c in sm.get_cut_list(show_warning=False)]
+    scenes = [[a.frame_num, b.frame_num] for a, b in sm.get_scene_list(start_in_scene=cfg["start_in_scene"])]
+    metrics = {}
+    if stats is not None:
+        for d in built:
+            for key in d.get_metrics():
+                vals = []
+                for i in range(len(frames)):
+                    v = stats.get_metrics(i, [key])[0] if stats.metrics_exist(i, [key]) else None
+                    vals.append(None if v is None else float(v))
+                metrics[key] = vals
+    return {"frames_processed": n, "cuts": cuts, "scenes": scenes, "metrics": metrics}
+
+
+def outcome(fn):
+    try:
+        return fn()
+    except Exception as ex:  # noqa: BLE001 -- the exception type IS the outcome
+        return {"raises": type(ex).__name__}
+
+
+def differ(a, b):
+    if a.keys() != b.keys():
+        return "outcome kinds: %s vs %s" % (sorted(a), sorted(b))
+    if "raises" in a:
+        return None if a["raises"] == b["raises"] else "raises %s vs %s" % (a["raises"], b["raises"])
+    for k in ("frames_processed", "cuts", "scenes"):
+        if a[k] != b[k]:
+            return "%s: %s vs %s" % (k, str(a[k])[:120], str(b[k])[:120])
+    if set(a["metrics"]) != set(b["metrics"]):
+        return "metric keys: %s vs %s" % (sorted(a["metrics"]), sorted(b["metrics"]))
+    for key, va in a["metrics"].items():
+        vb = b["metrics"][key]
+        for i, (x, y) in enumerate(zip(va, vb)):
+            if x != y and not (x is not None and y is not None and x != x and y != y):
+                return "%s[%d]: %r vs %r" % (key, i, x, y)
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--max-cases", type=int, default=100000)
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+    import logging
+    import warnings
+
+    logging.disable(logging.CRITICAL)
+    warnings.simplefilter("ignore")
+    engine = OracleEngine()
+    t_end = time.time() + args.seconds
+    cases, by, raised, bad = 0, {}, 0, []
+    while time.time() < t_end and cases < args.max_cases:
+        rng = np.random.default_rng([args.seed, cases])
+        frames, fps, dets, cfg = draw_case(rng)
+        cfg["batch_frames"] = int(rng.choice([1, 7, 64]))
+        a = outcome(lambda: run_side("ref", frames, fps, dets, cfg, None))
+        b = outcome(lambda: run_side("mirror", frames, fps, dets, cfg, engine))
+        why = differ(a, b)
+        for name, _ in dets:
+            by[name] = by.get(name, 0) + 1
+        raised += "raises" in a
+        if why is not None:
+            desc = {"case": cases, "why": why, "shape": list(frames.shape), "fps": fps, "detectors": dets, "scene_manager": cfg}
+            bad.append(desc)
+            if args.verbose:
+                print(json.dumps(desc), flush=True)
+            if len(bad) >= 20:
+                break
+        cases += 1
+    print(json.dumps({"seed": args.seed, "cases": cases, "by_detector": by, "cases_that_raise_on_both_sides": raised,
+                      "mismatches": bad[:20]}))
+
+
+if __name__ == "__main__":
+    main()
