@@ -9,8 +9,10 @@ noise), a frame rate, one to three detectors with random constructor arguments (
 a timecode string, weights with and without the edge term, ``luma_only``, ``kernel_size``, filter modes, window widths, bins,
 fade bias, FLOOR / CEILING, ``add_final_scene``, hash sizes), a StatsManager or none, and SceneManager settings (auto / manual
 downscale with each interpolation the mirror supports, crop, ``frame_skip``, ``end_time`` / ``duration`` as frames or seconds,
-``start_in_scene``), runs both sides and requires the SAME outcome: frames processed, cut list, scene list, every per-frame metric
-bit for bit -- or the same exception type.  Prints one JSON line: cases, by detector, the first mismatches with the seed and
+``start_in_scene``, presentation timestamps, a ``callback``, inputs both sides must refuse), runs both sides and requires the SAME
+outcome: frames processed, cut list, scene list, every per-frame metric bit for bit, the frames handed to the callback (number,
+shape, checksum), the text of the saved stats CSV, and a SECOND detection from a fresh StatsManager loaded from that CSV (the
+detectors then decide from cached metrics) -- or the same exception type.  Prints one JSON line: cases, by detector, the first mismatches with the seed and
 case number that reproduce them."""
 import argparse
 import json
@@ -176,6 +178,10 @@ def draw_case(rng):
     if rng.integers(0, 7) == 0:      # presentation timestamps instead of a constant frame rate (the reference's PyAV backend)
         steps = rng.choice([20, 40, 40, 40, 40, 60, 80], size=n - 1)
         sm["pts"] = [0] + [int(x) for x in np.cumsum(steps)]
+    if rng.integers(0, 4) == 0:
+        sm["callback"] = True            # detect_scenes(callback=...): which frames it is handed, when, with what picture
+    if sm["stats"] and rng.integers(0, 3) == 0:
+        sm["second_pass"] = True         # the metrics saved to CSV, loaded into a fresh StatsManager, detection again from the cache
     if rng.integers(0, 12) == 0:     # things both sides must refuse (or accept) alike
         k = int(rng.integers(0, 8))
         if k == 0:
@@ -198,6 +204,9 @@ def draw_case(rng):
 
 
 def run_side(side, frames, fps, dets, cfg, engine):
+    # (one frame rate for both sides: the reference-side stream class of oracle/gen_golden.py turns a float into
+    #  Fraction(fps).limit_denominator(10000), FrameTimecode snaps 23.976 to 24000/1001 -- both right, not the same clock)
+    fps = Fraction(fps).limit_denominator(10000)
     if side == "ref":
         stats = RefStatsManager() if cfg["stats"] else None
         sm = RefSceneManager(stats)
@@ -209,30 +218,65 @@ def run_side(side, frames, fps, dets, cfg, engine):
         video = (psd.ArrayVideoStream(frames, fps, pts=cfg["pts"], time_base=Fraction(1, 1000)) if "pts" in cfg
                  else psd.ArrayVideoStream(frames, fps))
         interp = psd.Interpolation
-    sm.auto_downscale = cfg["auto_downscale"]
-    if "downscale" in cfg:
-        sm.downscale = cfg["downscale"]
-    if "interpolation" in cfg:
-        sm.interpolation = interp[cfg["interpolation"]]
-    if "crop" in cfg:
-        sm.crop = cfg["crop"]
-    built = [build(side, name, kw, engine) for name, kw in dets]
-    for d in built:
-        sm.add_detector(d)
-    kwargs = {k: cfg[k] for k in ("frame_skip", "end_time", "duration") if k in cfg}
-    n = sm.detect_scenes(video, **kwargs)
-    cuts = [c.frame_num for c in sm.get_cut_list(show_warning=False)]
-    scenes = [[a.frame_num, b.frame_num] for a, b in sm.get_scene_list(start_in_scene=cfg["start_in_scene"])]
-    metrics = {}
-    if stats is not None:
+    def configure(sm):
+        sm.auto_downscale = cfg["auto_downscale"]
+        if "downscale" in cfg:
+            sm.downscale = cfg["downscale"]
+        if "interpolation" in cfg:
+            sm.interpolation = interp[cfg["interpolation"]]
+        if "crop" in cfg:
+            sm.crop = cfg["crop"]
+        built = [build(side, name, kw, engine) for name, kw in dets]
         for d in built:
-            for key in d.get_metrics():
-                vals = []
-                for i in range(len(frames)):
-                    v = stats.get_metrics(i, [key])[0] if stats.metrics_exist(i, [key]) else None
-                    vals.append(None if v is None else float(v))
-                metrics[key] = vals
-    return {"frames_processed": n, "cuts": cuts, "scenes": scenes, "metrics": metrics}
+            sm.add_detector(d)
+        return built
+
+    def detect(sm, video):
+        kwargs = {k: cfg[k] for k in ("frame_skip", "end_time", "duration") if k in cfg}
+        seen = []
+        if cfg.get("callback"):
+            import zlib
+
+            kwargs["callback"] = lambda img, pos: seen.append([int(pos), list(img.shape), zlib.crc32(np.ascontiguousarray(img).tobytes())])
+        n = sm.detect_scenes(video, **kwargs)
+        cuts = [c.frame_num for c in sm.get_cut_list(show_warning=False)]
+        scenes = [[a.frame_num, b.frame_num] for a, b in sm.get_scene_list(start_in_scene=cfg["start_in_scene"])]
+        return n, cuts, scenes, seen
+
+    def metrics_of(stats, built):
+        metrics = {}
+        if stats is not None:
+            for d in built:
+                for key in d.get_metrics():
+                    vals = []
+                    for i in range(len(frames)):
+                        v = stats.get_metrics(i, [key])[0] if stats.metrics_exist(i, [key]) else None
+                        vals.append(None if v is None else float(v))
+                    metrics[key] = vals
+        return metrics
+
+    built = configure(sm)
+    n, cuts, scenes, seen = detect(sm, video)
+    out = {"frames_processed": n, "cuts": cuts, "scenes": scenes, "metrics": metrics_of(stats, built), "callback": seen}
+    if cfg.get("second_pass") and stats is not None:
+        import tempfile
+
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "stats.csv")
+            stats.save_to_csv(path)
+            out["csv"] = open(path).read()
+            if side == "ref":
+                stats2 = RefStatsManager()
+                sm2 = RefSceneManager(stats2)
+            else:
+                stats2 = psd.StatsManager()
+                sm2 = psd.SceneManager(stats2, engine=engine, batch_frames=int(cfg.get("batch_frames", 64)))
+            out["loaded"] = stats2.load_from_csv(path)
+            built2 = configure(sm2)
+            video.reset()
+            n2, cuts2, scenes2, seen2 = detect(sm2, video)
+            out["second"] = {"frames_processed": n2, "cuts": cuts2, "scenes": scenes2, "metrics": metrics_of(stats2, built2), "callback": seen2}
+    return out
 
 
 def outcome(fn):
@@ -247,9 +291,15 @@ def differ(a, b):
         return "outcome kinds: %s vs %s" % (sorted(a), sorted(b))
     if "raises" in a:
         return None if a["raises"] == b["raises"] else "raises %s vs %s" % (a["raises"], b["raises"])
-    for k in ("frames_processed", "cuts", "scenes"):
-        if a[k] != b[k]:
-            return "%s: %s vs %s" % (k, str(a[k])[:120], str(b[k])[:120])
+    for k in ("frames_processed", "cuts", "scenes", "callback", "csv", "loaded"):
+        if a.get(k) != b.get(k):
+            return "%s: %s vs %s" % (k, str(a.get(k))[:160], str(b.get(k))[:160])
+    if ("second" in a) != ("second" in b):
+        return "second pass on one side only"
+    if "second" in a:
+        why = differ(a["second"], b["second"])
+        if why is not None:
+            return "second pass (metrics from the loaded CSV): " + why
     if set(a["metrics"]) != set(b["metrics"]):
         return "metric keys: %s vs %s" % (sorted(a["metrics"]), sorted(b["metrics"]))
     for key, va in a["metrics"].items():
