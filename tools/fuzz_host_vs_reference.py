@@ -178,6 +178,12 @@ def draw_case(rng):
     if rng.integers(0, 7) == 0:      # presentation timestamps instead of a constant frame rate (the reference's PyAV backend)
         steps = rng.choice([20, 40, 40, 40, 40, 60, 80], size=n - 1)
         sm["pts"] = [0] + [int(x) for x in np.cumsum(steps)]
+    k = int(rng.integers(0, 10))
+    if k == 0:
+        sm["mode"] = "per_frame"         # the plug-in API itself: process_frame() per frame and post_process(), no SceneManager
+    elif k == 1:
+        sm["mode"] = "reuse"             # one manager, two videos: with clear() in between or without
+        sm["clear_between"] = bool(rng.integers(0, 2))
     if rng.integers(0, 4) == 0:
         sm["callback"] = True            # detect_scenes(callback=...): which frames it is handed, when, with what picture
     if sm["stats"] and rng.integers(0, 3) == 0:
@@ -255,9 +261,43 @@ def run_side(side, frames, fps, dets, cfg, engine):
                     metrics[key] = vals
         return metrics
 
+    if cfg.get("mode") == "per_frame":
+        # SceneDetector.process_frame(timecode, frame) / post_process(timecode) as a caller of the plug-in API uses them
+        # (detector.py:48-73); a StatsManager is attached the way add_detector attaches it (scene_manager.py:337-352)
+        built = [build(side, name, kw, engine) for name, kw in dets]
+        for d in built:
+            if stats is not None:
+                d.stats_manager = stats
+                stats.register_metrics(d.get_metrics())
+        emitted = []
+        tc_cls = ref.FrameTimecode if side == "ref" else psd.FrameTimecode
+        base = video.base_timecode
+        for i in range(len(frames)):
+            tc = (base + i) if "pts" not in cfg else tc_cls(cfg["pts"][i] / 1000.0, fps)
+            for j, d in enumerate(built):
+                got = d.process_frame(tc, frames[i])
+                if got:
+                    emitted.append([i, j, [c.frame_num for c in got]])
+        last = (base + (len(frames) - 1)) if "pts" not in cfg else tc_cls(cfg["pts"][-1] / 1000.0, fps)
+        for j, d in enumerate(built):
+            got = d.post_process(last)
+            if got:
+                emitted.append(["post", j, [c.frame_num for c in got]])
+        return {"frames_processed": len(frames), "cuts": emitted, "scenes": [], "metrics": metrics_of(stats, built), "callback": [],
+                "event_buffer": [int(d.event_buffer_length) for d in built]}
     built = configure(sm)
     n, cuts, scenes, seen = detect(sm, video)
     out = {"frames_processed": n, "cuts": cuts, "scenes": scenes, "metrics": metrics_of(stats, built), "callback": seen}
+    if cfg.get("mode") == "reuse":
+        # the same manager on a second video (the first one backwards): what carries over, what clear() resets
+        if cfg["clear_between"]:
+            sm.clear()
+        rev = frames[::-1]
+        video2 = (MemoryStream(rev, fps) if side == "ref" else psd.ArrayVideoStream(rev, fps))
+        n2, cuts2, scenes2, seen2 = detect(sm, video2)
+        out["second"] = {"frames_processed": n2, "cuts": cuts2, "scenes": scenes2, "metrics": {}, "callback": seen2}
+        out["num_detectors"] = sm.get_num_detectors()
+        return out
     if cfg.get("second_pass") and stats is not None:
         import tempfile
 
@@ -291,7 +331,7 @@ def differ(a, b):
         return "outcome kinds: %s vs %s" % (sorted(a), sorted(b))
     if "raises" in a:
         return None if a["raises"] == b["raises"] else "raises %s vs %s" % (a["raises"], b["raises"])
-    for k in ("frames_processed", "cuts", "scenes", "callback", "csv", "loaded"):
+    for k in ("frames_processed", "cuts", "scenes", "callback", "csv", "loaded", "event_buffer", "num_detectors"):
         if a.get(k) != b.get(k):
             return "%s: %s vs %s" % (k, str(a.get(k))[:160], str(b.get(k))[:160])
     if ("second" in a) != ("second" in b):
