@@ -161,7 +161,10 @@ class FlashFilter:
     def filter(self, timecode: FrameTimecode, above_threshold: bool) -> list[FrameTimecode]:
         if self._disabled:
             return [timecode] if above_threshold else []
-        if getattr(timecode, "_pts", None) is not None:
+        # positions that are not plain frame numbers -- presentation timestamps, or timecodes a caller of process_frame() built
+        # from seconds -- are compared the way the reference compares everything, on timecode arithmetic (the frame-number path
+        # below is its equivalent for frame-backed positions; tools/fuzz_host_vs_reference.py found the seconds-backed case)
+        if getattr(timecode, "_pts", None) is not None or getattr(timecode, "_secs", None) is not None:
             return self._filter_by_time(timecode, above_threshold)
         need = self._resolve(timecode)
         now = timecode.frame_num

@@ -115,6 +115,7 @@ class SceneManager:
         self._frame_buffer: list[tuple[FrameTimecode, np.ndarray]] = []
         self._frame_buffer_size = 0
         self._crop = None
+        self._carry_frame = None     # the last frame of the previous detect_scenes() call (see there)
 
     # -- configuration (reference :265-335) ---------------------------------------------------------
     @property
@@ -195,6 +196,7 @@ class SceneManager:
 
     def clear_detectors(self) -> None:
         self._detector_list.clear()
+        self._carry_frame = None     # (the reference's detectors own this state: scene_manager.py:372-375 drops them)
 
     # -- results -----------------------------------------------------------------------------------
     def _get_cutting_list(self) -> list[FrameTimecode]:
@@ -376,7 +378,13 @@ class SceneManager:
         self._exception_info = None
         worker = threading.Thread(target=self._decode_thread, args=(video, frame_skip, end_time, batches, feeder), daemon=True)
         worker.start()
-        last_frame = None
+        # The reference's detectors keep what they derived from the last frame they saw (content_detector.py:189 ...), so a manager
+        # that is run on another video WITHOUT clear() scores that video's first frame against the previous video's last one.
+        # Here the previous frame belongs to the manager's shared pass: it survives the call, until clear() / clear_detectors()
+        # (a detector added in between still starts without a predecessor: each detector has its own "seen a frame" flag).
+        last_frame = self._carry_frame
+        if feeder and last_frame is not None:
+            feeder.seed_halo(last_frame)
         logger.info("Detecting scenes...")
         try:
             while not self._stop.is_set():
@@ -421,6 +429,7 @@ class SceneManager:
         if self._exception_info is not None:
             exc = self._exception_info[1]
             raise exc.with_traceback(self._exception_info[2])
+        self._carry_frame = last_frame
         self._last_pos = video.position
         for detector in self._detector_list:
             self._cutting_list += detector.post_process(video.position)
@@ -598,6 +607,19 @@ class _DeviceFeeder:
 
     def forget_halo(self) -> None:
         self._have_halo = False
+
+    def seed_halo(self, frame: np.ndarray) -> None:
+        """The frame that precedes the first batch (the previous call's last frame): uploaded whole, once per detect_scenes()."""
+        frame = np.ascontiguousarray(frame)
+        h, w, _ = frame.shape
+        nbytes = (h * w * 3 + 15) & ~15
+        if self._halo is None or self._halo[0].nbytes < nbytes:
+            if self._halo is not None:
+                self._halo[0].free()
+            self._halo = (self._engine.alloc(nbytes), tuple(frame.shape))
+        self._halo = (self._halo[0], tuple(frame.shape))
+        self._halo[0].upload(frame.reshape(-1))
+        self._have_halo = True
 
     def release(self, slot, keep_last: int) -> None:
         """The batch is scored: keep its last frame for the next batch, hand the buffer back to the decode thread."""

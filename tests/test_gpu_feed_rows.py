@@ -329,3 +329,39 @@ def test_cpus_near_the_device(hip_engine):
     assert lib.psd_cpus_near_device(h, None, 4, ctypes.byref(n)) == _native.PSD_ERR_INVALID
     assert lib.psd_cpus_near_device(h, short, 2, None) < 0
     assert os.sched_getaffinity(0) == mine           # asking moves nobody
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("auto_downscale", [False, True])
+def test_one_manager_on_two_videos_carries_the_last_frame(golden, hip_engine, oracle_engine, auto_downscale):
+    """A manager run on a second video without ``clear()`` scores its first frame against the first video's last one, like the
+    reference's detectors (tests/test_host_fuzz_vs_reference.py): through the device feeder that frame is re-uploaded as the first
+    batch's predecessor (``_DeviceFeeder.seed_halo``); with ``clear()`` in between nothing carries over."""
+    a = golden_clip(golden, "wide_d" if auto_downscale else "scenes_a")
+    b = a[: len(a) // 2][::-1].copy()          # starts in another shot than `a` ends in
+
+    def run(engine, clear_between, with_stats):
+        stats = psd.StatsManager() if with_stats else None
+        sm = psd.SceneManager(stats, engine=engine, batch_frames=16)
+        sm.auto_downscale = auto_downscale
+        dets = [psd.ContentDetector(threshold=12.0, min_scene_len=0, engine=engine), psd.AdaptiveDetector(min_content_val=5.0, min_scene_len=2, engine=engine),
+                psd.HistogramDetector(engine=engine)]
+        for d in dets:
+            sm.add_detector(d)
+        sm.detect_scenes(psd.ArrayVideoStream(a, 25.0))
+        first = [c.frame_num for c in sm.get_cut_list(show_warning=False)]
+        if clear_between:
+            sm.clear()
+            for d in dets:
+                sm.add_detector(d)
+        sm.detect_scenes(psd.ArrayVideoStream(b, 25.0))
+        return first, [c.frame_num for c in sm.get_cut_list(show_warning=False)]
+
+    results = {}
+    for clear_between in (False, True):
+        for with_stats in (False, True):
+            got, want = run(hip_engine, clear_between, with_stats), run(oracle_engine, clear_between, with_stats)
+            assert got == want, (clear_between, with_stats)
+            results[clear_between, with_stats] = got
+    # the carried frame shows: without clear() the second video's frame 0 is a cut (its predecessor is another shot's frame)
+    assert 0 in results[False, False][1] and 0 not in results[True, False][1]

@@ -76,3 +76,38 @@ def test_hash_detector_on_frames_smaller_than_its_thumbnail(fuzz, oracle_engine,
     a = fuzz.run_side("ref", frames, 25.0, dets, cfg, None)
     b = fuzz.run_side("mirror", frames, 25.0, dets, cfg, oracle_engine)
     assert fuzz.differ(a, b) is None, fuzz.differ(a, b)
+
+
+@pytest.mark.parametrize("mode", ["MERGE", "SUPPRESS"])
+def test_flash_filter_on_timecodes_built_from_seconds(fuzz, mode):
+    """A caller of ``process_frame()`` may hand over timecodes it built from seconds (``FrameTimecode(3.68, fps)``): the reference
+    compares ``(timecode - last_above) >= seconds`` on timecode arithmetic whatever backs the timecode; the mirror's frame-number
+    path is only its equivalent for frame-backed positions (two frames 20 ms apart can share a frame number at 29.97 fps)."""
+    import scenedetect as ref
+
+    rng = np.random.default_rng(7)
+    for trial in range(40):
+        fps = [29.97, 25.0, 23.976, 60.0][trial % 4]
+        length = [0.662, 0.3, "0.5s", 12, "00:00:00.400"][trial % 5]
+        steps = rng.choice([20, 40, 40, 40, 60, 80], size=150)
+        secs = np.concatenate([[0.0], np.cumsum(steps) / 1000.0])
+        above = rng.random(len(secs)) < 0.12
+        fa = ref.detector.FlashFilter(ref.detector.FlashFilter.Mode[mode], length)
+        fb = fuzz.psd.FlashFilter(fuzz.psd.FlashFilter.Mode[mode], length)
+        for i, t in enumerate(secs):
+            a = [c.frame_num for c in fa.filter(ref.FrameTimecode(float(t), fps), bool(above[i]))]
+            b = [c.frame_num for c in fb.filter(fuzz.psd.FrameTimecode(float(t), fps), bool(above[i]))]
+            assert a == b, (trial, i, fps, length, a, b)
+
+
+@pytest.mark.parametrize("clear_between", [False, True])
+def test_one_manager_on_two_videos(fuzz, oracle_engine, clear_between):
+    """Without ``clear()`` the reference's detectors score the second video's first frame against the first video's last one
+    (they keep what they derived from it) and their windows / cut positions carry over; with it everything starts again."""
+    frames, _ = fuzz.make_clip(21, 60, 36, 64, shot_len=(6, 14))
+    for dets in ([("AdaptiveDetector", {"min_scene_len": 2, "min_content_val": 5.0})], [("ContentDetector", {"threshold": 12.0, "min_scene_len": 0}), ("HistogramDetector", {})],
+                 [("HashDetector", {"size": 8}), ("ThresholdDetector", {"threshold": 60})]):
+        cfg = {"stats": True, "auto_downscale": False, "start_in_scene": False, "batch_frames": 7, "mode": "reuse", "clear_between": clear_between}
+        a = fuzz.outcome(lambda: fuzz.run_side("ref", frames, 25.0, dets, cfg, None))
+        b = fuzz.outcome(lambda: fuzz.run_side("mirror", frames, 25.0, dets, cfg, oracle_engine))
+        assert fuzz.differ(a, b) is None, (dets, fuzz.differ(a, b))

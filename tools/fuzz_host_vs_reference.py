@@ -356,6 +356,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-cases", type=int, default=100000)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--force", default="", help="comma list of case features to force: per_frame, reuse, pts, stats, second_pass, callback")
+    ap.add_argument("--binding", action="store_true",
+                    help="third side: the reference with INTEGRATION.md B's seams bound to the C-ABI (integration/scenedetect_amd.py over "
+                         "oracle/libpsd_oracle_abi.so, the CPU build of the ABI), compared with the plain reference")
     args = ap.parse_args()
     import logging
     import warnings
@@ -363,15 +367,46 @@ def main():
     logging.disable(logging.CRITICAL)
     warnings.simplefilter("ignore")
     engine = OracleEngine()
+    binding = amd = None
+    if args.binding:
+        import subprocess
+
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "libpsd_oracle_abi.so"])
+        sys.path.insert(0, os.path.join(ROOT, "integration"))
+        import scenedetect_amd as amd
+
+        binding = amd.Binding(os.path.join(ROOT, "oracle", "libpsd_oracle_abi.so"))
     t_end = time.time() + args.seconds
     cases, by, raised, bad = 0, {}, 0, []
     while time.time() < t_end and cases < args.max_cases:
         rng = np.random.default_rng([args.seed, cases])
         frames, fps, dets, cfg = draw_case(rng)
         cfg["batch_frames"] = int(rng.choice([1, 7, 64]))
+        for f in [x for x in args.force.split(",") if x]:
+            if f in ("per_frame", "reuse"):
+                cfg["mode"] = f
+                cfg.setdefault("clear_between", bool(cases & 1))
+            elif f == "pts" and "pts" not in cfg:
+                steps = rng.choice([20, 40, 40, 40, 40, 60, 80], size=len(frames) - 1)
+                cfg["pts"] = [0] + [int(x) for x in np.cumsum(steps)]
+            elif f in ("stats", "second_pass", "callback"):
+                cfg[f] = True
+                if f == "second_pass":
+                    cfg["stats"] = True
+                if cfg.get("stats"):
+                    cfg.pop("frame_skip", None)
         a = outcome(lambda: run_side("ref", frames, fps, dets, cfg, None))
         b = outcome(lambda: run_side("mirror", frames, fps, dets, cfg, engine))
         why = differ(a, b)
+        if why is None and binding is not None:
+            undo = amd.install(binding)
+            try:
+                c = outcome(lambda: run_side("ref", frames, fps, dets, cfg, None))
+            finally:
+                undo()
+            why = differ(a, c)
+            if why is not None:
+                why = "reference with the bound seams vs plain reference: " + why
         for name, _ in dets:
             by[name] = by.get(name, 0) + 1
         raised += "raises" in a
