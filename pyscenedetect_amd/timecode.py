@@ -76,7 +76,7 @@ def parse_timecode_seconds(text: str, rate: Fraction) -> float:
         secs = float(parts[-1]) if "." in parts[-1] else int(parts[-1])
         if not (hrs >= 0 and mins >= 0 and secs >= 0 and mins < 60 and secs < 60):
             raise ValueError("Invalid timecode range (values outside allowed range).")
-        return secs + hrs * 3600 + mins * 60
+        return secs + ((hrs * 60 * 60) + (mins * 60))      # (the reference's order, common.py:523: the integer part summed first)
     if text.endswith("s"):
         text = text[:-1]
     if not text.replace(".", "").isdigit():
