@@ -35,8 +35,10 @@ class StatsFileCorrupt(Exception):
 
 class StatsManager:
     def __init__(self, base_timecode: FrameTimecode | None = None):
+        # keyed by an int frame number or a FrameTimecode: both hash / compare to the same slot (FrameTimecode.__hash__ is the frame
+        # number), and the slot keeps the key object it was created with (reference stats_manager.py:106-110)
         self._frame_metrics: dict = {}
-        self._metric_keys: list[str] = []
+        self._metric_keys: set[str] = set()
         self._metrics_updated = False
         self._base_timecode = base_timecode
 
@@ -45,23 +47,24 @@ class StatsManager:
         return self._metric_keys
 
     def register_metrics(self, metric_keys) -> None:
-        for key in metric_keys:
-            if key not in self._metric_keys:
-                self._metric_keys.append(key)
+        self._metric_keys = self._metric_keys.union(set(metric_keys))
 
-    # (argument names as in the reference, stats_manager.py:126-153: `timecode` is a frame number or a FrameTimecode -- its hash
-    #  and equality are its frame number, common.py:783-791)
+    # (argument names and semantics as in the reference, stats_manager.py:126-153 and 300-314: `timecode` is a frame number or a
+    #  FrameTimecode; setting an EMPTY dict creates nothing and does not mark the manager dirty; an empty key list "exists" anywhere)
     def get_metrics(self, timecode, metric_keys) -> list:
-        row = self._frame_metrics.get(timecode, {})
-        return [row.get(key) for key in metric_keys]
+        row = self._frame_metrics.get(timecode)
+        return [row.get(key) if row is not None else None for key in metric_keys]
 
     def set_metrics(self, timecode, metric_kv_dict: dict) -> None:
-        self._metrics_updated = True
-        self._frame_metrics.setdefault(timecode, {}).update(metric_kv_dict)
+        for key in metric_kv_dict:
+            self._metrics_updated = True
+            if timecode not in self._frame_metrics:
+                self._frame_metrics[timecode] = {}
+            self._frame_metrics[timecode][key] = metric_kv_dict[key]
 
     def metrics_exist(self, timecode, metric_keys) -> bool:
         row = self._frame_metrics.get(timecode)
-        return row is not None and all(key in row for key in metric_keys)
+        return all([row is not None and key in row for key in metric_keys])
 
     def is_save_required(self) -> bool:
         return self._metrics_updated
@@ -70,7 +73,6 @@ class StatsManager:
         """``Frame Number, Timecode, <sorted metric keys>`` with 1-based frame numbers
         (reference ``stats_manager.py:164-203``: ``save_to_csv(csv_file, force_save=True)``).  ``base_timecode`` (keyword, not in
         the reference) overrides the time base ``detect_scenes`` left behind, for metrics keyed by plain frame numbers."""
-        base = base_timecode or self._base_timecode
         if not (force_save or self.is_save_required()):
             return
         close = False
@@ -82,11 +84,18 @@ class StatsManager:
             keys = sorted(self._metric_keys)
             writer.writerow([COLUMN_NAME_FRAME_NUMBER, COLUMN_NAME_TIMECODE] + keys)
             for key in sorted(self._frame_metrics.keys(), key=int):
-                tc = key if isinstance(key, FrameTimecode) else (base + int(key) if base is not None else None)
+                # A row whose key is a bare frame number -- set through the public API with an int, or read back by the deprecated
+                # load_from_csv -- has no timecode to print: the reference skips it (stats_manager.py:196-199; a later set_metrics
+                # with a FrameTimecode for the same frame updates the row but the dict keeps the int key), unless the caller names
+                # the time base (`base_timecode`, a keyword the reference does not have).
+                if isinstance(key, FrameTimecode):
+                    tc = key
+                elif base_timecode is not None:
+                    tc = base_timecode + int(key)
+                else:
+                    continue
                 row = self._frame_metrics[key]
-                writer.writerow(
-                    [int(key) + 1, tc.get_timecode() if tc is not None else ""] + [str(row.get(k, "None")) for k in keys]
-                )
+                writer.writerow([int(key) + 1, tc.get_timecode()] + [str(row.get(k, "None")) for k in keys])
         finally:
             if close:
                 csv_file.close()
@@ -126,11 +135,12 @@ class StatsManager:
             frame_number = int(row[0])
             if frame_number > 0:
                 frame_number -= 1
-            self.set_metrics(frame_number, {})
+            # (a row of "None"s creates nothing; a file that turns out corrupt half-way leaves what was read before it, the keys
+            #  unregistered and the manager dirty -- reference stats_manager.py:276-296)
             for key, text in zip(keys, row[2:]):
                 if text and text != "None":
                     try:
-                        self._frame_metrics[frame_number][key] = float(text)
+                        self.set_metrics(frame_number, {key: float(text)})
                     except ValueError:
                         raise StatsFileCorrupt(f"Corrupted value in stats file: {text}") from ValueError
             num_frames += 1

@@ -132,3 +132,29 @@ def test_timecode_fuzz_slice_and_the_parse_order_it_found():
         assert a == b, (case_no, case, a, b)
         ok += "ok" in a
     assert ok > 2000
+
+
+def test_stats_manager_fuzz_slice_and_what_it_found(tmp_path):
+    """``tools/fuzz_stats_vs_reference.py``: random programs on a StatsManager per side (83 k cases clean after the fixes).  Found: a
+    row keyed by a bare frame number is not written by ``save_to_csv`` (no timecode to print; the reference skips it); setting an empty
+    dict creates nothing and does not mark the manager dirty; an empty key list "exists" for any frame; a CSV that turns out corrupt
+    half-way leaves what was read before it, unregistered, and the manager dirty; ``metric_keys`` is a set."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_stats_vs_reference as S
+
+    import pyscenedetect_amd as psd
+
+    sm = psd.StatsManager()
+    sm.set_metrics(5, {})
+    assert not sm.is_save_required() and sm.metrics_exist(5, []) and not sm.metrics_exist(5, ["x"]) and isinstance(sm.metric_keys, set)
+    sm.register_metrics(["x"])
+    sm.set_metrics(5, {"x": 1.0})                                   # keyed by an int: no timecode
+    sm.set_metrics(psd.FrameTimecode(7, 25.0), {"x": 2.0})
+    sm.set_metrics(psd.FrameTimecode(5, 25.0), {"x": 3.0})          # same slot, the int key stays
+    path = tmp_path / "s.csv"
+    sm.save_to_csv(path)
+    assert path.read_text() == "Frame Number,Timecode,x\n8,00:00:00.280,2.0\n"
+    for case_no in range(1500):
+        fps, prog = S.draw_program(np.random.default_rng([77, case_no]))
+        a, b = S.run("ref", fps, prog, str(tmp_path)), S.run("ours", fps, prog, str(tmp_path))
+        assert a == b, (case_no, prog, a, b)
