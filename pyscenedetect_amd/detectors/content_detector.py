@@ -8,6 +8,7 @@ this class turns them into ``content_val`` with the reference's float operations
 """
 
 import math
+import operator
 import typing as ty
 
 import numpy as np
@@ -55,7 +56,9 @@ class ContentDetector(SceneDetector):
         if kernel_size is not None:
             if kernel_size < 3 or kernel_size % 2 == 0:
                 raise ValueError("kernel_size must be odd integer >= 3")
-            self._kernel_size = kernel_size
+            # (the reference builds numpy.ones((kernel_size, kernel_size)) here, content_detector.py:137: an odd float such as
+            #  27.0 gets past the range check and is a TypeError there)
+            self._kernel_size = operator.index(kernel_size)
         self._frame_score: float | None = None
         self._flash_filter = FlashFilter(mode=filter_mode, length=min_scene_len)
         self._have_last = False

@@ -158,3 +158,21 @@ def test_stats_manager_fuzz_slice_and_what_it_found(tmp_path):
         fps, prog = S.draw_program(np.random.default_rng([77, case_no]))
         a, b = S.run("ref", fps, prog, str(tmp_path)), S.run("ours", fps, prog, str(tmp_path))
         assert a == b, (case_no, prog, a, b)
+
+
+def test_api_surface_fuzz_slice():
+    """``tools/fuzz_api_vs_reference.py``: constructor arguments of every kind, SceneManager property assignments, the module helpers
+    (1.1 M cases clean after one fix: an odd FLOAT ``kernel_size`` passes the range check and is a TypeError in the reference, where
+    it builds the kernel).  Two documented differences are not drawn: CUBIC / LANCZOS4 are refused, and a non-Interpolation value is
+    refused at the assignment instead of at its first use."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_api_vs_reference as A
+
+    import pyscenedetect_amd as psd
+
+    with pytest.raises(TypeError):
+        psd.ContentDetector(kernel_size=27.0)
+    for case_no in range(4000):
+        case = A.draw_case(np.random.default_rng([5, case_no]))
+        a, b = A.outcome(lambda: A.run("ref", case)), A.outcome(lambda: A.run("ours", case))
+        assert a == b, (case_no, case, a, b)
