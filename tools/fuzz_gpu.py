@@ -242,8 +242,8 @@ def run(seed: int, seconds: float, max_cases: int, verbose: bool = False, engine
                 del dev
             else:  # hash
                 size = int(rng.choice([8, 16, 16, 32]))
-                if h < size or w < size:
-                    h, w = h + size, w + size
+                if (h < size or w < size) and rng.integers(0, 2):      # (the other half stays: thumbnails LARGER than the frame along
+                    h, w = h + size, w + size                             #  an axis -- OpenCV's enlarging INTER_AREA, round 5)
                     desc.update(h=h, w=w)
                 frames = draw_content(rng, n, h, w)
                 desc.update(size=size)
