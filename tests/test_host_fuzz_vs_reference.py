@@ -176,3 +176,27 @@ def test_api_surface_fuzz_slice():
         case = A.draw_case(np.random.default_rng([5, case_no]))
         a, b = A.outcome(lambda: A.run("ref", case)), A.outcome(lambda: A.run("ours", case))
         assert a == b, (case_no, case, a, b)
+
+
+def test_native_epilogues_against_the_reference_slice():
+    """``tools/fuzz_epilogue_vs_reference.py``: the whole-clip native decisions (``corpus.decide`` -> ``psd_epilogue_*``: what
+    ``detect_corpus`` and ``bench.py`` use) from oracle records against the reference's own SceneManager on the same clip
+    (9.1 k cases over two seeds: no difference)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import logging
+    import warnings
+
+    import fuzz_epilogue_vs_reference as E
+
+    level = logging.root.manager.disable
+    logging.disable(logging.CRITICAL)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for case_no in range(120):
+                frames, fps, name, kw, kernel = E.draw(np.random.default_rng([3, case_no]))
+                a = E.F.outcome(lambda: {"cuts": E.reference_cuts(frames, fps, name, kw, kernel)})
+                b = E.F.outcome(lambda: {"cuts": E.native_cuts(frames, fps, name, kw, kernel)})
+                assert a == b, (case_no, name, kw, kernel, a, b)
+    finally:
+        logging.disable(level)
