@@ -4,7 +4,7 @@ Build container only; records come from the CPU oracle; no GPU.
 
     python tools/fuzz_epilogue_vs_reference.py [--seconds 60] [--seed 1]
 
-Every case: a random synthetic clip, a frame rate, one detector of the four the epilogues replay (content / adaptive / hist /
+Every case: a random synthetic clip, a frame rate, one detector of the five the epilogues replay (content / adaptive / hist / hash /
 threshold) with random constructor arguments (``min_scene_len`` as frames / seconds / strings, both filter modes, edge weights, bins,
 fade bias, FLOOR / CEILING, ``add_final_scene``), the reference run WITHOUT a downscale -- and the cut list must be the same."""
 import argparse
@@ -26,13 +26,14 @@ import fuzz_host_vs_reference as F  # noqa: E402  (clips, the reference-side run
 from oracle.detectors_np import score_batch as oracle_score  # noqa: E402
 from pyscenedetect_amd import corpus  # noqa: E402
 
-NAMES = {"content": "ContentDetector", "adaptive": "AdaptiveDetector", "hist": "HistogramDetector", "threshold": "ThresholdDetector"}
+NAMES = {"content": "ContentDetector", "adaptive": "AdaptiveDetector", "hist": "HistogramDetector", "threshold": "ThresholdDetector",
+         "hash": "HashDetector"}
 
 
 def draw(rng):
     frames = F.draw_clip(rng)
     fps = [25.0, 30.0, 24.0, 29.97, 23.976, 60.0, 12.5][int(rng.integers(0, 7))]
-    name = list(NAMES)[int(rng.integers(0, 4))]
+    name = list(NAMES)[int(rng.integers(0, 5))]
     kw = {}
     if rng.integers(0, 4):
         kw["min_scene_len"] = F.draw_min_scene_len(rng)
@@ -62,6 +63,13 @@ def draw(rng):
             kw["threshold"] = float(round(rng.uniform(0.01, 0.6), 3))
         if rng.integers(0, 2):
             kw["bins"] = int(rng.choice([16, 32, 64, 100, 128, 200, 256]))
+    elif name == "hash":
+        if rng.integers(0, 2):
+            kw["threshold"] = float(round(rng.uniform(0.1, 0.6), 3))
+        if rng.integers(0, 2):
+            kw["size"] = int(rng.choice([8, 16]))
+        if rng.integers(0, 2):
+            kw["lowpass"] = int(rng.choice([1, 2, 4]))
     else:
         if rng.integers(0, 2):
             kw["threshold"] = int(rng.integers(3, 120))
@@ -87,6 +95,13 @@ def reference_cuts(frames, fps, name, kw, kernel):
 
 
 def native_cuts(frames, fps, name, kw, kernel):
+    if name == "hash":      # HashDetector: thumbnails (oracle) -> native DCT / median bits -> native decisions
+        from oracle import lib as orc
+        from pyscenedetect_amd import epilogue
+
+        size, lowpass = kw.get("size", 8), kw.get("lowpass", 2)
+        bits = epilogue.hash_bits(orc.hash_thumbs(frames, size * lowpass), size)
+        return [int(c) for c in epilogue.hash_cuts(bits, fps, kw.get("threshold", 0.35), kw.get("min_scene_len", 15))[0]]
     w = kw.get("weights")
     edges = name in ("content", "adaptive") and w is not None and w[3] > 0.0
     h, wd = frames.shape[1:3]
