@@ -27,21 +27,24 @@ sys.path[:0] = [os.path.join(ROOT, "oracle", "cv2_shim"), ROOT, "/root/reference
 
 import numpy as np  # noqa: E402
 
-import scenedetect as ref  # noqa: E402  (the reference, unmodified)
-from scenedetect.common import Interpolation as RefInterpolation  # noqa: E402
-from scenedetect.detector import FlashFilter as RefFlashFilter  # noqa: E402
-from scenedetect.detectors import (AdaptiveDetector as RefAdaptive, ContentDetector as RefContent, HashDetector as RefHash,  # noqa: E402
-                                   HistogramDetector as RefHistogram, ThresholdDetector as RefThreshold)
-from scenedetect.scene_manager import SceneManager as RefSceneManager  # noqa: E402
-from scenedetect.stats_manager import StatsManager as RefStatsManager  # noqa: E402
+try:        # the reference side: the build container only (``--engines`` on the GPU box compares two engines behind the mirror instead)
+    import scenedetect as ref  # noqa: E402  (the reference, unmodified)
+    from scenedetect.common import Interpolation as RefInterpolation  # noqa: E402
+    from scenedetect.detector import FlashFilter as RefFlashFilter  # noqa: E402
+    from scenedetect.detectors import (AdaptiveDetector as RefAdaptive, ContentDetector as RefContent, HashDetector as RefHash,  # noqa: E402
+                                       HistogramDetector as RefHistogram, ThresholdDetector as RefThreshold)
+    from scenedetect.scene_manager import SceneManager as RefSceneManager  # noqa: E402
+    from scenedetect.stats_manager import StatsManager as RefStatsManager  # noqa: E402
+    from oracle.gen_golden import MemoryStream, VfrMemoryStream  # noqa: E402
+
+    REF_CLASSES = {"ContentDetector": RefContent, "AdaptiveDetector": RefAdaptive, "HistogramDetector": RefHistogram,
+                   "ThresholdDetector": RefThreshold, "HashDetector": RefHash}
+except ImportError:
+    ref = None
 
 import pyscenedetect_amd as psd  # noqa: E402
 from oracle.detectors_np import OracleEngine  # noqa: E402
-from oracle.gen_golden import MemoryStream, VfrMemoryStream  # noqa: E402
 from pyscenedetect_amd.synth import make_clip  # noqa: E402
-
-REF_CLASSES = {"ContentDetector": RefContent, "AdaptiveDetector": RefAdaptive, "HistogramDetector": RefHistogram,
-               "ThresholdDetector": RefThreshold, "HashDetector": RefHash}
 
 
 def draw_min_scene_len(rng):
@@ -131,7 +134,7 @@ def build(side, name, kw, engine):
 
 def draw_clip(rng):
     h = int(rng.choice([24, 36, 37, 48, 54, 72]))
-    w = int(rng.choice([32, 53, 64, 80, 96, 128, 160, 300, 520]))
+    w = int(rng.choice([32, 53, 64, 80, 96, 128, 160, 300, 520, 640]))
     n = int(rng.integers(12, 110))
     kind = int(rng.integers(0, 5))
     seed = int(rng.integers(0, 1 << 30))
@@ -357,6 +360,9 @@ def main():
     ap.add_argument("--max-cases", type=int, default=100000)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--force", default="", help="comma list of case features to force: per_frame, reuse, pts, stats, second_pass, callback")
+    ap.add_argument("--engines", action="store_true",
+                    help="GPU box: the mirror over the HIP engine against the mirror over the oracle engine (no reference needed) -- the device "
+                         "feeder, tap-row uploads, crop / downscale modes, batch sizes, the carried frame, the per-frame resident path")
     ap.add_argument("--binding", action="store_true",
                     help="third side: the reference with INTEGRATION.md B's seams bound to the C-ABI (integration/scenedetect_amd.py over "
                          "oracle/libpsd_oracle_abi.so, the CPU build of the ABI), compared with the plain reference")
@@ -367,7 +373,13 @@ def main():
     logging.disable(logging.CRITICAL)
     warnings.simplefilter("ignore")
     engine = OracleEngine()
-    binding = amd = None
+    binding = amd = hip = None
+    if args.engines:
+        from pyscenedetect_amd.engine import ScoringEngine
+
+        hip = ScoringEngine(0)
+    elif ref is None:
+        raise SystemExit("the reference checkout is not here: only --engines works on this box")
     if args.binding:
         import subprocess
 
@@ -395,8 +407,12 @@ def main():
                     cfg["stats"] = True
                 if cfg.get("stats"):
                     cfg.pop("frame_skip", None)
-        a = outcome(lambda: run_side("ref", frames, fps, dets, cfg, None))
-        b = outcome(lambda: run_side("mirror", frames, fps, dets, cfg, engine))
+        if args.engines:
+            a = outcome(lambda: run_side("mirror", frames, fps, dets, cfg, engine))
+            b = outcome(lambda: run_side("mirror", frames, fps, dets, cfg, hip))
+        else:
+            a = outcome(lambda: run_side("ref", frames, fps, dets, cfg, None))
+            b = outcome(lambda: run_side("mirror", frames, fps, dets, cfg, engine))
         why = differ(a, b)
         if why is None and binding is not None:
             undo = amd.install(binding)
