@@ -83,7 +83,8 @@ class StatsManager:
             writer = csv.writer(csv_file, lineterminator="\n")
             keys = sorted(self._metric_keys)
             writer.writerow([COLUMN_NAME_FRAME_NUMBER, COLUMN_NAME_TIMECODE] + keys)
-            for key in sorted(self._frame_metrics.keys(), key=int):
+            for key in sorted(self._frame_metrics.keys()):      # (the keys' own order, like the reference: two timestamps that round
+                                                                  #  to one frame number are two rows, the earlier first)
                 # A row whose key is a bare frame number -- set through the public API with an int, or read back by the deprecated
                 # load_from_csv -- has no timecode to print: the reference skips it (stats_manager.py:196-199; a later set_metrics
                 # with a FrameTimecode for the same frame updates the row but the dict keeps the int key), unless the caller names
