@@ -30,6 +30,13 @@ class FrameScorer:
             raise ValueError("Image must be 8-bit BGR")
         if frame.ndim != 3 or frame.shape[2] != 3:
             raise ValueError("Image must have three color channels")
+        # A frame of another size than the one before: the reference's ContentDetector compares the planes it kept with the new
+        # ones behind `assert len(left.shape) == 2 and left.shape == right.shape` (content_detector.py:29-36); the terms that
+        # compare nothing across frames on the device (histogram, byte sum, thumbnails) go on, as in the reference.
+        last_shape = getattr(self, "_last_shape", None)
+        if last_shape is not None and last_shape != frame.shape and (flags & 9):      # HSV SAD | edges
+            raise AssertionError("frame size changed from %dx%d to %dx%d" % (last_shape[1], last_shape[0], frame.shape[1], frame.shape[0]))
+        self._last_shape = frame.shape
         engine = self.engine
         if hasattr(engine, "alloc") and hasattr(engine, "score_device"):
             return self._score_resident(engine, frame, flags, edge_kernel)

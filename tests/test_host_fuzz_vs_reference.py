@@ -200,3 +200,29 @@ def test_native_epilogues_against_the_reference_slice():
                 assert a == b, (case_no, name, kw, kernel, a, b)
     finally:
         logging.disable(level)
+
+
+def test_per_frame_api_refuses_a_size_change_like_the_reference(fuzz, oracle_engine):
+    """``process_frame()`` of the detectors that compare a frame with its predecessor (Content, Adaptive) on a frame of another size:
+    the reference asserts equal plane shapes (content_detector.py:33-34); the detectors that compare nothing across frames on the pixel
+    level go on on both sides.  And the manager skips such frames, with its error logged (scene_manager.py:655-664)."""
+    import scenedetect as ref
+
+    import pyscenedetect_amd as psd
+
+    frames, _ = fuzz.make_clip(8, 12, 36, 64, shot_len=(4, 6))
+    small = np.ascontiguousarray(frames[5][:30, :50])
+    for name, raises in (("ContentDetector", True), ("AdaptiveDetector", True), ("HistogramDetector", False), ("ThresholdDetector", False), ("HashDetector", False)):
+        for side, TC, det in (("ref", ref.FrameTimecode, fuzz.build("ref", name, {}, None)), ("mirror", psd.FrameTimecode, fuzz.build("mirror", name, {}, oracle_engine))):
+            for i in range(5):
+                det.process_frame(TC(i, 25.0), frames[i])
+            if raises:
+                with pytest.raises(AssertionError):
+                    det.process_frame(TC(5, 25.0), small)
+            else:
+                det.process_frame(TC(5, 25.0), small)
+    cfg = {"stats": True, "auto_downscale": False, "start_in_scene": False, "batch_frames": 7, "odd_frames": [3, 7]}
+    dets = [("ContentDetector", {"threshold": 10.0}), ("HistogramDetector", {})]
+    a = fuzz.outcome(lambda: fuzz.run_side("ref", frames, 25.0, dets, cfg, None))
+    b = fuzz.outcome(lambda: fuzz.run_side("mirror", frames, 25.0, dets, cfg, oracle_engine))
+    assert "ok" not in a and fuzz.differ(a, b) is None, fuzz.differ(a, b)

@@ -191,6 +191,15 @@ def draw_case(rng):
         sm["callback"] = True            # detect_scenes(callback=...): which frames it is handed, when, with what picture
     if sm["stats"] and rng.integers(0, 3) == 0:
         sm["second_pass"] = True         # the metrics saved to CSV, loaded into a fresh StatsManager, detection again from the cache
+        if rng.integers(0, 2):           # ... by ANOTHER set of detectors: some metrics cached, some not
+            sm["second_dets"] = [draw_detector(rng) for _ in range(int(rng.choice([1, 2, 3])))]
+    if rng.integers(0, 12) == 0:         # a few frames of another size in the stream (the reference logs an error and skips them)
+        k = int(rng.integers(1, 4))
+        sm["odd_frames"] = sorted({int(x) for x in rng.integers(1, n, k)})
+    if rng.integers(0, 25) == 0:
+        sm["fail_at"] = ("callback" if rng.integers(0, 2) else "read", int(rng.integers(0, n)))   # an exception from the caller's side
+        if sm["fail_at"][0] == "callback":
+            sm["callback"] = True
     if rng.integers(0, 12) == 0:     # things both sides must refuse (or accept) alike
         k = int(rng.integers(0, 8))
         if k == 0:
@@ -212,7 +221,28 @@ def draw_case(rng):
     return frames, fps, dets, sm
 
 
+class _Frames:
+    """The clip as the streams index it, with a few frames of another size and, maybe, a read that fails."""
+
+    def __init__(self, frames, odd, fail_read):
+        self.frames, self.odd, self.fail_read = frames, set(odd), fail_read
+        self.shape = frames.shape
+
+    def __len__(self):
+        return len(self.frames)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return _Frames(self.frames[i], [], None)
+        if self.fail_read is not None and i == self.fail_read:
+            raise OSError("decoder failure (fuzz)")
+        f = self.frames[i]
+        return np.ascontiguousarray(f[: max(1, f.shape[0] - 3), : max(1, f.shape[1] - 5)]) if i in self.odd else f
+
+
 def run_side(side, frames, fps, dets, cfg, engine):
+    if cfg.get("odd_frames") or (cfg.get("fail_at") or ("", 0))[0] == "read":
+        frames = _Frames(frames, cfg.get("odd_frames", []), cfg["fail_at"][1] if (cfg.get("fail_at") or ("", 0))[0] == "read" else None)
     # (one frame rate for both sides: the reference-side stream class of oracle/gen_golden.py turns a float into
     #  Fraction(fps).limit_denominator(10000), FrameTimecode snaps 23.976 to 24000/1001 -- both right, not the same clock)
     fps = Fraction(fps).limit_denominator(10000)
@@ -246,7 +276,14 @@ def run_side(side, frames, fps, dets, cfg, engine):
         if cfg.get("callback"):
             import zlib
 
-            kwargs["callback"] = lambda img, pos: seen.append([int(pos), list(img.shape), zlib.crc32(np.ascontiguousarray(img).tobytes())])
+            fail_cb = cfg["fail_at"][1] if (cfg.get("fail_at") or ("", 0))[0] == "callback" else None
+
+            def cb(img, pos):
+                seen.append([int(pos), list(img.shape), zlib.crc32(np.ascontiguousarray(img).tobytes())])
+                if fail_cb is not None and len(seen) > fail_cb % 5:
+                    raise KeyError("callback failure (fuzz)")
+
+            kwargs["callback"] = cb
         n = sm.detect_scenes(video, **kwargs)
         cuts = [c.frame_num for c in sm.get_cut_list(show_warning=False)]
         scenes = [[a.frame_num, b.frame_num] for a, b in sm.get_scene_list(start_in_scene=cfg["start_in_scene"])]
@@ -315,6 +352,8 @@ def run_side(side, frames, fps, dets, cfg, engine):
                 stats2 = psd.StatsManager()
                 sm2 = psd.SceneManager(stats2, engine=engine, batch_frames=int(cfg.get("batch_frames", 64)))
             out["loaded"] = stats2.load_from_csv(path)
+            if "second_dets" in cfg:
+                dets = cfg["second_dets"]          # (configure() reads `dets`)
             built2 = configure(sm2)
             video.reset()
             n2, cuts2, scenes2, seen2 = detect(sm2, video)
