@@ -132,7 +132,26 @@ def build(side, name, kw, engine):
     return cls(engine=engine, **kw)
 
 
+TINY = False     # --tiny: frames of a few pixels, clips of hundreds of frames: the decision logic (filters, windows, fades) per second
+
+
 def draw_clip(rng):
+    if TINY:
+        h, w, n = int(rng.integers(1, 7)), int(rng.integers(1, 9)), int(rng.integers(40, 700))
+        kind = int(rng.integers(0, 4))
+        lvl = rng.integers(0, 256, (n, 1, 1, 3))
+        if kind == 0:      # shots: a level per shot + noise
+            cuts = np.sort(rng.integers(0, n, int(rng.integers(1, 40))))
+            lvl = rng.integers(0, 256, (len(cuts) + 1, 1, 1, 3))[np.searchsorted(cuts, np.arange(n), side="right")]
+        elif kind == 1:    # fades in and out of black
+            t = np.arange(n)
+            lvl = (np.abs(np.sin(t / rng.uniform(5, 60))) * rng.integers(20, 256)).astype(int)[:, None, None, None] * np.ones(3, int)
+        elif kind == 2:    # slow drift with flashes
+            lvl = np.cumsum(rng.integers(-3, 4, (n, 1, 1, 3)), axis=0) + 128
+            flashes = rng.random(n) < 0.03
+            lvl[flashes] = 255
+        noise = rng.integers(-int(rng.integers(0, 6)), int(rng.integers(1, 6)), (n, h, w, 3))
+        return np.clip(lvl + noise, 0, 255).astype(np.uint8)
     h = int(rng.choice([24, 36, 37, 48, 54, 72]))
     w = int(rng.choice([32, 53, 64, 80, 96, 128, 160, 300, 520, 640]))
     n = int(rng.integers(12, 110))
@@ -399,6 +418,7 @@ def main():
     ap.add_argument("--max-cases", type=int, default=100000)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--force", default="", help="comma list of case features to force: per_frame, reuse, pts, stats, second_pass, callback")
+    ap.add_argument("--tiny", action="store_true", help="frames of a few pixels, clips of hundreds of frames: decision logic per second")
     ap.add_argument("--engines", action="store_true",
                     help="GPU box: the mirror over the HIP engine against the mirror over the oracle engine (no reference needed) -- the device "
                          "feeder, tap-row uploads, crop / downscale modes, batch sizes, the carried frame, the per-frame resident path")
@@ -409,6 +429,8 @@ def main():
     import logging
     import warnings
 
+    global TINY
+    TINY = args.tiny
     logging.disable(logging.CRITICAL)
     warnings.simplefilter("ignore")
     engine = OracleEngine()
