@@ -413,6 +413,24 @@ class ScoringEngine(TapRowPolicy):
                 out["frames"] = raw[:, : fh * fw * 3].reshape(n, fh, fw, 3)
             return out
 
+    def downscale_host(self, frames: np.ndarray, downscale: float, interpolation: int = 1) -> np.ndarray:
+        """Host frames uint8[N,H,W,3] as the reference's detectors and callbacks would be handed them behind a downscale
+        (``cv2.resize`` of ``scene_manager.py:666-678``), made on the device: one upload, ``analyze_device(want_frames=True)``."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if frames.ndim != 4 or frames.shape[3] != 3:
+            raise ValueError("frames must be uint8[N,H,W,3]")
+        n, h, w, _ = frames.shape
+        if n == 0 or downscale <= 1.0:
+            return frames.copy()
+        stride = (h * w * 3 + 15) & ~15
+        with self._lock:
+            src = self._scratch("ds_src", n * stride)
+            for i in range(n):
+                src.upload(frames[i].reshape(-1), i * stride)
+            out = self.analyze_device(src.ptr, n, h, w, stride, flags=0, downscale=downscale, interpolation=interpolation,
+                                      want_frames=True)
+            return np.array(out["frames"])
+
     # -- HashDetector thumbnails ---------------------------------------------------------------
     def hash_thumbs_device(self, d_frames: int, n: int, height: int, width: int, size: int,
                            row_stride: int | None = None, frame_stride: int | None = None) -> np.ndarray:

@@ -112,7 +112,9 @@ class SceneManager:
         self._interpolation = Interpolation.LINEAR
         self._exception_info = None
         self._stop = threading.Event()
-        self._frame_buffer: list[tuple[FrameTimecode, np.ndarray]] = []
+        # (position, frame, pending): ``pending`` is None for a frame that is already what the reference's buffer would hold, or
+        # (factor, interpolation) for a full-size frame of a call that needed no downscaled frames on the host (see _seen_frame)
+        self._frame_buffer: list[tuple] = []
         self._frame_buffer_size = 0
         self._crop = None
         self._carry_frame = None     # the last frame of the previous detect_scenes() call (see there)
@@ -227,11 +229,21 @@ class SceneManager:
             self._engine = default_engine()
         return self._engine
 
-    def _dispatch(self, position, frame_im, result, i: int, callback) -> bool:
+    def _seen_frame(self, idx: int) -> np.ndarray:
+        """The buffered frame as the reference's look-behind buffer holds it (scene_manager.py:422-425: the frame its decode
+        thread queued, i.e. cropped and DOWNSCALED).  A call without a callback and without plug-in detectors downloads no
+        downscaled frames; should a later call on the same manager hand one of its frames to a callback, it is made here."""
+        position, frame, pending = self._frame_buffer[idx]
+        if pending is not None:
+            frame = self._engine_or_default().downscale_host(np.asarray(frame)[None], pending[0], pending[1])[0]
+            self._frame_buffer[idx] = (position, frame, None)
+        return frame
+
+    def _dispatch(self, position, frame_im, result, i: int, callback, pending=None) -> bool:
         """One frame's worth of decisions for every detector (reference ``_process_frame`` :410-435).  ``result`` is the
         batch's device output (``_score_batch``), ``i`` the frame's index in it."""
         new_cuts = False
-        self._frame_buffer.append((position, frame_im))
+        self._frame_buffer.append((position, frame_im, pending))
         self._frame_buffer = self._frame_buffer[-(self._frame_buffer_size + 1):]
         h, w = result["size"] if result is not None else (frame_im.shape[0], frame_im.shape[1])
         for detector in self._detector_list:
@@ -252,9 +264,9 @@ class SceneManager:
             new_cuts = bool(cuts)
             if callback:
                 for cut in cuts:
-                    for buffered_pos, buffered in self._frame_buffer:
-                        if cut == buffered_pos:
-                            callback(buffered, buffered_pos)
+                    for idx, entry in enumerate(self._frame_buffer):
+                        if cut == entry[0]:
+                            callback(self._seen_frame(idx), entry[0])
         return new_cuts
 
     def _plan(self, callback, factor: float) -> dict:
@@ -368,7 +380,8 @@ class SceneManager:
 
         plan = self._plan(callback, factor)
         interp = self._interpolation.value          # one mode for the whole call: feeder and scoring must agree on it
-        engine = self._engine_or_default() if plan["device"] else None
+        # (a manager of plug-in detectors only still needs the engine behind a downscale: the frames they are handed are made there)
+        engine = self._engine_or_default() if (plan["device"] or plan["want_frames"]) else None
         # Engines with device batches: the decode thread uploads every frame straight into one of three device batch
         # buffers while this thread scores and decides the previous batch (host -> device copies overlap everything else).
         feeder = _DeviceFeeder(engine, self._batch_frames, factor, interp) if engine is not None and hasattr(engine, "analyze_device") else None
@@ -405,8 +418,9 @@ class SceneManager:
                         feeder.release(slot, keep_last=len(frames))
                     last_frame = frames[-1]
                 shown = result["frames"] if result is not None and result.get("frames") is not None else frames
+                pending = (factor, interp) if factor > 1.0 and shown is frames else None
                 for i, position in enumerate(positions):
-                    new_cuts = self._dispatch(position, shown[i], result, i, callback)
+                    new_cuts = self._dispatch(position, shown[i], result, i, callback, pending)
                     if progress_bar is not None:      # reference scene_manager.py:585-596
                         if new_cuts:
                             progress_bar.set_description(PROGRESS_BAR_DESCRIPTION % len(self._cutting_list), refresh=False)

@@ -126,8 +126,12 @@ class ArrayVideoStream(VideoStream):
         self._time_base = Fraction(time_base) if time_base is not None else None
         self._frames = frames
         self._n = len(frames)
-        first = np.asarray(frames[0]) if self._n else np.zeros((0, 0, 3), np.uint8)
-        self._size = (int(first.shape[1]), int(first.shape[0]))
+        shape = getattr(frames, "shape", None)
+        if shape is not None and len(shape) == 4:      # one array (or something shaped like one): no frame is read to learn the size
+            self._size = (int(shape[2]), int(shape[1]))
+        else:
+            first = np.asarray(frames[0]) if self._n else np.zeros((0, 0, 3), np.uint8)
+            self._size = (int(first.shape[1]), int(first.shape[0]))
         self._base = FrameTimecode(0, fps if isinstance(fps, (float, Fraction)) else float(fps))
         self._next = 0
         self._name = name

@@ -365,3 +365,69 @@ def test_one_manager_on_two_videos_carries_the_last_frame(golden, hip_engine, or
             results[clear_between, with_stats] = got
     # the carried frame shows: without clear() the second video's frame 0 is a cut (its predecessor is another shot's frame)
     assert 0 in results[False, False][1] and 0 not in results[True, False][1]
+
+
+_NEVER_RUN = pytest.mark.xfail(strict=False, reason="written after round 5's GPU budget was spent: the CPU twins in "
+                               "tests/test_host_fuzz_vs_reference.py are green, this one has not met hardware yet")
+
+
+class _MeanJump(psd.SceneDetector):
+    """A detector of the caller's own on the plug-in API only (no device path): it must be handed the downscaled frame."""
+
+    def __init__(self):
+        super().__init__()
+        self.seen, self.last = [], None
+
+    def process_frame(self, timecode, frame_img):
+        self.seen.append((timecode.frame_num, frame_img.shape, int(np.asarray(frame_img, dtype=np.int64).sum())))
+        mean = float(frame_img.mean())
+        cut = self.last is not None and abs(mean - self.last) >= 20.0
+        self.last = mean
+        return [timecode] if cut else []
+
+    def get_metrics(self):
+        return []
+
+
+@_NEVER_RUN
+@pytest.mark.parametrize("interpolation", ["LINEAR", "AREA"])
+def test_a_manager_of_plug_in_detectors_only_hands_them_downscaled_frames(hip_engine, oracle_engine, interpolation):
+    """reference scene_manager.py:666-678: every consumer sees the resized frame -- also when no built-in detector is registered
+    and nothing is scored (analyze_device(flags=0, want_frames=True) behind the row feeder)."""
+    frames = np.random.default_rng(8).integers(0, 256, (40, 270, 480, 3), dtype=np.uint8)
+    frames[17:] //= 3
+    runs = []
+    for engine in (hip_engine, oracle_engine):
+        det = _MeanJump()
+        sm = psd.SceneManager(engine=engine, batch_frames=16)
+        sm.auto_downscale = False
+        sm.downscale = 3
+        sm.interpolation = psd.Interpolation[interpolation]
+        sm.add_detector(det)
+        sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+        runs.append((det.seen, [c.frame_num for c in sm.get_cut_list(show_warning=False)]))
+    assert runs[0] == runs[1]
+    assert runs[0][0][0][1] == (90, 160, 3) and runs[0][1] == [17]
+    assert np.array_equal(hip_engine.downscale_host(frames[:5], 3, psd.Interpolation[interpolation].value),
+                          oracle_engine.downscale_host(frames[:5], 3, psd.Interpolation[interpolation].value))
+
+
+@_NEVER_RUN
+def test_callback_of_a_later_call_gets_the_downscaled_frame_an_earlier_call_buffered(hip_engine, oracle_engine):
+    """Detection in pieces: call 1 (no callback) buffers frame 20 at full size, call 2 reports the cut at 20 two frames late and
+    hands the buffered frame to its callback -- downscaled then (ScoringEngine.downscale_host), like the reference's buffer holds it."""
+    frames = np.random.default_rng(7).integers(118, 123, (50, 111, 480, 3), dtype=np.uint8)
+    frames[20:] += 90
+    runs = []
+    for engine in (hip_engine, oracle_engine):
+        sm = psd.SceneManager(engine=engine, batch_frames=7)
+        sm.auto_downscale = False
+        sm.downscale = 3
+        sm.add_detector(psd.AdaptiveDetector(engine=engine, weights=psd.ContentDetector.Components(1.0, 1.0, 2.0, 0.0)))
+        video = psd.ArrayVideoStream(frames, 24.0)
+        shown = []
+        sm.detect_scenes(video, duration=21)
+        sm.detect_scenes(video, callback=lambda img, pos: shown.append((pos.frame_num, img.shape, int(img.astype(np.int64).sum()))))
+        runs.append((shown, [c.frame_num for c in sm.get_cut_list(show_warning=False)]))
+    assert runs[0] == runs[1]
+    assert runs[0][1] == [20] and [s[:2] for s in runs[0][0]] == [(20, (37, 160, 3))]

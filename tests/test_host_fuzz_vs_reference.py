@@ -226,3 +226,59 @@ def test_per_frame_api_refuses_a_size_change_like_the_reference(fuzz, oracle_eng
     a = fuzz.outcome(lambda: fuzz.run_side("ref", frames, 25.0, dets, cfg, None))
     b = fuzz.outcome(lambda: fuzz.run_side("mirror", frames, 25.0, dets, cfg, oracle_engine))
     assert "ok" not in a and fuzz.differ(a, b) is None, fuzz.differ(a, b)
+
+
+def test_a_slice_of_the_wide_campaign(fuzz, oracle_engine):
+    """``--wide``: fractional / negative weights, larger kernels, odd hash sizes, detection from a seek position, detection in pieces
+    (``detect_scenes(duration=...)`` calls in a row on one video), a detector of the caller's own beside the others or alone."""
+    fuzz.WIDE = True
+    try:
+        own = 0
+        for case in range(120):
+            rng = np.random.default_rng([20250923, case])
+            frames, fps, dets, cfg = fuzz.draw_case(rng)
+            cfg["batch_frames"] = int(rng.choice([1, 7, 64]))
+            a = fuzz.outcome(lambda: fuzz.run_side("ref", frames, fps, dets, cfg, None))
+            b = fuzz.outcome(lambda: fuzz.run_side("mirror", frames, fps, dets, cfg, oracle_engine))
+            assert fuzz.differ(a, b) is None, (case, fuzz.differ(a, b), list(frames.shape), dets, cfg)
+            own += any(name == "MeanJump" for name, _ in dets)
+        assert own >= 5
+    finally:
+        fuzz.WIDE = False
+
+
+@pytest.mark.parametrize("alone", [True, False])
+def test_plug_in_detectors_see_the_downscaled_frame(fuzz, oracle_engine, alone):
+    """A detector written against the plug-in API (``detector.py:37-103``) is handed the frame the reference's decode thread
+    queued: cropped and downscaled (``scene_manager.py:666-678``).  A manager holding ONLY such detectors used to hand them the
+    full-size frame (no engine was asked to make the small one); found by hand while extending the fuzz, round 5."""
+    frames = np.random.default_rng(6).integers(0, 256, (20, 72, 640, 3), dtype=np.uint8)
+    frames[10:] //= 2
+    dets = [("MeanJump", {"jump": 20.0, "behind": 1})] + ([] if alone else [("ContentDetector", {})])
+    for cfg in ({"stats": True, "auto_downscale": True, "start_in_scene": True, "batch_frames": 7, "callback": True},
+                {"stats": False, "auto_downscale": False, "downscale": 3, "interpolation": "AREA", "crop": (7, 5, 600, 70),
+                 "start_in_scene": False, "batch_frames": 64}):
+        a = fuzz.run_side("ref", frames, 25.0, dets, cfg, None)
+        b = fuzz.run_side("mirror", frames, 25.0, dets, cfg, oracle_engine)
+        assert fuzz.differ(a, b) is None, fuzz.differ(a, b)
+        assert a["plugin_saw"][0][0][1][1] < 640 and a["cuts"]
+
+
+def test_callback_gets_downscaled_frames_buffered_by_an_earlier_call(fuzz, oracle_engine):
+    """Detection in pieces: the look-behind buffer (``scene_manager.py:422-425``) survives ``detect_scenes`` calls, so a cut found in
+    a later call can point at a frame an earlier call buffered -- downscaled, in the reference.  The mirror downloads downscaled
+    frames only for calls that have a callback; a frame buffered by a call without one is now downscaled when it is first handed
+    over (case 141 of seed 102, ``--wide``)."""
+    frames = np.random.default_rng(7).integers(100, 140, (50, 37, 160, 3), dtype=np.uint8)
+    frames[20:] += 90                     # a hard cut at frame 20, which AdaptiveDetector reports two frames late
+    dets = [("AdaptiveDetector", {"min_scene_len": 15, "weights": [1.0, 1.0, 2.0, 0.0]})]
+    small = 0
+    for first in (19, 20, 21, 22, 23):
+        cfg = {"stats": True, "auto_downscale": False, "downscale": 3, "interpolation": "LINEAR", "start_in_scene": True,
+               "callback": True, "chunks": [1, first], "batch_frames": 7}
+        a = fuzz.run_side("ref", frames, 24.0, dets, cfg, None)
+        b = fuzz.run_side("mirror", frames, 24.0, dets, cfg, oracle_engine)
+        assert fuzz.differ(a, b) is None, (first, fuzz.differ(a, b))
+        assert a["cuts"] == [20] and [x[0] for x in a["callback"]] in ([], [20])      # (no callback in the pieces' own calls)
+        small += bool(a["callback"]) and a["callback"][0][1] == [12, 53, 3]
+    assert small >= 2

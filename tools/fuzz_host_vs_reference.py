@@ -68,13 +68,15 @@ def draw_detector(rng):
     if name in ("ContentDetector", "AdaptiveDetector"):
         if rng.integers(0, 2):
             w = [float(rng.integers(0, 3)) for _ in range(3)] + [float(rng.integers(0, 2))]
+            if WIDE and rng.integers(0, 2):      # fractional and negative weights: the score divides by the sum of their magnitudes
+                w = [float(round(rng.uniform(-1.5, 2.5), 2)) if rng.integers(0, 4) else 0.0 for _ in range(4)]
             if sum(abs(x) for x in w) == 0:
                 w[2] = 1.0
             kw["weights"] = w
         if rng.integers(0, 4) == 0:
             kw["luma_only"] = True
         if rng.integers(0, 3) == 0:
-            kw["kernel_size"] = int(rng.choice([3, 5, 7, 9]))
+            kw["kernel_size"] = int(rng.choice([3, 5, 7, 9, 11, 15, 21, 31] if WIDE else [3, 5, 7, 9]))
     if name == "ContentDetector":
         if rng.integers(0, 3):
             kw["threshold"] = float(round(rng.uniform(4.0, 70.0), 2))
@@ -95,6 +97,8 @@ def draw_detector(rng):
     elif name == "ThresholdDetector":
         if rng.integers(0, 2):
             kw["threshold"] = float(rng.integers(3, 120)) if rng.integers(0, 2) else int(rng.integers(3, 120))
+            if WIDE and rng.integers(0, 3) == 0:     # a threshold with a fraction (the reference truncates it to an int)
+                kw["threshold"] = float(round(rng.uniform(0.0, 140.0), 2))
         if rng.integers(0, 2):
             kw["fade_bias"] = float(round(rng.uniform(-1.0, 1.0), 2))
         if rng.integers(0, 2):
@@ -105,14 +109,51 @@ def draw_detector(rng):
         if rng.integers(0, 2):
             kw["threshold"] = float(round(rng.uniform(0.1, 0.6), 3))
         if rng.integers(0, 2):
-            kw["size"] = int(rng.choice([8, 16]))
+            kw["size"] = int(rng.choice([2, 3, 4, 8, 12, 16, 32] if WIDE else [8, 16]))
         if rng.integers(0, 2):
-            kw["lowpass"] = int(rng.choice([1, 2, 4]))
+            kw["lowpass"] = int(rng.choice([1, 2, 3, 4, 5] if WIDE else [1, 2, 4]))
     return name, kw
+
+
+_PLUGINS = {}
+
+
+def plugin_class(base):
+    """A detector of the caller's own, written against the plug-in API only (detector.py:37-103): it sees frames, keeps a metric,
+    cuts on a jump of the frame's mean and looks ``behind`` frames back."""
+    if base not in _PLUGINS:
+        import zlib
+
+        class MeanJump(base):
+            def __init__(self, jump=12.0, behind=0):
+                super().__init__()
+                self.jump, self.behind, self.last, self.seen = jump, behind, None, []
+
+            def process_frame(self, timecode, frame_img):
+                self.seen.append([int(timecode.frame_num), list(frame_img.shape), zlib.crc32(np.ascontiguousarray(frame_img).tobytes())])
+                mean = float(np.asarray(frame_img, dtype=np.float64).mean())
+                if self.stats_manager is not None:
+                    self.stats_manager.set_metrics(timecode, {"mean_jump": mean})
+                cut = self.last is not None and abs(mean - self.last[1]) >= self.jump
+                out = [self.last[0]] if cut and self.behind else [timecode] if cut else []
+                self.last = (timecode, mean)
+                return out
+
+            def get_metrics(self):
+                return ["mean_jump"]
+
+            @property
+            def event_buffer_length(self):
+                return self.behind
+
+        _PLUGINS[base] = MeanJump
+    return _PLUGINS[base]
 
 
 def build(side, name, kw, engine):
     kw = dict(kw)
+    if name == "MeanJump":
+        return plugin_class(ref.detector.SceneDetector if side == "ref" else psd.SceneDetector)(**kw)
     if side == "ref":
         cls = REF_CLASSES[name]
         if "weights" in kw:
@@ -132,6 +173,7 @@ def build(side, name, kw, engine):
     return cls(engine=engine, **kw)
 
 
+WIDE = False     # --wide: detector arguments from wider ranges (fractional / negative weights, larger kernels, odd hash sizes, ...)
 TINY = False     # --tiny: frames of a few pixels, clips of hundreds of frames: the decision logic (filters, windows, fades) per second
 
 
@@ -176,6 +218,9 @@ def draw_case(rng):
     n, h, w = frames.shape[:3]
     fps = [25.0, 30.0, 24.0, 29.97, 23.976, 60.0, 12.5][int(rng.integers(0, 7))]
     dets = [draw_detector(rng) for _ in range(int(rng.choice([1, 1, 1, 2, 3])))]
+    if WIDE and rng.integers(0, 5) == 0:      # a detector of the caller's own: beside the others, or alone
+        own = ("MeanJump", {"jump": float(round(rng.uniform(2.0, 40.0), 1)), "behind": int(rng.choice([0, 0, 1, 4]))})
+        dets = [own] if rng.integers(0, 2) else dets + [own]
     sm = {"stats": bool(rng.integers(0, 3)), "auto_downscale": bool(rng.integers(0, 2))}
     if not sm["auto_downscale"] and rng.integers(0, 3) == 0:
         sm["downscale"] = int(rng.integers(1, 4))
@@ -219,6 +264,10 @@ def draw_case(rng):
         sm["fail_at"] = ("callback" if rng.integers(0, 2) else "read", int(rng.integers(0, n)))   # an exception from the caller's side
         if sm["fail_at"][0] == "callback":
             sm["callback"] = True
+    if WIDE and rng.integers(0, 4) == 0:
+        sm["seek"] = int(rng.integers(0, n + 1))              # detection starts somewhere inside the video (video.seek before detect_scenes)
+    if WIDE and rng.integers(0, 4) == 0:                  # detection in pieces: detect_scenes(duration=...) calls in a row on one video
+        sm["chunks"] = [int(rng.integers(1, max(2, n // 2))) for _ in range(int(rng.integers(1, 4)))]
     if rng.integers(0, 12) == 0:     # things both sides must refuse (or accept) alike
         k = int(rng.integers(0, 8))
         if k == 0:
@@ -345,8 +394,18 @@ def run_side(side, frames, fps, dets, cfg, engine):
         return {"frames_processed": len(frames), "cuts": emitted, "scenes": [], "metrics": metrics_of(stats, built), "callback": [],
                 "event_buffer": [int(d.event_buffer_length) for d in built]}
     built = configure(sm)
+    pieces = []
+    if "seek" in cfg:
+        video.seek(cfg["seek"])
+    for d in cfg.get("chunks", []):
+        got = sm.detect_scenes(video, duration=d, frame_skip=cfg.get("frame_skip", 0))
+        pieces.append([got, [c.frame_num for c in sm.get_cut_list(show_warning=False)],
+                       [[a.frame_num, b.frame_num] for a, b in sm.get_scene_list(start_in_scene=cfg["start_in_scene"])],
+                       video.frame_number, video.position.frame_num])
     n, cuts, scenes, seen = detect(sm, video)
-    out = {"frames_processed": n, "cuts": cuts, "scenes": scenes, "metrics": metrics_of(stats, built), "callback": seen}
+    out = {"frames_processed": n, "cuts": cuts, "scenes": scenes, "metrics": metrics_of(stats, built), "callback": seen,
+           "pieces": pieces, "stream": [video.frame_number, video.position.frame_num],
+           "plugin_saw": [d.seen for d in built if hasattr(d, "seen")]}
     if cfg.get("mode") == "reuse":
         # the same manager on a second video (the first one backwards): what carries over, what clear() resets
         if cfg["clear_between"]:
@@ -392,7 +451,7 @@ def differ(a, b):
         return "outcome kinds: %s vs %s" % (sorted(a), sorted(b))
     if "raises" in a:
         return None if a["raises"] == b["raises"] else "raises %s vs %s" % (a["raises"], b["raises"])
-    for k in ("frames_processed", "cuts", "scenes", "callback", "csv", "loaded", "event_buffer", "num_detectors"):
+    for k in ("frames_processed", "cuts", "scenes", "callback", "csv", "loaded", "event_buffer", "num_detectors", "pieces", "stream", "plugin_saw"):
         if a.get(k) != b.get(k):
             return "%s: %s vs %s" % (k, str(a.get(k))[:160], str(b.get(k))[:160])
     if ("second" in a) != ("second" in b):
@@ -418,6 +477,7 @@ def main():
     ap.add_argument("--max-cases", type=int, default=100000)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--force", default="", help="comma list of case features to force: per_frame, reuse, pts, stats, second_pass, callback")
+    ap.add_argument("--wide", action="store_true", help="wider argument ranges, detection from a seek position, detection in pieces")
     ap.add_argument("--tiny", action="store_true", help="frames of a few pixels, clips of hundreds of frames: decision logic per second")
     ap.add_argument("--engines", action="store_true",
                     help="GPU box: the mirror over the HIP engine against the mirror over the oracle engine (no reference needed) -- the device "
@@ -429,8 +489,8 @@ def main():
     import logging
     import warnings
 
-    global TINY
-    TINY = args.tiny
+    global TINY, WIDE
+    TINY, WIDE = args.tiny, args.wide
     logging.disable(logging.CRITICAL)
     warnings.simplefilter("ignore")
     engine = OracleEngine()
