@@ -109,6 +109,10 @@ class FramePair:
             raise ValueError("Image must be 8-bit BGR")
         frame = np.ascontiguousarray(frame)
         b = self._b
+        if self._have_prev and self._shape != frame.shape:
+            # the reference compares the planes it kept with the new ones behind `assert left.shape == right.shape`
+            # (content_detector.py:29-36) and keeps the old planes: same error, same state
+            raise AssertionError("frame size changed from %dx%d to %dx%d" % (self._shape[1], self._shape[0], frame.shape[1], frame.shape[0]))
         if self._shape != frame.shape:
             self.release()
             for i in range(2):

@@ -37,7 +37,13 @@ def test_same_records_through_the_same_binding():
             (a, ha), (b, hb) = pg.score_next(frames[t], flags, kernel), pc.score_next(frames[t], flags, kernel)
             assert ha == hb == (t > 0) and bytes(a) == bytes(b), f"pair: flags {flags} kernel {kernel} frame {t}"
             assert bytes(a) == bytes(gpu.score(frames[t], frames[t - 1] if t else None, flags, kernel))
-        other = np.ascontiguousarray(frames[0][:50, :70])            # a size change starts over (no predecessor)
+        # a frame of another size is refused like the reference's own comparison refuses it (`assert left.shape == right.shape`,
+        # content_detector.py:29-36) and the pair stays as it was; released, it starts over with any size
+        other = np.ascontiguousarray(frames[0][:50, :70])
+        with pytest.raises(AssertionError):
+            pg.score_next(other, flags, kernel)
+        assert bytes(pg.score_next(frames[-1], flags, kernel)[0]) == bytes(pc.score_next(frames[-1], flags, kernel)[0])
+        pg.release()
         assert pg.score_next(other, flags, kernel)[1] is False and pg.score_next(other, flags, kernel)[1] is True
     with pytest.raises(ValueError):
         gpu.score(frames[0], None, B.EDGES, 4)

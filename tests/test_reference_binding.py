@@ -75,3 +75,23 @@ def test_binding_only_touches_the_c_abi():
     src = open(os.path.join(ROOT, "integration", "scenedetect_amd.py")).read()
     assert "import pyscenedetect_amd" not in src and "from pyscenedetect_amd" not in src
     assert "import ctypes" in src and "psd_score_batch" in src
+
+
+def test_bound_content_detector_refuses_a_size_change_like_the_plain_one(patched_reference):
+    """Per-frame API: ``ContentDetector.process_frame`` on a frame of another size than its predecessor raises AssertionError in the
+    plain reference (``_mean_pixel_distance``, content_detector.py:29-36) and keeps the planes it had; the bound seam used to start
+    over with a score of 0.0 (``--binding --wide`` campaign of round 5, seed 109 case 60 and 17 more)."""
+    import scenedetect
+
+    frames = np.random.default_rng(3).integers(0, 256, (6, 40, 64, 3), dtype=np.uint8)
+    det = scenedetect.detectors.ContentDetector()
+    base = scenedetect.FrameTimecode(0, 25.0)
+    for i in range(3):
+        det.process_frame(base + i, frames[i])
+    with pytest.raises(AssertionError):
+        det.process_frame(base + 3, np.ascontiguousarray(frames[3][:30, :50]))
+    stats = scenedetect.StatsManager()          # the frame after is scored against frame 2, the last one that was accepted
+    det.stats_manager = stats
+    det.process_frame(base + 4, frames[4])
+    want = np.abs(frames[4].max(axis=2).astype(int) - frames[2].max(axis=2).astype(int)).mean()
+    assert stats.get_metrics(4, ["delta_lum"])[0] == want

@@ -30,6 +30,9 @@ NAMES = {"content": "ContentDetector", "adaptive": "AdaptiveDetector", "hist": "
          "hash": "HashDetector"}
 
 
+WIDE = False
+
+
 def draw(rng):
     frames = F.draw_clip(rng)
     fps = [25.0, 30.0, 24.0, 29.97, 23.976, 60.0, 12.5][int(rng.integers(0, 7))]
@@ -41,7 +44,9 @@ def draw(rng):
     if name in ("content", "adaptive"):
         if rng.integers(0, 2):
             w = [float(rng.integers(0, 3)) for _ in range(3)] + [float(rng.integers(0, 2))]
-            if sum(w) == 0:
+            if WIDE and rng.integers(0, 2):      # fractional and negative weights (the score divides by the sum of their magnitudes)
+                w = [float(round(rng.uniform(-1.5, 2.5), 2)) if rng.integers(0, 4) else 0.0 for _ in range(4)]
+            if sum(abs(x) for x in w) == 0:
                 w[2] = 1.0
             kw["weights"] = w
         if rng.integers(0, 3) == 0:
@@ -67,12 +72,14 @@ def draw(rng):
         if rng.integers(0, 2):
             kw["threshold"] = float(round(rng.uniform(0.1, 0.6), 3))
         if rng.integers(0, 2):
-            kw["size"] = int(rng.choice([8, 16]))
+            kw["size"] = int(rng.choice([2, 3, 4, 8, 12, 16, 32] if WIDE else [8, 16]))
         if rng.integers(0, 2):
-            kw["lowpass"] = int(rng.choice([1, 2, 4]))
+            kw["lowpass"] = int(rng.choice([1, 2, 3, 4, 5] if WIDE else [1, 2, 4]))
     else:
         if rng.integers(0, 2):
             kw["threshold"] = int(rng.integers(3, 120))
+            if WIDE and rng.integers(0, 3) == 0:
+                kw["threshold"] = float(round(rng.uniform(0.0, 140.0), 2))     # the reference truncates it to an int
         if rng.integers(0, 2):
             kw["fade_bias"] = float(round(rng.uniform(-1.0, 1.0), 2))
         if rng.integers(0, 2):
@@ -121,7 +128,11 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--wide", action="store_true", help="fractional / negative weights, fractional fade thresholds, odd hash sizes")
+    ap.add_argument("--tiny", action="store_true", help="frames of a few pixels, clips of hundreds of frames")
     args = ap.parse_args()
+    global WIDE
+    WIDE, F.TINY = args.wide, args.tiny
     logging.disable(logging.CRITICAL)
     warnings.simplefilter("ignore")
     t_end = time.time() + args.seconds

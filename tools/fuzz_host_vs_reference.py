@@ -268,6 +268,21 @@ def draw_case(rng):
         sm["seek"] = int(rng.integers(0, n + 1))              # detection starts somewhere inside the video (video.seek before detect_scenes)
     if WIDE and rng.integers(0, 4) == 0:                  # detection in pieces: detect_scenes(duration=...) calls in a row on one video
         sm["chunks"] = [int(rng.integers(1, max(2, n // 2))) for _ in range(int(rng.integers(1, 4)))]
+    if WIDE and "chunks" in sm and rng.integers(0, 3) == 0:
+        sm["add_between"] = draw_detector(rng)            # a detector that joins after the first piece
+        if rng.integers(0, 3) == 0:
+            sm["drop_between"] = True                     # ... after clear_detectors()
+    if WIDE and rng.integers(0, 12) == 0:                 # the package's detect() (scenedetect/__init__.py:110-219) on an opened video
+        sm["mode"] = "detect"
+        k = int(rng.integers(0, 4))
+        if k:
+            sm["start_time"] = [None, int(rng.integers(0, n)), float(round(rng.uniform(0, n / fps), 3)),
+                                "00:00:%06.3f" % rng.uniform(0, n / fps)][k]
+        sm.pop("end_time", None)
+        k = int(rng.integers(0, 5))
+        if k:
+            sm["end_time"] = [None, int(rng.integers(0, n + 5)), float(round(rng.uniform(0, (n + 5) / fps), 3)),
+                              "00:00:%06.3f" % rng.uniform(0, (n + 5) / fps), "%.2fs" % rng.uniform(0, (n + 5) / fps)][k]
     if rng.integers(0, 12) == 0:     # things both sides must refuse (or accept) alike
         k = int(rng.integers(0, 8))
         if k == 0:
@@ -393,6 +408,23 @@ def run_side(side, frames, fps, dets, cfg, engine):
                 emitted.append(["post", j, [c.frame_num for c in got]])
         return {"frames_processed": len(frames), "cuts": emitted, "scenes": [], "metrics": metrics_of(stats, built), "callback": [],
                 "event_buffer": [int(d.event_buffer_length) for d in built]}
+    if cfg.get("mode") == "detect":
+        import tempfile
+
+        det = build(side, dets[0][0], dets[0][1], engine)
+        kwargs = {k: cfg[k] for k in ("start_time", "end_time") if k in cfg}
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "stats.csv") if cfg["stats"] else None
+            if side == "ref":
+                opened, ref.open_video = ref.open_video, (lambda *a, **k: video)
+                try:
+                    scenes = ref.detect("memory", det, stats_file_path=path, start_in_scene=cfg["start_in_scene"], **kwargs)
+                finally:
+                    ref.open_video = opened
+            else:
+                scenes = psd.detect(video, det, stats_file_path=path, start_in_scene=cfg["start_in_scene"], engine=engine, **kwargs)
+            return {"scenes": [[a.frame_num, b.frame_num] for a, b in scenes], "csv": open(path).read() if path else "",
+                    "stream": [video.frame_number, video.position.frame_num]}
     built = configure(sm)
     pieces = []
     if "seek" in cfg:
@@ -402,6 +434,12 @@ def run_side(side, frames, fps, dets, cfg, engine):
         pieces.append([got, [c.frame_num for c in sm.get_cut_list(show_warning=False)],
                        [[a.frame_num, b.frame_num] for a, b in sm.get_scene_list(start_in_scene=cfg["start_in_scene"])],
                        video.frame_number, video.position.frame_num])
+        if "add_between" in cfg and len(pieces) == 1:
+            if cfg.get("drop_between"):
+                sm.clear_detectors()
+                built = []
+            built.append(build(side, cfg["add_between"][0], cfg["add_between"][1], engine))
+            sm.add_detector(built[-1])
     n, cuts, scenes, seen = detect(sm, video)
     out = {"frames_processed": n, "cuts": cuts, "scenes": scenes, "metrics": metrics_of(stats, built), "callback": seen,
            "pieces": pieces, "stream": [video.frame_number, video.position.frame_num],
@@ -460,6 +498,8 @@ def differ(a, b):
         why = differ(a["second"], b["second"])
         if why is not None:
             return "second pass (metrics from the loaded CSV): " + why
+    if "metrics" not in a:
+        return None
     if set(a["metrics"]) != set(b["metrics"]):
         return "metric keys: %s vs %s" % (sorted(a["metrics"]), sorted(b["metrics"]))
     for key, va in a["metrics"].items():
