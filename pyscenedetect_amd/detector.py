@@ -14,7 +14,22 @@ from enum import Enum
 
 import numpy as np
 
-from pyscenedetect_amd.timecode import FrameTimecode, Timecode, parse_timecode_seconds
+from pyscenedetect_amd.timecode import FrameTimecode, Timecode, adopt, give_back, parse_timecode_seconds
+
+
+def plug_in_api(method):
+    """``process_frame`` / ``post_process`` of the built-in detectors as ANY caller of the plug-in API may use them (reference
+    ``detector.py:48-73``) -- the reference's own SceneManager included, whose timecodes are ``scenedetect.FrameTimecode`` objects:
+    those are adopted for the detector's arithmetic and every cut goes back as the caller's own object."""
+    import functools
+
+    @functools.wraps(method)
+    def call(self, timecode, *args, **kwargs):
+        own = adopt(timecode)
+        cuts = method(self, own, *args, **kwargs)
+        return cuts if own is timecode else [give_back(cut) for cut in cuts]
+
+    return call
 
 
 class SceneDetector(ABC):
@@ -67,6 +82,11 @@ class SceneDetector(ABC):
     def process_thumb(self, timecode: FrameTimecode, thumb) -> list[FrameTimecode]:
         """Decide from a precomputed thumbnail (``psd_hash_thumbs*``)."""
         raise NotImplementedError
+
+
+def _time_backed(timecode) -> bool:
+    """A position held as a presentation timestamp or as seconds (not as a frame number)."""
+    return timecode is not None and (getattr(timecode, "_pts", None) is not None or getattr(timecode, "_secs", None) is not None)
 
 
 class FlashFilter:
@@ -164,7 +184,9 @@ class FlashFilter:
         # positions that are not plain frame numbers -- presentation timestamps, or timecodes a caller of process_frame() built
         # from seconds -- are compared the way the reference compares everything, on timecode arithmetic (the frame-number path
         # below is its equivalent for frame-backed positions; tools/fuzz_host_vs_reference.py found the seconds-backed case)
-        if getattr(timecode, "_pts", None) is not None or getattr(timecode, "_secs", None) is not None:
+        # (... and so is a frame-backed position that meets a time-backed one this filter kept from an earlier video: one manager
+        #  on a VFR and then a CFR stream without clear(), seed 115 case 3309)
+        if _time_backed(timecode) or _time_backed(self._last_above) or _time_backed(self._merge_start):
             return self._filter_by_time(timecode, above_threshold)
         need = self._resolve(timecode)
         now = timecode.frame_num

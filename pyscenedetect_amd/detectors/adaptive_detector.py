@@ -3,8 +3,9 @@
 
 import numpy as np
 
+from pyscenedetect_amd.detector import plug_in_api
 from pyscenedetect_amd.detectors.content_detector import ContentDetector
-from pyscenedetect_amd.timecode import FrameTimecode
+from pyscenedetect_amd.timecode import FrameTimecode, give_back
 
 
 class AdaptiveDetector(ContentDetector):
@@ -71,7 +72,7 @@ class AdaptiveDetector(ContentDetector):
             ratio = min(candidate / mean, 255.0)
         stats = self.stats_manager
         if stats is not None:
-            stats.set_metrics(candidate_tc, {self._adaptive_ratio_key: ratio})
+            stats.set_metrics(give_back(candidate_tc), {self._adaptive_ratio_key: ratio})
         is_peak = ratio >= self.adaptive_threshold and candidate >= self.min_content_val
         # The reference measures the gap from the CURRENT position but reports the candidate
         # (adaptive_detector.py:139-142); kept as is.
@@ -81,6 +82,7 @@ class AdaptiveDetector(ContentDetector):
         self._last_cut = candidate_tc
         return [candidate_tc]
 
+    @plug_in_api
     def process_frame(self, timecode: FrameTimecode, frame_img: np.ndarray) -> list[FrameTimecode]:
         record = self._scorer.score(frame_img, self.score_flags(), self.edge_kernel_size())
         return self.process_record(timecode, record, frame_img.shape[0], frame_img.shape[1])

@@ -14,9 +14,9 @@ import typing as ty
 import numpy as np
 
 from pyscenedetect_amd import _native
-from pyscenedetect_amd.detector import FlashFilter, SceneDetector
+from pyscenedetect_amd.detector import FlashFilter, SceneDetector, plug_in_api
 from pyscenedetect_amd.detectors._scorer import FrameScorer
-from pyscenedetect_amd.timecode import FrameTimecode
+from pyscenedetect_amd.timecode import FrameTimecode, give_back
 
 
 def estimated_kernel_size(frame_width: int, frame_height: int) -> int:
@@ -100,7 +100,7 @@ class ContentDetector(SceneDetector):
         if self.stats_manager is not None:
             metrics = {self.FRAME_SCORE_KEY: frame_score}
             metrics.update(components._asdict())
-            self.stats_manager.set_metrics(timecode, metrics)
+            self.stats_manager.set_metrics(give_back(timecode), metrics)
         return frame_score
 
     def process_record(self, timecode: FrameTimecode, record, height: int, width: int) -> list[FrameTimecode]:
@@ -108,6 +108,7 @@ class ContentDetector(SceneDetector):
         above = self._frame_score >= self._threshold
         return self._flash_filter.filter(timecode=timecode, above_threshold=above)
 
+    @plug_in_api
     def process_frame(self, timecode: FrameTimecode, frame_img: np.ndarray) -> list[FrameTimecode]:
         record = self._scorer.score(frame_img, self.score_flags(), self.edge_kernel_size())
         return self.process_record(timecode, record, frame_img.shape[0], frame_img.shape[1])

@@ -14,9 +14,9 @@ import typing as ty
 import numpy as np
 
 from pyscenedetect_amd import _native
-from pyscenedetect_amd.detector import SceneDetector
+from pyscenedetect_amd.detector import SceneDetector, plug_in_api
 from pyscenedetect_amd.detectors._scorer import FrameScorer
-from pyscenedetect_amd.timecode import FrameTimecode
+from pyscenedetect_amd.timecode import FrameTimecode, give_back
 
 
 def bin_lut(bins: int) -> np.ndarray:
@@ -117,10 +117,11 @@ class HistogramDetector(SceneDetector):
                 cut_list.append(timecode)
                 self._last_cut = timecode
             if self.stats_manager is not None:
-                self.stats_manager.set_metrics(timecode, {self._metric_key: hist_diff})
+                self.stats_manager.set_metrics(give_back(timecode), {self._metric_key: hist_diff})
         self._last_hist = hist
         return cut_list
 
+    @plug_in_api
     def process_frame(self, timecode: FrameTimecode, frame_img: np.ndarray) -> list[FrameTimecode]:
         if frame_img.dtype != np.uint8:
             raise ValueError("Image must be 8-bit rgb for HistogramDetector")

@@ -11,9 +11,9 @@ from enum import Enum
 import numpy as np
 
 from pyscenedetect_amd import _native
-from pyscenedetect_amd.detector import SceneDetector
+from pyscenedetect_amd.detector import SceneDetector, plug_in_api
 from pyscenedetect_amd.detectors._scorer import FrameScorer
-from pyscenedetect_amd.timecode import FrameTimecode
+from pyscenedetect_amd.timecode import FrameTimecode, give_back, new_like
 
 
 class ThresholdDetector(SceneDetector):
@@ -57,12 +57,12 @@ class ThresholdDetector(SceneDetector):
             self.last_scene_cut = timecode
         cuts: list[FrameTimecode] = []
         stats = self.stats_manager
-        if stats is not None and stats.metrics_exist(timecode, self._metric_keys):
-            frame_avg = stats.get_metrics(timecode, self._metric_keys)[0]
+        if stats is not None and stats.metrics_exist(give_back(timecode), self._metric_keys):
+            frame_avg = stats.get_metrics(give_back(timecode), self._metric_keys)[0]
         else:
             frame_avg = np.float64(int(record["byte_sum"]) / float(height * width * 3))
             if stats is not None:
-                stats.set_metrics(timecode, {self._metric_keys[0]: frame_avg})
+                stats.set_metrics(give_back(timecode), {self._metric_keys[0]: frame_avg})
         if self.processed_frame:
             if self.last_fade["type"] == "in" and self._faded_out(frame_avg):
                 self.last_fade["type"] = "out"
@@ -72,7 +72,7 @@ class ThresholdDetector(SceneDetector):
                     f_out = self.last_fade["frame"]
                     duration = timecode.frame_num - f_out.frame_num
                     split = f_out.frame_num + round(duration * (1.0 + self.fade_bias) / 2.0)
-                    cuts.append(FrameTimecode(split, fps=timecode))
+                    cuts.append(new_like(timecode, split))
                     self.last_scene_cut = timecode
                 self.last_fade["type"] = "in"
                 self.last_fade["frame"] = timecode
@@ -83,13 +83,15 @@ class ThresholdDetector(SceneDetector):
         self.processed_frame = True
         return cuts
 
+    @plug_in_api
     def process_frame(self, timecode: FrameTimecode, frame_img: np.ndarray) -> list[FrameTimecode]:
         stats = self.stats_manager
-        if stats is not None and stats.metrics_exist(timecode, self._metric_keys):
+        if stats is not None and stats.metrics_exist(give_back(timecode), self._metric_keys):
             return self.process_record(timecode, None, frame_img.shape[0], frame_img.shape[1])
         record = self._scorer.score(frame_img, self.score_flags())
         return self.process_record(timecode, record, frame_img.shape[0], frame_img.shape[1])
 
+    @plug_in_api
     def post_process(self, timecode: FrameTimecode) -> list[FrameTimecode]:
         cuts: list[FrameTimecode] = []
         elapsed = timecode if self.last_scene_cut is None else timecode - self.last_scene_cut

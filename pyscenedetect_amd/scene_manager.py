@@ -358,7 +358,8 @@ class SceneManager:
             effective_frame_size = (1 + min(x1, frame_width) - x0, 1 + min(y1, frame_height) - y0)
         factor = compute_downscale_factor(max(effective_frame_size)) if self.auto_downscale else self.downscale
 
-        self._base_timecode = video.base_timecode
+        # (every timecode a stream hands over becomes one of this package's: the stream may be one of the reference's backends)
+        self._base_timecode = FrameTimecode(video.base_timecode)
         if self._stats_manager is not None:
             self._stats_manager._base_timecode = self._base_timecode
         start_frame_num = video.frame_number
@@ -371,7 +372,7 @@ class SceneManager:
         if show_progress:          # reference scene_manager.py:549-563 (the total from the stream's duration, 0 if unknown)
             total_frames = 0
             if video.duration is not None:
-                if end_time is not None and end_time < video.duration:
+                if end_time is not None and end_time < FrameTimecode(video.duration):
                     total_frames = end_time - start_frame_num
                 else:
                     total_frames = video.duration.frame_num - start_frame_num
@@ -444,9 +445,9 @@ class SceneManager:
             exc = self._exception_info[1]
             raise exc.with_traceback(self._exception_info[2])
         self._carry_frame = last_frame
-        self._last_pos = video.position
+        self._last_pos = FrameTimecode(video.position)
         for detector in self._detector_list:
-            self._cutting_list += detector.post_process(video.position)
+            self._cutting_list += detector.post_process(FrameTimecode(video.position))
         return video.frame_number - start_frame_num
 
     def _decode_thread(self, video, frame_skip: int, end_time, out_queue: queue.Queue, feeder=None) -> None:
@@ -492,7 +493,7 @@ class SceneManager:
                     x0, y0, x1, y1 = self._crop
                     frame_im = frame_im[y0:y1, x0:x1]
                 if self._start_pos is None:
-                    self._start_pos = video.position
+                    self._start_pos = FrameTimecode(video.position)
                 if feeder is not None:
                     if slot is not None and slot["shape"] != frame_im.shape:
                         flush()              # a batch holds frames of one size
@@ -502,14 +503,16 @@ class SceneManager:
                             break
                     feeder.put(slot, len(frames), frame_im)
                 frames.append(frame_im)
-                positions.append(FrameTimecode(video.position))  # also accepts the reference's FrameTimecode
+                position = FrameTimecode(video.position)         # also accepts the reference's FrameTimecode
+                positions.append(position)
                 if len(frames) >= self._batch_frames:
                     flush()
                 if frame_skip > 0:
                     for _ in range(frame_skip):
                         if not video.read(decode=False):
                             break
-                if end_time is not None and not (video.position + 1) < end_time:
+                    position = FrameTimecode(video.position)
+                if end_time is not None and not (position + 1) < end_time:
                     break
             flush()
         except KeyboardInterrupt:
@@ -520,7 +523,7 @@ class SceneManager:
             self._stop.set()
         finally:
             if self._start_pos is None:
-                self._start_pos = video.position
+                self._start_pos = FrameTimecode(video.position)
             out_queue.put(None)
 
 

@@ -337,12 +337,44 @@ def _is_foreign_timecode(obj) -> bool:
 
 
 def _adopt_foreign(obj) -> "FrameTimecode":
-    """Take over a foreign timecode, keeping its presentation timestamp when it has one."""
+    """Take over a foreign timecode, keeping its presentation timestamp (or its seconds) when that is what it holds."""
     rate = framerate_to_fraction(obj.frame_rate)
     inner = getattr(obj, "_time", None)
     if inner is not None and hasattr(inner, "pts") and hasattr(inner, "time_base"):
         return FrameTimecode(Timecode(int(inner.pts), Fraction(inner.time_base)), rate)
+    if inner is not None and type(inner).__name__ == "_Seconds" and isinstance(getattr(inner, "value", None), float):
+        return FrameTimecode(float(inner.value), rate)          # (the reference's seconds-backed form, common.py:254-258)
     return FrameTimecode(int(obj.frame_num), rate)
+
+
+class _AdoptedTimecode(FrameTimecode):
+    """A foreign timecode taken over for a detector's own arithmetic; ``origin`` is the object it came from, which is what the
+    caller gets back (a cut list must hold the caller's own kind of timecode: the reference's SceneManager sorts and compares
+    the cuts of all its detectors with its stream's positions, scene_manager.py:403-408)."""
+
+    __slots__ = ("origin",)
+
+
+def adopt(timecode):
+    """``timecode`` as one of this package's; a foreign one (``scenedetect.FrameTimecode``) remembers where it came from."""
+    if isinstance(timecode, FrameTimecode) or not _is_foreign_timecode(timecode):
+        return timecode
+    own = _AdoptedTimecode(timecode)
+    own.origin = timecode
+    return own
+
+
+def give_back(timecode):
+    """The caller's own object for a timecode that was adopted; anything else as it is."""
+    return getattr(timecode, "origin", timecode)
+
+
+def new_like(timecode, frame_num: int):
+    """Frame ``frame_num`` at the rate of ``timecode``, as the same kind of object (``FrameTimecode(n, fps=timecode)``)."""
+    origin = getattr(timecode, "origin", None)
+    if origin is not None:
+        return adopt(type(origin)(frame_num, fps=origin))
+    return FrameTimecode(frame_num, fps=timecode)
 
 
 def _as_rate(fps) -> Fraction:

@@ -282,3 +282,100 @@ def test_callback_gets_downscaled_frames_buffered_by_an_earlier_call(fuzz, oracl
         assert a["cuts"] == [20] and [x[0] for x in a["callback"]] in ([], [20])      # (no callback in the pieces' own calls)
         small += bool(a["callback"]) and a["callback"][0][1] == [12, 53, 3]
     assert small >= 2
+
+
+@pytest.mark.parametrize("pts", [False, True])
+def test_mirror_reads_one_of_the_references_streams(fuzz, oracle_engine, pts):
+    """A user who keeps the reference's decoder backend and swaps the rest: the mirror's SceneManager and detectors over a
+    reference ``VideoStream`` whose positions are the REFERENCE's FrameTimecode objects.  ``post_process`` / ``_last_pos`` /
+    ``_start_pos`` used to receive those objects raw, and ThresholdDetector(add_final_scene) or any ``duration`` then raised
+    TypeError in the reference's timecode arithmetic (``--wide --cross``, seed 110: 20 of the first 73 cases)."""
+    frames = np.random.default_rng(9).integers(0, 256, (60, 36, 64, 3), dtype=np.uint8)
+    frames[20:31] //= 40
+    frames[45:] //= 2
+    dets = [("ThresholdDetector", {"add_final_scene": True, "min_scene_len": 5}), ("ContentDetector", {"min_scene_len": "0.2s"}),
+            ("AdaptiveDetector", {"min_scene_len": 0.3})]
+    for extra in ({}, {"duration": 1.3}, {"end_time": 50, "frame_skip": 1, "stats": False}, {"seek": 7, "chunks": [9, 20]}):
+        cfg = {"stats": True, "auto_downscale": True, "start_in_scene": True, "batch_frames": 7, "callback": True, **extra}
+        if pts:
+            cfg["pts"] = [int(x) for x in np.cumsum([0] + [40, 20, 60] * 20)[:60]]
+        a = fuzz.run_side("ref", frames, 25.0, dets, cfg, None)
+        c = fuzz.run_side("cross", frames, 25.0, dets, cfg, oracle_engine)
+        assert fuzz.differ(a, c) is None, (extra, fuzz.differ(a, c))
+        assert a["cuts"]
+
+
+def test_mirror_detectors_registered_with_the_references_own_manager(fuzz, oracle_engine):
+    """The plug-in API as the reference itself drives it: ``scenedetect.SceneManager().add_detector(pyscenedetect_amd.XDetector())``
+    over a reference stream with a reference StatsManager.  The cuts of all detectors end up in ONE list the reference sorts and
+    compares with its stream's positions (``scene_manager.py:403-408``), so every cut must be a ``scenedetect.FrameTimecode``:
+    ThresholdDetector used to build its fade cuts as this package's class (TypeError in the reference's ``sorted``), and the
+    FlashFilter took presentation timestamps of the reference's class for frame numbers (``--wide --plug``, seed 112: 11 of 476)."""
+    import scenedetect
+
+    frames = np.random.default_rng(9).integers(0, 256, (60, 36, 64, 3), dtype=np.uint8)
+    frames[20:31] //= 40
+    frames[45:] //= 2
+    dets = [("ThresholdDetector", {"add_final_scene": True, "min_scene_len": 5}), ("ContentDetector", {"min_scene_len": "0.2s"}),
+            ("AdaptiveDetector", {"min_scene_len": 0.3}), ("HistogramDetector", {}), ("HashDetector", {})]
+    for extra in ({}, {"pts": [int(x) for x in np.cumsum([0] + [40, 20, 60] * 20)[:60]]}, {"mode": "per_frame"},
+                  {"mode": "per_frame", "pts": [int(x) for x in np.cumsum([0] + [40, 20, 60] * 20)[:60]]},
+                  {"second_pass": True}, {"seek": 7, "chunks": [9, 20]}):
+        cfg = {"stats": True, "auto_downscale": True, "start_in_scene": True, "batch_frames": 7, "callback": True, **extra}
+        a = fuzz.run_side("ref", frames, 25.0, dets, cfg, None)
+        c = fuzz.run_side("plug", frames, 25.0, dets, cfg, oracle_engine)
+        assert fuzz.differ(a, c) is None, (extra, fuzz.differ(a, c))
+        assert a["cuts"]
+    # what comes back is the caller's own kind of timecode
+    det = fuzz.build("plug", "ThresholdDetector", {"min_scene_len": 2}, oracle_engine)
+    base = scenedetect.FrameTimecode(0, 25.0)
+    cuts = []
+    for i in range(40):
+        cuts += det.process_frame(base + i, frames[i])
+    assert cuts and all(type(c) is scenedetect.FrameTimecode for c in cuts)
+
+
+def test_a_slice_of_the_plug_and_cross_campaigns(fuzz, oracle_engine):
+    fuzz.WIDE = True
+    try:
+        for case in range(80):
+            rng = np.random.default_rng([20250924, case])
+            frames, fps, dets, cfg = fuzz.draw_case(rng)
+            cfg["batch_frames"] = int(rng.choice([1, 7, 64]))
+            a = fuzz.outcome(lambda: fuzz.run_side("ref", frames, fps, dets, cfg, None))
+            for side in ("plug", "cross"):
+                c = fuzz.outcome(lambda: fuzz.run_side(side, frames, fps, dets, cfg, oracle_engine))
+                assert fuzz.differ(a, c) is None, (side, case, fuzz.differ(a, c), list(frames.shape), dets, cfg)
+    finally:
+        fuzz.WIDE = False
+
+
+@pytest.mark.parametrize("mode", ["MERGE", "SUPPRESS"])
+def test_flash_filter_frame_backed_position_after_a_time_backed_one(fuzz, mode):
+    """One ContentDetector on a VFR stream and then, without clear(), on a CFR one: the filter's ``_last_above`` is a presentation
+    timestamp, the next position a frame number, and the reference compares them on timecode arithmetic
+    (``(timecode - last_above) >= secs``, detector.py:171-224: the difference is taken in the timestamp's time base).  The mirror
+    took its frame-number path for every frame-backed position (seed 115 case 3309: one cut too many)."""
+    import scenedetect
+    from scenedetect.common import Timecode as RefTimecode
+    from scenedetect.detector import FlashFilter as RefFlashFilter
+
+    import pyscenedetect_amd as psd
+    from fractions import Fraction
+
+    fps = Fraction(30000, 1001)
+    for length in ("0.182s", 5, 0.4):
+        a, b = RefFlashFilter(RefFlashFilter.Mode[mode], length), psd.FlashFilter(psd.FlashFilter.Mode[mode], length)
+        rng = np.random.default_rng(11)
+        got_a, got_b, pts = [], [], 0
+        for i in range(300):
+            above = bool(rng.random() < 0.3)
+            if i < 150:         # the first video: positions are presentation timestamps in milliseconds
+                pts += int(rng.choice([20, 40, 40, 60, 80]))
+                ta = scenedetect.FrameTimecode(RefTimecode(pts, Fraction(1, 1000)), fps)
+                tb = psd.FrameTimecode(psd.Timecode(pts, Fraction(1, 1000)), fps)
+            else:               # the second: frame numbers, starting over at 0
+                ta, tb = scenedetect.FrameTimecode(3 * (i - 150), fps), psd.FrameTimecode(3 * (i - 150), fps)
+            got_a += [(i, c.frame_num) for c in a.filter(ta, above)]
+            got_b += [(i, c.frame_num) for c in b.filter(tb, above)]
+        assert got_a == got_b and len(got_a) > 10, (length, got_a, got_b)

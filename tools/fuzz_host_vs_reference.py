@@ -153,7 +153,7 @@ def plugin_class(base):
 def build(side, name, kw, engine):
     kw = dict(kw)
     if name == "MeanJump":
-        return plugin_class(ref.detector.SceneDetector if side == "ref" else psd.SceneDetector)(**kw)
+        return plugin_class(ref.detector.SceneDetector if side in ("ref", "plug") else psd.SceneDetector)(**kw)
     if side == "ref":
         cls = REF_CLASSES[name]
         if "weights" in kw:
@@ -251,6 +251,8 @@ def draw_case(rng):
     elif k == 1:
         sm["mode"] = "reuse"             # one manager, two videos: with clear() in between or without
         sm["clear_between"] = bool(rng.integers(0, 2))
+        if WIDE and rng.integers(0, 2):
+            sm["pts2"] = [0] + [int(x) for x in np.cumsum(rng.choice([20, 40, 40, 40, 40, 60, 80], size=n - 1))]
     if rng.integers(0, 4) == 0:
         sm["callback"] = True            # detect_scenes(callback=...): which frames it is handed, when, with what picture
     if sm["stats"] and rng.integers(0, 3) == 0:
@@ -329,7 +331,7 @@ def run_side(side, frames, fps, dets, cfg, engine):
     # (one frame rate for both sides: the reference-side stream class of oracle/gen_golden.py turns a float into
     #  Fraction(fps).limit_denominator(10000), FrameTimecode snaps 23.976 to 24000/1001 -- both right, not the same clock)
     fps = Fraction(fps).limit_denominator(10000)
-    if side == "ref":
+    if side in ("ref", "plug"):      # "plug": the mirror's DETECTORS under the reference's own SceneManager, StatsManager and stream
         stats = RefStatsManager() if cfg["stats"] else None
         sm = RefSceneManager(stats)
         video = VfrMemoryStream(frames, fps, cfg["pts"], Fraction(1, 1000)) if "pts" in cfg else MemoryStream(frames, fps)
@@ -339,6 +341,8 @@ def run_side(side, frames, fps, dets, cfg, engine):
         sm = psd.SceneManager(stats, engine=engine, batch_frames=int(cfg.get("batch_frames", 64)))
         video = (psd.ArrayVideoStream(frames, fps, pts=cfg["pts"], time_base=Fraction(1, 1000)) if "pts" in cfg
                  else psd.ArrayVideoStream(frames, fps))
+        if side == "cross":      # the mirror's manager and detectors over one of the REFERENCE's streams (its timecodes, its positions)
+            video = VfrMemoryStream(frames, fps, cfg["pts"], Fraction(1, 1000)) if "pts" in cfg else MemoryStream(frames, fps)
         interp = psd.Interpolation
     def configure(sm):
         sm.auto_downscale = cfg["auto_downscale"]
@@ -393,7 +397,7 @@ def run_side(side, frames, fps, dets, cfg, engine):
                 d.stats_manager = stats
                 stats.register_metrics(d.get_metrics())
         emitted = []
-        tc_cls = ref.FrameTimecode if side == "ref" else psd.FrameTimecode
+        tc_cls = ref.FrameTimecode if side in ("ref", "plug") else psd.FrameTimecode
         base = video.base_timecode
         for i in range(len(frames)):
             tc = (base + i) if "pts" not in cfg else tc_cls(cfg["pts"][i] / 1000.0, fps)
@@ -415,7 +419,7 @@ def run_side(side, frames, fps, dets, cfg, engine):
         kwargs = {k: cfg[k] for k in ("start_time", "end_time") if k in cfg}
         with tempfile.TemporaryDirectory() as tmp:
             path = os.path.join(tmp, "stats.csv") if cfg["stats"] else None
-            if side == "ref":
+            if side in ("ref", "plug"):
                 opened, ref.open_video = ref.open_video, (lambda *a, **k: video)
                 try:
                     scenes = ref.detect("memory", det, stats_file_path=path, start_in_scene=cfg["start_in_scene"], **kwargs)
@@ -449,7 +453,10 @@ def run_side(side, frames, fps, dets, cfg, engine):
         if cfg["clear_between"]:
             sm.clear()
         rev = frames[::-1]
-        video2 = (MemoryStream(rev, fps) if side == "ref" else psd.ArrayVideoStream(rev, fps))
+        video2 = (MemoryStream(rev, fps) if side in ("ref", "cross", "plug") else psd.ArrayVideoStream(rev, fps))
+        if "pts2" in cfg:      # the second video with presentation timestamps (whatever the first one had)
+            video2 = (VfrMemoryStream(rev, fps, cfg["pts2"], Fraction(1, 1000)) if side in ("ref", "cross", "plug")
+                      else psd.ArrayVideoStream(rev, fps, pts=cfg["pts2"], time_base=Fraction(1, 1000)))
         n2, cuts2, scenes2, seen2 = detect(sm, video2)
         out["second"] = {"frames_processed": n2, "cuts": cuts2, "scenes": scenes2, "metrics": {}, "callback": seen2}
         out["num_detectors"] = sm.get_num_detectors()
@@ -461,7 +468,7 @@ def run_side(side, frames, fps, dets, cfg, engine):
             path = os.path.join(tmp, "stats.csv")
             stats.save_to_csv(path)
             out["csv"] = open(path).read()
-            if side == "ref":
+            if side in ("ref", "plug"):
                 stats2 = RefStatsManager()
                 sm2 = RefSceneManager(stats2)
             else:
@@ -522,6 +529,12 @@ def main():
     ap.add_argument("--engines", action="store_true",
                     help="GPU box: the mirror over the HIP engine against the mirror over the oracle engine (no reference needed) -- the device "
                          "feeder, tap-row uploads, crop / downscale modes, batch sizes, the carried frame, the per-frame resident path")
+    ap.add_argument("--cross", action="store_true",
+                    help="third side: the mirror's SceneManager and detectors reading one of the REFERENCE's VideoStream objects (a user who "
+                         "keeps the reference's decoder backend and swaps the rest)")
+    ap.add_argument("--plug", action="store_true",
+                    help="third side: the mirror's detectors registered with the REFERENCE's SceneManager (its stream, its StatsManager, "
+                         "its timecodes): the plug-in API as the reference itself drives it")
     ap.add_argument("--binding", action="store_true",
                     help="third side: the reference with INTEGRATION.md B's seams bound to the C-ABI (integration/scenedetect_amd.py over "
                          "oracle/libpsd_oracle_abi.so, the CPU build of the ABI), compared with the plain reference")
@@ -584,6 +597,16 @@ def main():
             why = differ(a, c)
             if why is not None:
                 why = "reference with the bound seams vs plain reference: " + why
+        if why is None and args.cross and not args.engines:
+            c = outcome(lambda: run_side("cross", frames, fps, dets, cfg, engine))
+            why = differ(a, c)
+            if why is not None:
+                why = "mirror over the reference's stream vs plain reference: " + why
+        if why is None and args.plug and not args.engines:
+            c = outcome(lambda: run_side("plug", frames, fps, dets, cfg, engine))
+            why = differ(a, c)
+            if why is not None:
+                why = "mirror's detectors under the reference's manager vs plain reference: " + why
         for name, _ in dets:
             by[name] = by.get(name, 0) + 1
         raised += "raises" in a
