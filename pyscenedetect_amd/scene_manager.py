@@ -22,7 +22,7 @@ import numpy as np
 
 from pyscenedetect_amd.detector import SceneDetector
 from pyscenedetect_amd.stats_manager import StatsManager
-from pyscenedetect_amd.timecode import FrameTimecode
+from pyscenedetect_amd.timecode import FrameTimecode, adopt, give_back
 
 logger = logging.getLogger("pyscenedetect")
 
@@ -94,12 +94,33 @@ def get_scenes_from_cuts(cut_list, start_pos, end_pos):
     return list(zip(bounds[:-1], bounds[1:]))
 
 
+def _score_flags(detector) -> int:
+    """The ``PSD_SCORE_*`` terms a detector wants from the device; 0 for a detector that only knows the plug-in API (one written
+    against the reference's ``scenedetect.SceneDetector`` has none of this package's extension methods)."""
+    fn = getattr(detector, "score_flags", None)
+    return int(fn()) if fn is not None else 0
+
+
+def _edge_kernel(detector) -> int:
+    fn = getattr(detector, "edge_kernel_size", None)
+    return int(fn()) if fn is not None else 0
+
+
+def _thumb_size(detector) -> int:
+    fn = getattr(detector, "hash_thumb_size", None)
+    return int(fn()) if fn is not None else 0
+
+
 class SceneManager:
     def __init__(self, stats_manager: StatsManager | None = None, engine=None,
                  batch_frames: int = DEFAULT_BATCH_FRAMES):
         self._cutting_list: list[FrameTimecode] = []
         self._detector_list: list[SceneDetector] = []
         self._stats_manager = stats_manager
+        if stats_manager is not None and not isinstance(stats_manager, StatsManager):
+            # (the reference's StatsManager writes only rows keyed by ITS FrameTimecode class: filled by this manager it saves a header)
+            logger.warning("stats_manager is a %s.%s, not a pyscenedetect_amd.StatsManager: metrics keyed by this package's timecodes "
+                           "may not be saved by it.", type(stats_manager).__module__, type(stats_manager).__name__)
         self._engine = engine
         self._batch_frames = max(1, int(batch_frames))
         self._start_pos = None
@@ -247,19 +268,23 @@ class SceneManager:
         self._frame_buffer = self._frame_buffer[-(self._frame_buffer_size + 1):]
         h, w = result["size"] if result is not None else (frame_im.shape[0], frame_im.shape[1])
         for detector in self._detector_list:
-            if result is not None and result["records"] is not None and detector.score_flags():
+            flags, size = _score_flags(detector), _thumb_size(detector)
+            if result is not None and result["records"] is not None and flags:
                 record = result["records"][i]
-                k = detector.edge_kernel_size()
-                if len(result["edge_xor"]) > 1 and (detector.score_flags() & 8):
+                k = _edge_kernel(detector)
+                if len(result["edge_xor"]) > 1 and (flags & 8):
                     record = record.copy()      # this detector's own dilation size (content_detector.py:135-137)
                     record["edge_xor"] = result["edge_xor"][k][i]
                 cuts = detector.process_record(position, record, h, w)
-            elif result is not None and detector.hash_thumb_size() and detector.hash_thumb_size() in result["thumbs"]:
-                size = detector.hash_thumb_size()
+            elif result is not None and size and size in result["thumbs"]:
                 bits = result["bits"].get((size, getattr(detector, "hash_size", None)))
                 cuts = detector.process_thumb(position, result["thumbs"][size][i], bits=None if bits is None else bits[i])
-            else:
+            elif isinstance(detector, SceneDetector):
                 cuts = detector.process_frame(position, frame_im)
+            else:
+                # a detector of another library's making (a subclass of the reference's ABC): it is handed the stream's own position
+                # object where the stream is of that library too, and what it returns joins the cut list as this package's timecodes
+                cuts = [adopt(cut) for cut in detector.process_frame(give_back(position), frame_im)]
             self._cutting_list += cuts
             new_cuts = bool(cuts)
             if callback:
@@ -273,13 +298,13 @@ class SceneManager:
         """What one pass over a batch has to produce for the registered detectors."""
         flags, kernels, thumb_sizes, fallback = 0, [], [], False
         for det in self._detector_list:
-            f = det.score_flags()
+            f = _score_flags(det)
             flags |= f
-            if f & 8 and det.edge_kernel_size() not in kernels:
-                kernels.append(det.edge_kernel_size())
-            if det.hash_thumb_size() and det.hash_thumb_size() not in thumb_sizes:
-                thumb_sizes.append(det.hash_thumb_size())
-            if not f and not det.hash_thumb_size():
+            if f & 8 and _edge_kernel(det) not in kernels:
+                kernels.append(_edge_kernel(det))
+            if _thumb_size(det) and _thumb_size(det) not in thumb_sizes:
+                thumb_sizes.append(_thumb_size(det))
+            if not f and not _thumb_size(det):
                 fallback = True      # a plug-in detector without a device path: process_frame(frame) like the reference
         # detectors on process_frame() and callbacks get the frame the reference would hand them: the DOWNSCALED one
         # (its decode thread resizes before queueing, scene_manager.py:666-678)
@@ -321,7 +346,7 @@ class SceneManager:
         # DCT / median for the whole batch at once (native, threaded) instead of once per frame
         res["bits"] = {}
         for det in self._detector_list:
-            size, hs = det.hash_thumb_size(), getattr(det, "hash_size", None)
+            size, hs = _thumb_size(det), getattr(det, "hash_size", None)
             if size and hs is not None and size in res["thumbs"] and (size, hs) not in res["bits"]:
                 res["bits"][(size, hs)] = epilogue.hash_bits(res["thumbs"][size], hs)
         return res
@@ -447,7 +472,10 @@ class SceneManager:
         self._carry_frame = last_frame
         self._last_pos = FrameTimecode(video.position)
         for detector in self._detector_list:
-            self._cutting_list += detector.post_process(FrameTimecode(video.position))
+            if isinstance(detector, SceneDetector):
+                self._cutting_list += detector.post_process(FrameTimecode(video.position))
+            else:
+                self._cutting_list += [adopt(cut) for cut in detector.post_process(video.position)]
         return video.frame_number - start_frame_num
 
     def _decode_thread(self, video, frame_skip: int, end_time, out_queue: queue.Queue, feeder=None) -> None:
@@ -503,7 +531,8 @@ class SceneManager:
                             break
                     feeder.put(slot, len(frames), frame_im)
                 frames.append(frame_im)
-                position = FrameTimecode(video.position)         # also accepts the reference's FrameTimecode
+                position = video.position                        # a copy of this package's kind; the reference's FrameTimecode is
+                position = FrameTimecode(position) if isinstance(position, FrameTimecode) else adopt(position)   # adopted, its origin kept
                 positions.append(position)
                 if len(frames) >= self._batch_frames:
                     flush()

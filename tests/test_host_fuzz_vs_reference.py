@@ -379,3 +379,22 @@ def test_flash_filter_frame_backed_position_after_a_time_backed_one(fuzz, mode):
             got_a += [(i, c.frame_num) for c in a.filter(ta, above)]
             got_b += [(i, c.frame_num) for c in b.filter(tb, above)]
         assert got_a == got_b and len(got_a) > 10, (length, got_a, got_b)
+
+
+@pytest.mark.parametrize("side", ["guest", "guest_cross"])
+def test_a_detector_written_against_the_references_abc_under_the_mirrors_manager(fuzz, oracle_engine, side):
+    """A user's own detector, derived from ``scenedetect.SceneDetector`` (none of this package's extension methods), registered with
+    ``pyscenedetect_amd.SceneManager`` beside the built-in ones: it used to stop ``detect_scenes`` with AttributeError
+    (``score_flags``).  It is a plug-in detector like any other: downscaled frames, its metrics in the manager's StatsManager (the
+    reference's timecodes as keys are adopted), its cuts in the one cut list; over the reference's stream it is handed the
+    stream's own position objects."""
+    frames = np.random.default_rng(12).integers(0, 256, (50, 72, 640, 3), dtype=np.uint8)
+    frames[13:] //= 2
+    frames[31:] //= 3
+    dets = [("MeanJump", {"jump": 15.0, "behind": 1}), ("ContentDetector", {}), ("ThresholdDetector", {"min_scene_len": 3})]
+    for extra in ({}, {"pts": [int(x) for x in np.cumsum([0] + [40, 20, 60] * 17)[:50]]}, {"second_pass": True}, {"seek": 5, "chunks": [10]}):
+        cfg = {"stats": True, "auto_downscale": True, "start_in_scene": True, "batch_frames": 7, "callback": True, **extra}
+        a = fuzz.run_side("ref", frames, 25.0, dets, cfg, None)
+        c = fuzz.run_side(side, frames, 25.0, dets, cfg, oracle_engine)
+        assert fuzz.differ(a, c) is None, (extra, fuzz.differ(a, c))
+        assert a["cuts"] and a["plugin_saw"][0][0][1] == [29, 256, 3]

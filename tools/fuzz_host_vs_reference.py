@@ -153,7 +153,7 @@ def plugin_class(base):
 def build(side, name, kw, engine):
     kw = dict(kw)
     if name == "MeanJump":
-        return plugin_class(ref.detector.SceneDetector if side in ("ref", "plug") else psd.SceneDetector)(**kw)
+        return plugin_class(ref.detector.SceneDetector if side in ("ref", "plug", "guest", "guest_cross") else psd.SceneDetector)(**kw)
     if side == "ref":
         cls = REF_CLASSES[name]
         if "weights" in kw:
@@ -341,7 +341,7 @@ def run_side(side, frames, fps, dets, cfg, engine):
         sm = psd.SceneManager(stats, engine=engine, batch_frames=int(cfg.get("batch_frames", 64)))
         video = (psd.ArrayVideoStream(frames, fps, pts=cfg["pts"], time_base=Fraction(1, 1000)) if "pts" in cfg
                  else psd.ArrayVideoStream(frames, fps))
-        if side == "cross":      # the mirror's manager and detectors over one of the REFERENCE's streams (its timecodes, its positions)
+        if side in ("cross", "guest_cross"):      # the mirror's manager and detectors over one of the REFERENCE's streams (its timecodes, its positions)
             video = VfrMemoryStream(frames, fps, cfg["pts"], Fraction(1, 1000)) if "pts" in cfg else MemoryStream(frames, fps)
         interp = psd.Interpolation
     def configure(sm):
@@ -453,9 +453,9 @@ def run_side(side, frames, fps, dets, cfg, engine):
         if cfg["clear_between"]:
             sm.clear()
         rev = frames[::-1]
-        video2 = (MemoryStream(rev, fps) if side in ("ref", "cross", "plug") else psd.ArrayVideoStream(rev, fps))
+        video2 = (MemoryStream(rev, fps) if side in ("ref", "cross", "plug", "guest_cross") else psd.ArrayVideoStream(rev, fps))
         if "pts2" in cfg:      # the second video with presentation timestamps (whatever the first one had)
-            video2 = (VfrMemoryStream(rev, fps, cfg["pts2"], Fraction(1, 1000)) if side in ("ref", "cross", "plug")
+            video2 = (VfrMemoryStream(rev, fps, cfg["pts2"], Fraction(1, 1000)) if side in ("ref", "cross", "plug", "guest_cross")
                       else psd.ArrayVideoStream(rev, fps, pts=cfg["pts2"], time_base=Fraction(1, 1000)))
         n2, cuts2, scenes2, seen2 = detect(sm, video2)
         out["second"] = {"frames_processed": n2, "cuts": cuts2, "scenes": scenes2, "metrics": {}, "callback": seen2}
@@ -532,6 +532,9 @@ def main():
     ap.add_argument("--cross", action="store_true",
                     help="third side: the mirror's SceneManager and detectors reading one of the REFERENCE's VideoStream objects (a user who "
                          "keeps the reference's decoder backend and swaps the rest)")
+    ap.add_argument("--guest", action="store_true",
+                    help="further sides, for cases that hold the plug-in detector: that detector derived from the REFERENCE's ABC (no extension "
+                         "methods of this package) registered with the mirror's SceneManager, over the mirror's stream and over the reference's")
     ap.add_argument("--plug", action="store_true",
                     help="third side: the mirror's detectors registered with the REFERENCE's SceneManager (its stream, its StatsManager, "
                          "its timecodes): the plug-in API as the reference itself drives it")
@@ -602,6 +605,13 @@ def main():
             why = differ(a, c)
             if why is not None:
                 why = "mirror over the reference's stream vs plain reference: " + why
+        if why is None and args.guest and not args.engines and any(name == "MeanJump" for name, _ in dets):
+            for side in ("guest", "guest_cross"):
+                c = outcome(lambda: run_side(side, frames, fps, dets, cfg, engine))
+                why = differ(a, c)
+                if why is not None:
+                    why = "a detector on the reference's ABC under the mirror's manager (%s) vs plain reference: %s" % (side, why)
+                    break
         if why is None and args.plug and not args.engines:
             c = outcome(lambda: run_side("plug", frames, fps, dets, cfg, engine))
             why = differ(a, c)
