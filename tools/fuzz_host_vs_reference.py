@@ -266,6 +266,8 @@ def draw_case(rng):
         sm["fail_at"] = ("callback" if rng.integers(0, 2) else "read", int(rng.integers(0, n)))   # an exception from the caller's side
         if sm["fail_at"][0] == "callback":
             sm["callback"] = True
+    if WIDE and rng.integers(0, 5) == 0:
+        sm["layout"] = ["negstride", "padded", "readonly"][int(rng.integers(0, 3))]
     if WIDE and rng.integers(0, 4) == 0:
         sm["seek"] = int(rng.integers(0, n + 1))              # detection starts somewhere inside the video (video.seek before detect_scenes)
     if WIDE and rng.integers(0, 4) == 0:                  # detection in pieces: detect_scenes(duration=...) calls in a row on one video
@@ -326,6 +328,15 @@ class _Frames:
 
 
 def run_side(side, frames, fps, dets, cfg, engine):
+    if cfg.get("layout") == "negstride":      # what `rgb[..., ::-1]` hands a detector: the same pixels, the channel axis walked backwards
+        frames = np.ascontiguousarray(frames[..., ::-1])[..., ::-1]
+    elif cfg.get("layout") == "padded":       # frames that are windows of larger buffers (a decoder's padded planes)
+        big = np.zeros((frames.shape[0], frames.shape[1] + 2, frames.shape[2] + 3, 3), np.uint8)
+        big[:, 1:-1, 2:-1] = frames
+        frames = big[:, 1:-1, 2:-1]
+    elif cfg.get("layout") == "readonly":
+        frames = frames.copy()
+        frames.setflags(write=False)
     if cfg.get("odd_frames") or (cfg.get("fail_at") or ("", 0))[0] == "read":
         frames = _Frames(frames, cfg.get("odd_frames", []), cfg["fail_at"][1] if (cfg.get("fail_at") or ("", 0))[0] == "read" else None)
     # (one frame rate for both sides: the reference-side stream class of oracle/gen_golden.py turns a float into
