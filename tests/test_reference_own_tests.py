@@ -8,7 +8,8 @@ imports cv2 and video fixtures) and importlib import mode (so that the reference
 Cases that open a video file are deselected BY NAME below; everything else must pass.  These are reference-held
 assertions -- stronger than the differential goldens of test_timecode.py / test_host_golden.py.  (First run of this file found
 four gaps: the deprecated ``get_framerate`` / ``equal_framerate`` / ``framerate`` names, ``Timecode`` as a minimum scene
-length, and ``pathlib.Path`` stats files.)  Skipped where the reference checkout does not exist (the GPU box)."""
+length, and ``pathlib.Path`` stats files.)  ``test_api.py`` -- the reference's "common workflow patterns" -- runs too, on a synthetic
+clip (see NEEDS_A_VIDEO below).  Skipped where the reference checkout does not exist (the GPU box)."""
 import os
 import re
 import subprocess
@@ -26,7 +27,13 @@ NEEDS_A_VIDEO = {
     "test_timecode.py": [],
     "test_benchmark_evaluator.py": [],      # (against tools/bbc_scoring.py, the harness's scorer on boxes without the reference)
 }
-EXPECT_AT_LEAST = {"test_timecode.py": 35, "test_stats_manager.py": 5, "test_scene_manager.py": 5, "test_benchmark_evaluator.py": 24}
+# test_api.py: "common workflow patterns used when integrating the PySceneDetect API" -- detect() with start / end times and a stats
+# file, SceneManager with seek / end_time, StatsManager.save_to_csv, a callback.  They assert nothing about WHERE the cuts are, so they
+# run on the alias package's synthetic clip (tests/ref_alias/workflow_plugin.py provides the fixture the reference's conftest would);
+# left out: open_video's deprecated keyword, cv2.VideoCapture, the deprecated import shims (decoders / packaging, out of scope).
+NEEDS_A_VIDEO["test_api.py"] = ["test_api_open_video_framerate_legacy_alias", "test_api_device_callback", "test_deprecated_modules"]
+WITH_PLUGIN = {"test_api.py"}
+EXPECT_AT_LEAST = {"test_api.py": 8, "test_timecode.py": 35, "test_stats_manager.py": 5, "test_scene_manager.py": 5, "test_benchmark_evaluator.py": 24}
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_TESTS), reason="the reference checkout is only in the build container")
@@ -36,6 +43,8 @@ def test_reference_test_file_passes_against_the_mirror(name, tmp_path):
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests", "ref_alias"), ROOT])
     cmd = [sys.executable, "-m", "pytest", "--noconftest", "--import-mode=importlib", "-p", "no:cacheprovider", "-q",
            os.path.join(REF_TESTS, name)]
+    if name in WITH_PLUGIN:
+        cmd[3:3] = ["-p", "workflow_plugin"]
     if NEEDS_A_VIDEO[name]:      # (exact names: none of them is a prefix of a case that stays)
         cmd += ["-k", "not (" + " or ".join(NEEDS_A_VIDEO[name]) + ")"]
     run = subprocess.run(cmd, cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
