@@ -20,16 +20,35 @@ from pyscenedetect_amd.video_stream import ArrayVideoStream, FrameRateUnavailabl
 __version__ = "0.1.0"
 
 
+def open_video(path, frame_rate=None, backend: str = "opencv", **kwargs):
+    """Counterpart of ``scenedetect.open_video()`` (reference ``scenedetect/__init__.py:89-157``).  Decoding is outside this
+    package: where the reference is installed its backends do it -- their ``VideoStream`` objects are
+    read by this package's ``SceneManager`` unchanged -- and without it this raises ``VideoOpenFailure``."""
+    try:
+        import scenedetect as _reference
+    except ImportError as ex:
+        raise VideoOpenFailure("pyscenedetect_amd decodes nothing itself: install scenedetect for its video backends, or pass decoded "
+                               "frames (an array uint8[N,H,W,3] or an ArrayVideoStream)") from ex
+    if frame_rate is not None:
+        kwargs["frame_rate"] = frame_rate
+    return _reference.open_video(path, backend=backend, **kwargs)
+
+
 def detect(video, detector, stats_file_path=None, show_progress=False, start_time=None, end_time=None,
-           start_in_scene=False, fps=25.0, engine=None):
-    """Counterpart of ``scenedetect.detect()`` (reference ``scenedetect/__init__.py:160-219``) for
-    already-decoded frames: ``video`` is a frame source (anything with the ``VideoStream`` members
-    ``SceneManager.detect_scenes`` uses, e.g. one of the reference's backends) or an array
-    ``uint8[N,H,W,3]`` of BGR frames.  Returns the scene list ``[(start, end), ...]``."""
+           start_in_scene=False, backend: str = "opencv", fps=25.0, engine=None):
+    """Counterpart of ``scenedetect.detect()`` (reference ``scenedetect/__init__.py:160-219``): ``video`` is an array
+    ``uint8[N,H,W,3]`` of BGR frames (at ``fps``), a frame source (anything with the ``VideoStream`` members
+    ``SceneManager.detect_scenes`` uses, e.g. one of the reference's backends), or -- like the reference's ``video_path`` -- a path
+    or list of paths, opened by :func:`open_video` with ``backend``.  Returns the scene list ``[(start, end), ...]``."""
+    import os as _os
+
     import numpy as _np
 
     if isinstance(video, _np.ndarray):
         video = ArrayVideoStream(video, fps)
+    elif isinstance(video, (str, _os.PathLike)) or (isinstance(video, (list, tuple)) and video
+                                                    and all(isinstance(v, (str, _os.PathLike)) for v in video)):
+        video = open_video(video, backend=backend)
     if start_time is not None:
         video.seek(start_time if isinstance(start_time, (int, FrameTimecode)) else FrameTimecode(start_time, video.frame_rate))
     manager = SceneManager(StatsManager() if stats_file_path else None, engine=engine)
@@ -42,6 +61,6 @@ def detect(video, detector, stats_file_path=None, show_progress=False, start_tim
 __all__ = [
     "AdaptiveDetector", "ArrayVideoStream", "compute_downscale_factor", "ContentDetector", "CropRegion", "CutList", "detect",
     "expand_scenes_to_bounds", "FlashFilter", "FrameMetricRegistered", "FrameRate", "FrameRateUnavailable", "FrameTimecode", "get_scenes_from_cuts",
-    "HashDetector", "HistogramDetector", "Interpolation", "SceneDetector", "SceneList", "SceneManager", "SeekError", "StatsFileCorrupt",
+    "HashDetector", "HistogramDetector", "Interpolation", "open_video", "SceneDetector", "SceneList", "SceneManager", "SeekError", "StatsFileCorrupt",
     "StatsManager", "ThresholdDetector", "Timecode", "TimecodeLike", "TimecodePair", "VideoOpenFailure", "VideoStream",
 ]

@@ -398,3 +398,45 @@ def test_a_detector_written_against_the_references_abc_under_the_mirrors_manager
         c = fuzz.run_side(side, frames, 25.0, dets, cfg, oracle_engine)
         assert fuzz.differ(a, c) is None, (extra, fuzz.differ(a, c))
         assert a["cuts"] and a["plugin_saw"][0][0][1] == [29, 256, 3]
+
+
+def test_detect_takes_a_path_like_the_references_and_leaves_decoding_to_its_backends(fuzz, oracle_engine, monkeypatch):
+    """``pyscenedetect_amd.detect("file.mp4", detector, backend=...)``: the path is opened by the reference's ``open_video`` where
+    that package is installed (decoding is out of scope; its streams are read unchanged) -- same scene list as from
+    the decoded frames, same as the reference's own ``detect()``; without the reference, ``VideoOpenFailure``."""
+    import builtins
+
+    import scenedetect
+
+    import pyscenedetect_amd as psd
+    from oracle.gen_golden import MemoryStream
+    from pyscenedetect_amd.synth import make_clip
+
+    frames, _ = make_clip(21, 200, 36, 64, shot_len=(30, 70))
+    opened = []
+
+    def fake_open(path, backend="opencv", **kwargs):
+        opened.append((path, backend))
+        return MemoryStream(frames, 25.0)
+
+    monkeypatch.setattr(scenedetect, "open_video", fake_open)
+    kwargs = {"start_time": 1.0, "end_time": "00:00:06.000", "start_in_scene": True}
+    want = [(a.frame_num, b.frame_num) for a, b in scenedetect.detect("clip.mp4", scenedetect.ContentDetector(), **kwargs)]
+    got = [(a.frame_num, b.frame_num) for a, b in psd.detect("clip.mp4", psd.ContentDetector(engine=oracle_engine), backend="pyav",
+                                                              engine=oracle_engine, **kwargs)]
+    from_frames = [(a.frame_num, b.frame_num) for a, b in psd.detect(frames, psd.ContentDetector(engine=oracle_engine),
+                                                                     engine=oracle_engine, **kwargs)]
+    assert got == want == from_frames and len(got) >= 3
+    assert opened == [("clip.mp4", "opencv"), ("clip.mp4", "pyav")]
+    psd.detect(["a.mp4", "b.mp4"], psd.ContentDetector(engine=oracle_engine), engine=oracle_engine)
+    assert opened[-1][0] == ["a.mp4", "b.mp4"]
+    real_import = builtins.__import__
+
+    def no_reference(name, *args, **kw):
+        if name == "scenedetect":
+            raise ImportError("No module named 'scenedetect'")
+        return real_import(name, *args, **kw)
+
+    monkeypatch.setattr(builtins, "__import__", no_reference)
+    with pytest.raises(psd.VideoOpenFailure, match="decodes nothing itself"):
+        psd.detect("clip.mp4", psd.ContentDetector(engine=oracle_engine), engine=oracle_engine)
