@@ -86,7 +86,7 @@ class SceneDetector(ABC):
 
 def _time_backed(timecode) -> bool:
     """A position held as a presentation timestamp or as seconds (not as a frame number)."""
-    return timecode is not None and (getattr(timecode, "_pts", None) is not None or getattr(timecode, "_secs", None) is not None)
+    return timecode is not None and getattr(timecode, "_frames", 0) is None      # (this package's timecodes: exactly one backing is set)
 
 
 class FlashFilter:

@@ -139,6 +139,7 @@ class SceneManager:
         self._frame_buffer_size = 0
         self._crop = None
         self._carry_frame = None     # the last frame of the previous detect_scenes() call (see there)
+        self._roles: list[tuple] = []  # (detector, score flags, thumbnail size, edge kernel) per registered detector (_dispatch)
 
     # -- configuration (reference :265-335) ---------------------------------------------------------
     @property
@@ -267,11 +268,12 @@ class SceneManager:
         self._frame_buffer.append((position, frame_im, pending))
         self._frame_buffer = self._frame_buffer[-(self._frame_buffer_size + 1):]
         h, w = result["size"] if result is not None else (frame_im.shape[0], frame_im.shape[1])
-        for detector in self._detector_list:
-            flags, size = _score_flags(detector), _thumb_size(detector)
+        roles = self._roles
+        if len(roles) != len(self._detector_list) or any(r[0] is not d for r, d in zip(roles, self._detector_list)):
+            roles = self._roles = [(d, _score_flags(d), _thumb_size(d), _edge_kernel(d)) for d in self._detector_list]
+        for detector, flags, size, k in roles:      # (what each detector wants from the device: asked once, not per frame)
             if result is not None and result["records"] is not None and flags:
                 record = result["records"][i]
-                k = _edge_kernel(detector)
                 if len(result["edge_xor"]) > 1 and (flags & 8):
                     record = record.copy()      # this detector's own dilation size (content_detector.py:135-137)
                     record["edge_xor"] = result["edge_xor"][k][i]
