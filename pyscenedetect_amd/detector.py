@@ -111,8 +111,8 @@ class FlashFilter:
             self._length_secs = length
         elif isinstance(length, str) and not length.strip().isdigit():
             self._length_secs = parse_timecode_seconds(length, 100)
-        elif isinstance(length, (Timecode, FrameTimecode)):      # any TimecodeLike (reference detector.py:136-137)
-            self._length_secs = length.seconds
+        elif isinstance(length, (Timecode, FrameTimecode)) or (hasattr(length, "seconds") and not isinstance(length, (int, str))):
+            self._length_secs = length.seconds       # any TimecodeLike (reference detector.py:136-137), of whichever library
         else:
             self._length_frames = int(length)
         self._threshold_frames = None  # resolved on the first frame

@@ -205,8 +205,7 @@ class FrameTimecode:
 
     # -- conversions of the other operand --------------------------------------------------------
     def _frames_of(self, other) -> int:
-        if _is_foreign_timecode(other):
-            other = FrameTimecode(other)
+        other = _own(other)
         if isinstance(other, int):
             return other
         if isinstance(other, float):
@@ -222,8 +221,7 @@ class FrameTimecode:
         raise TypeError("Cannot obtain frame number for this timecode.")
 
     def _seconds_of(self, other) -> float:
-        if _is_foreign_timecode(other):
-            other = FrameTimecode(other)
+        other = _own(other)
         if isinstance(other, int):
             return float(other) / float(self._rate)
         if isinstance(other, float):
@@ -236,8 +234,7 @@ class FrameTimecode:
 
     def _cmp_key(self, other):
         """(mine, theirs) in the unit the reference would compare in."""
-        if _is_foreign_timecode(other):
-            other = FrameTimecode(other)
+        other = _own(other)
         if isinstance(other, FrameTimecode):
             if self._pts is not None and other._pts is not None and self._rate == other._rate:
                 return self._pts.pts * self._pts.time_base, other._pts.pts * other._pts.time_base
@@ -278,8 +275,7 @@ class FrameTimecode:
 
     # -- arithmetic --------------------------------------------------------------------------------
     def _shifted(self, other, sign: int) -> "FrameTimecode":
-        if _is_foreign_timecode(other):
-            other = FrameTimecode(other)
+        other = _own(other)
         out = FrameTimecode(self)
         theirs = other._pts if isinstance(other, FrameTimecode) else (other if isinstance(other, Timecode) else None)
         mine = self._pts
@@ -334,6 +330,17 @@ class FrameTimecode:
 def _is_foreign_timecode(obj) -> bool:
     """Another library's frame timecode (e.g. ``scenedetect.FrameTimecode``): duck-typed."""
     return not isinstance(obj, (FrameTimecode, Timecode)) and hasattr(obj, "frame_num") and hasattr(obj, "frame_rate")
+
+
+def _own(obj):
+    """An operand of another library's making as this package's: its FrameTimecode, or its bare ``Timecode(pts, time_base)``."""
+    if isinstance(obj, (FrameTimecode, Timecode, int, float, str)) or obj is None:
+        return obj
+    if hasattr(obj, "frame_num") and hasattr(obj, "frame_rate"):
+        return FrameTimecode(obj)
+    if hasattr(obj, "pts") and hasattr(obj, "time_base"):
+        return Timecode(int(obj.pts), Fraction(obj.time_base))
+    return obj
 
 
 def _adopt_foreign(obj) -> "FrameTimecode":

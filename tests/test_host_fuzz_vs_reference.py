@@ -440,3 +440,21 @@ def test_detect_takes_a_path_like_the_references_and_leaves_decoding_to_its_back
     monkeypatch.setattr(builtins, "__import__", no_reference)
     with pytest.raises(psd.VideoOpenFailure, match="decodes nothing itself"):
         psd.detect("clip.mp4", psd.ContentDetector(engine=oracle_engine), engine=oracle_engine)
+
+
+def test_min_scene_len_as_an_object_of_the_references_classes(fuzz, oracle_engine):
+    """``min_scene_len`` is a TimecodeLike: whoever keeps part of the reference may hand this package's detectors one of the
+    REFERENCE's ``FrameTimecode`` / ``Timecode`` objects.  The FlashFilter took such an object for a frame count and the other
+    detectors could not compare with a bare foreign ``Timecode`` (TypeError; ``--wide --cross``, seed 124: case 19 and four more)."""
+    frames = np.random.default_rng(13).integers(0, 256, (70, 36, 64, 3), dtype=np.uint8)
+    for a in range(8, 70, 9):
+        frames[a:] = 255 - frames[a:]
+    for obj in (("Timecode", 597, 1000), ("FrameTimecode", 0.9, 25.0), ("FrameTimecode", 17, 30.0)):
+        dets = [(name, {"min_scene_len": obj}) for name in ("ContentDetector", "AdaptiveDetector", "HistogramDetector", "HashDetector",
+                                                              "ThresholdDetector")]
+        cfg = {"stats": True, "auto_downscale": False, "start_in_scene": False, "batch_frames": 7}
+        a = fuzz.run_side("ref", frames, 25.0, dets, cfg, None)
+        for side in ("mirror", "cross", "plug"):          # (mirror: this package's classes; cross / plug: the reference's)
+            c = fuzz.run_side(side, frames, 25.0, dets, cfg, oracle_engine)
+            assert fuzz.differ(a, c) is None, (obj, side, fuzz.differ(a, c))
+        assert len(a["cuts"]) >= 2

@@ -48,6 +48,14 @@ from pyscenedetect_amd.synth import make_clip  # noqa: E402
 
 
 def draw_min_scene_len(rng):
+    if WIDE and rng.integers(0, 6) == 0:      # a TimecodeLike that is an object: FrameTimecode (frames or seconds at its own rate) or Timecode
+        k = int(rng.integers(0, 3))
+        rate = [25.0, 30.0, 23.976][int(rng.integers(0, 3))]
+        if k == 0:
+            return ("FrameTimecode", int(rng.integers(0, 30)), rate)
+        if k == 1:
+            return ("FrameTimecode", float(round(rng.uniform(0.05, 1.5), 3)), rate)
+        return ("Timecode", int(rng.integers(0, 1500)), 1000)
     k = int(rng.integers(0, 5))
     if k == 0:
         return int(rng.integers(0, 30))
@@ -152,6 +160,11 @@ def plugin_class(base):
 
 def build(side, name, kw, engine):
     kw = dict(kw)
+    if isinstance(kw.get("min_scene_len"), tuple):      # the object form, in the class of the side that builds the detector
+        kind, value, scale = kw["min_scene_len"]
+        # (the mixed set-ups mix here too: whoever keeps part of the reference builds such objects with ITS classes)
+        mod = psd if side == "mirror" else ref.common
+        kw["min_scene_len"] = (mod.FrameTimecode(value, scale) if kind == "FrameTimecode" else mod.Timecode(value, Fraction(1, scale)))
     if name == "MeanJump":
         return plugin_class(ref.detector.SceneDetector if side in ("ref", "plug", "guest", "guest_cross") else psd.SceneDetector)(**kw)
     if side == "ref":
