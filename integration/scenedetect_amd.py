@@ -46,6 +46,8 @@ class Binding:
         lib.psd_memcpy_h2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
         lib.psd_score_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
                                                ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        lib.psd_hash_thumbs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
+                                        ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         self._lib = lib
         self._engine = ctypes.c_void_p()
         self._pairs = []
@@ -83,6 +85,18 @@ class Binding:
         if rc != 0:
             raise (ValueError if rc == -1 else RuntimeError)(self._lib.psd_last_error().decode())
         return rec
+
+
+    def hash_thumb(self, frame: np.ndarray, size: int) -> np.ndarray:
+        """``cv2.resize(cv2.cvtColor(frame, BGR2GRAY), (size, size), INTER_AREA)`` from the device (``psd_hash_thumbs``)."""
+        if frame.dtype != np.uint8 or frame.ndim != 3 or frame.shape[2] != 3:
+            raise ValueError("Image must be 8-bit BGR")
+        frame = np.ascontiguousarray(frame)
+        h, w, _ = frame.shape
+        out = np.empty((size, size), np.uint8)
+        self._check(self._lib.psd_hash_thumbs(self._engine, frame.ctypes.data, 1, h, w, frame.strides[0], frame.nbytes, int(size),
+                                              out.ctypes.data))
+        return out
 
 
 class FramePair:
@@ -151,9 +165,11 @@ def install(binding: Binding):
     import cv2
     from scenedetect.detectors import content_detector, histogram_detector, threshold_detector
     from scenedetect.detectors.content_detector import ContentDetector
+    from scenedetect.detectors.hash_detector import HashDetector
     from scenedetect.detectors.histogram_detector import HistogramDetector
 
-    saved = (ContentDetector._calculate_frame_score, HistogramDetector.calculate_histogram, threshold_detector.numpy)
+    saved = (ContentDetector._calculate_frame_score, HistogramDetector.calculate_histogram, threshold_detector.numpy,
+             HashDetector.hash_frame)
 
     def _calculate_frame_score(self, timecode, frame_img):
         calculate_edges = (self._weights.delta_edges > 0.0) or self.stats_manager is not None
@@ -186,7 +202,19 @@ def install(binding: Binding):
             hist = cv2.normalize(hist, hist).flatten()
         return hist
 
+    def hash_frame(frame_img, hash_size, factor) -> np.ndarray:
+        # the grey INTER_AREA thumbnail comes from the device (hash_detector.py:125-129); the lines below it stay as they are (:131-151)
+        resized_img = binding.hash_thumb(frame_img, hash_size * factor)
+        max_value = np.max(np.max(resized_img))
+        if max_value == 0:
+            max_value = 1
+        resized_img = np.asarray(np.float32(resized_img) / max_value)
+        dct_low_freq = cv2.dct(resized_img)[:hash_size, :hash_size]
+        med = np.median(np.asarray(dct_low_freq, dtype=np.float32))
+        return dct_low_freq > med
+
     ContentDetector._calculate_frame_score = _calculate_frame_score
+    HashDetector.hash_frame = staticmethod(hash_frame)
     HistogramDetector.calculate_histogram = staticmethod(calculate_histogram)
     threshold_detector.numpy = _NumpyWithDeviceMean(binding)
 
@@ -194,6 +222,7 @@ def install(binding: Binding):
         ContentDetector._calculate_frame_score = saved[0]
         HistogramDetector.calculate_histogram = staticmethod(saved[1])
         threshold_detector.numpy = saved[2]
+        HashDetector.hash_frame = staticmethod(saved[3])
         _ = content_detector, histogram_detector
 
     return uninstall

@@ -1,6 +1,6 @@
 /*
  * abi_cpu.c -- the entry points of include/psd_engine.h that a per-frame binding touches (psd_create, psd_destroy,
- * psd_score_batch, psd_last_error, psd_abi_version, and for a previous frame kept "on the device": psd_device_alloc,
+ * psd_score_batch, psd_hash_thumbs, psd_last_error, psd_abi_version, and for a previous frame kept "on the device": psd_device_alloc,
  * psd_device_free, psd_memcpy_h2d, psd_score_batch_device -- device memory is host memory here), implemented on the CPU oracle.
  *
  * TEST INFRASTRUCTURE ONLY, like everything under oracle/.  It exists so that the reference-side binding of
@@ -27,6 +27,9 @@ void orc_score_batch_flags(const uint8_t* frames, int n, int h, int w, size_t ro
 void orc_bgr2hsv_planes(const uint8_t* src, size_t src_step, uint8_t* hp, uint8_t* sp, uint8_t* vp, int h, int w);
 void orc_canny(const uint8_t* src, size_t step, int h, int w, double low_thresh, double high_thresh, uint8_t* dst);
 void orc_dilate_rect(const uint8_t* src, size_t step, int h, int w, int kh, int kw, uint8_t* dst);
+void orc_bgr2gray(const uint8_t* src, size_t src_step, uint8_t* dst, size_t dst_step, int h, int w);
+int orc_resize_area_u8(const uint8_t* src, size_t sstep, int sh, int sw, uint8_t* dst, size_t dstep, int dh, int dw);
+void orc_resize_area_upscale_u8(const uint8_t* src, size_t sstep, int sh, int sw, int cn, uint8_t* dst, size_t dstep, int dh, int dw);
 
 struct psd_engine { int unused; };
 static __thread char g_err[256];
@@ -142,4 +145,30 @@ int psd_score_batch_device(psd_engine* e, const uint8_t* d_frames, int n, int he
 {
     (void)stream;
     return psd_score_batch(e, d_frames, n, height, width, row_stride, frame_stride, d_prev, flags, edge_kernel, out);
+}
+
+/* HashDetector's front half: cv2.cvtColor(BGR2GRAY) + cv2.resize((size, size), INTER_AREA) per frame
+ * (scenedetect/detectors/hash_detector.py:125-129), like oracle/lib.py's hash_thumbs. */
+int psd_hash_thumbs(psd_engine* e, const uint8_t* h_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
+                    int size, uint8_t* h_thumbs)
+{
+    if (!e || n < 0 || height <= 0 || width <= 0 || size <= 0 || (n > 0 && (!h_frames || !h_thumbs)) || row_stride < (size_t)width * 3) {
+        snprintf(g_err, sizeof g_err, "psd_hash_thumbs: bad arguments");
+        return PSD_ERR_INVALID;
+    }
+    uint8_t* gray = (uint8_t*)malloc((size_t)height * width);
+    if (!gray) return PSD_ERR_NOMEM;
+    for (int t = 0; t < n; ++t) {
+        uint8_t* out = h_thumbs + (size_t)t * size * size;
+        orc_bgr2gray(h_frames + (size_t)t * frame_stride, row_stride, gray, (size_t)width, height, width);
+        if (size > width || size > height)
+            orc_resize_area_upscale_u8(gray, (size_t)width, height, width, 1, out, (size_t)size, size, size);
+        else if (orc_resize_area_u8(gray, (size_t)width, height, width, out, (size_t)size, size, size) != 0) {
+            free(gray);
+            snprintf(g_err, sizeof g_err, "psd_hash_thumbs: unsupported size");
+            return PSD_ERR_UNSUPPORTED;
+        }
+    }
+    free(gray);
+    return PSD_OK;
 }

@@ -45,6 +45,10 @@ def test_same_records_through_the_same_binding():
         assert bytes(pg.score_next(frames[-1], flags, kernel)[0]) == bytes(pc.score_next(frames[-1], flags, kernel)[0])
         pg.release()
         assert pg.score_next(other, flags, kernel)[1] is False and pg.score_next(other, flags, kernel)[1] is True
+    # HashDetector's seam: the grey INTER_AREA thumbnail (psd_hash_thumbs)
+    for size in (16, 32):
+        for t in (0, 3, 7):
+            assert np.array_equal(gpu.hash_thumb(frames[t], size), cpu.hash_thumb(frames[t], size)), f"thumb {size} frame {t}"
     with pytest.raises(ValueError):
         gpu.score(frames[0], None, B.EDGES, 4)
     with pytest.raises(ValueError):

@@ -95,3 +95,57 @@ def test_bound_content_detector_refuses_a_size_change_like_the_plain_one(patched
     det.process_frame(base + 4, frames[4])
     want = np.abs(frames[4].max(axis=2).astype(int) - frames[2].max(axis=2).astype(int)).mean()
     assert stats.get_metrics(4, ["delta_lum"])[0] == want
+
+
+def test_bound_hash_detector_takes_its_thumbnails_from_the_c_abi(patched_reference, golden):
+    """``HashDetector.hash_frame``'s ``cvtColor(BGR2GRAY)`` + ``resize(INTER_AREA)`` lines bound to ``psd_hash_thumbs``
+    (hash_detector.py:125-129; the DCT / median lines stay): same cuts and ``hash_dist`` metrics as the unbound reference, for
+    thumbnails smaller and larger than the frame."""
+    import scenedetect
+    import scenedetect_amd
+    from scenedetect.detectors import HashDetector
+
+    from tests.conftest import golden_clip
+
+    frames = golden_clip(golden, "scenes_a")
+    calls = []
+    original = scenedetect_amd.Binding.hash_thumb
+
+    def spy(self, frame, size):
+        calls.append(size)
+        return original(self, frame, size)
+
+    def run(**kw):
+        stats = scenedetect.StatsManager()
+        sm = scenedetect.SceneManager(stats)
+        sm.auto_downscale = False
+        det = HashDetector(**kw)
+        sm.add_detector(det)
+        sm.detect_scenes(patched_reference.MemoryStream(frames, 25.0))
+        key = det.get_metrics()[0]
+        return ([c.frame_num for c in sm.get_cut_list(show_warning=False)],
+                [stats.get_metrics(i, [key])[0] if stats.metrics_exist(i, [key]) else None for i in range(len(frames))])
+
+    for kw in ({}, {"size": 8, "lowpass": 4}, {"size": 32, "lowpass": 3}):          # 32, 32 and 96-pixel thumbnails of 72 x 128 frames
+        scenedetect_amd.Binding.hash_thumb = spy
+        try:
+            bound = run(**kw)
+        finally:
+            scenedetect_amd.Binding.hash_thumb = original
+        n_calls = len(calls)
+        assert n_calls >= len(frames)
+        saved = HashDetector.hash_frame
+        # the unbound method: what install() saved
+        import runpy
+
+        import scenedetect.detectors.hash_detector as module
+
+        plain_class = runpy.run_path(module.__file__)["HashDetector"]      # (a scratch copy of the source: nothing is reloaded)
+        try:
+            HashDetector.hash_frame = staticmethod(plain_class.hash_frame)
+            plain = run(**kw)
+        finally:
+            HashDetector.hash_frame = staticmethod(saved)
+        assert len(calls) == n_calls                       # the plain run did not touch the binding
+        assert bound == plain and len(bound[0]) >= 2, kw
+        calls.clear()
