@@ -60,11 +60,13 @@ class StatsManager:
     def set_metrics(self, timecode, metric_kv_dict: dict) -> None:
         if _is_foreign_timecode(timecode):
             timecode = FrameTimecode(timecode)
-        for key in metric_kv_dict:
-            self._metrics_updated = True
-            if timecode not in self._frame_metrics:
-                self._frame_metrics[timecode] = {}
-            self._frame_metrics[timecode][key] = metric_kv_dict[key]
+        if not metric_kv_dict:
+            return
+        self._metrics_updated = True
+        row = self._frame_metrics.get(timecode)          # (one lookup for the whole dict: every lookup hashes and compares a timecode)
+        if row is None:
+            row = self._frame_metrics[timecode] = {}
+        row.update(metric_kv_dict)
 
     def metrics_exist(self, timecode, metric_keys) -> bool:
         if _is_foreign_timecode(timecode):

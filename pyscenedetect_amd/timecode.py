@@ -153,6 +153,8 @@ class FrameTimecode:
     def equal_frame_rate(self, other) -> bool:
         if isinstance(other, FrameTimecode):
             other = other._rate
+        if other is self._rate:          # (positions of one stream share their rate object: no float arithmetic for the usual case)
+            return True
         return abs(float(self._rate) - float(other)) < MAX_FPS_DELTA
 
     # -- names the reference still answers to, each with one DeprecationWarning (common.py:292-306, 325-350, 375-383, 396-414)

@@ -34,10 +34,10 @@ def run(n, stats, det='content'):
     t = time.perf_counter(); sm.detect_scenes(v); dt = time.perf_counter() - t
     return dt / n * 1e6
 if __name__ == '__main__':
-    n = 60000
+    n = 30000
     for stats in (False, True):
         for det in ('content', 'adaptive'):
-            print(f"stats={stats} {det}: {min(run(n, stats, det) for _ in range(3)):.2f} us/frame")
+            print(f"stats={stats} {det}: {min(run(n, stats, det) for _ in range(7)):.2f} us/frame")
     if len(sys.argv) > 1:
         cProfile.run("run(60000, False)", "/tmp/psd_host_loop.prof")
         pstats.Stats("/tmp/psd_host_loop.prof").sort_stats("tottime").print_stats(18)
