@@ -509,3 +509,72 @@ def test_decode_thread_moves_onto_the_cpus_the_engine_names_and_nobody_else_does
     assert seen["near"] == one
     assert seen["nothing"] == mine and seen["refused"] == mine and seen["plain"] == mine
     assert os.sched_getaffinity(0) == mine
+
+
+def test_no_thread_outlives_detect_scenes(golden, oracle_engine):
+    """Thread hygiene (reference ``scene_manager.py:598-613``: "the decode thread must never be abandoned", and its test session's
+    thread-leak report, ``tests/conftest.py:186-211``): whatever ends a ``detect_scenes`` call -- the end of the video, ``end_time``, an
+    exception from the caller's callback or from the stream's ``read``, ``stop()`` from the callback -- no thread of the manager (the
+    decode thread, with a device engine also the feeder's) is alive afterwards."""
+    import threading
+
+    frames = golden_clip(golden, "scenes_a")
+    before = {t.ident for t in threading.enumerate()}
+
+    class Failing(psd.ArrayVideoStream):
+        def read(self, decode=True):
+            if self.frame_number == 40:
+                raise OSError("decoder failure")
+            return super().read(decode)
+
+    def run(video, **kwargs):
+        sm = psd.SceneManager(psd.StatsManager(), engine=oracle_engine, batch_frames=7)
+        sm.add_detector(psd.ContentDetector(engine=oracle_engine))
+        sm.add_detector(psd.AdaptiveDetector(engine=oracle_engine))
+        if kwargs.pop("stop", False):
+            kwargs["callback"] = lambda img, pos: sm.stop()
+        return sm.detect_scenes(video, **kwargs)
+
+    def failing_callback(img, pos):
+        raise KeyError("caller's callback failed")
+
+    assert run(psd.ArrayVideoStream(frames, 25.0)) == len(frames)
+    assert run(psd.ArrayVideoStream(frames, 25.0), end_time=50) == 50
+    with pytest.raises(KeyError):
+        run(psd.ArrayVideoStream(frames, 25.0), callback=failing_callback)
+    with pytest.raises(OSError):
+        run(Failing(frames, 25.0))
+    assert run(psd.ArrayVideoStream(frames, 25.0), stop=True) <= len(frames)
+    for _ in range(50):                     # (a thread that is finishing gets a moment)
+        left = [t for t in threading.enumerate() if t.ident not in before and t.name != "tqdm_monitor"]
+        if not left:
+            break
+        import time
+
+        time.sleep(0.02)
+    assert not left, [t.name for t in left]
+
+
+def test_happy_path_logs_nothing_at_error_level(golden, oracle_engine, caplog):
+    """The reference's test session fails any test that logs at ERROR level (``tests/conftest.py:91-101``); so do runs of the mirror:
+    every detector, downscale, crop, callback and a StatsManager on a clean clip log no error (a frame of another size does, as in
+    the reference, ``scene_manager.py:645-664``)."""
+    import logging
+
+    frames = golden_clip(golden, "wide_d")
+    with caplog.at_level(logging.DEBUG):
+        sm = psd.SceneManager(psd.StatsManager(), engine=oracle_engine, batch_frames=16)
+        sm.crop = (3, 2, 300, 170)
+        for cls in (psd.ContentDetector, psd.AdaptiveDetector, psd.HistogramDetector, psd.ThresholdDetector, psd.HashDetector):
+            sm.add_detector(cls(engine=oracle_engine))
+        sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0), callback=lambda img, pos: None)
+        assert sm.get_scene_list(start_in_scene=True)
+    assert not [r for r in caplog.records if r.levelno >= logging.ERROR], [r.getMessage() for r in caplog.records]
+    caplog.clear()
+    odd = list(frames[:12])
+    odd[5] = np.ascontiguousarray(odd[5][:-4, :-6])
+    with caplog.at_level(logging.DEBUG):
+        sm = psd.SceneManager(engine=oracle_engine)
+        sm.add_detector(psd.ContentDetector(engine=oracle_engine))
+        assert sm.detect_scenes(psd.ArrayVideoStream(odd, 25.0)) == 12
+    assert len([r for r in caplog.records if r.levelno >= logging.ERROR]) == 1
