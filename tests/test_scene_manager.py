@@ -578,3 +578,44 @@ def test_happy_path_logs_nothing_at_error_level(golden, oracle_engine, caplog):
         sm.add_detector(psd.ContentDetector(engine=oracle_engine))
         assert sm.detect_scenes(psd.ArrayVideoStream(odd, 25.0)) == 12
     assert len([r for r in caplog.records if r.levelno >= logging.ERROR]) == 1
+
+
+def test_long_stream_keeps_memory_bounded(oracle_engine):
+    """The reference's stress test (``tests/release/test_long_video.py:34-84``: RSS <= 3x baseline on a 15-minute clip) on a synthetic
+    stream of 40 000 frames that exist one at a time: without a StatsManager the manager keeps the look-behind buffer and one batch,
+    nothing that grows with the video (the reference's loop holds Queue(4) frames, ``scene_manager.py:113,422-425``)."""
+    import gc
+
+    psutil = pytest.importorskip("psutil")
+
+    class Endless:
+        """Frames made on demand: a shot every 97 frames, noise on top."""
+        shape = (40000, 36, 64, 3)
+
+        def __len__(self):
+            return self.shape[0]
+
+        def __getitem__(self, i):
+            rng = np.random.default_rng(i)
+            return (rng.integers(0, 24, (36, 64, 3)) + 13 * ((i // 97) % 17)).astype(np.uint8)
+
+    def rss():
+        gc.collect()
+        return psutil.Process().memory_info().rss
+
+    def run(n):
+        frames = Endless()
+        frames.shape = (n,) + frames.shape[1:]
+        sm = psd.SceneManager(engine=oracle_engine)
+        sm.auto_downscale = False
+        sm.add_detector(psd.ContentDetector(engine=oracle_engine))
+        sm.add_detector(psd.AdaptiveDetector(engine=oracle_engine))
+        assert sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0)) == n
+        return len(sm.get_cut_list(show_warning=False))
+
+    run(2000)                                   # warm: libraries, scratch buffers
+    base = rss()
+    cuts = run(40000)
+    grown = rss() - base
+    assert cuts >= 100
+    assert grown < 24 << 20, f"RSS grew by {grown >> 20} MiB over 40 000 frames of 7 KB"      # (all frames together: 276 MB)
