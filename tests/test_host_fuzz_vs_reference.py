@@ -458,3 +458,23 @@ def test_min_scene_len_as_an_object_of_the_references_classes(fuzz, oracle_engin
             c = fuzz.run_side(side, frames, 25.0, dets, cfg, oracle_engine)
             assert fuzz.differ(a, c) is None, (obj, side, fuzz.differ(a, c))
         assert len(a["cuts"]) >= 2
+
+
+def test_a_slice_of_the_campaign_over_the_simulated_device_engine(fuzz, oracle_engine):
+    """``--sim``: the mirror over a host-memory stand-in of the DEVICE engine (poisoned buffers, batched row uploads that land at the
+    fence, slots, the halo frame, frames wanted or pending, the resident per-frame path) against the reference -- the Python half of
+    the GPU path, on CPU; among the cases: managers of plug-in detectors only and callbacks on frames an earlier call buffered."""
+    fuzz.WIDE = True
+    try:
+        modes = set()
+        for case in range(100):
+            rng = np.random.default_rng([20250925, case])
+            frames, fps, dets, cfg = fuzz.draw_case(rng)
+            cfg["batch_frames"] = int(rng.choice([1, 7, 64]))
+            a = fuzz.outcome(lambda: fuzz.run_side("ref", frames, fps, dets, cfg, None))
+            c = fuzz.outcome(lambda: fuzz.run_side("mirror", frames, fps, dets, cfg, fuzz.sim_engine(oracle_engine)))
+            assert fuzz.differ(a, c) is None, (case, fuzz.differ(a, c), list(frames.shape), dets, cfg)
+            modes.add(cfg.get("mode", "manager"))
+        assert {"manager", "per_frame", "reuse"} <= modes
+    finally:
+        fuzz.WIDE = False

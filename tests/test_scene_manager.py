@@ -619,3 +619,35 @@ def test_long_stream_keeps_memory_bounded(oracle_engine):
     grown = rss() - base
     assert cuts >= 100
     assert grown < 24 << 20, f"RSS grew by {grown >> 20} MiB over 40 000 frames of 7 KB"      # (all frames together: 276 MB)
+
+
+@pytest.mark.parametrize("fps", [25.0, 29.97, 23.976, 60.0])
+def test_threshold_cuts_do_not_depend_on_what_backs_the_positions(oracle_engine, fps):
+    """The reference's cross-backend regression (``tests/release/test_backends.py:102-137``): a fade's cut frame is computed on frame
+    numbers (``threshold_detector.py:146-157``), so a stream whose positions are frame numbers, one whose positions are
+    sub-microsecond presentation timestamps (PyAV) and one with millisecond-truncated ones (OpenCV's CAP_PROP_POS_MSEC) give the
+    same cuts -- fades of every length, so that midpoints land on .5 boundaries."""
+    from fractions import Fraction
+
+    n = 400
+    level = np.full(n, 120, np.int64)
+    start = 20
+    for length in range(3, 22):                 # fade-outs / -ins of growing length
+        level[start:start + length] = 2
+        start += length + 9
+    frames = np.broadcast_to(level[:, None, None, None], (n, 8, 12, 3)).astype(np.uint8)
+    rate = psd.FrameTimecode(0, fps).frame_rate
+    micro = [round(Fraction(i) / rate * 1_000_000) for i in range(n)]
+    milli = [int(Fraction(i) / rate * 1000) for i in range(n)]          # truncated, like CAP_PROP_POS_MSEC
+
+    def cuts(video, **kw):
+        sm = psd.SceneManager(engine=oracle_engine)
+        sm.add_detector(psd.ThresholdDetector(min_scene_len=2, engine=oracle_engine, **kw))
+        sm.detect_scenes(video)
+        return [c.frame_num for c in sm.get_cut_list(show_warning=False)]
+
+    for kw in ({}, {"fade_bias": 0.31}, {"fade_bias": -1.0}, {"fade_bias": 1.0}):
+        by_frames = cuts(psd.ArrayVideoStream(frames, fps), **kw)
+        assert len(by_frames) >= 15
+        assert cuts(psd.ArrayVideoStream(frames, fps, pts=micro, time_base=Fraction(1, 1_000_000)), **kw) == by_frames
+        assert cuts(psd.ArrayVideoStream(frames, fps, pts=milli, time_base=Fraction(1, 1000)), **kw) == by_frames

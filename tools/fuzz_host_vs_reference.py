@@ -508,6 +508,53 @@ def run_side(side, frames, fps, dets, cfg, engine):
     return out
 
 
+def sim_engine(oracle):
+    """A stand-in of the DEVICE engine in host memory (tests/test_feed_rows.py: buffers that start poisoned, batched row uploads that
+    land only at the fence) with the rest of what SceneManager, the feeder and the per-frame scorer ask of ``ScoringEngine``: the
+    Python half of the GPU path -- device feeder, tap rows, slots and halo, frames wanted or pending, the resident per-frame path --
+    runs on CPU under the same fuzz."""
+    from tests.test_feed_rows import _AsyncHostBuffer, _BatchingEngine
+
+    class Buffer(_AsyncHostBuffer):
+        def upload(self, host, offset=0):
+            host = np.ascontiguousarray(host)
+            self.mem[offset: offset + host.nbytes] = host.reshape(-1).view(np.uint8)
+
+    class Sim(_BatchingEngine):
+        def alloc(self, nbytes):
+            self.buffers.append(Buffer(nbytes, self))
+            return self.buffers[-1]
+
+        def analyze_device(self, d_frames, n, height, width, frame_stride, d_prev=None, flags=0, edge_kernels=(0,), downscale=1.0,
+                           hash_sizes=(), interpolation=1, want_frames=False):
+            out = super().analyze_device(d_frames, n, height, width, frame_stride, d_prev=d_prev, flags=flags, edge_kernels=edge_kernels,
+                                         downscale=downscale, hash_sizes=hash_sizes, interpolation=interpolation, want_frames=want_frames)
+            if flags & 8:      # (the stand-in of the tests scores the first dilation size only; ScoringEngine.analyze_device: every one)
+                frames = self._view(d_frames, n, height, width, frame_stride)
+                prev = self._view(d_prev, 1, height, width, frame_stride)[0] if d_prev else None
+                kw = {"downscale": downscale, "interpolation": interpolation} if downscale > 1.0 else {}
+                for k in list(dict.fromkeys(edge_kernels))[1:]:
+                    out["edge_xor"][k] = self.oracle.score_host(frames, prev=prev, flags=8, edge_kernel=k, **kw)["edge_xor"]
+            return out
+
+        def score_host(self, *a, **k):
+            return self.oracle.score_host(*a, **k)
+
+        def hash_thumbs_host(self, *a, **k):
+            return self.oracle.hash_thumbs_host(*a, **k)
+
+        def downscale_host(self, *a, **k):
+            return self.oracle.downscale_host(*a, **k)
+
+        def score_device(self, d_frames, n, height, width, row_stride=None, frame_stride=None, d_prev=None, flags=0, edge_kernel=0, **_):
+            stride = height * width * 3 if frame_stride is None else frame_stride
+            frames = self._view(d_frames, n, height, width, stride)
+            prev = self._view(d_prev, 1, height, width, stride)[0] if d_prev else None
+            return self.oracle.score_host(frames, prev=prev, flags=flags, edge_kernel=edge_kernel)
+
+    return Sim(oracle)
+
+
 def outcome(fn):
     try:
         return fn()
@@ -559,6 +606,9 @@ def main():
     ap.add_argument("--guest", action="store_true",
                     help="further sides, for cases that hold the plug-in detector: that detector derived from the REFERENCE's ABC (no extension "
                          "methods of this package) registered with the mirror's SceneManager, over the mirror's stream and over the reference's")
+    ap.add_argument("--sim", action="store_true",
+                    help="further side: the mirror over a host-memory stand-in of the DEVICE engine (feeder, tap rows, slots, halo, resident "
+                         "per-frame path): the Python half of the GPU path on CPU")
     ap.add_argument("--plug", action="store_true",
                     help="third side: the mirror's detectors registered with the REFERENCE's SceneManager (its stream, its StatsManager, "
                          "its timecodes): the plug-in API as the reference itself drives it")
@@ -636,6 +686,11 @@ def main():
                 if why is not None:
                     why = "a detector on the reference's ABC under the mirror's manager (%s) vs plain reference: %s" % (side, why)
                     break
+        if why is None and args.sim and not args.engines:
+            c = outcome(lambda: run_side("mirror", frames, fps, dets, cfg, sim_engine(engine)))
+            why = differ(a, c)
+            if why is not None:
+                why = "mirror over the simulated device engine vs plain reference: " + why
         if why is None and args.plug and not args.engines:
             c = outcome(lambda: run_side("plug", frames, fps, dets, cfg, engine))
             why = differ(a, c)
