@@ -407,6 +407,7 @@ class SceneManager:
         prev_position = None
 
         plan = self._plan(callback, factor)
+        self._roles = []                            # (asked again with the first frame of every call: a detector's wishes may have changed)
         interp = self._interpolation.value          # one mode for the whole call: feeder and scoring must agree on it
         # (a manager of plug-in detectors only still needs the engine behind a downscale: the frames they are handed are made there)
         engine = self._engine_or_default() if (plan["device"] or plan["want_frames"]) else None
