@@ -113,12 +113,12 @@ class FrameTimecode:
             if timecode < 0.0:
                 raise ValueError("Timecode frame number must be positive and greater than zero.")
             self._secs = timecode
-        elif isinstance(timecode, int):
+        else:
+            # Whatever is left is taken for a frame number, as in the reference (common.py:259-264: "only `int` remains"): a numpy
+            # integer from an array of cuts is one, and what cannot be compared with 0 fails in that comparison (TypeError).
             if timecode < 0:
                 raise ValueError("Timecode frame number must be positive and greater than zero.")
             self._frames = timecode
-        else:
-            raise TypeError(f"unsupported timecode type {type(timecode)}")
 
     # -- views ---------------------------------------------------------------------------------
     @property

@@ -204,3 +204,22 @@ def test_pts_backed_comparisons_match_reference():
     x = _TC(_PTS(1001, Fraction(1, 30000)), 25.0)
     y = _TC(_PTS(1001, Fraction(1, 30000)), 30.0)
     assert {"ok": {"eq": x == y, "lt": x < y, "hash_x": hash(x), "hash_y": hash(y)}} == _CASES["pts_cross_rate"]
+
+
+def test_numpy_integers_are_frame_numbers_like_in_the_reference():
+    """``FrameTimecode(frame, fps)`` with a frame number that came out of an array (``numpy.int64``): the reference takes whatever is
+    not a string, float or timecode for a frame number (``common.py:259-264``); the mirror refused numpy integers with TypeError
+    (found when the fuzzers started to compare exception TEXTS: ``FrameTimecode(None, fps)`` fails in the reference's ``timecode < 0``)."""
+    import numpy as np
+
+    from pyscenedetect_amd import FrameTimecode
+
+    cuts = np.array([0, 15, 198, 377])
+    tcs = [FrameTimecode(c, 25.0) for c in cuts]
+    assert [int(t.frame_num) for t in tcs] == [0, 15, 198, 377]
+    assert tcs[2].get_timecode() == "00:00:07.920" and tcs[1] < tcs[2] and (tcs[3] - tcs[2]).frame_num == 179
+    assert FrameTimecode(np.int32(7), 30.0) == 7
+    with pytest.raises(ValueError):
+        FrameTimecode(np.int64(-1), 25.0)
+    with pytest.raises(TypeError, match="not supported between"):
+        FrameTimecode(None, 25.0)

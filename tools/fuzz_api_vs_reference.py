@@ -165,7 +165,7 @@ def run(side, case):
                     else:
                         out.append(["ok", sm.get_num_detectors()])
                 except Exception as ex:  # noqa: BLE001
-                    out.append(["raises", type(ex).__name__])
+                    out.append(["raises", type(ex).__name__, "" if isinstance(ex, AssertionError) else str(ex)])
             return out
         if case[0] == "downscale_factor":
             f = ref_sm.compute_downscale_factor if side == "ref" else our_sm.compute_downscale_factor
@@ -181,7 +181,7 @@ def outcome(fn):
     try:
         return {"ok": fn()}
     except Exception as ex:  # noqa: BLE001
-        return {"raises": type(ex).__name__}
+        return {"raises": type(ex).__name__, "message": str(ex)}
 
 
 def draw_case(rng):

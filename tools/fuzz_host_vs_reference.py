@@ -558,15 +558,17 @@ def sim_engine(oracle):
 def outcome(fn):
     try:
         return fn()
-    except Exception as ex:  # noqa: BLE001 -- the exception type IS the outcome
-        return {"raises": type(ex).__name__}
+    except Exception as ex:  # noqa: BLE001 -- the exception type IS the outcome, and so is its text (the reference's bare asserts have none)
+        return {"raises": type(ex).__name__, "message": "" if isinstance(ex, AssertionError) else str(ex)}
 
 
 def differ(a, b):
     if a.keys() != b.keys():
         return "outcome kinds: %s vs %s" % (sorted(a), sorted(b))
     if "raises" in a:
-        return None if a["raises"] == b["raises"] else "raises %s vs %s" % (a["raises"], b["raises"])
+        if a["raises"] != b["raises"]:
+            return "raises %s vs %s" % (a["raises"], b["raises"])
+        return None if a.get("message") == b.get("message") else "%s says %r vs %r" % (a["raises"], a.get("message"), b.get("message"))
     for k in ("frames_processed", "cuts", "scenes", "callback", "csv", "loaded", "event_buffer", "num_detectors", "pieces", "stream", "plugin_saw"):
         if a.get(k) != b.get(k):
             return "%s: %s vs %s" % (k, str(a.get(k))[:160], str(b.get(k))[:160])

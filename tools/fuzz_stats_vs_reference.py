@@ -181,7 +181,7 @@ def run(side, fps, prog, tmp, other_text=None):
                     res = Stats.valid_header(step[1])
                 out.append(["ok", res])
             except Exception as ex:  # noqa: BLE001 -- the type is the outcome
-                out.append(["raises", type(ex).__name__])
+                out.append(["raises", type(ex).__name__, "" if isinstance(ex, AssertionError) else str(ex)])
     return out
 
 

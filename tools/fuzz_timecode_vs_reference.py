@@ -78,7 +78,8 @@ def draw_value(rng):
     if k == 13:
         return ("float", -float(rng.uniform(0.01, 5)))
     if k == 14:
-        return ("none", None)
+        return ("none", None) if rng.integers(0, 3) else ("numpy", [["int64", "int32", "int64", "float64", "intp"][int(rng.integers(0, 5))],
+                                                                     int(rng.integers(0, 200))])
     return ("float", float(rng.integers(0, 1000)) / float(rng.choice([1, 2, 4, 8, 25, 30, 1000])))
 
 
@@ -87,6 +88,8 @@ def make(side, value, fps_spec):
     TC, T = (RefTC, RefT) if side == "ref" else (OurTC, OurT)
     if kind == "pts":
         return TC(T(v[0], Fraction(v[1][0], v[1][1])), fps_of(side, fps_spec))
+    if kind == "numpy":          # a frame number that came out of an array
+        v = getattr(np, v[0])(v[1])
     return TC(v, fps_of(side, fps_spec))
 
 
@@ -95,6 +98,8 @@ def operand(side, spec, fps_spec):
     kind, v = spec
     if kind == "tc":
         return make(side, v[0], v[1])
+    if kind == "numpy":
+        return getattr(np, v[0])(v[1])
     return v
 
 
@@ -106,7 +111,7 @@ def views(tc, precision, rounding):
         try:
             out[name] = fn()
         except Exception as ex:  # noqa: BLE001
-            out[name] = "raises:" + type(ex).__name__
+            out[name] = "raises:" + type(ex).__name__ + ":" + str(ex)
     return out
 
 
@@ -140,7 +145,7 @@ def outcome(fn):
     try:
         return {"ok": fn()}
     except Exception as ex:  # noqa: BLE001
-        return {"raises": type(ex).__name__}
+        return {"raises": type(ex).__name__, "message": str(ex)}
 
 
 def draw_case(rng):
@@ -152,8 +157,9 @@ def draw_case(rng):
         if op == "same_rate" or rng.integers(0, 2):
             rhs = ("tc", [draw_value(rng), fps2])
         else:
-            rhs = ("plain", draw_value(rng)[1])
-            if isinstance(rhs[1], list):
+            drawn = draw_value(rng)
+            rhs = ("numpy", drawn[1]) if drawn[0] == "numpy" else ("plain", drawn[1])
+            if rhs[0] == "plain" and isinstance(rhs[1], list):
                 rhs = ("plain", 3)
         prog.append((op, rhs))
     return {"a": draw_value(rng), "fps": fps, "fps2": fps2, "program": prog, "precision": int(rng.integers(0, 7)), "rounding": bool(rng.integers(0, 2))}
