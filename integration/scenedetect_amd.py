@@ -181,9 +181,11 @@ def install(binding: Binding):
         if not had_prev:
             return 0.0
         n = float(frame_img.shape[0] * frame_img.shape[1])
+        # numpy scalars, as `_mean_pixel_distance` returns them (content_detector.py:29-36): the arithmetic below is then the
+        # reference's own, weights that sum to zero included (NaN and a RuntimeWarning, no ZeroDivisionError)
         score_components = ContentDetector.Components(
-            delta_hue=rec.sad_h / n, delta_sat=rec.sad_s / n, delta_lum=rec.sad_v / n,
-            delta_edges=(255 * rec.edge_xor) / n if calculate_edges else 0.0)
+            delta_hue=np.int64(rec.sad_h) / n, delta_sat=np.int64(rec.sad_s) / n, delta_lum=np.int64(rec.sad_v) / n,
+            delta_edges=np.int64(255 * rec.edge_xor) / n if calculate_edges else 0.0)
         frame_score = sum(c * w for (c, w) in zip(score_components, self._weights, strict=True)) / sum(abs(w) for w in self._weights)
         if self.stats_manager is not None:
             metrics = {self.FRAME_SCORE_KEY: frame_score}

@@ -49,11 +49,12 @@ def detect(video, detector, stats_file_path=None, show_progress=False, start_tim
     elif isinstance(video, (str, _os.PathLike)) or (isinstance(video, (list, tuple)) and video
                                                     and all(isinstance(v, (str, _os.PathLike)) for v in video)):
         video = open_video(video, backend=backend)
-    if start_time is not None:
-        video.seek(start_time if isinstance(start_time, (int, FrameTimecode)) else FrameTimecode(start_time, video.frame_rate))
+    if start_time is not None:      # (both times through the constructor first, as in the reference: its checks, its error texts)
+        video.seek(FrameTimecode(start_time, video.frame_rate))
+    end_timecode = FrameTimecode(end_time, video.frame_rate) if end_time is not None else None
     manager = SceneManager(StatsManager() if stats_file_path else None, engine=engine)
     manager.add_detector(detector)
-    manager.detect_scenes(video, end_time=end_time, show_progress=show_progress)
+    manager.detect_scenes(video, end_time=end_timecode, show_progress=show_progress)
     if manager.stats_manager is not None:
         manager.stats_manager.save_to_csv(stats_file_path)
     return manager.get_scene_list(start_in_scene=start_in_scene)

@@ -67,12 +67,17 @@ class AdaptiveDetector(ContentDetector):
                 neighbours = neighbours + value
         mean = neighbours / (2.0 * w)
         if abs(mean) < 0.00001:
-            ratio = 255.0 if candidate >= self.min_content_val else 0.0
+            ratio = stored = 255.0 if candidate >= self.min_content_val else 0.0
         else:
-            ratio = min(candidate / mean, 255.0)
+            quotient = candidate / mean
+            if 255.0 < quotient:             # min(quotient, 255.0): the cap is a Python float in the reference ...
+                ratio = stored = 255.0
+            else:                            # ... the quotient a numpy.float64 (its scores are), NaN included
+                ratio = quotient
+                stored = np.float64(quotient) if self.stats_manager is not None else quotient
         stats = self.stats_manager
         if stats is not None:
-            stats.set_metrics(give_back(candidate_tc), {self._adaptive_ratio_key: ratio})
+            stats.set_metrics(give_back(candidate_tc), {self._adaptive_ratio_key: stored})
         is_peak = ratio >= self.adaptive_threshold and candidate >= self.min_content_val
         # The reference measures the gap from the CURRENT position but reports the candidate
         # (adaptive_detector.py:139-142); kept as is.

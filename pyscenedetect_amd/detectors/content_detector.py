@@ -94,12 +94,16 @@ class ContentDetector(SceneDetector):
             delta_lum=int(record["sad_v"]) / num_pixels,
             delta_edges=(255 * int(record["edge_xor"])) / num_pixels if self.score_flags() & _native.SCORE_EDGES else 0.0,
         )
-        frame_score = sum(c * w for c, w in zip(components, self._weights, strict=True)) / sum(
-            abs(w) for w in self._weights
-        )
+        weighted = sum(c * w for c, w in zip(components, self._weights, strict=True))
+        weight_sum = sum(abs(w) for w in self._weights)
+        # The reference computes all of this on numpy scalars (`numpy.sum(...) / float(num_pixels)`, content_detector.py:29-36): the same
+        # IEEE arithmetic as Python's floats -- except that weights which sum to zero give a NaN score and a RuntimeWarning there,
+        # not a ZeroDivisionError -- and what it stores are numpy.float64 objects.  Python floats here (a third of the per-frame cost of
+        # this function less), numpy where it shows.
+        frame_score = weighted / weight_sum if weight_sum != 0.0 else np.float64(weighted) / weight_sum
         if self.stats_manager is not None:
-            metrics = {self.FRAME_SCORE_KEY: frame_score}
-            metrics.update(components._asdict())
+            metrics = {self.FRAME_SCORE_KEY: np.float64(frame_score)}
+            metrics.update({key: np.float64(value) for key, value in components._asdict().items()})
             self.stats_manager.set_metrics(give_back(timecode), metrics)
         return frame_score
 

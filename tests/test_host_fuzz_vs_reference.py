@@ -478,3 +478,21 @@ def test_a_slice_of_the_campaign_over_the_simulated_device_engine(fuzz, oracle_e
         assert {"manager", "per_frame", "reuse"} <= modes
     finally:
         fuzz.WIDE = False
+
+
+def test_weights_that_sum_to_zero_and_the_types_of_the_metrics(fuzz, oracle_engine):
+    """The reference computes its content scores on numpy scalars: ``Components(0, 0, 0, 0)`` divides 0.0 by 0.0 into NaN (a
+    RuntimeWarning, no cut, NaN metrics) where Python floats raise ZeroDivisionError -- the mirror and the bound seam of INTEGRATION.md
+    B did -- and what lands in the StatsManager are ``numpy.float64`` objects (``average_rgb`` too; ``hist_diff`` and ``hash_dist`` are
+    floats, the capped ``adaptive_ratio`` a float 255.0).  Found when the fuzz began to compare the TYPES of the metrics."""
+    frames = np.random.default_rng(14).integers(0, 256, (30, 36, 64, 3), dtype=np.uint8)
+    frames[15:] //= 3
+    cfg = {"stats": True, "auto_downscale": False, "start_in_scene": True, "batch_frames": 7}
+    for dets in ([("ContentDetector", {"weights": [0.0, 0.0, 0.0, 0.0]})], [("AdaptiveDetector", {"weights": [0.0, 0.0, 0.0, 0.0]})],
+                 [("ContentDetector", {}), ("AdaptiveDetector", {"window_width": 1}), ("HistogramDetector", {}), ("ThresholdDetector", {}),
+                  ("HashDetector", {})]):
+        a = fuzz.run_side("ref", frames, 25.0, dets, cfg, None)
+        for side in ("mirror", "plug", "cross"):
+            c = fuzz.run_side(side, frames, 25.0, dets, cfg, oracle_engine)
+            assert fuzz.differ(a, c) is None, (dets[0], side, fuzz.differ(a, c))
+    assert a["metrics"]["content_val (types)"] == ["float64"] and a["metrics"]["hist_diff [bins=128] (types)"] == ["float"]

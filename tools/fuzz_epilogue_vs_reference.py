@@ -46,7 +46,7 @@ def draw(rng):
             w = [float(rng.integers(0, 3)) for _ in range(3)] + [float(rng.integers(0, 2))]
             if WIDE and rng.integers(0, 2):      # fractional and negative weights (the score divides by the sum of their magnitudes)
                 w = [float(round(rng.uniform(-1.5, 2.5), 2)) if rng.integers(0, 4) else 0.0 for _ in range(4)]
-            if sum(abs(x) for x in w) == 0:
+            if sum(abs(x) for x in w) == 0 and not (WIDE and rng.integers(0, 2)):      # (all zero: NaN scores, no cut, no exception)
                 w[2] = 1.0
             kw["weights"] = w
         if rng.integers(0, 3) == 0:

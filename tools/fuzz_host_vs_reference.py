@@ -78,7 +78,7 @@ def draw_detector(rng):
             w = [float(rng.integers(0, 3)) for _ in range(3)] + [float(rng.integers(0, 2))]
             if WIDE and rng.integers(0, 2):      # fractional and negative weights: the score divides by the sum of their magnitudes
                 w = [float(round(rng.uniform(-1.5, 2.5), 2)) if rng.integers(0, 4) else 0.0 for _ in range(4)]
-            if sum(abs(x) for x in w) == 0:
+            if sum(abs(x) for x in w) == 0 and not (WIDE and rng.integers(0, 2)):      # (all zero: NaN scores in the reference, no exception)
                 w[2] = 1.0
             kw["weights"] = w
         if rng.integers(0, 4) == 0:
@@ -410,6 +410,8 @@ def run_side(side, frames, fps, dets, cfg, engine):
                         v = stats.get_metrics(i, [key])[0] if stats.metrics_exist(i, [key]) else None
                         vals.append(None if v is None else float(v))
                     metrics[key] = vals
+                    metrics[key + " (types)"] = sorted({type(stats.get_metrics(i, [key])[0]).__name__ for i in range(len(frames))
+                                                        if stats.metrics_exist(i, [key])})
         return metrics
 
     if cfg.get("mode") == "per_frame":
