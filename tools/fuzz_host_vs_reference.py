@@ -453,7 +453,11 @@ def run_side(side, frames, fps, dets, cfg, engine):
                     ref.open_video = opened
             else:
                 scenes = psd.detect(video, det, stats_file_path=path, start_in_scene=cfg["start_in_scene"], engine=engine, **kwargs)
-            return {"scenes": [[a.frame_num, b.frame_num] for a, b in scenes], "csv": open(path).read() if path else "",
+            text = ""
+            if path:
+                with open(path) as f:
+                    text = f.read()
+            return {"scenes": [[a.frame_num, b.frame_num] for a, b in scenes], "csv": text,
                     "stream": [video.frame_number, video.position.frame_num]}
     built = configure(sm)
     pieces = []
@@ -493,7 +497,8 @@ def run_side(side, frames, fps, dets, cfg, engine):
         with tempfile.TemporaryDirectory() as tmp:
             path = os.path.join(tmp, "stats.csv")
             stats.save_to_csv(path)
-            out["csv"] = open(path).read()
+            with open(path) as f:
+                out["csv"] = f.read()
             if side in ("ref", "plug"):
                 stats2 = RefStatsManager()
                 sm2 = RefSceneManager(stats2)
@@ -558,15 +563,27 @@ def sim_engine(oracle):
 
 
 def outcome(fn):
-    try:
-        return fn()
-    except Exception as ex:  # noqa: BLE001 -- the exception type IS the outcome, and so is its text (the reference's bare asserts have none)
-        return {"raises": type(ex).__name__, "message": "" if isinstance(ex, AssertionError) else str(ex)}
+    """What running one side gave: its results or its exception (type and text; the reference's bare asserts have no text), and the
+    warnings it emitted on the way (category and text: deprecations, numpy's RuntimeWarnings)."""
+    import warnings
+
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        try:
+            out = fn()
+        except Exception as ex:  # noqa: BLE001 -- the exception type IS the outcome
+            out = {"raises": type(ex).__name__, "message": "" if isinstance(ex, AssertionError) else str(ex)}
+    # (not compared: ResourceWarnings, and the logging module's own complaint about the reference's `logger.warn(...)` call)
+    out["warnings"] = sorted({(w.category.__name__, str(w.message)) for w in caught if not issubclass(w.category, ResourceWarning)
+                              and "'warn' method is deprecated" not in str(w.message)})
+    return out
 
 
 def differ(a, b):
     if a.keys() != b.keys():
         return "outcome kinds: %s vs %s" % (sorted(a), sorted(b))
+    if a.get("warnings") != b.get("warnings"):
+        return "warnings: %s vs %s" % (str(a.get("warnings"))[:200], str(b.get("warnings"))[:200])
     if "raises" in a:
         if a["raises"] != b["raises"]:
             return "raises %s vs %s" % (a["raises"], b["raises"])
