@@ -6,9 +6,12 @@ Detectors write the same metric keys as the reference (``content_val``, ``delta_
 """
 
 import csv
+import logging
 import os
 
 from pyscenedetect_amd.timecode import FrameTimecode, _is_foreign_timecode
+
+logger = logging.getLogger("pyscenedetect")
 
 COLUMN_NAME_FRAME_NUMBER = "Frame Number"
 COLUMN_NAME_TIMECODE = "Timecode"
@@ -119,6 +122,8 @@ class StatsManager:
         there but still what lets ``ThresholdDetector`` reuse a cached ``average_rgb``).  Rows are keyed by 0-based
         frame number.  Returns the number of rows, or None for a missing / empty file; raises
         :class:`StatsFileCorrupt` for anything that is not a stats file."""
+        # (logged once per call and once more for the recursion on the opened file, like the reference, stats_manager.py:241-248)
+        logger.warning("load_from_csv() is deprecated and will be removed in a future release.")
         if isinstance(csv_file, (str, bytes, os.PathLike)):
             if not os.path.exists(csv_file):
                 return None

@@ -564,15 +564,37 @@ def sim_engine(oracle):
 
 def outcome(fn):
     """What running one side gave: its results or its exception (type and text; the reference's bare asserts have no text), and the
-    warnings it emitted on the way (category and text: deprecations, numpy's RuntimeWarnings)."""
+    warnings it emitted on the way (category and text: deprecations, numpy's RuntimeWarnings) and what it logged at WARNING level and above."""
+    import logging
     import warnings
 
-    with warnings.catch_warnings(record=True) as caught:
-        warnings.simplefilter("always")
-        try:
-            out = fn()
-        except Exception as ex:  # noqa: BLE001 -- the exception type IS the outcome
-            out = {"raises": type(ex).__name__, "message": "" if isinstance(ex, AssertionError) else str(ex)}
+    class Capture(logging.Handler):
+        def __init__(self):
+            super().__init__(logging.WARNING)
+            self.records = []
+
+        def emit(self, record):
+            self.records.append([record.levelname, record.getMessage()])
+
+    log, capture = logging.getLogger("pyscenedetect"), Capture()      # (the reference's logger; the mirror logs to the same name)
+    saved = (log.level, log.propagate, logging.root.manager.disable)
+    log.addHandler(capture)
+    log.setLevel(logging.DEBUG)
+    log.propagate = False
+    logging.disable(logging.NOTSET)
+    try:
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            try:
+                out = fn()
+            except Exception as ex:  # noqa: BLE001 -- the exception type IS the outcome
+                out = {"raises": type(ex).__name__, "message": "" if isinstance(ex, AssertionError) else str(ex)}
+    finally:
+        log.removeHandler(capture)
+        log.setLevel(saved[0])
+        log.propagate = saved[1]
+        logging.disable(saved[2])
+    out["log"] = capture.records            # what was logged at WARNING level and above, in order
     # (not compared: ResourceWarnings, and the logging module's own complaint about the reference's `logger.warn(...)` call)
     out["warnings"] = sorted({(w.category.__name__, str(w.message)) for w in caught if not issubclass(w.category, ResourceWarning)
                               and "'warn' method is deprecated" not in str(w.message)})
@@ -582,6 +604,8 @@ def outcome(fn):
 def differ(a, b):
     if a.keys() != b.keys():
         return "outcome kinds: %s vs %s" % (sorted(a), sorted(b))
+    if a.get("log") != b.get("log"):
+        return "log: %s vs %s" % (str(a.get("log"))[:240], str(b.get("log"))[:240])
     if a.get("warnings") != b.get("warnings"):
         return "warnings: %s vs %s" % (str(a.get("warnings"))[:200], str(b.get("warnings"))[:200])
     if "raises" in a:
