@@ -519,6 +519,8 @@ class SceneManager:
                         logger.error(f"ERROR: Frame at {video.position!s} has incorrect size and cannot be "
                                      f"processed: decoded size = {decoded_size}, expected = {self._frame_size}. "
                                      "Video may be corrupt.")
+                    if self._frame_size_errors == MAX_FRAME_SIZE_ERRORS:
+                        logger.warning("WARNING: Too many errors emitted, skipping future messages.")
                     continue
                 if self._crop:
                     x0, y0, x1, y1 = self._crop

@@ -477,7 +477,7 @@ def run_side(side, frames, fps, dets, cfg, engine):
     n, cuts, scenes, seen = detect(sm, video)
     out = {"frames_processed": n, "cuts": cuts, "scenes": scenes, "metrics": metrics_of(stats, built), "callback": seen,
            "pieces": pieces, "stream": [video.frame_number, video.position.frame_num],
-           "plugin_saw": [d.seen for d in built if hasattr(d, "seen")]}
+           "plugin_saw": [d.seen for d in built if hasattr(d, "seen")], "public_state": [public_state(d) for d in built]}
     if cfg.get("mode") == "reuse":
         # the same manager on a second video (the first one backwards): what carries over, what clear() resets
         if cfg["clear_between"]:
@@ -513,6 +513,25 @@ def run_side(side, frames, fps, dets, cfg, engine):
             n2, cuts2, scenes2, seen2 = detect(sm2, video)
             out["second"] = {"frames_processed": n2, "cuts": cuts2, "scenes": scenes2, "metrics": metrics_of(stats2, built2), "callback": seen2}
     return out
+
+
+def public_state(detector):
+    """The detector's public instance attributes after the run (reference: ThresholdDetector's ``last_fade`` / ``last_scene_cut`` /
+    ``processed_frame`` ..., AdaptiveDetector's parameters), timecodes as frame numbers."""
+    from enum import Enum
+
+    def plain(v):
+        if hasattr(v, "frame_num") and hasattr(v, "frame_rate"):
+            return ["timecode", int(v.frame_num)]
+        if isinstance(v, dict):
+            return {str(k): plain(x) for k, x in sorted(v.items())}
+        if isinstance(v, Enum):
+            return ["enum", v.name]
+        if hasattr(v, "pts") and hasattr(v, "time_base"):
+            return ["pts", int(v.pts), str(v.time_base)]
+        return [type(v).__name__, repr(v)]
+
+    return {k: plain(v) for k, v in sorted(vars(detector).items()) if not k.startswith("_") and k not in ("seen", "last", "jump", "behind")}
 
 
 def sim_engine(oracle):
@@ -612,7 +631,7 @@ def differ(a, b):
         if a["raises"] != b["raises"]:
             return "raises %s vs %s" % (a["raises"], b["raises"])
         return None if a.get("message") == b.get("message") else "%s says %r vs %r" % (a["raises"], a.get("message"), b.get("message"))
-    for k in ("frames_processed", "cuts", "scenes", "callback", "csv", "loaded", "event_buffer", "num_detectors", "pieces", "stream", "plugin_saw"):
+    for k in ("frames_processed", "cuts", "scenes", "callback", "csv", "loaded", "event_buffer", "num_detectors", "pieces", "stream", "plugin_saw", "public_state"):
         if a.get(k) != b.get(k):
             return "%s: %s vs %s" % (k, str(a.get(k))[:160], str(b.get(k))[:160])
     if ("second" in a) != ("second" in b):
