@@ -372,6 +372,7 @@ class SceneManager:
 
         effective_frame_size = video.frame_size
         if self._crop:
+            logger.debug(f"Crop set: top left = {self._crop[0:2]}, bottom right = {self._crop[2:4]}")
             x0, y0, x1, y1 = self._crop
             frame_width, frame_height = video.frame_size
             if x0 >= frame_width or y0 >= frame_height:
@@ -384,6 +385,8 @@ class SceneManager:
                 logger.warning("Warning: crop ends outside of video boundary.")
             effective_frame_size = (1 + min(x1, frame_width) - x0, 1 + min(y1, frame_height) - y0)
         factor = compute_downscale_factor(max(effective_frame_size)) if self.auto_downscale else self.downscale
+        logger.debug("Processing resolution: %d x %d, downscale: %1.1f", int(effective_frame_size[0] / factor),
+                     int(effective_frame_size[1] / factor), factor)
 
         # (every timecode a stream hands over becomes one of this package's: the stream may be one of the reference's backends)
         self._base_timecode = FrameTimecode(video.base_timecode)

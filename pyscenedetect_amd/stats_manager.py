@@ -85,6 +85,7 @@ class StatsManager:
         (reference ``stats_manager.py:164-203``: ``save_to_csv(csv_file, force_save=True)``).  ``base_timecode`` (keyword, not in
         the reference) overrides the time base ``detect_scenes`` left behind, for metrics keyed by plain frame numbers."""
         if not (force_save or self.is_save_required()):
+            logger.info("No metrics to write.")
             return
         close = False
         if isinstance(csv_file, (str, bytes, os.PathLike)):      # a path in any spelling (reference stats_manager.py:187)
@@ -94,6 +95,7 @@ class StatsManager:
             writer = csv.writer(csv_file, lineterminator="\n")
             keys = sorted(self._metric_keys)
             writer.writerow([COLUMN_NAME_FRAME_NUMBER, COLUMN_NAME_TIMECODE] + keys)
+            logger.info("Writing %d frames to CSV...", len(self._frame_metrics))
             for key in sorted(self._frame_metrics.keys()):      # (the keys' own order, like the reference: two timestamps that round
                                                                   #  to one frame number are two rows, the earlier first)
                 # A row whose key is a bare frame number -- set through the public API with an int, or read back by the deprecated
@@ -159,5 +161,6 @@ class StatsManager:
                         raise StatsFileCorrupt(f"Corrupted value in stats file: {text}") from ValueError
             num_frames += 1
         self.register_metrics(keys)
+        logger.info("Loaded %d metrics for %d frames.", num_cols - 2, num_frames)
         self._metrics_updated = False
         return num_frames

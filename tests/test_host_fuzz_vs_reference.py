@@ -195,8 +195,8 @@ def test_native_epilogues_against_the_reference_slice():
             warnings.simplefilter("ignore")
             for case_no in range(120):
                 frames, fps, name, kw, kernel = E.draw(np.random.default_rng([3, case_no]))
-                a = E.F.outcome(lambda: {"cuts": E.reference_cuts(frames, fps, name, kw, kernel)})
-                b = E.F.outcome(lambda: {"cuts": E.native_cuts(frames, fps, name, kw, kernel)})
+                a = E.F.decisions(E.F.outcome(lambda: {"cuts": E.reference_cuts(frames, fps, name, kw, kernel)}))
+                b = E.F.decisions(E.F.outcome(lambda: {"cuts": E.native_cuts(frames, fps, name, kw, kernel)}))
                 assert a == b, (case_no, name, kw, kernel, a, b)
     finally:
         logging.disable(level)

@@ -140,8 +140,8 @@ def main():
     while time.time() < t_end:
         rng = np.random.default_rng([args.seed, cases])
         frames, fps, name, kw, kernel = draw(rng)
-        a = F.outcome(lambda: {"cuts": reference_cuts(frames, fps, name, kw, kernel)})
-        b = F.outcome(lambda: {"cuts": native_cuts(frames, fps, name, kw, kernel)})
+        a = F.decisions(F.outcome(lambda: {"cuts": reference_cuts(frames, fps, name, kw, kernel)}))
+        b = F.decisions(F.outcome(lambda: {"cuts": native_cuts(frames, fps, name, kw, kernel)}))
         by[name] = by.get(name, 0) + 1
         if a != b:
             desc = {"case": cases, "shape": list(frames.shape), "fps": fps, "detector": name, "params": kw, "kernel": kernel, "ref": str(a)[:200], "native": str(b)[:200]}

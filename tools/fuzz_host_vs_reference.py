@@ -534,6 +534,11 @@ def public_state(detector):
     return {k: plain(v) for k, v in sorted(vars(detector).items()) if not k.startswith("_") and k not in ("seen", "last", "jump", "behind")}
 
 
+def decisions(out):
+    """An outcome without what only a full run has (warnings, log records): for sides that replay decisions from records."""
+    return {k: v for k, v in out.items() if k not in ("warnings", "log")}
+
+
 def sim_engine(oracle):
     """A stand-in of the DEVICE engine in host memory (tests/test_feed_rows.py: buffers that start poisoned, batched row uploads that
     land only at the fence) with the rest of what SceneManager, the feeder and the per-frame scorer ask of ``ScoringEngine``: the
@@ -583,13 +588,13 @@ def sim_engine(oracle):
 
 def outcome(fn):
     """What running one side gave: its results or its exception (type and text; the reference's bare asserts have no text), and the
-    warnings it emitted on the way (category and text: deprecations, numpy's RuntimeWarnings) and what it logged at WARNING level and above."""
+    warnings it emitted on the way (category and text: deprecations, numpy's RuntimeWarnings) and everything it logged."""
     import logging
     import warnings
 
     class Capture(logging.Handler):
         def __init__(self):
-            super().__init__(logging.WARNING)
+            super().__init__(logging.DEBUG)
             self.records = []
 
         def emit(self, record):
@@ -613,7 +618,7 @@ def outcome(fn):
         log.setLevel(saved[0])
         log.propagate = saved[1]
         logging.disable(saved[2])
-    out["log"] = capture.records            # what was logged at WARNING level and above, in order
+    out["log"] = sorted(capture.records)    # everything that was logged (two threads log: the order between them is not an outcome)
     # (not compared: ResourceWarnings, and the logging module's own complaint about the reference's `logger.warn(...)` call)
     out["warnings"] = sorted({(w.category.__name__, str(w.message)) for w in caught if not issubclass(w.category, ResourceWarning)
                               and "'warn' method is deprecated" not in str(w.message)})
