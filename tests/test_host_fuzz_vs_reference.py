@@ -50,7 +50,7 @@ def test_a_slice_of_the_campaign(fuzz, oracle_engine):
         cfg["batch_frames"] = int(rng.choice([1, 7, 64]))
         a = fuzz.outcome(lambda: fuzz.run_side("ref", frames, fps, dets, cfg, None))
         b = fuzz.outcome(lambda: fuzz.run_side("mirror", frames, fps, dets, cfg, oracle_engine))
-        assert fuzz.differ(a, b) is None, (case, fuzz.differ(a, b), list(frames.shape), dets, cfg)
+        assert fuzz.differ(a, b, cfg) is None, (case, fuzz.differ(a, b, cfg), list(frames.shape), dets, cfg)
         raised += "raises" in a
     assert raised >= 3          # the slice holds cases both sides refuse
 
@@ -240,7 +240,7 @@ def test_a_slice_of_the_wide_campaign(fuzz, oracle_engine):
             cfg["batch_frames"] = int(rng.choice([1, 7, 64]))
             a = fuzz.outcome(lambda: fuzz.run_side("ref", frames, fps, dets, cfg, None))
             b = fuzz.outcome(lambda: fuzz.run_side("mirror", frames, fps, dets, cfg, oracle_engine))
-            assert fuzz.differ(a, b) is None, (case, fuzz.differ(a, b), list(frames.shape), dets, cfg)
+            assert fuzz.differ(a, b, cfg) is None, (case, fuzz.differ(a, b, cfg), list(frames.shape), dets, cfg)
             own += any(name == "MeanJump" for name, _ in dets)
         assert own >= 5
     finally:
@@ -345,7 +345,7 @@ def test_a_slice_of_the_plug_and_cross_campaigns(fuzz, oracle_engine):
             a = fuzz.outcome(lambda: fuzz.run_side("ref", frames, fps, dets, cfg, None))
             for side in ("plug", "cross"):
                 c = fuzz.outcome(lambda: fuzz.run_side(side, frames, fps, dets, cfg, oracle_engine))
-                assert fuzz.differ(a, c) is None, (side, case, fuzz.differ(a, c), list(frames.shape), dets, cfg)
+                assert fuzz.differ(a, c, cfg) is None, (side, case, fuzz.differ(a, c, cfg), list(frames.shape), dets, cfg)
     finally:
         fuzz.WIDE = False
 
@@ -473,7 +473,7 @@ def test_a_slice_of_the_campaign_over_the_simulated_device_engine(fuzz, oracle_e
             cfg["batch_frames"] = int(rng.choice([1, 7, 64]))
             a = fuzz.outcome(lambda: fuzz.run_side("ref", frames, fps, dets, cfg, None))
             c = fuzz.outcome(lambda: fuzz.run_side("mirror", frames, fps, dets, cfg, fuzz.sim_engine(oracle_engine)))
-            assert fuzz.differ(a, c) is None, (case, fuzz.differ(a, c), list(frames.shape), dets, cfg)
+            assert fuzz.differ(a, c, cfg) is None, (case, fuzz.differ(a, c, cfg), list(frames.shape), dets, cfg)
             modes.add(cfg.get("mode", "manager"))
         assert {"manager", "per_frame", "reuse"} <= modes
     finally:
