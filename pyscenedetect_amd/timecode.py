@@ -92,6 +92,8 @@ class FrameTimecode:
     def __init__(self, timecode, fps=None):
         if _is_foreign_timecode(timecode):
             timecode = _adopt_foreign(timecode)
+        elif not isinstance(timecode, (FrameTimecode, Timecode, int, float, str)) and hasattr(timecode, "pts") and hasattr(timecode, "time_base"):
+            timecode = Timecode(int(timecode.pts), Fraction(timecode.time_base))      # another library's bare Timecode
         if isinstance(timecode, FrameTimecode):
             self._frames, self._secs, self._pts = timecode._frames, timecode._secs, timecode._pts
             self._rate = timecode._rate if fps is None else _as_rate(fps)
