@@ -431,3 +431,30 @@ def test_callback_of_a_later_call_gets_the_downscaled_frame_an_earlier_call_buff
         runs.append((shown, [c.frame_num for c in sm.get_cut_list(show_warning=False)]))
     assert runs[0] == runs[1]
     assert runs[0][1] == [20] and [s[:2] for s in runs[0][0]] == [(20, (37, 160, 3))]
+
+
+@_NEVER_RUN
+def test_a_slice_of_the_engines_fuzz_with_the_wide_ingredients(hip_engine, oracle_engine):
+    """``tools/fuzz_host_vs_reference.py --engines --wide`` (the mirror over the HIP engine against the mirror over the oracle engine: device
+    feeder, tap rows, crop / downscale modes, batch sizes, the carried frame, the resident per-frame path) with the ingredients added after
+    the last GPU run of round 5 -- detection from a seek position and in pieces, a plug-in detector alone or beside the others, frame
+    layouts, detect(), object min_scene_len -- and every comparison on (exception texts, metric types, warnings, logs, public state).  The
+    original ingredients ran on hardware (1.6 k cases, `profiles/r05_y_*`); on CPU the same cases pass over the simulated device engine."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "tools")]
+    import fuzz_host_vs_reference as F
+
+    F.WIDE = True
+    try:
+        for case in range(60):
+            rng = np.random.default_rng([20250926, case])
+            frames, fps, dets, cfg = F.draw_case(rng)
+            cfg["batch_frames"] = int(rng.choice([1, 7, 64]))
+            a = F.outcome(lambda: F.run_side("mirror", frames, fps, dets, cfg, oracle_engine))
+            b = F.outcome(lambda: F.run_side("mirror", frames, fps, dets, cfg, hip_engine))
+            assert F.differ(a, b, cfg) is None, (case, F.differ(a, b, cfg), list(frames.shape), dets, cfg)
+    finally:
+        F.WIDE = False
