@@ -433,7 +433,9 @@ def test_callback_of_a_later_call_gets_the_downscaled_frame_an_earlier_call_buff
     assert runs[0][1] == [20] and [s[:2] for s in runs[0][0]] == [(20, (37, 160, 3))]
 
 
-@_NEVER_RUN
+@pytest.mark.skipif(__import__("os").environ.get("PSD_GPU_UNVERIFIED") != "1",
+                    reason="60 random cases of ingredients that have not met hardware yet: opt in with PSD_GPU_UNVERIFIED=1 (first GPU call "
+                           "of a next session, DESIGN.md 7 item 8) rather than risk the suite on them")
 def test_a_slice_of_the_engines_fuzz_with_the_wide_ingredients(hip_engine, oracle_engine):
     """``tools/fuzz_host_vs_reference.py --engines --wide`` (the mirror over the HIP engine against the mirror over the oracle engine: device
     feeder, tap rows, crop / downscale modes, batch sizes, the carried frame, the resident per-frame path) with the ingredients added after
