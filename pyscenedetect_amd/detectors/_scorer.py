@@ -15,6 +15,8 @@ class FrameScorer:
     def __init__(self, engine=None):
         self._engine = engine
         self._last = None
+        self._seed = None           # a predecessor handed over by a SceneManager's shared pass, not yet on the device (seed())
+        self.scored_since_seed = False
 
     @property
     def engine(self):
@@ -23,6 +25,24 @@ class FrameScorer:
 
             self._engine = default_engine()
         return self._engine
+
+    def seed(self, frame: np.ndarray) -> None:
+        """``frame`` precedes whatever is scored next: a SceneManager's shared pass saw it on this detector's behalf (the reference's
+        detector would hold the planes it derived from it, ``content_detector.py:189``), so a caller who goes on with
+        ``process_frame()`` on the same detector gets the score against it."""
+        self._last = self._seed = np.array(frame, copy=True)
+        self._last_shape = self._last.shape
+        self.scored_since_seed = False
+
+    def last_frame(self):
+        """The frame scored last through this scorer (None before the first), for a SceneManager that takes over from direct
+        ``process_frame()`` calls."""
+        state = getattr(self, "_resident", None)
+        if self._seed is None and state is not None and state["have_prev"]:
+            h, w, _ = state["shape"]
+            raw = state["bufs"][state["cur"] ^ 1].download(h * w * 3)      # (the buffer the last call filled)
+            return raw.reshape(h, w, 3)
+        return self._last
 
     def score(self, frame_img: np.ndarray, flags: int, edge_kernel: int = 0):
         frame = np.asarray(frame_img)
@@ -37,6 +57,7 @@ class FrameScorer:
         if last_shape is not None and last_shape != frame.shape and (flags & 9):      # HSV SAD | edges
             raise AssertionError("frame size changed from %dx%d to %dx%d" % (last_shape[1], last_shape[0], frame.shape[1], frame.shape[0]))
         self._last_shape = frame.shape
+        self.scored_since_seed = True
         engine = self.engine
         if hasattr(engine, "alloc") and hasattr(engine, "score_device"):
             return self._score_resident(engine, frame, flags, edge_kernel)
@@ -45,6 +66,7 @@ class FrameScorer:
             prev = None
         rec = engine.score_host(frame[None], prev=prev, flags=flags, edge_kernel=edge_kernel)[0]
         self._last = np.array(frame, copy=True)
+        self._seed = None
         return rec
 
     def _score_resident(self, engine, frame: np.ndarray, flags: int, edge_kernel: int):
@@ -58,6 +80,12 @@ class FrameScorer:
             self._resident = state
         cur = state["cur"]
         buf, other = state["bufs"][cur], state["bufs"][cur ^ 1]
+        if self._seed is not None:              # a predecessor from a manager's pass: it goes where the previous frame would be
+            if self._seed.shape == frame.shape:
+                other.upload(np.ascontiguousarray(self._seed).reshape(-1))
+                state["have_prev"] = True
+            self._seed = None
+            self._last = None                   # (the resident path keeps its frames on the device)
         buf.upload(np.ascontiguousarray(frame).reshape(-1))
         rec = engine.score_device(buf.ptr, 1, h, w, d_prev=other.ptr if state["have_prev"] else None, flags=flags,
                                   edge_kernel=edge_kernel)[0]

@@ -428,6 +428,13 @@ class SceneManager:
         # Here the previous frame belongs to the manager's shared pass: it survives the call, until clear() / clear_detectors()
         # (a detector added in between still starts without a predecessor: each detector has its own "seen a frame" flag).
         last_frame = self._carry_frame
+        # ... and a caller who fed one of the detectors frames through process_frame() since (or before any run of this manager) has
+        # moved that state on: the frame the detector scored last is the predecessor then
+        for detector, flags, _size, _k in [(d, _score_flags(d), 0, 0) for d in self._detector_list]:
+            scorer = getattr(detector, "_scorer", None)
+            if flags & 9 and scorer is not None and getattr(scorer, "scored_since_seed", False) and engine is not None:
+                last_frame = scorer.last_frame()
+                break
         if feeder and last_frame is not None:
             feeder.seed_halo(last_frame)
         logger.info("Detecting scenes...")
@@ -476,6 +483,11 @@ class SceneManager:
             exc = self._exception_info[1]
             raise exc.with_traceback(self._exception_info[2])
         self._carry_frame = last_frame
+        if last_frame is not None:      # (the other way round: process_frame() on one of these detectors goes on from this frame)
+            for detector in self._detector_list:
+                scorer = getattr(detector, "_scorer", None)
+                if scorer is not None and hasattr(scorer, "seed") and _score_flags(detector) & 9:
+                    scorer.seed(last_frame)
         self._last_pos = FrameTimecode(video.position)
         for detector in self._detector_list:
             if isinstance(detector, SceneDetector):

@@ -496,3 +496,25 @@ def test_weights_that_sum_to_zero_and_the_types_of_the_metrics(fuzz, oracle_engi
             c = fuzz.run_side(side, frames, 25.0, dets, cfg, oracle_engine)
             assert fuzz.differ(a, c) is None, (dets[0], side, fuzz.differ(a, c))
     assert a["metrics"]["content_val (types)"] == ["float64"] and a["metrics"]["hist_diff [bins=128] (types)"] == ["float"]
+
+
+@pytest.mark.parametrize("manager_first", [True, False])
+def test_one_detector_under_a_manager_and_fed_by_hand(fuzz, oracle_engine, manager_first):
+    """The SAME detector objects under ``SceneManager.detect_scenes`` for half of a clip and on ``process_frame()`` calls for the other
+    half: a reference detector carries what it derived from the last frame it saw (``content_detector.py:189``), so the first frame
+    of the second half is scored against the last frame of the first.  The mirror's shared pass and its per-frame scorer each kept
+    their own predecessor (score 0.0 at the seam); they hand it over now, both ways -- over the oracle engine and over the simulated
+    device engine (resident per-frame buffers, the feeder's halo frame)."""
+    frames = np.random.default_rng(15).integers(0, 256, (40, 36, 64, 3), dtype=np.uint8)
+    frames[26:] //= 3
+    dets = [("ContentDetector", {"min_scene_len": 3}), ("AdaptiveDetector", {"window_width": 1, "min_scene_len": 3}),
+            ("HistogramDetector", {}), ("ThresholdDetector", {}), ("HashDetector", {})]
+    cfg = {"stats": True, "auto_downscale": False, "start_in_scene": True, "batch_frames": 7, "mode": "mixed", "manager_first": manager_first}
+    a = fuzz.run_side("ref", frames, 25.0, dets, cfg, None)
+    seam = a["metrics"]["content_val"][20]
+    assert seam is not None and seam > 1.0                      # the seam frame has a score against its predecessor
+    for engine in (oracle_engine, fuzz.sim_engine(oracle_engine)):
+        b = fuzz.run_side("mirror", frames, 25.0, dets, cfg, engine)
+        assert fuzz.differ(a, b) is None, (type(engine).__name__, fuzz.differ(a, b))
+    c = fuzz.run_side("plug", frames, 25.0, dets, cfg, oracle_engine)
+    assert fuzz.differ(a, c) is None, fuzz.differ(a, c)

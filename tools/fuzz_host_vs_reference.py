@@ -285,6 +285,10 @@ def draw_case(rng):
         sm["seek"] = int(rng.integers(0, n + 1))              # detection starts somewhere inside the video (video.seek before detect_scenes)
     if WIDE and rng.integers(0, 4) == 0:                  # detection in pieces: detect_scenes(duration=...) calls in a row on one video
         sm["chunks"] = [int(rng.integers(1, max(2, n // 2))) for _ in range(int(rng.integers(1, 4)))]
+    if WIDE and rng.integers(0, 14) == 0:      # one set of detectors under a manager for half of the clip and fed by hand for the other
+        sm["mode"] = "mixed"
+        sm["manager_first"] = bool(rng.integers(0, 2))
+        sm.pop("pts", None)
     if WIDE and "chunks" in sm and rng.integers(0, 3) == 0:
         sm["add_between"] = draw_detector(rng)            # a detector that joins after the first piece
         if rng.integers(0, 3) == 0:
@@ -459,6 +463,33 @@ def run_side(side, frames, fps, dets, cfg, engine):
                     text = f.read()
             return {"scenes": [[a.frame_num, b.frame_num] for a, b in scenes], "csv": text,
                     "stream": [video.frame_number, video.position.frame_num]}
+    if cfg.get("mode") == "mixed":
+        # (both halves must see frames of one size: no downscale, no crop; no aborted runs)
+        cfg = {k: v for k, v in cfg.items() if k not in ("downscale", "crop", "frame_skip", "fail_at", "odd_frames", "end_time", "duration")}
+        cfg["auto_downscale"] = False
+        # SceneManager.detect_scenes on one half of the clip, SceneDetector.process_frame by hand on the other, the SAME detector objects:
+        # what a detector derived from the last frame it saw goes with it (reference content_detector.py:189)
+        built = configure(sm)
+        half = len(frames) // 2
+        tc_cls = ref.FrameTimecode if side in ("ref", "plug") else psd.FrameTimecode
+        emitted = []
+
+        def by_hand(lo, hi):
+            for i in range(lo, hi):
+                for j, d in enumerate(built):
+                    got = d.process_frame(tc_cls(i, fps), frames[i])
+                    if got:
+                        emitted.append([i, j, [c.frame_num for c in got]])
+
+        if cfg["manager_first"]:
+            n = sm.detect_scenes(video, duration=half)
+            by_hand(half, len(frames))
+        else:
+            by_hand(0, half)
+            video.seek(half)
+            n = sm.detect_scenes(video)
+        return {"frames_processed": n, "cuts": [c.frame_num for c in sm.get_cut_list(show_warning=False)], "by_hand": emitted,
+                "metrics": metrics_of(stats, built), "public_state": [public_state(d) for d in built]}
     built = configure(sm)
     pieces = []
     if "seek" in cfg:
@@ -551,6 +582,10 @@ def sim_engine(oracle):
             host = np.ascontiguousarray(host)
             self.mem[offset: offset + host.nbytes] = host.reshape(-1).view(np.uint8)
 
+        def download(self, nbytes=None, offset=0):
+            nbytes = self.nbytes - offset if nbytes is None else nbytes
+            return self.mem[offset: offset + nbytes].copy()
+
     class Sim(_BatchingEngine):
         def alloc(self, nbytes):
             self.buffers.append(Buffer(nbytes, self))
@@ -640,7 +675,7 @@ def differ(a, b, cfg=None):
         if a["raises"] != b["raises"]:
             return "raises %s vs %s" % (a["raises"], b["raises"])
         return None if a.get("message") == b.get("message") else "%s says %r vs %r" % (a["raises"], a.get("message"), b.get("message"))
-    for k in ("frames_processed", "cuts", "scenes", "callback", "csv", "loaded", "event_buffer", "num_detectors", "pieces", "stream", "plugin_saw", "public_state"):
+    for k in ("frames_processed", "cuts", "scenes", "callback", "csv", "loaded", "event_buffer", "num_detectors", "pieces", "stream", "plugin_saw", "public_state", "by_hand"):
         if a.get(k) != b.get(k):
             return "%s: %s vs %s" % (k, str(a.get(k))[:160], str(b.get(k))[:160])
     if ("second" in a) != ("second" in b):
@@ -719,9 +754,12 @@ def main():
         frames, fps, dets, cfg = draw_case(rng)
         cfg["batch_frames"] = int(rng.choice([1, 7, 64]))
         for f in [x for x in args.force.split(",") if x]:
-            if f in ("per_frame", "reuse"):
+            if f in ("per_frame", "reuse", "mixed"):
                 cfg["mode"] = f
                 cfg.setdefault("clear_between", bool(cases & 1))
+                cfg.setdefault("manager_first", bool(cases & 2))
+                if f == "mixed":
+                    cfg.pop("pts", None)
             elif f == "pts" and "pts" not in cfg:
                 steps = rng.choice([20, 40, 40, 40, 40, 60, 80], size=len(frames) - 1)
                 cfg["pts"] = [0] + [int(x) for x in np.cumsum(steps)]
