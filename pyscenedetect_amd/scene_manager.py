@@ -428,13 +428,16 @@ class SceneManager:
         # Here the previous frame belongs to the manager's shared pass: it survives the call, until clear() / clear_detectors()
         # (a detector added in between still starts without a predecessor: each detector has its own "seen a frame" flag).
         last_frame = self._carry_frame
-        # ... and a caller who fed one of the detectors frames through process_frame() since (or before any run of this manager) has
-        # moved that state on: the frame the detector scored last is the predecessor then
-        for detector, flags, _size, _k in [(d, _score_flags(d), 0, 0) for d in self._detector_list]:
-            scorer = getattr(detector, "_scorer", None)
-            if flags & 9 and scorer is not None and getattr(scorer, "scored_since_seed", False) and engine is not None:
-                last_frame = scorer.last_frame()
-                break
+        # ... and the detectors know better where they have been in the meantime: fed by hand through process_frame(), or run under
+        # ANOTHER manager (which left its last frame with them, below) -- the frame a detector saw last is the predecessor then
+        if engine is not None:
+            for detector in self._detector_list:
+                scorer = getattr(detector, "_scorer", None)
+                if _score_flags(detector) & 9 and scorer is not None and hasattr(scorer, "last_frame"):
+                    seen = scorer.last_frame()
+                    if seen is not None:
+                        last_frame = seen
+                        break
         if feeder and last_frame is not None:
             feeder.seed_halo(last_frame)
         logger.info("Detecting scenes...")

@@ -288,6 +288,8 @@ def draw_case(rng):
     if WIDE and rng.integers(0, 14) == 0:      # one set of detectors under a manager for half of the clip and fed by hand for the other
         sm["mode"] = "mixed"
         sm["manager_first"] = bool(rng.integers(0, 2))
+        if rng.integers(0, 3) == 0:
+            sm["two_managers"] = True
         sm.pop("pts", None)
     if WIDE and "chunks" in sm and rng.integers(0, 3) == 0:
         sm["add_between"] = draw_detector(rng)            # a detector that joins after the first piece
@@ -481,7 +483,16 @@ def run_side(side, frames, fps, dets, cfg, engine):
                     if got:
                         emitted.append([i, j, [c.frame_num for c in got]])
 
-        if cfg["manager_first"]:
+        if cfg.get("two_managers"):      # ... or under ANOTHER manager for the other half (a fresh one, the same detector objects)
+            n = sm.detect_scenes(video, duration=half)
+            other = (RefSceneManager(stats) if side in ("ref", "plug")
+                     else psd.SceneManager(stats, engine=engine, batch_frames=int(cfg.get("batch_frames", 64))))
+            other.auto_downscale = False
+            for d in built:
+                other.add_detector(d)
+            n += other.detect_scenes(video)
+            emitted = [c.frame_num for c in other.get_cut_list(show_warning=False)]
+        elif cfg["manager_first"]:
             n = sm.detect_scenes(video, duration=half)
             by_hand(half, len(frames))
         else:
@@ -758,6 +769,8 @@ def main():
                 cfg["mode"] = f
                 cfg.setdefault("clear_between", bool(cases & 1))
                 cfg.setdefault("manager_first", bool(cases & 2))
+                if f == "mixed" and cases % 3 == 0:
+                    cfg["two_managers"] = True
                 if f == "mixed":
                     cfg.pop("pts", None)
             elif f == "pts" and "pts" not in cfg:
