@@ -651,3 +651,43 @@ def test_threshold_cuts_do_not_depend_on_what_backs_the_positions(oracle_engine,
         assert len(by_frames) >= 15
         assert cuts(psd.ArrayVideoStream(frames, fps, pts=micro, time_base=Fraction(1, 1_000_000)), **kw) == by_frames
         assert cuts(psd.ArrayVideoStream(frames, fps, pts=milli, time_base=Fraction(1, 1000)), **kw) == by_frames
+
+
+def test_managers_on_parallel_threads_equal_serial_runs(golden, oracle_engine):
+    """The reference's fan-out parity test (``tests/test_fan_out.py:157-212``: detectors in parallel threads give what serial runs
+    give; detectors need not be thread-safe but instances must not share state, ``benchmark/sweep.py:160-180``): four managers, each
+    with its own detectors and stream, on four threads at once."""
+    import threading
+
+    jobs = [("scenes_a", psd.ContentDetector, {}), ("fades_b", psd.ThresholdDetector, {"add_final_scene": True}),
+            ("ragged_c", psd.AdaptiveDetector, {"window_width": 1}), ("scenes_a", psd.HistogramDetector, {})]
+
+    def run(clip, cls, kw):
+        stats = psd.StatsManager()
+        sm = psd.SceneManager(stats, engine=oracle_engine, batch_frames=7)
+        det = cls(engine=oracle_engine, **kw)
+        sm.add_detector(det)
+        frames = golden_clip(golden, clip)
+        sm.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+        key = det.get_metrics()[0]
+        return ([c.frame_num for c in sm.get_cut_list(show_warning=False)],
+                [stats.get_metrics(i, [key])[0] if stats.metrics_exist(i, [key]) else None for i in range(len(frames))])
+
+    serial = [run(*job) for job in jobs]
+    for _ in range(3):
+        parallel, errors = [None] * len(jobs), []
+
+        def work(i):
+            try:
+                parallel[i] = run(*jobs[i])
+            except BaseException as ex:  # noqa: BLE001
+                errors.append(ex)
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert parallel == serial
+    assert any(cuts for cuts, _ in serial)
