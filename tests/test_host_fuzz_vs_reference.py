@@ -518,3 +518,55 @@ def test_one_detector_under_a_manager_and_fed_by_hand(fuzz, oracle_engine, manag
         assert fuzz.differ(a, b) is None, (type(engine).__name__, fuzz.differ(a, b))
     c = fuzz.run_side("plug", frames, 25.0, dets, cfg, oracle_engine)
     assert fuzz.differ(a, c) is None, fuzz.differ(a, c)
+
+
+def test_mirror_managers_consume_the_references_fan_out_stream(fuzz, oracle_engine):
+    """``benchmark/sweep.py:142-187`` runs N SceneManagers on N threads, each reading one consumer of the reference's
+    ``FanOutVideoStream`` (one decode, N readers).  A user who keeps that harness and swaps the managers and detectors: three of this
+    package's managers on three threads over three consumers of one reference stream give what the reference's managers give."""
+    import threading
+
+    import scenedetect
+    from scenedetect._fan_out import FanOutVideoStream
+
+    import pyscenedetect_amd as psd
+    from oracle.gen_golden import MemoryStream
+
+    from pyscenedetect_amd.synth import make_clip
+
+    frames, _ = make_clip(16, 90, 36, 64, shot_len=(12, 20))
+    frames[40:52] //= 40
+
+    def sweep(make_manager, detectors):
+        fan = FanOutVideoStream(MemoryStream(frames, 25.0), n=len(detectors))
+        fan.start()
+        results, errors = [None] * len(detectors), []
+
+        def worker(i):
+            try:
+                sm = make_manager()
+                sm.auto_downscale = False
+                sm.add_detector(detectors[i])
+                n = sm.detect_scenes(fan.stream(i))
+                results[i] = (n, [c.frame_num for c in sm.get_cut_list(show_warning=False)],
+                              [(a.frame_num, b.frame_num) for a, b in sm.get_scene_list(start_in_scene=True)])
+            except BaseException as ex:  # noqa: BLE001
+                errors.append(ex)
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(detectors))]
+        try:
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            fan.close()
+        assert not errors, errors
+        return results
+
+    want = sweep(scenedetect.SceneManager, [scenedetect.ContentDetector(min_scene_len=5), scenedetect.ThresholdDetector(min_scene_len=3),
+                                            scenedetect.AdaptiveDetector(min_scene_len=5, window_width=1)])
+    got = sweep(lambda: psd.SceneManager(engine=oracle_engine, batch_frames=7),
+                [psd.ContentDetector(min_scene_len=5, engine=oracle_engine), psd.ThresholdDetector(min_scene_len=3, engine=oracle_engine),
+                 psd.AdaptiveDetector(min_scene_len=5, window_width=1, engine=oracle_engine)])
+    assert got == want and all(cuts for _, cuts, _ in want)
