@@ -1,19 +1,35 @@
-"""Differential fuzz of the HOST side: the unmodified reference (``/root/reference/scenedetect`` over the cv2 shim) against
-the mirror (``pyscenedetect_amd`` over the CPU oracle engine), on random clips, detector sets, detector parameters and
+"""Differential fuzz of the HOST side: the unmodified reference (``/root/reference/scenedetect`` over the cv2 shim) against the
+mirror (``pyscenedetect_amd`` over the CPU oracle engine), on random clips, detector sets, detector parameters and
 SceneManager settings.  Build container only (the reference is not on the GPU box); no GPU involved.
 
-    python tools/fuzz_host_vs_reference.py [--seconds 120] [--seed 1] [--max-cases 100000] [--verbose]
+    python tools/fuzz_host_vs_reference.py [--seconds 120] [--seed 1] [--wide] [--tiny] [--force ...] [--verbose]
+                                           [--cross] [--plug] [--guest] [--sim] [--binding]      |      --engines (GPU box)
 
-Every case draws a small synthetic clip (``pyscenedetect_amd.synth.make_clip``, sometimes with fades to black, sometimes uniform
-noise), a frame rate, one to three detectors with random constructor arguments (thresholds, ``min_scene_len`` as frames / seconds /
-a timecode string, weights with and without the edge term, ``luma_only``, ``kernel_size``, filter modes, window widths, bins,
-fade bias, FLOOR / CEILING, ``add_final_scene``, hash sizes), a StatsManager or none, and SceneManager settings (auto / manual
-downscale with each interpolation the mirror supports, crop, ``frame_skip``, ``end_time`` / ``duration`` as frames or seconds,
-``start_in_scene``, presentation timestamps, a ``callback``, inputs both sides must refuse), runs both sides and requires the SAME
-outcome: frames processed, cut list, scene list, every per-frame metric bit for bit, the frames handed to the callback (number,
-shape, checksum), the text of the saved stats CSV, and a SECOND detection from a fresh StatsManager loaded from that CSV (the
-detectors then decide from cached metrics) -- or the same exception type.  Prints one JSON line: cases, by detector, the first mismatches with the seed and
-case number that reproduce them."""
+INGREDIENTS.  Every case draws a small synthetic clip (``pyscenedetect_amd.synth.make_clip``, sometimes with fades to black, sometimes
+uniform noise; ``--tiny``: frames of a few pixels, hundreds of frames), a frame rate, one to three detectors with random constructor
+arguments (thresholds, ``min_scene_len`` as frames / seconds / a timecode string -- ``--wide``: as a FrameTimecode / Timecode object --,
+weights with and without the edge term -- ``--wide``: fractional, negative, all zero --, ``luma_only``, ``kernel_size``, filter modes,
+window widths, bins, fade bias, FLOOR / CEILING, ``add_final_scene``, hash sizes), a StatsManager or none, and SceneManager settings
+(auto / manual downscale with each interpolation the mirror supports, crop, ``frame_skip``, ``end_time`` / ``duration`` as frames or
+seconds, ``start_in_scene``, presentation timestamps, a ``callback``, a few frames of another size, exceptions from the caller's
+callback or the stream's ``read``, inputs both sides must refuse).  MODES: one manager run; the plug-in API by hand (``process_frame`` /
+``post_process``); one manager on two videos with or without ``clear()``; a second detection from the saved stats CSV; with ``--wide``
+also detection from a seek position and in pieces (a detector joining in between), the package's ``detect()``, frame layouts
+(``rgb[..., ::-1]`` views, windows of padded buffers, read-only arrays), a detector of the caller's own on the plug-in API, and the SAME
+detector objects under a manager for half of the clip and fed by hand -- or under another manager -- for the other half.
+
+SIDES.  The plain reference is always side one, the mirror over the oracle engine side two.  ``--cross``: the mirror's manager and
+detectors reading one of the REFERENCE's VideoStream objects.  ``--plug``: the mirror's detectors registered with the REFERENCE's own
+SceneManager / StatsManager.  ``--guest``: a detector derived from the reference's SceneDetector ABC under the mirror's manager.
+``--sim``: the mirror over a host-memory stand-in of the DEVICE engine (feeder, tap rows, slots, halo frame, resident per-frame
+buffers): the Python half of the GPU path.  ``--binding``: the reference with INTEGRATION.md B's seams bound to the C-ABI (its CPU
+build).  ``--engines`` (GPU box, no reference needed): the mirror over the HIP engine against the mirror over the oracle engine.
+
+OUTCOME, required to be the SAME on every side: frames processed, cut list, scene list, every per-frame metric bit for bit AND the type
+of its values, the frames handed to the callback and to a plug-in detector (number, shape, checksum), the text of the saved stats CSV,
+the second detection from it, the stream's position afterwards, the detectors' public attributes afterwards, every warning (category
+and text) and every log record (level and text) -- or the same exception type with the same text.  Prints one JSON line: cases, by
+detector, the first mismatches with the seed and case number that reproduce them."""
 import argparse
 import json
 import os
