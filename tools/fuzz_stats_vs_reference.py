@@ -185,6 +185,41 @@ def run(side, fps, prog, tmp, other_text=None):
     return out
 
 
+def logged(fn):
+    """The program's results followed by what it logged (level and text; temporary paths blanked) and the warnings it emitted."""
+    import logging
+    import re
+    import warnings
+
+    class Capture(logging.Handler):
+        def __init__(self):
+            super().__init__(logging.DEBUG)
+            self.records = []
+
+        def emit(self, record):
+            self.records.append([record.levelname, re.sub(r"/tmp/\S+", "<tmp>", record.getMessage())])
+
+    log, capture = logging.getLogger("pyscenedetect"), Capture()
+    saved = (log.level, log.propagate, logging.root.manager.disable)
+    log.addHandler(capture)
+    log.setLevel(logging.DEBUG)
+    log.propagate = False
+    logging.disable(logging.NOTSET)
+    try:
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            out = list(fn())
+    finally:
+        log.removeHandler(capture)
+        log.setLevel(saved[0])
+        log.propagate = saved[1]
+        logging.disable(saved[2])
+    out.append(["log", capture.records])
+    out.append(["warnings", sorted({(w.category.__name__, re.sub(r"/tmp/\S+", "<tmp>", str(w.message))) for w in caught
+                                    if not issubclass(w.category, ResourceWarning)})])
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
@@ -197,7 +232,7 @@ def main():
         while time.time() < t_end:
             rng = np.random.default_rng([args.seed, cases])
             fps, prog = draw_program(rng)
-            a, b = run("ref", fps, prog, tmp), run("ours", fps, prog, tmp)
+            a, b = logged(lambda: run("ref", fps, prog, tmp)), logged(lambda: run("ours", fps, prog, tmp))
             if a != b:
                 first = next(i for i, (x, y) in enumerate(zip(a, b)) if x != y)
                 desc = {"case": cases, "fps": fps, "step": first, "op": prog[first], "ref": str(a[first])[:300], "ours": str(b[first])[:300], "program": prog[:first + 1]}
