@@ -23,6 +23,8 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "scene
 def _lib_path():
     from tests.conftest import _gpu_available
 
+    if os.environ.get("PSD_ORACLE_ABI_LIB"):          # (tools/sanitize/run_oracle_sanitized.py: the CPU build under ASan / UBSan)
+        return os.environ["PSD_ORACLE_ABI_LIB"]
     if _gpu_available():
         return os.path.join(ROOT, "pyscenedetect_amd", "libpsd_hip.so")
     import subprocess

@@ -22,8 +22,12 @@ def main():
         subprocess.check_call(["gcc", "-O1", "-g", "-msse4.2", "-fPIC", "-std=c11", "-fno-fast-math", "-ffp-contract=off",
                                "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared", "-o", LIB,
                                os.path.join(ROOT, "oracle", "cv2_restate.c"), "-lm"])
+        abi = os.path.join(OUT, "libpsd_oracle_abi_san.so")      # the CPU build of the C-ABI (oracle/abi_cpu.c) as well
+        subprocess.check_call(["gcc", "-O1", "-g", "-msse4.2", "-fPIC", "-std=c11", "-fno-fast-math", "-ffp-contract=off",
+                               "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared", "-o", abi,
+                               os.path.join(ROOT, "oracle", "abi_cpu.c"), os.path.join(ROOT, "oracle", "cv2_restate.c"), "-lm"])
         asan = sorted(glob.glob("/usr/lib/x86_64-linux-gnu/libasan.so.*"))[0]
-        env = dict(os.environ, PSD_SANITIZED="1", LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+        env = dict(os.environ, PSD_SANITIZED="1", PSD_ORACLE_ABI_LIB=abi, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
                    UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
         raise SystemExit(subprocess.call([sys.executable, os.path.abspath(__file__)], env=env))
     sys.path[:0] = [os.path.join(ROOT, "oracle", "cv2_shim"), ROOT]
@@ -37,7 +41,7 @@ def main():
 
     rc = pytest.main(["-q", "-x", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_oracle.py"),
                       os.path.join(ROOT, "tests", "test_published_values.py"), os.path.join(ROOT, "tests", "test_host_golden.py"),
-                      os.path.join(ROOT, "tests", "test_scene_manager.py")])
+                      os.path.join(ROOT, "tests", "test_scene_manager.py"), os.path.join(ROOT, "tests", "test_reference_binding.py")])
     if rc != 0:
         raise SystemExit(rc)
     if os.path.isdir("/root/reference/scenedetect"):      # random shapes, crops, downscales, thumbnails, kernels through the same build
