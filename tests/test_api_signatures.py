@@ -64,3 +64,35 @@ def test_function_signatures(name):
     assert [g[0] for g in got[:len(want)]] == [w[0] for w in want], (name, got, want)
     for g, w in zip(got, want):
         assert same_default(g[1], w[1]), (name, w[0], g[1], w[1])
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/scenedetect"), reason="the reference checkout is only in the build container")
+def test_module_paths_of_the_hot_path_carry_over():
+    """An import written for the reference needs only the package name changed: every module of the hot path exists under the same path
+    (``scenedetect.common`` -> ``pyscenedetect_amd.common`` ...) and holds every public name the reference defines there (SURVEY.md 2,
+    rows 1-8 and 16; output, decoding and CLI modules are out of scope)."""
+    import importlib
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    added = [p for p in (os.path.join(root, "oracle", "cv2_shim"), "/root/reference") if p not in sys.path]
+    sys.path[:0] = added
+    try:
+        out_of_scope = {"scene_manager": {"save_images", "write_scene_list", "write_scene_list_html", "PathFormatter", "SceneMetadata",
+                                          "VideoMetadata", "default_formatter", "is_ffmpeg_available", "is_mkvmerge_available",
+                                          "split_video_ffmpeg", "split_video_mkvmerge", "write_scene_list_edl", "write_scene_list_fcp7",
+                                          "write_scene_list_fcpx", "write_scene_list_otio"}}
+        for path in ("common", "detector", "detectors", "detectors.content_detector", "detectors.adaptive_detector",
+                     "detectors.histogram_detector", "detectors.threshold_detector", "detectors.hash_detector", "scene_manager",
+                     "stats_manager", "video_stream"):
+            theirs = importlib.import_module("scenedetect." + path)
+            ours = importlib.import_module("pyscenedetect_amd." + path)
+            defined = [n for n in dir(theirs) if not n.startswith("_")
+                       and getattr(getattr(theirs, n), "__module__", None) == theirs.__name__]
+            defined += list(getattr(theirs, "__all__", []))
+            missing = sorted(set(defined) - set(dir(ours)) - out_of_scope.get(path, set()))
+            assert not missing, (path, missing)
+    finally:
+        for p in added:
+            sys.path.remove(p)
