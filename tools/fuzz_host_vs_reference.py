@@ -226,6 +226,8 @@ def draw_clip(rng):
     h = int(rng.choice([24, 36, 37, 48, 54, 72]))
     w = int(rng.choice([32, 53, 64, 80, 96, 128, 160, 300, 520, 640]))
     n = int(rng.integers(12, 110))
+    if WIDE and rng.integers(0, 25) == 0:      # now and then frames large enough for the feeder's tap-row uploads (factor 3.75 .. 7.5)
+        h, w, n = int(rng.choice([135, 180, 270])), int(rng.choice([960, 1280, 1920])), int(rng.integers(12, 24))
     kind = int(rng.integers(0, 5))
     seed = int(rng.integers(0, 1 << 30))
     if kind == 0:
