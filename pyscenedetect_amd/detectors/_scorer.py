@@ -30,7 +30,9 @@ class FrameScorer:
         """``frame`` precedes whatever is scored next: a SceneManager's shared pass saw it on this detector's behalf (the reference's
         detector would hold the planes it derived from it, ``content_detector.py:189``), so a caller who goes on with
         ``process_frame()`` on the same detector gets the score against it."""
-        self._last = self._seed = np.array(frame, copy=True)
+        # (a reference, not a copy: the manager's own carried frame is one too -- frames a stream hands out are not written to again,
+        #  the decode queue of the reference and the batches here both rest on that)
+        self._last = self._seed = np.asarray(frame)
         self._last_shape = self._last.shape
         self.scored_since_seed = False
 
