@@ -38,7 +38,8 @@ PARAMS = {
     "ThresholdDetector": ["threshold", "min_scene_len", "fade_bias", "add_final_scene", "method"],
     "HashDetector": ["threshold", "size", "lowpass", "min_scene_len"],
 }
-ODD = [None, -1, 0, 1, 2, 3, 4, 7, 16, 255, 256, 1000, -0.5, 0.0, 0.5, 1.0, 2.5, 27.0, 1e9, "3", "0.5", "1.5s", "00:00:01.000", "abc", "", True, False, [1, 2], (1, 1, 1, 1)]
+ODD = [None, -1, 0, 1, 2, 3, 4, 7, 16, 255, 256, 1000, -0.5, 0.0, 0.5, 1.0, 2.5, 27.0, 1e9, "3", "0.5", "1.5s", "00:00:01.000", "abc", "", True, False, [1, 2], (1, 1, 1, 1),
+       np.int64(3), np.int32(15), np.uint8(7), np.float64(2.5), np.float32(0.5), np.bool_(True)]      # (numbers that came out of an array)
 
 
 def draw_arg(rng, name):
