@@ -223,3 +223,16 @@ def test_numpy_integers_are_frame_numbers_like_in_the_reference():
         FrameTimecode(np.int64(-1), 25.0)
     with pytest.raises(TypeError, match="not supported between"):
         FrameTimecode(None, 25.0)
+
+
+def test_timecodes_survive_pickle_and_deepcopy():
+    """Results cross process boundaries (one process per GPU, cut lists gathered on every rank): a timecode of each backing comes back
+    equal, with the same hash and the same text."""
+    import copy
+    import pickle
+
+    from pyscenedetect_amd import Timecode
+
+    for tc in (FrameTimecode(5, 25.0), FrameTimecode(1.5, 29.97), FrameTimecode(Timecode(1500, Fraction(1, 1000)), 24.0)):
+        for twin in (pickle.loads(pickle.dumps(tc)), copy.deepcopy(tc)):
+            assert twin == tc and hash(twin) == hash(tc) and twin.get_timecode() == tc.get_timecode() and twin.frame_rate == tc.frame_rate
