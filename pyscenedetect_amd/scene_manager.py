@@ -450,6 +450,13 @@ class SceneManager:
                 result = None
                 if engine is not None:
                     if last_frame is not None and last_frame.shape != frames[0].shape:
+                        # frames of another size than the one a detector saw last: the reference's ContentDetector compares the planes it
+                        # kept with the new ones behind `assert left.shape == right.shape` (content_detector.py:29-36) -- a second video
+                        # of another size without clear(), a manager taking over from process_frame() calls on other frames
+                        for detector in self._detector_list:
+                            if _score_flags(detector) & 9 and getattr(detector, "_have_last", False):
+                                raise AssertionError("frame size changed from %dx%d to %dx%d" % (
+                                    last_frame.shape[1], last_frame.shape[0], frames[0].shape[1], frames[0].shape[0]))
                         last_frame = None
                         if feeder:
                             feeder.forget_halo()

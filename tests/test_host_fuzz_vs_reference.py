@@ -570,3 +570,20 @@ def test_mirror_managers_consume_the_references_fan_out_stream(fuzz, oracle_engi
                 [psd.ContentDetector(min_scene_len=5, engine=oracle_engine), psd.ThresholdDetector(min_scene_len=3, engine=oracle_engine),
                  psd.AdaptiveDetector(min_scene_len=5, window_width=1, engine=oracle_engine)])
     assert got == want and all(cuts for _, cuts, _ in want)
+
+
+def test_a_manager_taking_over_frames_of_another_size_raises_like_the_reference(fuzz, oracle_engine):
+    """``process_frame()`` by hand, then a SceneManager with the same detectors on frames of ANOTHER size: the reference's ContentDetector
+    compares the planes it kept with the new ones behind ``assert left.shape == right.shape`` (``content_detector.py:29-36``), and the
+    AssertionError leaves ``detect_scenes``.  The mirror's shared pass dropped the predecessor silently (seed 200 case 34: the second
+    half of a clip began with a frame of another size); detectors that compare nothing across frames go on, as in the reference."""
+    frames = np.random.default_rng(17).integers(0, 256, (30, 36, 64, 3), dtype=np.uint8)
+    for dets, raises in (([("ContentDetector", {})], True), ([("AdaptiveDetector", {}), ("HashDetector", {})], True),
+                         ([("HistogramDetector", {}), ("ThresholdDetector", {}), ("HashDetector", {})], False)):
+        cfg = {"stats": True, "auto_downscale": False, "start_in_scene": True, "batch_frames": 7, "mode": "mixed", "manager_first": False,
+               "odd_frames": [15]}
+        a = fuzz.outcome(lambda: fuzz.run_side("ref", frames, 25.0, dets, cfg, None))
+        assert ("raises" in a) == raises and a.get("raises", "AssertionError") == "AssertionError"
+        for side, engine in (("mirror", oracle_engine), ("mirror", fuzz.sim_engine(oracle_engine)), ("plug", oracle_engine)):
+            b = fuzz.outcome(lambda: fuzz.run_side(side, frames, 25.0, dets, cfg, engine))
+            assert fuzz.differ(a, b, cfg) is None, (dets, side, fuzz.differ(a, b, cfg))

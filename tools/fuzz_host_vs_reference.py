@@ -282,6 +282,8 @@ def draw_case(rng):
     elif k == 1:
         sm["mode"] = "reuse"             # one manager, two videos: with clear() in between or without
         sm["clear_between"] = bool(rng.integers(0, 2))
+        if WIDE and rng.integers(0, 4) == 0:
+            sm["other_size2"] = True
         if WIDE and rng.integers(0, 2):
             sm["pts2"] = [0] + [int(x) for x in np.cumsum(rng.choice([20, 40, 40, 40, 40, 60, 80], size=n - 1))]
     if rng.integers(0, 4) == 0:
@@ -543,6 +545,8 @@ def run_side(side, frames, fps, dets, cfg, engine):
         if cfg["clear_between"]:
             sm.clear()
         rev = frames[::-1]
+        if cfg.get("other_size2"):      # the second video has another frame size (the reference's SAD detectors then refuse it without clear())
+            rev = np.ascontiguousarray(rev[:, : max(1, rev.shape[1] - 4), : max(1, rev.shape[2] - 6)])
         video2 = (MemoryStream(rev, fps) if side in ("ref", "cross", "plug", "guest_cross") else psd.ArrayVideoStream(rev, fps))
         if "pts2" in cfg:      # the second video with presentation timestamps (whatever the first one had)
             video2 = (VfrMemoryStream(rev, fps, cfg["pts2"], Fraction(1, 1000)) if side in ("ref", "cross", "plug", "guest_cross")
