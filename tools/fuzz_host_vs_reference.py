@@ -694,8 +694,8 @@ def outcome(fn):
 
 
 def differ(a, b, cfg=None):
-    if cfg is not None and cfg.get("fail_at") and cfg.get("odd_frames"):
-        # a run that the caller's callback or the stream's read ENDS: how far the decode thread had read ahead by then (and logged about
+    if cfg is not None and cfg.get("odd_frames") and (cfg.get("fail_at") or "raises" in a or "raises" in b):
+        # a run that the caller's callback, the stream's read or a detector's exception ENDS: how far the decode thread had read ahead by then (and logged about
         # the frames it met) is a matter of timing in the reference (its queue holds four frames) and of the batch size here
         a, b = {k: v for k, v in a.items() if k != "log"}, {k: v for k, v in b.items() if k != "log"}
     if a.keys() != b.keys():
