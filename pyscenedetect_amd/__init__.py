@@ -34,9 +34,10 @@ def open_video(path, frame_rate=None, backend: str = "opencv", **kwargs):
     return _reference.open_video(path, backend=backend, **kwargs)
 
 
-def detect(video, detector, stats_file_path=None, show_progress=False, start_time=None, end_time=None,
+def detect(video_path, detector, stats_file_path=None, show_progress=False, start_time=None, end_time=None,
            start_in_scene=False, backend: str = "opencv", fps=25.0, engine=None):
-    """Counterpart of ``scenedetect.detect()`` (reference ``scenedetect/__init__.py:160-219``): ``video`` is an array
+    """Counterpart of ``scenedetect.detect()`` (reference ``scenedetect/__init__.py:160-219``, same parameters in the same order;
+    ``fps`` and ``engine`` are this package's): ``video_path`` is an array
     ``uint8[N,H,W,3]`` of BGR frames (at ``fps``), a frame source (anything with the ``VideoStream`` members
     ``SceneManager.detect_scenes`` uses, e.g. one of the reference's backends), or -- like the reference's ``video_path`` -- a path
     or list of paths, opened by :func:`open_video` with ``backend``.  Returns the scene list ``[(start, end), ...]``."""
@@ -44,6 +45,7 @@ def detect(video, detector, stats_file_path=None, show_progress=False, start_tim
 
     import numpy as _np
 
+    video = video_path
     if isinstance(video, _np.ndarray):
         video = ArrayVideoStream(video, fps)
     elif isinstance(video, (str, _os.PathLike)) or (isinstance(video, (list, tuple)) and video

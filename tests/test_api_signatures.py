@@ -52,15 +52,8 @@ def test_function_signatures(name):
     fn = getattr(scene_manager, name, None) or getattr(psd, name)
     want = GOLD["functions"][name]
     got = [[p.name, "<required>" if p.default is inspect.Parameter.empty else repr(p.default)] for p in inspect.signature(fn).parameters.values()]
-    if name == "detect":
-        # the mirror's detect() takes decoded frames or a stream where the reference takes a path (decoders are out of scope);
-        # the parameters behind it follow the reference
-        names = [g[0] for g in got]
-        for w in want[1:]:
-            if w[0] in ("backend",):
-                continue
-            assert w[0] in names, (w[0], names)
-        return
+    # (detect(): the reference's parameters in its order -- `video_path` also takes decoded frames or a stream, a path goes to the
+    #  reference's decoders where installed -- followed by this package's `fps` and `engine`)
     assert [g[0] for g in got[:len(want)]] == [w[0] for w in want], (name, got, want)
     for g, w in zip(got, want):
         assert same_default(g[1], w[1]), (name, w[0], g[1], w[1])
