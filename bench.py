@@ -436,17 +436,31 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
     attempt("histogram_threshold_4k", f"BASELINE configs[2]: HistogramDetector + ThresholdDetector, {frames_small} x 3840x2160, uniform bytes", run_4k)
     torch.cuda.empty_cache()
 
-    def run_flow_small(kind):
+    def run_flow_secondary(kind):
+        # The two flows at the length BASELINE.md quotes them at (round-5 review: the driver-visible line ran them shortened and read
+        # other fractions than the table): one GPU's share of the corpus, 3 x 2048 x 1080p + 512 x 4K, and the 11-clip BBC stand-in
+        # with 6000+ frames per clip -- 51 GB each, generated once and scored through BOTH pipelines: the reference's default (every
+        # frame behind SceneManager's auto-downscale: the primary numbers of the line) and full resolution (`full_resolution`).
         import copy
 
         a = copy.copy(args)
-        a.workload, a.corpus_frames, a.bbc_frames, a.steps, a.warmup, a.no_cpu_baseline = kind, 512, 2000, 3, 1, False
+        a.workload, a.corpus_frames, a.bbc_frames, a.steps, a.warmup, a.no_cpu_baseline = kind, args.flow_corpus_frames, args.flow_bbc_frames, 3, 1, False
         a.height = a.width = 0
         a.cpu_sample = 256
-        r = run_flow(a, eng, device, 1, 0, device.index or 0, False, True)
+        a.flow_pipeline = "default"
+        fw = FlowWorkload(kind, eng, device, 0, 1, a)
+        keys = ("value", "unit", "ms_per_step", "roofline", "pipeline", "cuts_found", "ground_truth", "parity_sample", "cpu_baseline")
+
+        def brief(r):
+            return {k: r[k] for k in keys} | {"frames_1080p_equivalent_per_s": r["config"]["frames_1080p_equivalent_per_s"],
+                                              "frames_total": r["config"]["frames_total"]}
+
+        out_ = brief(run_flow(a, eng, device, 1, 0, device.index or 0, False, True, fw=fw))
+        fw.set_pipeline("full")
+        out_["full_resolution"] = brief(run_flow(a, eng, device, 1, 0, device.index or 0, False, True, fw=fw))
+        del fw
         torch.cuda.empty_cache()
-        return {k: r[k] for k in ("value", "unit", "ms_per_step", "roofline", "cuts_found", "ground_truth", "parity_sample", "cpu_baseline")} | \
-            {"frames_1080p_equivalent_per_s": r["config"]["frames_1080p_equivalent_per_s"], "frames_total": r["config"]["frames_total"]}
+        return out_
     def run_host_fed():
         # PCIe-inclusive and never `value`: SceneManager.detect_scenes over frames in pageable host memory, the reference's
         # default pipeline (auto downscale to 256 wide, ContentDetector).  The decode thread uploads only the rows the
@@ -609,10 +623,13 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
     attempt("host_fed_default_pipeline", f"PCIe-inclusive: SceneManager.detect_scenes (auto downscale, ContentDetector, no StatsManager: the "
             f"reference's default) over 3072 x {w}x{h} shot-like frames (768 distinct ones, four times over) in pageable host memory; only the source "
             "rows that carry taps are uploaded, 16 frames per call", near_gpu(run_host_fed))
-    attempt("corpus_mixed_1080p_4k_all_four", "BASELINE configs[4] at reduced length: 3 x 1080p x 512 + 1 x 4K x 128 shot-like frames, all four "
-            "detectors, clips packed per resolution (bench.py --workload corpus is the full-length run)", lambda: run_flow_small("corpus"))
-    attempt("bbc_standin_adaptive", "BASELINE configs[3] at reduced length: AdaptiveDetector over the 11-clip 640x360 stand-in, 2000+ frames per "
-            "clip (bench.py --workload bbc is the full-length run)", lambda: run_flow_small("bbc"))
+    attempt("corpus_mixed_1080p_4k_all_four", f"BASELINE configs[4], one GPU's share at full length: 3 x 1080p x {args.flow_corpus_frames} + 1 x 4K x "
+            f"{max(1, args.flow_corpus_frames // 4)} shot-like frames, all four detectors, clips packed per resolution, every frame behind the "
+            "reference's default downscale (= bench.py --workload corpus); `full_resolution`: the same clips without the resize",
+            lambda: run_flow_secondary("corpus"))
+    attempt("bbc_standin_adaptive", f"BASELINE configs[3] at full length: AdaptiveDetector over the 11-clip 640x360 stand-in, {args.flow_bbc_frames}+ "
+            "frames per clip, every frame behind the reference's default downscale (= bench.py --workload bbc); `full_resolution`: without the resize",
+            lambda: run_flow_secondary("bbc"))
     return out
 
 
@@ -632,6 +649,10 @@ class FlowWorkload:
         from pyscenedetect_amd.distributed import assign_clips
 
         self.kind, self.eng, self.rank, self.world = kind, eng, rank, world
+        # "default": every clip scored as scenedetect.detect(video, detector) scores it -- resized by SceneManager's auto_downscale
+        # to about 256 pixels (scene_manager.py:110,123-140,666-678; what the reference's benchmark runs, benchmark/__main__.py:44-61);
+        # "full": no resize (SceneManager.auto_downscale = False), the form rounds 2-5 timed
+        self.set_pipeline(getattr(args, "flow_pipeline", "default"))
         if kind == "corpus":
             f = args.corpus_frames
             hw = [(args.height, args.width), (2 * args.height, 2 * args.width)] if args.height and args.width else [(1080, 1920), (2160, 3840)]
@@ -650,6 +671,8 @@ class FlowWorkload:
                          f"({hw[1]}x{hw[0]}, {sum(x[0] for x in self.specs)} frames, generated on the device; the real set "
                          "and a decoder are not in this image), sharded by clip (BASELINE.json configs[3])")
             shot_len = (40, 400)
+        self.what_clips = self.what
+        self.set_pipeline(self.pipeline)
         if small:
             shot_len = (8, 40)
         self.plan = assign_clips([n * h * w for n, h, w in self.specs], world)
@@ -663,8 +686,29 @@ class FlowWorkload:
         self.frames_total = sum(sp[0] for sp in self.specs)
         self.result = None
 
+    def set_pipeline(self, pipeline: str) -> None:
+        self.pipeline = pipeline
+        self.downscale = "auto" if pipeline == "default" else None
+        if hasattr(self, "what_clips"):
+            self.what = self.what_clips + ("; every frame behind the reference's default downscale (SceneManager.auto_downscale, one factor per "
+                                           "resolution: psd_score_segments_downscaled_device)" if self.downscale else
+                                           "; FULL-resolution frames (auto_downscale off)")
+        self.result = None
+
+    def scored(self, h: int, w: int) -> tuple[float, int, int]:
+        from pyscenedetect_amd.engine import downscale_size
+
+        return downscale_size(h, w, self.downscale)
+
     def my_bytes(self) -> int:
-        return sum(self.specs[i][0] * self.specs[i][1] * self.specs[i][2] * 3 for i in self.plan[self.rank])
+        """Algorithmic bytes of this rank's clips: 3 B/px once; behind the downscale the source rows that carry taps
+        (two per destination row, never more than all rows: DESIGN.md 4.4)."""
+        total = 0
+        for i in self.plan[self.rank]:
+            n, h, w = self.specs[i]
+            factor, dh, _ = self.scored(h, w)
+            total += n * (min(h, 2 * dh) if factor > 1.0 else h) * w * 3
+        return total
 
     def step(self) -> float:
         """One pass over the whole corpus; returns this rank's kernel time (ms, HIP events, summed over its launches)."""
@@ -672,7 +716,7 @@ class FlowWorkload:
 
         if hasattr(self.eng, "kernel_ms_acc"):
             self.eng.kernel_ms_acc = 0.0
-        self.result = detect_corpus(self.eng, self.clips, 25.0, self.detectors)
+        self.result = detect_corpus(self.eng, self.clips, 25.0, self.detectors, auto_downscale=self.downscale == "auto")
         return float(getattr(self.eng, "kernel_ms_acc", 0.0))
 
     def parity(self, budget_frames: int, threads: int) -> tuple[str, dict]:
@@ -695,11 +739,29 @@ class FlowWorkload:
             seen.add((h, w))
             k = int(max(2, min(n, budget_frames * (1080 * 1920) // (h * w))))
             frames = self.clips[i][:k].cpu().numpy()
+            factor, dh, dw = self.scored(h, w)
             bounds = [(j * k // threads, (j + 1) * k // threads) for j in range(threads)]
             bounds = [b for b in bounds if b[1] > b[0]]
+
+            resize = None
+            if factor > 1.0:            # the oracle's cv2.resize (INTER_LINEAR) in front, like the reference's decode thread
+                shim = os.path.join(ROOT, "oracle", "cv2_shim")
+                if shim not in sys.path:
+                    sys.path.append(shim)
+                import cv2  # the oracle's shim: cv2.resize restated (scene_manager.py:670-678)
+
+                def resize(host, dw=dw, dh=dh):
+                    return np.stack([cv2.resize(f, (dw, dh)) for f in host])
+
+            def oracle_part(r, resize=resize):
+                part = frames[r[0] - 1 if r[0] else 0:r[1]]
+                if resize is not None:
+                    part = resize(part)
+                return orc.score_batch(part[1:] if r[0] else part, part[0] if r[0] else None, flags=flags & 7)
+
             t0 = time.perf_counter()
             with ThreadPoolExecutor(threads) as ex:
-                parts = list(ex.map(lambda r: orc.score_batch(frames[r[0]:r[1]], frames[r[0] - 1] if r[0] else None, flags=flags & 7), bounds))
+                parts = list(ex.map(oracle_part, bounds))
             t_cpu += time.perf_counter() - t0
             n_cpu += k * (h * w) / (1080 * 1920)
             want = np.concatenate(parts)
@@ -709,19 +771,22 @@ class FlowWorkload:
                 bad.append(f"records of clip {i}")
             # ... and deep into the clip (it sits somewhere inside a packed batch): its middle and its last frames
             deep = [r for r in parity_runs(n, max(2, k // 4)) if r[0] >= k]
-            for (a, b), w_ in zip(deep, oracle_records_at(self.clips[i], deep, flags, threads)):
+            for (a, b), w_ in zip(deep, oracle_records_at(self.clips[i], deep, flags, threads, resize)):
                 if any(not np.array_equal(got_all[f][a:b], w_[f]) for f in fields):
                     bad.append(f"records of clip {i}, frames {a}-{b - 1}")
-            want_cuts = corpus.decide(want, h, w, 25.0, self.detectors)
-            if corpus.decide(got, h, w, 25.0, self.detectors) != want_cuts:
+            want_cuts = corpus.decide(want, dh, dw, 25.0, self.detectors)
+            if corpus.decide(got, dh, dw, 25.0, self.detectors) != want_cuts:
                 bad.append(f"cuts of clip {i}")
             # ... and what the timed flow itself returned for this clip (every detector decides causally up to a short
             # look-ahead, so away from the end of the prefix the lists must agree)
             for name, cuts in want_cuts.items():
                 if [c for c in self.result[i][name] if c < k - 32] != [c for c in cuts if c < k - 32]:
                     bad.append(f"{name} cuts the flow returned for clip {i}")
-            notes.append(f"clip {i} ({w}x{h}): first {k} frames" + ("".join(f", frames {a}-{b - 1}" for a, b in deep)))
-        msg = ("records and cut lists identical to the oracle: " + "; ".join(notes)) if not bad else "MISMATCH vs oracle: " + ", ".join(bad)
+            notes.append(f"clip {i} ({w}x{h}" + (f" -> {dw}x{dh}" if factor > 1.0 else "") + f"): first {k} frames" +
+                         ("".join(f", frames {a}-{b - 1}" for a, b in deep)))
+        how = ("the reference pipeline's records and cut lists (cv2.resize to the auto-downscale size, then the detectors' arithmetic) "
+               "identical to the oracle's: " if self.downscale else "records and cut lists of FULL-resolution frames identical to the oracle: ")
+        msg = (how + "; ".join(notes)) if not bad else "MISMATCH vs oracle: " + ", ".join(bad)
         cpu = {"value": round(n_cpu / t_cpu, 2) if t_cpu > 0 else None, "unit": "1080p-equivalent frames/s", "cores": threads, "kind": "port",
                "sample": "the parity prefixes (" + "; ".join(notes) + f") through oracle/cv2_restate.c, {threads} threads, pixel work only"}
         return msg, cpu
@@ -730,7 +795,7 @@ class FlowWorkload:
         # the flow returns decisions; the records they came from are re-scored for the parity prefix (same engine calls)
         from pyscenedetect_amd import corpus
 
-        return corpus.score_clip(self.eng, self.clips[i], corpus.required_flags(self.detectors))
+        return corpus.score_clip(self.eng, self.clips[i], corpus.required_flags(self.detectors), downscale=self.downscale)
 
     def truth_f1(self) -> dict | None:
         """Precision / recall / F1 of this rank's clips against the generator's ground truth, scored the way the reference's
@@ -759,9 +824,11 @@ class FlowWorkload:
         return out
 
 
-def run_flow(args, eng, device, world, rank, local_rank, use_dist, on_gpu) -> dict | None:
-    """--workload corpus|bbc: W untimed passes, then K timed passes between barriers; MAX over ranks; rank 0 reports."""
-    fw = FlowWorkload(args.workload, eng, device, rank, world, args, small=not on_gpu)
+def run_flow(args, eng, device, world, rank, local_rank, use_dist, on_gpu, fw=None) -> dict | None:
+    """--workload corpus|bbc: W untimed passes, then K timed passes between barriers; MAX over ranks; rank 0 reports.
+    `fw`: clips that exist already (the default run scores one set through both pipelines)."""
+    if fw is None:
+        fw = FlowWorkload(args.workload, eng, device, rank, world, args, small=not on_gpu)
 
     def barrier():
         if use_dist:
@@ -807,9 +874,14 @@ def run_flow(args, eng, device, world, rank, local_rank, use_dist, on_gpu) -> di
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
                      "traffic_source": "not counted for this workload (same kernels as --detector all / content: profiles/hbm_traffic.json)",
-                     "kernel": "psd::score_frames_dma_kernel (one launch per resolution, clips packed; rank 0's launches)",
+                     "kernel": ("psd::resize_walk_kernel<SEG> (fused downscale + score; one launch per resolution, clips packed; rank 0's launches)"
+                                if fw.downscale else "psd::score_frames_dma_kernel (one launch per resolution, clips packed; rank 0's launches)"),
                      "avg_launch_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": algo,
-                     "note": "per step of rank 0: 3 B/px of its clips / the summed HIP-event time of its launches"},
+                     "note": ("per step of rank 0: the source rows of its clips that carry taps (2 x the resized height, DESIGN.md 4.4) / the "
+                              "summed HIP-event time of its launches" if fw.downscale else
+                              "per step of rank 0: 3 B/px of its clips / the summed HIP-event time of its launches")},
+        "pipeline": ("the reference's default (SceneManager.auto_downscale: what detect(video, detector) and benchmark/__main__.py run)"
+                     if fw.downscale else "full resolution (auto_downscale off)"),
         "cuts_found": sum(len(v) for r in (fw.result or []) for v in r.values()),
         "ground_truth": fw.truth_f1(),
     }
@@ -894,6 +966,11 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
     ap.add_argument("--workload", default="headline", choices=["headline", "corpus", "bbc"],
                     help="headline = one resident batch (BASELINE configs[1], or what --detector/--res/--downscale select); "
                          "corpus = configs[4] (mixed 1080p/4K clips, four detectors, sharded by clip); bbc = configs[3]")
+    ap.add_argument("--flow-pipeline", default="default", choices=["default", "full"],
+                    help="--workload corpus|bbc: default = every clip behind the reference's auto-downscale (what detect() scores); "
+                         "full = full-resolution frames (auto_downscale off; the form rounds 2-5 timed)")
+    ap.add_argument("--flow-corpus-frames", type=int, default=2048, help="length of the corpus flow inside the default run's `secondary`")
+    ap.add_argument("--flow-bbc-frames", type=int, default=6000, help="length of the BBC flow inside the default run's `secondary`")
     ap.add_argument("--corpus-frames", type=int, default=2048, help="frames per 1080p clip of --workload corpus (4K clips: a quarter)")
     ap.add_argument("--bbc-frames", type=int, default=6000, help="frames of the shortest of the 11 clips of --workload bbc")
     ap.add_argument("--exchange", default="default", choices=["default", "step", "stream", "inline", "off"], help=argparse.SUPPRESS)

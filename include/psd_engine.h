@@ -40,13 +40,16 @@
 extern "C" {
 #endif
 
-#define PSD_ABI_VERSION 6 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records);
+#define PSD_ABI_VERSION 7 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records);
                             * 3: additive over 2 (psd_frame_sums: records without the histogram, psd_score_collect_sums, psd_epilogue_*_sums);
                             * 4: additive over 3 (psd_resize_source_rows, psd_upload_rows: a host feeder uploads only the rows a downscale reads);
                             * 5: additive over 4 (psd_upload_rows_batch: many frames' rows gathered by worker threads into page-locked
                             *    memory and uploaded asynchronously; psd_last_walk_geometry);
                             * 6: additive over 5 (psd_cpus_near_device: the CPUs of the GPU's NUMA node, for hosts that place their decode
-                            *    threads and frame buffers themselves) */
+                            *    threads and frame buffers themselves);
+                            * 7: additive over 6 (psd_score_segments_downscaled_device: MANY clips packed into one batch behind the
+                            *    reference's default downscale -- what `detect(path, detector_cls())` of benchmark/__main__.py:44-61
+                            *    computes per video, for a whole shard of videos in one launch) */
 
 typedef enum psd_status {
     PSD_OK = 0,
@@ -278,6 +281,27 @@ int psd_score_downscaled_device(psd_engine* e, const uint8_t* d_frames, int n, i
 int psd_score_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w,
                                        size_t frame_stride, const uint8_t* d_prev, int dst_h, int dst_w,
                                        int interpolation, uint32_t flags, int edge_kernel, void* stream);
+
+/* psd_score_segments_device behind the downscale: MANY clips of one resolution packed into ONE batch, every frame resized as
+ * SceneManager does by default (auto_downscale: scene_manager.py:110,123-140, applied at :666-678) and then scored.  This is the
+ * arithmetic of the reference's own benchmark -- detect(video, detector_cls()) per video, benchmark/__main__.py:44-61, i.e. a
+ * SceneManager with auto_downscale=True in front of every detector -- for a whole shard of videos in one launch
+ * (north_star: "frames from many videos are packed into one device batch and sharded").
+ *   seg_first[0..n_seg)  batch indices of the first frame of every clip, ascending; such a frame has no predecessor, so the
+ *                        records equal those of n_seg separate psd_score_downscaled_device calls (and of n_seg SceneManagers).
+ *   dst_h, dst_w         max(1, round(src / factor)) per axis, factor = compute_downscale_factor(max(src_w, src_h)).
+ * Everything else as psd_score_downscaled_device: INTER_LINEAR with any set of the HSV, luma-histogram and byte-sum terms is ONE
+ * fused kernel (the resized frames never exist in memory; the clip-start flag is an SGPR read in front of the next frame's DMA
+ * issue); the edge term and INTER_NEAREST / INTER_AREA resize into an engine-owned buffer first.  The submit form pairs with
+ * psd_score_collect() / psd_score_collect_sums(). */
+int psd_score_segments_downscaled_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w,
+                                         size_t frame_stride, const int32_t* seg_first, int n_seg, int dst_h, int dst_w,
+                                         int interpolation, uint32_t flags, int edge_kernel, psd_frame_scores* out,
+                                         void* stream);
+int psd_score_segments_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w,
+                                                size_t frame_stride, const int32_t* seg_first, int n_seg, int dst_h,
+                                                int dst_w, int interpolation, uint32_t flags, int edge_kernel,
+                                                void* stream);
 
 /* psd_resize_device(..., PSD_INTER_LINEAR, ...) */
 int psd_resize_linear_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w,

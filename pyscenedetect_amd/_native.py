@@ -27,7 +27,7 @@ SCORE_EDGES = 8
 SCORE_ALL = 15
 
 MAX_INFLIGHT = 4
-ABI_VERSION = 6  # PSD_ABI_VERSION of include/psd_engine.h this binding was written against
+ABI_VERSION = 7  # PSD_ABI_VERSION of include/psd_engine.h this binding was written against
 
 #: numpy view of ``psd_frame_scores`` (1064 bytes).
 RECORD_DTYPE = np.dtype(
@@ -148,6 +148,8 @@ SYMBOLS = {
     "psd_resize_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _sz, _i, _vp]),
     "psd_score_downscaled_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _i, _u32, _i, _vp, _vp]),
     "psd_score_downscaled_submit_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _i, _u32, _i, _vp]),
+    "psd_score_segments_downscaled_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _i, _i, _u32, _i, _vp, _vp]),
+    "psd_score_segments_downscaled_submit_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _i, _i, _u32, _i, _vp]),
     "psd_resize_linear_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _sz, _vp]),
     "psd_hash_thumbs_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp]),
     "psd_hash_thumbs": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp]),

@@ -4,6 +4,13 @@ This is the batch face of the engine for BASELINE.json configs 4-5: clips are pa
 GPUs of a node (one process per GPU, sharded by clip), every clip is scored ONCE for the union of
 what the requested detectors need, the per-frame records are all-gathered (RCCL), and every rank
 runs the native decision epilogues -- so the result does not depend on the number of GPUs.
+
+What is computed per clip is what the reference computes per video: its benchmark runs
+``detect(video, detector_cls())`` (``benchmark/__main__.py:44-61``), i.e. a ``SceneManager`` with
+``auto_downscale=True`` whose decode thread resizes every frame to about 256 pixels width
+(``scene_manager.py:110,123-140,666-678``) before any detector sees it.  ``detect_corpus`` does the
+same by default (``auto_downscale=True``): every resolution of the corpus gets its own factor and the
+packed batches go through ``psd_score_segments_downscaled_device``.
 """
 
 import numpy as np
@@ -56,18 +63,36 @@ def decide(records: np.ndarray, height: int, width: int, fps, detectors: dict) -
     return out
 
 
-def score_clip(engine, clip, flags: int, edge_kernel: int = 0) -> np.ndarray:
+def scored_size(height: int, width: int, downscale=None) -> tuple[int, int]:
+    """``(height, width)`` of the frames the detectors see for source frames of ``height x width``: what ``decide()`` divides
+    by and what sizes the edge term's dilation kernel (``content_detector.py:36,39-46`` on the resized frame)."""
+    from pyscenedetect_amd.engine import downscale_size
+
+    _, dh, dw = downscale_size(height, width, downscale)
+    return dh, dw
+
+
+def score_clip(engine, clip, flags: int, edge_kernel: int = 0, downscale=None, interpolation: int = 1) -> np.ndarray:
     """Records of one clip held either in host memory (ndarray) or in HBM (anything with
-    ``data_ptr()``/``shape``, e.g. a torch uint8 tensor on this engine's device)."""
+    ``data_ptr()``/``shape``, e.g. a torch uint8 tensor on this engine's device); ``downscale`` as in ``score_clips``."""
+    from pyscenedetect_amd.engine import downscale_size
+
+    n, h, w, c = clip.shape
+    factor, dh, dw = downscale_size(h, w, downscale)
     if hasattr(clip, "data_ptr"):
-        n, h, w, c = clip.shape
         if c != 3 or not clip.is_contiguous():
             raise ValueError("device clips must be contiguous uint8[n,H,W,3]")
+        if factor > 1.0:
+            return engine.score_device_downscaled(clip.data_ptr(), n, h, w, dh, dw, flags=flags, edge_kernel=edge_kernel,
+                                                  interpolation=interpolation)
         return engine.score_device(clip.data_ptr(), n, h, w, flags=flags, edge_kernel=edge_kernel)
+    if factor > 1.0:
+        return engine.score_host(clip[0:len(clip)], flags=flags, edge_kernel=edge_kernel, downscale=factor, interpolation=interpolation)
     return engine.score_host(clip[0:len(clip)], flags=flags, edge_kernel=edge_kernel)
 
 
-def score_clips(engine, clips, flags: int, edge_kernel: int = 0, on_ready=None, sums_only: bool | None = None) -> list[np.ndarray]:
+def score_clips(engine, clips, flags: int, edge_kernel: int = 0, on_ready=None, sums_only: bool | None = None,
+                downscale=None, interpolation: int = 1) -> list[np.ndarray]:
     """Records of every clip; engines that can pack clips of one resolution into shared batches (``ScoringEngine.score_clips``:
     one launch per term per batch, SAD chain broken at clip starts) do so, others score clip by clip.
     ``on_ready(i, records)``: called per clip as its records arrive (see ``ScoringEngine.score_clips``).
@@ -76,19 +101,28 @@ def score_clips(engine, clips, flags: int, edge_kernel: int = 0, on_ready=None, 
     Threshold decisions read, and all that travels from the device, through the host and over the all-gather);
     ``sums_only=False`` -> ``RECORD_DTYPE`` (with the 256-bin luma histogram).  The default ``None`` means "sums only unless
     ``flags`` asks for the luma histogram" -- whatever kind of engine is behind it, so every rank of a process group returns
-    the same dtype for the same flags."""
+    the same dtype for the same flags.
+
+    ``downscale`` / ``interpolation``: the resize in front of the detectors -- ``"auto"`` (the reference's default pipeline,
+    a factor per resolution), a number, or ``None`` (``ScoringEngine.score_clips``)."""
     from pyscenedetect_amd.engine import _sums_of
 
     if sums_only is None:
         # without a HistogramDetector nobody reads the 1 KiB luma histogram of a record
         sums_only = not (flags & _native.SCORE_LUMA_HIST)
-    if hasattr(engine, "score_clips"):
-        import inspect
+    import inspect
 
-        params = inspect.signature(engine.score_clips).parameters
+    from pyscenedetect_amd.engine import downscale_size
+
+    params = inspect.signature(engine.score_clips).parameters if hasattr(engine, "score_clips") else {}
+    # does any clip get resized at all?  (an engine that packs clips but knows no downscale still packs a corpus of small clips)
+    resized = downscale is not None and any(downscale_size(c.shape[1], c.shape[2], downscale)[0] > 1.0 for c in clips)
+    if hasattr(engine, "score_clips") and (not resized or "downscale" in params):
         kw = {"sums_only": sums_only} if "sums_only" in params else {}
         if on_ready is not None and "on_ready" in params:
             kw["on_ready"] = on_ready
+        if resized:
+            kw["downscale"], kw["interpolation"] = downscale, interpolation
         out = engine.score_clips(clips, flags=flags, edge_kernel=edge_kernel, **kw)
         if sums_only and "sums_only" not in params:
             out = [_sums_of(r) for r in out]
@@ -98,19 +132,27 @@ def score_clips(engine, clips, flags: int, edge_kernel: int = 0, on_ready=None, 
         return out
     out = []
     for i, c in enumerate(clips):
-        recs = score_clip(engine, c, flags, edge_kernel)
+        recs = score_clip(engine, c, flags, edge_kernel, downscale, interpolation)
         out.append(_sums_of(recs) if sums_only else recs)
         if on_ready is not None:
             on_ready(i, out[-1])
     return out
 
 
-def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: int = 0) -> list[dict]:
+def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: int = 0, auto_downscale: bool = True,
+                  downscale=1, interpolation: int = 1) -> list[dict]:
     """Detect cuts in every clip of ``clips`` (each ``uint8[n,H,W,3]``, sizes may differ).
+
+    ``auto_downscale`` / ``downscale`` / ``interpolation`` are ``SceneManager``'s attributes of the same names
+    (``scene_manager.py:282-335``) with the same defaults: by default every clip is scored as ``detect(video, detector)``
+    scores it -- resized by ``compute_downscale_factor(max(frame_size))`` to about 256 pixels -- so the cut lists are those
+    of the reference's default pipeline (and of its benchmark, ``benchmark/__main__.py:44-61``).  ``auto_downscale=False``
+    with ``downscale=1`` scores full-resolution frames.
 
     With an initialised ``torch.distributed`` process group the clips are sharded over the ranks
     (``distributed.score_clips_distributed``) and every rank returns the full result."""
     flags = required_flags(detectors)
+    ds = "auto" if auto_downscale else (downscale if downscale is not None and downscale > 1 else None)
     use_dist = False
     try:
         import torch.distributed as dist
@@ -121,15 +163,16 @@ def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: 
     if use_dist:
         from pyscenedetect_amd.distributed import score_clips_distributed
 
-        records = score_clips_distributed(engine, clips, flags, edge_kernel, group)
+        records = score_clips_distributed(engine, clips, flags, edge_kernel, group, downscale=ds, interpolation=interpolation)
     fps_list = fps if isinstance(fps, (list, tuple)) else [fps] * len(clips)
+    sizes = [scored_size(c.shape[1], c.shape[2], ds) for c in clips]       # what the detectors see (and divide by)
     if not use_dist:
         # one process: a clip is decided as soon as its records are on the host, while the batches behind it are still on the GPU
         result: list = [None] * len(clips)
 
         def decide_now(i, recs):
-            result[i] = decide(recs, clips[i].shape[1], clips[i].shape[2], fps_list[i], detectors)
+            result[i] = decide(recs, sizes[i][0], sizes[i][1], fps_list[i], detectors)
 
-        score_clips(engine, clips, flags, edge_kernel, on_ready=decide_now)
+        score_clips(engine, clips, flags, edge_kernel, on_ready=decide_now, downscale=ds, interpolation=interpolation)
         return result
-    return [decide(r, c.shape[1], c.shape[2], f, detectors) for r, c, f in zip(records, clips, fps_list)]
+    return [decide(r, hw[0], hw[1], f, detectors) for r, hw, f in zip(records, sizes, fps_list)]

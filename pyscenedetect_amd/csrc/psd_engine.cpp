@@ -439,6 +439,8 @@ int psd_score_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int h
     return submit_end(e, *s, stream);
 }
 
+static int check_segments(const int32_t* seg_first, int n_seg, int n);
+
 // clip-start flags of a packed batch -> the slot's device array (through its pinned mirror, on the launch stream)
 static int upload_segments(psd_slot& s, int n, const int32_t* seg_first, int n_seg, hipStream_t stream)
 {
@@ -464,13 +466,8 @@ int psd_score_segments_submit_device(psd_engine* e, const uint8_t* d_frames, int
     if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
     int rc = validate(d_frames, n, height, width, row_stride, frame_stride, flags, edge_kernel);
     if (rc != PSD_OK) return rc;
-    if (n_seg < 0 || (n_seg > 0 && !seg_first)) { psd_set_error("invalid segment table"); return PSD_ERR_INVALID; }
-    for (int i = 0; i < n_seg; i++) {
-        if (seg_first[i] < 0 || seg_first[i] >= n || (i > 0 && seg_first[i] <= seg_first[i - 1])) {
-            psd_set_error("segment table must hold ascending frame indices inside the batch (entry %d = %d, n = %d)", i, seg_first[i], n);
-            return PSD_ERR_INVALID;
-        }
-    }
+    rc = check_segments(seg_first, n_seg, n);
+    if (rc != PSD_OK) return rc;
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : e->stream;
     psd_slot* s = nullptr;
     rc = submit_begin(e, n, flags, stream, &s);
@@ -509,25 +506,49 @@ static int resize_any(psd_engine* e, const uint8_t* d_src, int n, int src_h, int
     return psd::resize_other(e, d_src, n, src_h, src_w, src_frame_stride, d_dst, dst_h, dst_w, dst_frame_stride, interpolation, stream);
 }
 
-int psd_score_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w, size_t frame_stride,
-                                       const uint8_t* d_prev, int dst_h, int dst_w, int interpolation, uint32_t flags,
-                                       int edge_kernel, void* stream_)
+static int check_segments(const int32_t* seg_first, int n_seg, int n)
+{
+    if (n_seg < 0 || (n_seg > 0 && !seg_first)) { psd_set_error("invalid segment table"); return PSD_ERR_INVALID; }
+    for (int i = 0; i < n_seg; i++) {
+        if (seg_first[i] < 0 || seg_first[i] >= n || (i > 0 && seg_first[i] <= seg_first[i - 1])) {
+            psd_set_error("segment table must hold ascending frame indices inside the batch (entry %d = %d, n = %d)", i, seg_first[i], n);
+            return PSD_ERR_INVALID;
+        }
+    }
+    return PSD_OK;
+}
+
+// cv2.resize in front of the terms of `flags` (scene_manager.py:666-678 + the detectors' process_frame), one submission.
+// `segmented`: the batch is several clips back to back (seg_first: their first frames); d_prev is then null.
+static int downscaled_submit(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w, size_t frame_stride,
+                             const uint8_t* d_prev, bool segmented, const int32_t* seg_first, int n_seg, int dst_h, int dst_w,
+                             int interpolation, uint32_t flags, int edge_kernel, void* stream_)
 {
     if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
     int rc = validate(d_frames, n, src_h, src_w, (size_t)src_w * 3, frame_stride, flags, edge_kernel);
     if (rc != PSD_OK) return rc;
     if (dst_h <= 0 || dst_w <= 0) { psd_set_error("invalid target size %dx%d", dst_w, dst_h); return PSD_ERR_INVALID; }
+    if (segmented) {
+        rc = check_segments(seg_first, n_seg, n);
+        if (rc != PSD_OK) return rc;
+    }
     hipStream_t stream = stream_ ? (hipStream_t)stream_ : e->stream;
     psd_slot* s = nullptr;
     rc = submit_begin(e, n, flags, stream, &s);
     if (rc != PSD_OK) return rc;
     if (n > 0) {
+        const uint8_t* d_seg = nullptr;
+        if (segmented) {
+            rc = upload_segments(*s, n, seg_first, n_seg, stream);
+            if (rc != PSD_OK) return rc;
+            d_seg = s->d_seg;
+        }
         bool done = false;
         if (interpolation == PSD_INTER_LINEAR && !(flags & PSD_SCORE_EDGES)) {
             // Content / Adaptive / Histogram / Threshold detectors, any set of them, behind the default downscale: the resized
             // frame never leaves the CU (only the edge term needs it in memory)
             rc = psd::resize_linear_score(e, d_frames, n, src_h, src_w, (size_t)src_w * 3, frame_stride, d_prev, nullptr, dst_h, dst_w, 0,
-                                          s->d_recs, stream, &s->launches, nullptr, false, flags);
+                                          s->d_recs, stream, &s->launches, d_seg, false, flags);
             if (rc == PSD_OK) done = true;
             else if (rc != PSD_ERR_UNSUPPORTED) return rc;
         }
@@ -556,11 +577,41 @@ int psd_score_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, i
             if (rc != PSD_OK) return rc;
             s->launches += 1;
             rc = score_terms(e, *s, e->d_small + sstride, n, dst_h, dst_w, (size_t)dst_w * 3, sstride, d_prev ? e->d_small : nullptr, flags,
-                             edge_kernel, stream);
+                             edge_kernel, stream, d_seg);
             if (rc != PSD_OK) return rc;
         }
     }
     return submit_end(e, *s, stream);
+}
+
+int psd_score_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w, size_t frame_stride,
+                                       const uint8_t* d_prev, int dst_h, int dst_w, int interpolation, uint32_t flags,
+                                       int edge_kernel, void* stream)
+{
+    return downscaled_submit(e, d_frames, n, src_h, src_w, frame_stride, d_prev, false, nullptr, 0, dst_h, dst_w, interpolation, flags,
+                             edge_kernel, stream);
+}
+
+int psd_score_segments_downscaled_submit_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w,
+                                                size_t frame_stride, const int32_t* seg_first, int n_seg, int dst_h, int dst_w,
+                                                int interpolation, uint32_t flags, int edge_kernel, void* stream)
+{
+    return downscaled_submit(e, d_frames, n, src_h, src_w, frame_stride, nullptr, true, seg_first, n_seg, dst_h, dst_w, interpolation,
+                             flags, edge_kernel, stream);
+}
+
+int psd_score_segments_downscaled_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w, size_t frame_stride,
+                                         const int32_t* seg_first, int n_seg, int dst_h, int dst_w, int interpolation,
+                                         uint32_t flags, int edge_kernel, psd_frame_scores* out, void* stream)
+{
+    if (e && e->pending != 0) {
+        psd_set_error("psd_score_segments_downscaled_device: asynchronous submissions are still pending");
+        return PSD_ERR_INVALID;
+    }
+    int rc = psd_score_segments_downscaled_submit_device(e, d_frames, n, src_h, src_w, frame_stride, seg_first, n_seg, dst_h, dst_w,
+                                                         interpolation, flags, edge_kernel, stream);
+    if (rc != PSD_OK) return rc;
+    return psd_score_collect(e, out, n);
 }
 
 int psd_score_downscaled_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w, size_t frame_stride,

@@ -288,7 +288,9 @@ __device__ __forceinline__ void rs_lds_add(const u32* p, u32 inc)
 // later, writes it as 128 packed words to hpart[t][tile] with plain coalesced stores; hist_reduce_kernel adds the tiles of a
 // frame up.  (Global atomics instead -- up to 256 per tile and frame, 75 M per 4096-frame launch on one address per bin and
 // frame from every XCD -- would cost more than the pixels.)  The byte sum rides with the three SADs.
-template <bool STORE, bool HSV, int G, bool LUMA = false>
+// SEG: the instance for batches of packed clips (p.seg != nullptr; psd_score_segments_downscaled_device): a frame that starts
+// a clip has no predecessor.  The plain instances carry none of the flag's code.
+template <bool STORE, bool HSV, int G, bool LUMA = false, bool SEG = false>
 __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t rs_stage[];
@@ -388,6 +390,14 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     const int ahead = p.depth - 1;             // frames in flight beyond the current one
     if (tb < t1) issue(frame_ptr(tb), 0);
     if (ahead > 1 && tb + 1 < t1) issue(frame_ptr(tb + 1), 1);
+    // Clip-start flag of the NEXT frame to be stepped.  It is requested behind that frame's DMA issue and turned into an SGPR at
+    // the top of the frame's own step, right behind the wait that has covered it: hipcc waits for a loaded register where it is
+    // first read and knows nothing of the kernel's own s_waitcnt, so a flag read behind the issue of the frame AFTER would put an
+    // s_waitcnt vmcnt(0) there and drain the prefetch the wave has just started (psd_score_kernels.hip, round 5).
+    u32 seg_next = 0;
+    if constexpr (SEG) {
+        if (tb < t1 && tb >= 0) seg_next = p.seg[tb];
+    }
     for (int t = tb; t < t1; t++) {
         const int step = t - tb;
         const int buf = ahead > 1 ? step % 3 : (step & 1);
@@ -404,8 +414,16 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (LUMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's hidden histogram increments of frame t-1
+        u32 flag_now = 0;
+        if constexpr (SEG) {
+            flag_now = __builtin_amdgcn_readfirstlane(seg_next);
+            asm volatile("" ::"s"(flag_now) : "memory");
+        }
         lds_barrier();                         // every wave's rows of frame t have landed; frame t-1 is fully consumed (LDS only: no vmcnt drain)
         if (t + ahead < t1) issue(frame_ptr(t + ahead), ahead > 1 ? (step + 2) % 3 : (buf ^ 1));
+        if constexpr (SEG) {
+            if (t + 1 < t1) seg_next = p.seg[t + 1];   // (t + 1 >= 0: the halo frame in front of the batch is t = -1 at the earliest)
+        }
         const int rel = t - t0;                // chunk-relative frame index (-1 for the halo frame)
         if ((HSV || LUMA) && rel >= 8 && (rel & 7) == 0 && tid < 32) {
             // frames rel-8 .. rel-1 are complete (all waves added them before this frame's barrier)
@@ -430,7 +448,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         u32 sh = 0, ss = 0, sv = 0, bsum = 0;
         const bool count_luma = LUMA && t >= t0;           // (the halo frame only feeds the HSV carry)
         u32* hcur = lhist[LUMA ? (rel & 1) : 0];
-        const bool chain = have_prev && !(HSV && t >= 0 && p.seg != nullptr && p.seg[t] != 0);
+        const bool chain = have_prev && !(SEG && flag_now != 0);
 #pragma unroll
         for (int g = 0; g < G; g++) {
             if (!live[g]) continue;
@@ -556,15 +574,25 @@ __global__ __launch_bounds__(256) void resize_linear_generic_kernel(const uint8_
     for (int c = 0; c < 3; c++) D[c] = (uint8_t)interp(ra[x.o0 + c], ra[x.o1 + c], rb[x.o0 + c], rb[x.o1 + c], a0, a1, b0, b1);
 }
 
+template <bool STORE, bool HSV, bool LUMA, bool SEG>
+static void launch_walk_g(const RsParams& p, int g, int grid, size_t lds, hipStream_t stream)
+{
+    switch (g) {
+    case 1: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 1, LUMA, SEG>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    case 2: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 2, LUMA, SEG>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    case 4: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 4, LUMA, SEG>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    default: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 8, LUMA, SEG>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    }
+}
+
 template <bool STORE, bool HSV, bool LUMA = false>
 static void launch_walk(const RsParams& p, int g, int grid, size_t lds, hipStream_t stream)
 {
-    switch (g) {
-    case 1: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 1, LUMA>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
-    case 2: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 2, LUMA>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
-    case 4: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 4, LUMA>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
-    default: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 8, LUMA>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    // (the clip-start flags only matter to the HSV carry: instances without the HSV term have no SEG form)
+    if constexpr (HSV) {
+        if (p.seg != nullptr) { launch_walk_g<STORE, HSV, LUMA, true>(p, g, grid, lds, stream); return; }
     }
+    launch_walk_g<STORE, HSV, LUMA, false>(p, g, grid, lds, stream);
 }
 
 // cv2.resize(INTER_LINEAR) of n frames and / or the HSV term of the resized frames.

@@ -100,11 +100,14 @@ def score_clip_sharded(engine, get_frames, n_frames: int, flags: int, edge_kerne
     return np.concatenate(parts) if parts else np.zeros(0, RECORD_DTYPE)
 
 
-def score_clips_distributed(engine, clips, flags: int, edge_kernel: int = 0, group=None) -> list[np.ndarray]:
+def score_clips_distributed(engine, clips, flags: int, edge_kernel: int = 0, group=None, downscale=None,
+                            interpolation: int = 1) -> list[np.ndarray]:
     """Score independent clips sharded by clip; returns every clip's records on every rank.
 
     ``clips`` is a list of objects with ``len()`` and ``[a:b]`` slicing to ``uint8[n,H,W,3]``
-    (each rank only touches the clips assigned to it).
+    (each rank only touches the clips assigned to it).  ``downscale`` / ``interpolation``: the resize in front of the
+    detectors, as in ``corpus.score_clips`` (``"auto"``: the reference's default pipeline, a factor per resolution).
+    The shards are balanced on the SOURCE pixels either way: that is what a rank reads from HBM.
     """
     import torch.distributed as dist
 
@@ -114,9 +117,12 @@ def score_clips_distributed(engine, clips, flags: int, edge_kernel: int = 0, gro
     from pyscenedetect_amd.corpus import score_clips
 
     # this rank's clips, packed by resolution into shared device batches where the engine can (one launch per batch)
-    mine = score_clips(engine, [clips[i] for i in plan[rank]], flags, edge_kernel)
-    # (a rank without clips must still send the dtype the others send: what score_clips would have returned)
-    sums = hasattr(engine, "score_clips") and not (flags & SCORE_LUMA_HIST)
+    mine = score_clips(engine, [clips[i] for i in plan[rank]], flags, edge_kernel, downscale=downscale, interpolation=interpolation)
+    # (a rank without clips must still send the dtype the others send: what corpus.score_clips returns for these flags WHATEVER
+    #  engine is behind it -- sums unless the luma histogram was asked for.  Until round 6 this line also asked whether the engine
+    #  packs clips, so with a clip-by-clip engine, no HistogramDetector and more ranks than clips the idle ranks offered 1064-byte
+    #  records to an all-gather of 40-byte ones: found by the world-8 gloo test of the resized corpus.)
+    sums = not (flags & SCORE_LUMA_HIST)
     local = np.concatenate(mine) if mine else np.zeros(0, SUMS_DTYPE if sums else RECORD_DTYPE)
     parts = all_gather_records(local, group)
     out: list = [None] * len(clips)

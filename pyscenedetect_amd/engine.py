@@ -518,8 +518,28 @@ class ScoringEngine(TapRowPolicy):
                                                                  frame_stride, seg.ctypes.data if len(seg) else None, len(seg),
                                                                  int(flags), int(edge_kernel), stream))
 
+    def submit_device_segments_downscaled(self, d_frames: int, n: int, src_h: int, src_w: int, dst_h: int, dst_w: int, seg_first,
+                                          frame_stride: int | None = None, flags: int = SCORE_HSV_SAD, edge_kernel: int = 0,
+                                          interpolation: int = 1, stream: int | None = None) -> None:
+        """SEVERAL clips packed back to back (``seg_first``: the batch index of every clip's first frame), each frame resized
+        to ``(dst_w, dst_h)`` as the reference's ``SceneManager`` does by default and then scored
+        (``psd_score_segments_downscaled_submit_device``); pair with :meth:`collect`."""
+        frame_stride = src_h * src_w * 3 if frame_stride is None else frame_stride
+        seg = np.ascontiguousarray(seg_first, dtype=np.int32)
+        _native.check(self._lib.psd_score_segments_downscaled_submit_device(
+            self._h, d_frames, int(n), int(src_h), int(src_w), frame_stride, seg.ctypes.data if len(seg) else None, len(seg),
+            int(dst_h), int(dst_w), int(interpolation), int(flags), int(edge_kernel), stream))
+
+    def score_device_segments_downscaled(self, d_frames: int, n: int, src_h: int, src_w: int, dst_h: int, dst_w: int, seg_first,
+                                         frame_stride: int | None = None, flags: int = SCORE_HSV_SAD, edge_kernel: int = 0,
+                                         interpolation: int = 1, stream: int | None = None, sums_only: bool = False) -> np.ndarray:
+        self.submit_device_segments_downscaled(d_frames, n, src_h, src_w, dst_h, dst_w, seg_first, frame_stride, flags, edge_kernel,
+                                               interpolation, stream)
+        return self.collect(n, sums_only)
+
     def score_clips(self, clips, flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0,
-                    max_batch_bytes: int = 4 << 30, sums_only: bool = False, on_ready=None) -> list[np.ndarray]:
+                    max_batch_bytes: int = 4 << 30, sums_only: bool = False, on_ready=None, downscale=None,
+                    interpolation: int = 1) -> list[np.ndarray]:
         """Records of many clips (host ``uint8[n,H,W,3]`` arrays, or device tensors with ``data_ptr()``): clips of one
         resolution share device batches of up to ``max_batch_bytes``, scored with ONE launch per term per batch
         (``psd_score_segments_device``) instead of one per clip -- thousands of short clips are launch-bound otherwise.
@@ -527,7 +547,13 @@ class ScoringEngine(TapRowPolicy):
         the host-side copy of one batch's records overlaps the kernels of the next.
         The result equals ``[score_host(c) for c in clips]`` (``sums_only``: without the histogram, ``SUMS_DTYPE``).
         ``on_ready(i, records)`` is called for every clip as soon as its records are on the host -- while later batches
-        are still being scored -- so the caller's decisions overlap the remaining kernels."""
+        are still being scored -- so the caller's decisions overlap the remaining kernels.
+
+        ``downscale``: what the reference's ``SceneManager`` puts in front of its detectors (``scene_manager.py:110,123-140,
+        666-678``) -- ``"auto"`` = ``auto_downscale`` (the default of ``detect()``: every resolution gets its own factor,
+        ``compute_downscale_factor(max(width, height))``), a number = ``SceneManager.downscale``, ``None`` / 1 = none.  The
+        records are then those of the RESIZED frames (``psd_score_segments_downscaled_device``; ``downscale_size`` gives
+        their size), i.e. ``[score_host(c, downscale=factor) for c in clips]``."""
         out: list = [None] * len(clips)
         ready = on_ready if on_ready is not None else (lambda i, r: None)
         dtype = SUMS_DTYPE if sums_only else RECORD_DTYPE
@@ -580,6 +606,7 @@ class ScoringEngine(TapRowPolicy):
                 a0 = a - 1 if inside else a
                 seg = [0] + [int(f - a0) for f in first if a < f < b]
                 pieces.append((len(runs) - 1, base + a0 * stride, b - a0, seg, a, inside, h, w))
+        small = {hw: downscale_size(hw[0], hw[1], downscale) for hw in groups}     # (factor, dst_h, dst_w) per resolution
         in_flight: list = []
         k = 0
 
@@ -595,7 +622,12 @@ class ScoringEngine(TapRowPolicy):
             while k < len(pieces) or in_flight:
                 while k < len(pieces) and len(in_flight) < _native.MAX_INFLIGHT:
                     pc = pieces[k]
-                    self.submit_device_segments(pc[1], pc[2], pc[6], pc[7], pc[3], flags=flags, edge_kernel=edge_kernel)
+                    factor, dh, dw = small[(pc[6], pc[7])]
+                    if factor > 1.0:
+                        self.submit_device_segments_downscaled(pc[1], pc[2], pc[6], pc[7], dh, dw, pc[3], flags=flags,
+                                                               edge_kernel=edge_kernel, interpolation=interpolation)
+                    else:
+                        self.submit_device_segments(pc[1], pc[2], pc[6], pc[7], pc[3], flags=flags, edge_kernel=edge_kernel)
                     in_flight.append(pc)
                     k += 1
                 pc = in_flight.pop(0)
@@ -622,6 +654,7 @@ class ScoringEngine(TapRowPolicy):
             raise
         for (h, w), idxs in groups.items():
             stride = h * w * 3
+            factor, dh, dw = small[(h, w)]
             per_batch = max(1, max_batch_bytes // stride)
             host = [i for i in idxs if not hasattr(clips[i], "data_ptr")]
             k = 0
@@ -632,7 +665,8 @@ class ScoringEngine(TapRowPolicy):
                     frames += clips[host[k]].shape[0]
                     k += 1
                 if len(batch) == 1 and frames > per_batch:      # one clip larger than a batch: the chunked host path
-                    recs = self.score_host(np.asarray(clips[batch[0]]), flags=flags, edge_kernel=edge_kernel)
+                    recs = self.score_host(np.asarray(clips[batch[0]]), flags=flags, edge_kernel=edge_kernel,
+                                           downscale=factor if factor > 1.0 else 1.0, interpolation=interpolation)
                     out[batch[0]] = _sums_of(recs) if sums_only else recs
                     ready(batch[0], out[batch[0]])
                     continue
@@ -643,7 +677,11 @@ class ScoringEngine(TapRowPolicy):
                     buf.upload(c.reshape(-1), off * stride)
                     first.append(off)
                     off += c.shape[0]
-                recs = self.score_device_segments(buf.ptr, frames, h, w, first, flags=flags, edge_kernel=edge_kernel, sums_only=sums_only)
+                if factor > 1.0:
+                    recs = self.score_device_segments_downscaled(buf.ptr, frames, h, w, dh, dw, first, flags=flags, edge_kernel=edge_kernel,
+                                                                 interpolation=interpolation, sums_only=sums_only)
+                else:
+                    recs = self.score_device_segments(buf.ptr, frames, h, w, first, flags=flags, edge_kernel=edge_kernel, sums_only=sums_only)
                 for j, f0 in zip(batch, first):
                     out[j] = recs[f0:f0 + clips[j].shape[0]].copy()
                     ready(j, out[j])
@@ -710,6 +748,27 @@ class ScoringEngine(TapRowPolicy):
         return out
 
 
+def downscale_size(height: int, width: int, downscale=None) -> tuple[float, int, int]:
+    """``(factor, dst_h, dst_w)`` of the resize the reference's ``SceneManager`` puts in front of its detectors for frames of
+    ``height x width``: ``downscale="auto"`` is ``auto_downscale=True`` (the default, what ``detect()`` and the reference's
+    benchmark run: ``compute_downscale_factor(max(frame_size))``, ``scene_manager.py:123-140,525-528``), a number is
+    ``SceneManager.downscale``, ``None`` / anything ``<= 1`` no resize.  The target size is ``max(1, round(size / factor))``
+    per axis (``scene_manager.py:670-678``; Python's ``round``: half to even) and only applies for ``factor > 1.0``."""
+    if downscale is None:
+        return 1.0, int(height), int(width)
+    if isinstance(downscale, str):
+        if downscale != "auto":
+            raise ValueError("downscale must be None, 'auto' or a number")
+        from pyscenedetect_amd.scene_manager import compute_downscale_factor
+
+        factor = compute_downscale_factor(max(int(width), int(height)))
+    else:
+        factor = downscale
+    if not factor > 1.0:
+        return 1.0, int(height), int(width)
+    return float(factor), max(1, round(height / factor)), max(1, round(width / factor))
+
+
 def _plan_pieces(total: int, first, frame_bytes: int, last_run: bool = True) -> list[int]:
     """Frame indices at which ``score_clips`` cuts a run of ``total`` resident frames (clip starts at ``first``) into
     submissions: ``[0, total]`` or ``[0, cut, total]``.
@@ -760,7 +819,8 @@ def _locked(fn):
 # the synchronous calls hold the engine's lock from their first step to their last (the submit_* / collect pairs of the
 # pipelined API stay the caller's to serialise)
 for _name in ("score_host", "_score_host_downscaled", "analyze_frames", "hash_thumbs_device", "hash_thumbs_host", "score_device",
-              "score_device_downscaled", "score_device_segments", "score_clips", "edge_map", "resize_device"):
+              "score_device_downscaled", "score_device_segments", "score_device_segments_downscaled", "score_clips", "edge_map",
+              "resize_device"):
     setattr(ScoringEngine, _name, _locked(getattr(ScoringEngine, _name)))
 
 _default_tls = threading.local()

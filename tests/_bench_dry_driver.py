@@ -28,6 +28,18 @@ class StandInEngine:
         self.submit_device(ptr, n, h, w, flags=flags)
         return self.collect(n)
 
+    def score_device_downscaled(self, ptr, n, h, w, dst_h, dst_w, frame_stride=None, d_prev=None, flags=1, edge_kernel=0, interpolation=1,
+                                stream=None):
+        shim = os.path.join(ROOT, "oracle", "cv2_shim")
+        if shim not in sys.path:
+            sys.path.append(shim)
+        import cv2  # the oracle's shim
+
+        buf = (ctypes.c_uint8 * (n * h * w * 3)).from_address(ptr)
+        frames = np.frombuffer(buf, np.uint8).reshape(n, h, w, 3)
+        small = np.stack([cv2.resize(f, (dst_w, dst_h), interpolation=interpolation) for f in frames])
+        return orc.score_batch(small, flags=flags & 7)
+
     def collect(self, n, sums_only=False):
         rec = self._pending.pop(0)
         assert len(rec) == n

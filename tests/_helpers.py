@@ -56,3 +56,34 @@ def assert_same_run(got, want, tag, metric_tol=0.0):
                 assert a == b or (math.isnan(a) and math.isnan(b)), f"{tag}: {key}[{i}] {a!r} != {b!r}"
             else:
                 assert abs(a - b) <= metric_tol, f"{tag}: {key}[{i}] {a!r} != {b!r}"
+
+
+# ---- tests/golden/corpus_default_pipeline.json (oracle/gen_corpus_golden.py): the reference's DEFAULT pipeline per clip -----------
+CORPUS_DETECTORS = {"content": {}, "adaptive": {"window_width": 2, "min_content_val": 15.0}, "hist": {}, "threshold": {}}
+_corpus_cache = {}
+
+
+def corpus_golden():
+    import json
+    import os
+
+    if "golden" not in _corpus_cache:
+        root = os.path.dirname(os.path.abspath(__file__))
+        with open(os.path.join(root, "golden", "corpus_default_pipeline.json")) as f:
+            _corpus_cache["golden"] = json.load(f)
+    return _corpus_cache["golden"]
+
+
+def corpus_clip(name):
+    """The frames of a clip of the corpus golden, regenerated from its seed (and checked to be the same bytes)."""
+    import numpy as np
+
+    from pyscenedetect_amd.synth import make_clip_fast
+
+    if name not in _corpus_cache:
+        c = corpus_golden()["clips"][name]
+        kw = {k: tuple(v) if isinstance(v, list) else v for k, v in c["kwargs"].items()}
+        frames, _ = make_clip_fast(c["seed"], c["n"], c["h"], c["w"], **kw)
+        assert int(frames.sum(dtype=np.uint64)) == c["sum_all"], "synthetic clip differs from the one the golden run used"
+        _corpus_cache[name] = frames
+    return _corpus_cache[name]

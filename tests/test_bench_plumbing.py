@@ -77,12 +77,17 @@ def test_gpus_2_without_a_launcher_starts_two_ranks():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("workload,gpus", [("corpus", 1), ("corpus", 2), ("bbc", 2)])
-def test_flow_workloads(workload, gpus):
+@pytest.mark.parametrize("workload,gpus,size,pipeline", [("corpus", 1, (36, 64), "default"), ("corpus", 2, (90, 160), "default"),
+                                                         ("bbc", 2, (90, 320), "default"), ("bbc", 1, (90, 320), "full")])
+def test_flow_workloads(workload, gpus, size, pipeline):
     """BASELINE configs[3] / [4] as bench workloads: same JSON contract, parity sample against the oracle, sharded by
-    clip over gloo when N = 2 (self-launched)."""
-    extra = ["--workload", workload, "--corpus-frames", "48", "--bbc-frames", "40", "--cpu-sample", "64"]
-    out = subprocess.run([sys.executable, DRIVER, "--gpus", str(gpus), *ARGS, *extra], capture_output=True, text=True,
+    clip over gloo when N = 2 (self-launched).  By default the flows score what the reference's detect() scores (frames wider
+    than 256 pixels behind its auto-downscale: 320 x 90 -> 256 x 72; the corpus' second resolution 320 x 180 -> 256 x 144);
+    --flow-pipeline full is the labelled full-resolution form."""
+    extra = ["--workload", workload, "--corpus-frames", "48", "--bbc-frames", "40", "--cpu-sample", "64", "--flow-pipeline", pipeline]
+    args = [a for a in ARGS]
+    args[args.index("--height") + 1], args[args.index("--width") + 1] = str(size[0]), str(size[1])
+    out = subprocess.run([sys.executable, DRIVER, "--gpus", str(gpus), *args, *extra], capture_output=True, text=True,
                          env=_env_without_launcher(), cwd=ROOT, timeout=280)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -91,5 +96,11 @@ def test_flow_workloads(workload, gpus):
     assert KEYS <= set(j) and j["n_gpus"] == gpus and j["config"]["ranks_seen"] == gpus and j["value"] > 0
     assert j["scaling"] == ("weak" if workload == "corpus" else "strong")
     assert j["config"]["clips"] == (4 * gpus if workload == "corpus" else 11)
-    assert j["parity_sample"].startswith("records and cut lists identical to the oracle"), j["parity_sample"]
+    if pipeline == "default":
+        assert j["parity_sample"].startswith("the reference pipeline's records and cut lists"), j["parity_sample"]
+        assert j["pipeline"].startswith("the reference's default") and "default downscale" in j["config"]["workload"]
+        assert ("-> 256x" in j["parity_sample"]) == (size != (36, 64))
+    else:
+        assert j["parity_sample"].startswith("records and cut lists of FULL-resolution frames identical"), j["parity_sample"]
+        assert j["pipeline"].startswith("full resolution") and "-> 256x" not in j["parity_sample"]
     assert j["cpu_baseline"]["kind"] == "port" and j["roofline"]["bound"] == "hbm"

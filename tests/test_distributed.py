@@ -34,6 +34,8 @@ ALL_FOUR = {"content": {"min_scene_len": 8}, "adaptive": {"min_scene_len": 8}, "
 
 
 NO_HIST = {"content": {"min_scene_len": 8}, "adaptive": {"min_scene_len": 8}, "threshold": {"threshold": 40}}
+# clips wider than 256 pixels: the reference's default pipeline (auto_downscale) resizes them, each resolution by its own factor
+CORPUS_WIDE = [(40, 90, 320), (35, 135, 480), (25, 36, 64), (30, 180, 288), (22, 90, 320)]
 
 
 class PackingOracle:
@@ -45,11 +47,12 @@ class PackingOracle:
         self.eng = OracleEngine()
         self.asked_for_sums = []
 
-    def score_clips(self, clips, flags, edge_kernel=0, sums_only=False):
-        from pyscenedetect_amd.engine import _sums_of
+    def score_clips(self, clips, flags, edge_kernel=0, sums_only=False, downscale=None, interpolation=1):
+        from pyscenedetect_amd.engine import _sums_of, downscale_size
 
         self.asked_for_sums.append(sums_only)
-        recs = [self.eng.score_host(c, flags=flags, edge_kernel=edge_kernel) for c in clips]
+        recs = [self.eng.score_host(c, flags=flags, edge_kernel=edge_kernel, downscale=downscale_size(c.shape[1], c.shape[2], downscale)[0],
+                                    interpolation=interpolation) for c in clips]
         return [_sums_of(r) for r in recs] if sums_only else recs
 
 
@@ -92,6 +95,13 @@ def _worker(rank, world, port, tmp):
         json.dump(res, f)
     res = detect_corpus(PackingOracle(), corpus[:1], 25.0, NO_HIST)     # fewer clips than ranks: rank 1 sends nothing
     with open(os.path.join(tmp, f"nohist_one{rank}.json"), "w") as f:
+        json.dump(res, f)
+    # the reference's default pipeline (auto_downscale, the default of detect_corpus) on clips that it resizes: sharded by clip,
+    # every rank resizes and scores its own, the 40-byte sums are all-gathered, every rank decides with the RESIZED size
+    wide = [make_clip(80 + i, n, h, w, shot_len=(9, 14), noise=12.0)[0] for i, (n, h, w) in enumerate(CORPUS_WIDE)]
+    res = {"all_four": detect_corpus(eng, wide, 25.0, ALL_FOUR), "packed_sums": detect_corpus(PackingOracle(), wide, 25.0, NO_HIST),
+           "manual_area": detect_corpus(eng, wide, 25.0, NO_HIST, auto_downscale=False, downscale=2, interpolation=3)}
+    with open(os.path.join(tmp, f"wide{rank}.json"), "w") as f:
         json.dump(res, f)
     np.save(os.path.join(tmp, f"recs{rank}.npy"), recs)
     np.save(os.path.join(tmp, f"cuts{rank}.npy"), np.array(cuts))
@@ -149,6 +159,32 @@ def test_two_ranks_equal_one(tmp_path):
         sm.add_detector(psd.ContentDetector(min_scene_len=8, engine=eng))
         sm.detect_scenes(psd.ArrayVideoStream(clip, 25.0))
         assert [c.frame_num for c in sm.get_cut_list(show_warning=False)] == res["content"]
+    _check_wide(tmp_path, world, eng)
+
+
+def _check_wide(tmp_path, world, eng):
+    """Every rank's result for the resized corpus == one process == a default SceneManager per clip (auto_downscale on)."""
+    import json
+
+    import pyscenedetect_amd as psd
+    from pyscenedetect_amd.corpus import detect_corpus
+    from pyscenedetect_amd.engine import downscale_size
+    from pyscenedetect_amd.synth import make_clip
+
+    wide = [make_clip(80 + i, n, h, w, shot_len=(9, 14), noise=12.0)[0] for i, (n, h, w) in enumerate(CORPUS_WIDE)]
+    assert sum(downscale_size(h, w, "auto")[0] > 1.0 for _, h, w in CORPUS_WIDE) == 4
+    single = {"all_four": detect_corpus(eng, wide, 25.0, ALL_FOUR)}
+    single["packed_sums"] = [{k: v for k, v in clip.items() if k != "hist"} for clip in single["all_four"]]
+    single["manual_area"] = detect_corpus(eng, wide, 25.0, NO_HIST, auto_downscale=False, downscale=2, interpolation=3)
+    assert single["all_four"] != detect_corpus(eng, wide, 25.0, ALL_FOUR, auto_downscale=False), "the resize changes decisions on this corpus"
+    for r in range(world):
+        assert json.load(open(tmp_path / f"wide{r}.json")) == single
+    for clip, res in zip(wide, single["all_four"]):
+        sm = psd.SceneManager(engine=eng)                    # auto_downscale is the default, as in the reference
+        sm.add_detector(psd.ContentDetector(min_scene_len=8, engine=eng))
+        sm.add_detector(psd.HistogramDetector(engine=eng))
+        sm.detect_scenes(psd.ArrayVideoStream(clip, 25.0))
+        assert [c.frame_num for c in sm.get_cut_list(show_warning=False)] == sorted(set(res["content"]) | set(res["hist"]))
 
 
 @pytest.mark.timeout(600)
@@ -176,3 +212,4 @@ def test_four_and_eight_ranks_equal_one(tmp_path, world):
         assert json.load(open(tmp_path / f"corpus{r}.json")) == single
         assert json.load(open(tmp_path / f"nohist{r}.json")) == nohist
         assert json.load(open(tmp_path / f"nohist_one{r}.json")) == nohist[:1]
+    _check_wide(tmp_path, world, eng)

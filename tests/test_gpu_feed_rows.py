@@ -375,10 +375,6 @@ def test_one_manager_on_two_videos_carries_the_last_frame(golden, hip_engine, or
     assert 0 in results[False, False][1] and 0 in results["same", False][1] and 0 not in results["fresh", False][1]
 
 
-_NEVER_RUN = pytest.mark.xfail(strict=False, reason="written after round 5's GPU budget was spent: the CPU twins in "
-                               "tests/test_host_fuzz_vs_reference.py are green, this one has not met hardware yet")
-
-
 class _MeanJump(psd.SceneDetector):
     """A detector of the caller's own on the plug-in API only (no device path): it must be handed the downscaled frame."""
 
@@ -397,7 +393,6 @@ class _MeanJump(psd.SceneDetector):
         return []
 
 
-@_NEVER_RUN
 @pytest.mark.parametrize("interpolation", ["LINEAR", "AREA"])
 def test_a_manager_of_plug_in_detectors_only_hands_them_downscaled_frames(hip_engine, oracle_engine, interpolation):
     """reference scene_manager.py:666-678: every consumer sees the resized frame -- also when no built-in detector is registered
@@ -420,7 +415,6 @@ def test_a_manager_of_plug_in_detectors_only_hands_them_downscaled_frames(hip_en
                           oracle_engine.downscale_host(frames[:5], 3, psd.Interpolation[interpolation].value))
 
 
-@_NEVER_RUN
 def test_callback_of_a_later_call_gets_the_downscaled_frame_an_earlier_call_buffered(hip_engine, oracle_engine):
     """Detection in pieces: call 1 (no callback) buffers frame 20 at full size, call 2 reports the cut at 20 two frames late and
     hands the buffered frame to its callback -- downscaled then (ScoringEngine.downscale_host), like the reference's buffer holds it."""
@@ -441,15 +435,14 @@ def test_callback_of_a_later_call_gets_the_downscaled_frame_an_earlier_call_buff
     assert runs[0][1] == [20] and [s[:2] for s in runs[0][0]] == [(20, (37, 160, 3))]
 
 
-@pytest.mark.skipif(__import__("os").environ.get("PSD_GPU_UNVERIFIED") != "1",
-                    reason="60 random cases of ingredients that have not met hardware yet: opt in with PSD_GPU_UNVERIFIED=1 (first GPU call "
-                           "of a next session, DESIGN.md 7 item 8) rather than risk the suite on them")
 def test_a_slice_of_the_engines_fuzz_with_the_wide_ingredients(hip_engine, oracle_engine):
     """``tools/fuzz_host_vs_reference.py --engines --wide`` (the mirror over the HIP engine against the mirror over the oracle engine: device
     feeder, tap rows, crop / downscale modes, batch sizes, the carried frame, the resident per-frame path) with the ingredients added after
     the last GPU run of round 5 -- detection from a seek position and in pieces, a plug-in detector alone or beside the others, frame
     layouts, detect(), object min_scene_len -- and every comparison on (exception texts, metric types, warnings, logs, public state).  The
-    original ingredients ran on hardware (1.6 k cases, `profiles/r05_y_*`); on CPU the same cases pass over the simulated device engine."""
+    original ingredients ran on hardware (1.6 k cases, `profiles/r05_y_*`); on CPU the same cases pass over the simulated device engine.
+    (Round 5 kept this slice behind an opt-in switch and its two neighbours above behind xfail marks because they had been written
+    after that round's GPU minutes were spent; the driver's run showed them passing, and all three are unconditional now.)"""
     import os
     import sys
 

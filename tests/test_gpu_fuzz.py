@@ -1,7 +1,8 @@
 """A fixed-seed slice of tools/fuzz_gpu.py: random frame shapes (single rows / columns, pixel counts around multiples of 16,
 widths around the tile sizes), contents (noise, flat, grey, two-level, saturated primaries, dark), memory layouts (padded
 rows / frames, misaligned bases, strided frames), term sets and entry points (score_host, score_frames, downscale with every
-interpolation mode, score_clips with host / device / packed device clips, the edge term with fixed and automatic dilation
+interpolation mode, score_clips with host / device / packed device clips -- since round 6 also behind the reference's default
+downscale and every other resize setting (psd_score_segments_downscaled_device) --, the edge term with fixed and automatic dilation
 sizes, hash thumbnails) through the HIP engine, records identical to the CPU oracle.  The long runs (20 k cases without a
 mismatch, `profiles/r05_*_fuzz*.json`) are `python tools/fuzz_gpu.py --seconds 100`."""
 import os
@@ -23,5 +24,5 @@ def test_fuzz_slice_equals_the_oracle(hip_engine, seed):
     assert out["cases"] == 700, out
     assert not out["mismatches"], out["mismatches"][:3]
     # every entry point was reached
-    for entry in ("score_host", "score_frames", "downscale", "downscale/score_frames", "clips", "edges", "hash"):
+    for entry in ("score_host", "score_frames", "downscale", "downscale/score_frames", "clips", "clips/downscaled", "edges", "hash"):
         assert out["by_entry"].get(entry, 0) > 0, out["by_entry"]

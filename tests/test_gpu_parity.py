@@ -140,13 +140,7 @@ def test_reference_golden_runs_through_hip(golden, hip_engine, clip):
     frames = golden_clip(golden, clip)
     for name in golden["clips"][clip]["results"]:
         cls_name, kwargs, with_stats = golden["configs"][name]
-        uses_edges = cls_name in ("ContentDetector", "AdaptiveDetector") and (with_stats or kwargs.get("weights"))
-        try:
-            got = run_config(frames, cls_name, kwargs, with_stats, hip_engine)
-        except NotImplementedError:
-            if uses_edges:
-                pytest.xfail("edge term not implemented on the device yet")
-            raise
+        got = run_config(frames, cls_name, kwargs, with_stats, hip_engine)      # (incl. the edge term: PSD_ERR_UNSUPPORTED fails the test)
         assert_same_run(got, golden["clips"][clip]["results"][name], f"{clip}/{name}")
 
 
@@ -165,10 +159,7 @@ def test_edges_match_oracle(hip_engine):
     from pyscenedetect_amd.synth import make_clip
 
     frames, _ = make_clip(9, 12, 90, 160, shot_len=(4, 6))
-    try:
-        got = hip_engine.score_host(frames, flags=E.SCORE_ALL)
-    except NotImplementedError:
-        pytest.xfail("edge term not implemented on the device yet")
+    got = hip_engine.score_host(frames, flags=E.SCORE_ALL)
     want = oracle_score(frames, edges=True)
     same(got, want, FIELDS + ("edge_xor",))
 

@@ -6,7 +6,12 @@ Build container only; records come from the CPU oracle; no GPU.
 
 Every case: a random synthetic clip, a frame rate, one detector of the five the epilogues replay (content / adaptive / hist / hash /
 threshold) with random constructor arguments (``min_scene_len`` as frames / seconds / strings, both filter modes, edge weights, bins,
-fade bias, FLOOR / CEILING, ``add_final_scene``), the reference run WITHOUT a downscale -- and the cut list must be the same."""
+fade bias, FLOOR / CEILING, ``add_final_scene``), the reference run WITHOUT a downscale -- and the cut list must be the same.
+
+``--downscale`` (round 6): the reference run WITH the resize its SceneManager puts in front of the detectors -- its default
+``auto_downscale`` or a manual factor, each interpolation the engine implements -- against ``corpus.detect_corpus`` over the oracle engine
+with the same setting: the packed / sharded flow computes what ``detect(video, detector)`` computes (every fourth clip is wider than 256
+pixels, where the default pipeline resizes)."""
 import argparse
 import json
 import logging
@@ -89,7 +94,17 @@ def draw(rng):
     return frames, fps, name, kw, kernel
 
 
-def reference_cuts(frames, fps, name, kw, kernel):
+def draw_downscale(rng):
+    """SceneManager's resize settings: {"auto_downscale": bool[, "downscale": int][, "interpolation": name]}"""
+    cfg = {"auto_downscale": bool(rng.integers(0, 3))}
+    if not cfg["auto_downscale"]:
+        cfg["downscale"] = int(rng.integers(1, 5))
+    if rng.integers(0, 3) == 0:
+        cfg["interpolation"] = ["LINEAR", "NEAREST", "AREA"][int(rng.integers(0, 3))]
+    return cfg
+
+
+def reference_cuts(frames, fps, name, kw, kernel, resize=None):
     ref_kw = dict(kw)
     if "filter_mode" in ref_kw:
         ref_kw["filter_mode"] = ["MERGE", "SUPPRESS"][ref_kw["filter_mode"]]
@@ -98,7 +113,22 @@ def reference_cuts(frames, fps, name, kw, kernel):
     if kernel:
         ref_kw["kernel_size"] = kernel
     cfg = {"stats": False, "auto_downscale": False, "start_in_scene": False}
+    cfg.update(resize or {})
     return F.run_side("ref", frames, fps, [(NAMES[name], ref_kw)], cfg, None)["cuts"]
+
+
+def corpus_cuts(frames, fps, name, kw, kernel, resize):
+    """The same decision from the packed flow's entry point over the oracle engine (``corpus.detect_corpus``: records of the resized
+    frames -> ``decide`` with the resized size)."""
+    from oracle.detectors_np import OracleEngine
+
+    params = dict(kw)
+    if "weights" in params:
+        params["weights"] = tuple(params["weights"])
+    interp = {"NEAREST": 0, "LINEAR": 1, "AREA": 3}[resize.get("interpolation", "LINEAR")]
+    res = corpus.detect_corpus(OracleEngine(), [frames], fps, {name: params}, edge_kernel=kernel, auto_downscale=resize["auto_downscale"],
+                               downscale=resize.get("downscale", 1), interpolation=interp)
+    return [int(c) for c in res[0][name]]
 
 
 def native_cuts(frames, fps, name, kw, kernel):
@@ -130,6 +160,7 @@ def main():
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--wide", action="store_true", help="fractional / negative weights, fractional fade thresholds, odd hash sizes")
     ap.add_argument("--tiny", action="store_true", help="frames of a few pixels, clips of hundreds of frames")
+    ap.add_argument("--downscale", action="store_true", help="the reference behind its resize (auto / manual, each interpolation) against detect_corpus")
     args = ap.parse_args()
     global WIDE
     WIDE, F.TINY = args.wide, args.tiny
@@ -140,11 +171,19 @@ def main():
     while time.time() < t_end:
         rng = np.random.default_rng([args.seed, cases])
         frames, fps, name, kw, kernel = draw(rng)
-        a = F.decisions(F.outcome(lambda: {"cuts": reference_cuts(frames, fps, name, kw, kernel)}))
-        b = F.decisions(F.outcome(lambda: {"cuts": native_cuts(frames, fps, name, kw, kernel)}))
+        resize = None
+        if args.downscale:
+            while name == "hash":      # (HashDetector is not one of the corpus flow's detectors)
+                frames, fps, name, kw, kernel = draw(rng)
+            resize = draw_downscale(rng)
+            a = F.decisions(F.outcome(lambda: {"cuts": reference_cuts(frames, fps, name, kw, kernel, resize)}))
+            b = F.decisions(F.outcome(lambda: {"cuts": corpus_cuts(frames, fps, name, kw, kernel, resize)}))
+        else:
+            a = F.decisions(F.outcome(lambda: {"cuts": reference_cuts(frames, fps, name, kw, kernel)}))
+            b = F.decisions(F.outcome(lambda: {"cuts": native_cuts(frames, fps, name, kw, kernel)}))
         by[name] = by.get(name, 0) + 1
         if a != b:
-            desc = {"case": cases, "shape": list(frames.shape), "fps": fps, "detector": name, "params": kw, "kernel": kernel, "ref": str(a)[:200], "native": str(b)[:200]}
+            desc = {"case": cases, "resize": resize, "shape": list(frames.shape), "fps": fps, "detector": name, "params": kw, "kernel": kernel, "ref": str(a)[:200], "native": str(b)[:200]}
             bad.append(desc)
             if args.verbose:
                 print(json.dumps(desc), flush=True)

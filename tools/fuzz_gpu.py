@@ -207,14 +207,24 @@ def run(seed: int, seconds: float, max_cases: int, verbose: bool = False, engine
                 # several clips of one or two sizes, resident, packed by the engine into shared batches
                 flags = int(rng.integers(1, 8))
                 sizes = [(h, w)] + ([draw_shape(rng)] if rng.integers(0, 2) else [])
+                # round 6: half of the cases behind the resize the reference's SceneManager puts in front of its detectors
+                # (psd_score_segments_downscaled_device): its default "auto" or a factor, each interpolation, now and then the edge term
+                ds, interp = None, 1
+                if rng.integers(0, 2):
+                    ds = "auto" if rng.integers(0, 2) else float(rng.choice([1.25, 1.5, 2.0, 2.5, 3.0, 7.5, rng.uniform(1.05, 6.0)]))
+                    interp = int(rng.choice([1, 1, 1, 0, 3]))
+                    if rng.integers(0, 5) == 0:
+                        flags |= 8
                 clips, wants = [], []
                 for _ in range(int(rng.integers(1, 6)) if not BIG else 2):
                     ch, cw = sizes[int(rng.integers(0, len(sizes)))]
                     cn = int(rng.integers(1, 12)) if not BIG else int(rng.integers(1, 3))
                     fr = draw_content(rng, cn, ch, cw)
                     clips.append(fr)
-                    wants.append(ora.score_host(fr, None, flags=flags))
-                desc.update(flags=flags, clips=[c.shape[:3] for c in clips])
+                    wants.append(ora.score_host(fr, None, flags=flags, downscale=E.downscale_size(ch, cw, ds)[0], interpolation=interp))
+                desc.update(flags=flags, clips=[c.shape[:3] for c in clips], downscale=ds, interp=interp)
+                if ds is not None:
+                    desc["entry"] = "clips/downscaled" 
                 import torch
 
                 if torch.cuda.is_available():
@@ -234,8 +244,9 @@ def run(seed: int, seconds: float, max_cases: int, verbose: bool = False, engine
                             dev.append(c)
                 else:
                     dev = clips
-                gots = eng.score_clips(dev, flags=flags)
-                fields = [f for f in FIELDS if (f in ("sad_h", "sad_s", "sad_v") and flags & 1) or (f in ("hist", "byte_sum") and flags & 6)]
+                gots = eng.score_clips(dev, flags=flags, downscale=ds, interpolation=interp)
+                fields = [f for f in FIELDS if (f in ("sad_h", "sad_s", "sad_v") and flags & 1) or (f in ("hist", "byte_sum") and flags & 6)
+                          or (f == "edge_xor" and flags & 8)]
                 diff = []
                 for g, wnt in zip(gots, wants):
                     diff += [f for f in fields if f in g.dtype.names and not np.array_equal(g[f], wnt[f])]
