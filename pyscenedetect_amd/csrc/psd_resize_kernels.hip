@@ -255,33 +255,108 @@ __device__ __forceinline__ u32 interp(u32 p00, u32 p01, u32 p10, u32 p11, int a0
     return (u32)(((mul_i24(b0, h0 >> 4) >> 16) + (mul_i24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xffu;
 }
 
-// OpenCV's 8-bit BGR -> HSV (RGB2HSV_b, hue range 180) for one pixel, tables pre-shifted by 4 (psd_score_kernels.hip)
-__device__ __forceinline__ void hsv_px(u32 b, u32 g, u32 r, const u32* lut_s, const u32* lut_h, u32& h, u32& s, u32& v)
-{
-    v = max(max(b, g), r);
-    const u32 vmin = min(min(b, g), r);
-    const u32 diff = v - vmin;
-    // (sdiv << 4 <= 255 * 4096 * 16 < 2^24, hdiv << 4 < 2^21, |hraw| <= 1275: 24-bit multiplies, exact)
-    s = ((mul_u24(diff, lut_s[v]) + (2048u << 4)) >> 16) & 0xffu;
-    const int d = (int)diff;
-    const int hraw = v == r ? (int)g - (int)b : v == g ? (int)b - (int)r + 2 * d : (int)r - (int)g + 4 * d;
-    int hh = (mul_i24(hraw, (int)lut_h[diff]) + (2048 << 4)) >> 16;
-    if (hh < 0) hh += 180;
-    h = (u32)hh;
-}
-
-constexpr int RS_WG = 256, RS_NW = 4, RS_SLOTS = 16;
+constexpr int RS_WG = 256, RS_NW = 4, RS_SLOTS = 16, RS_REP = 16;
 
 // LDS increment the compiler does not see as an LDS store: hipcc orders every LDS store / atomic behind ALL outstanding LDS-DMA
 // (s_waitcnt vmcnt(0)), i.e. behind the staging of the NEXT frame, which would serialise the prefetch with this frame's
-// arithmetic (psd_score_kernels.hip, lds_add_hidden).  The histogram words never overlap the staging buffers; the barrier of
+// arithmetic (psd_score_kernels.hip, lds_add_hidden).  The histogram / sum words never overlap the staging buffers; the barrier of
 // the next frame is preceded by an explicit lgkmcnt(0).
 __device__ __forceinline__ void rs_lds_add(const u32* p, u32 inc)
 {
     asm volatile("ds_add_u32 %0, %1" ::"v"((u32)(uintptr_t)p), "v"(inc) : "memory");
 }
 
-// grid.x = n_tiles * n_chunks.  Dynamic LDS: 2 buffers x (2 R rows x row_pad bytes).
+typedef unsigned short rs_u16x2 __attribute__((ext_vector_type(2)));
+
+// The four taps of one destination pixel, three channels (round 6).  Both taps of a row are ADJACENT source pixels (the table's
+// second tap is only ever clamped onto the first where its coefficient is 0), i.e. six consecutive bytes b0 g0 r0 b1 g1 r1 at
+// byte offset 3 * sx of the staged row: three dwords instead of six byte reads (rs_taps_load).  v_perm_b32 pairs a channel's two bytes as
+// 16-bit halves and v_dot2_u32_u16 against (a0 << 4 | a1 << 20) IS OpenCV's horizontal pass times 16, in one instruction:
+//   hx = (p0 a0 + p1 a1) << 4;   OpenCV: ((b0 (h0 >> 4)) >> 16) + ((b1 (h1 >> 4)) >> 16) + 2) >> 2
+// and (hx & 0xffff00) = (h >> 4) << 8, so the vertical products are the upper halves of 24-bit multiplies by b << 8
+// (v_mul_hi_u32_u24: (((h >> 4) << 8) (b << 8)) >> 32 = ((h >> 4) b) >> 16, exact: both factors are below 2^23).
+// 36 VALU + 4 LDS instructions per pixel where the byte-wise form took ~65 + 12.
+struct RsPx { u32 off, a4, b80, b81; };      // off: byte offset of the first tap inside a staging buffer (row 2 lr, 3 sx)
+
+// How the six tap bytes of a row come out of LDS: three dwords from the dword-aligned address below the tap (ds_read2_b32 +
+// ds_read_b32: dword alignment is all they ask for), then two v_alignbyte_b32 shift the tap to byte 0.  (The obvious form -- ONE
+// unaligned 8-byte read at the tap, which hipcc emits as ds_read_b64 and gfx950 executes correctly -- runs on a slow path of the
+// LDS: with 40 % fewer VALU instructions than the byte-wise kernel it was 8 - 27 % SLOWER, the aligned form 10 - 36 % faster:
+// profiles/r06_d_ab_resize_taps.txt.)  The loads are inline assembly -- hipcc would fuse them into one "unaligned" ds_read_b96
+// -- so the wait for them is the kernel's own, inside the same asm statement (rs_taps_load).
+typedef u32 rs_u32x2 __attribute__((ext_vector_type(2)));
+struct RsTaps { rs_u32x2 a01, b01; u32 a2, b2; };     // rows a / b: dwords 0..1 and dword 2 from the aligned address
+
+// The loads of C pixels AND the wait for them in ONE asm statement: the compiler does not know that an asm load's register is
+// only filled later, so between a load statement and a separate s_waitcnt statement it may copy the register (it did, in the
+// G = 1 / 2 instances: stale taps on 1080p and 4K sources while the G = 4 instance happened to be scheduled safely).  Outputs are
+// early-clobber: the later loads of the statement still read their address registers.
+#define RS_LD4(i)                                        \
+    "ds_read2_b32 %[a" #i "], %[p" #i "] offset1:1\n\t" \
+    "ds_read_b32 %[c" #i "], %[p" #i "] offset:8\n\t"   \
+    "ds_read2_b32 %[b" #i "], %[q" #i "] offset1:1\n\t" \
+    "ds_read_b32 %[d" #i "], %[q" #i "] offset:8\n\t"
+#define RS_OUT(i, t) [a##i] "=&v"(t.a01), [c##i] "=&v"(t.a2), [b##i] "=&v"(t.b01), [d##i] "=&v"(t.b2)
+#define RS_IN(i, pa, rp) [p##i] "v"(pa), [q##i] "v"(pa + rp)
+
+template <int C>
+__device__ __forceinline__ void rs_taps_load(const u32 (&addr)[C], u32 row_pad, RsTaps (&t)[C])
+{
+    static_assert(C == 1 || C == 2 || C == 4, "");
+    if constexpr (C == 1) {
+        asm volatile(RS_LD4(0) "s_waitcnt lgkmcnt(0)" : RS_OUT(0, t[0]) : RS_IN(0, addr[0], row_pad) : "memory");
+    } else if constexpr (C == 2) {
+        asm volatile(RS_LD4(0) RS_LD4(1) "s_waitcnt lgkmcnt(0)" : RS_OUT(0, t[0]), RS_OUT(1, t[1])
+                     : RS_IN(0, addr[0], row_pad), RS_IN(1, addr[1], row_pad) : "memory");
+    } else {
+        asm volatile(RS_LD4(0) RS_LD4(1) RS_LD4(2) RS_LD4(3) "s_waitcnt lgkmcnt(0)"
+                     : RS_OUT(0, t[0]), RS_OUT(1, t[1]), RS_OUT(2, t[2]), RS_OUT(3, t[3])
+                     : RS_IN(0, addr[0], row_pad), RS_IN(1, addr[1], row_pad), RS_IN(2, addr[2], row_pad), RS_IN(3, addr[3], row_pad) : "memory");
+    }
+}
+
+template <bool AREA2>
+__device__ __forceinline__ void rs_interp(const RsTaps& w, u32 shift, const RsPx& t, u32 (&c)[3])
+{
+    const u32 ax = __builtin_amdgcn_alignbyte(w.a01.y, w.a01.x, shift), ay = __builtin_amdgcn_alignbyte(w.a2, w.a01.y, shift);
+    const u32 bx = __builtin_amdgcn_alignbyte(w.b01.y, w.b01.x, shift), by = __builtin_amdgcn_alignbyte(w.b2, w.b01.y, shift);
+    const rs_u16x2 a4 = __builtin_bit_cast(rs_u16x2, t.a4);
+    constexpr u32 SEL[3] = {0x0C030C00u, 0x0C040C01u, 0x0C050C02u};     // (byte k, byte 3 + k) of the eight as two 16-bit halves
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const u32 ha = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(ay, ax, SEL[k])), a4, 0u, false);
+        const u32 hb = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_u16x2, __builtin_amdgcn_perm(by, bx, SEL[k])), a4, 0u, false);
+        if (AREA2) {
+            c[k] = (ha + hb + 2u) >> 2;                // a4 = (1, 1): the rounded box mean of OpenCV's exact 2 x 2 case
+        } else {
+            const u32 xa = ha & 0x00ffff00u, xb = hb & 0x00ffff00u;
+            __builtin_assume(t.b80 <= (2048u << 8) && t.b81 <= (2048u << 8));      // (24-bit factors: v_mul_hi_u32_u24)
+            const u32 ta = (u32)(((unsigned long long)xa * (unsigned long long)t.b80) >> 32);
+            const u32 tb = (u32)(((unsigned long long)xb * (unsigned long long)t.b81) >> 32);
+            c[k] = (ta + tb + 2u) >> 2;
+        }
+        __builtin_assume(c[k] <= 255u);
+    }
+}
+
+// OpenCV's 8-bit BGR -> HSV (RGB2HSV_b, hue range 180) for one pixel, tables pre-shifted by 4; every product fits 24 bits
+// (sdiv << 4 <= 255 * 4096 * 16 / 255 ..., hdiv << 4 < 2^21, |hraw| <= 1275), the rounding additions ride in the multiply-adds
+__device__ __forceinline__ void rs_hsv(u32 b, u32 g, u32 r, const u32* lut_s, const u32* lut_h, u32& h, u32& s, u32& v)
+{
+    v = max(max(b, g), r);
+    const u32 vmin = min(min(b, g), r);
+    const u32 diff = v - vmin;
+    const u32 ls = lut_s[v], lh = lut_h[diff];
+    __builtin_assume(ls < (1u << 24) && lh < (1u << 21) && diff <= 255u);  // (24-bit factors: v_mad_u32_u24 / v_mad_i32_i24)
+    s = (diff * ls + (2048u << 4)) >> 16;
+    const int d = (int)diff;
+    const int hraw = v == r ? (int)g - (int)b : v == g ? (int)b - (int)r + 2 * d : (int)r - (int)g + 4 * d;
+    __builtin_assume(hraw >= -2048 && hraw < 2048);                        // (|hraw| <= 1275)
+    const int hh = (hraw * (int)lh + (2048 << 4)) >> 16;
+    h = min((u32)hh, (u32)(hh + 180));                                     // hh in [-90, 179]: the negative ones wrap by + 180
+}
+
+// grid.x = n_tiles * n_chunks.  Dynamic LDS: depth buffers x (2 R rows x row_pad bytes) + 16 bytes of slack (the 8-byte tap reads).
 // LUMA: the luma histogram and the byte sum of the RESIZED frame as well (HistogramDetector / ThresholdDetector behind the
 // reference's default downscale, histogram_detector.py:156-159 and threshold_detector.py:127 on what scene_manager.py:666-678
 // hands them).  A workgroup counts its tile's pixels of frame t into one of two 256-bin LDS histograms and, one barrier
@@ -295,7 +370,8 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t rs_stage[];
     __shared__ u32 lut_s[HSV ? 256 : 1], lut_h[HSV ? 256 : 1];
-    __shared__ u32 sums[RS_SLOTS][4];
+    // per-frame sums (sad_h, sad_s, sad_v, byte_sum), RS_REP copies each: a lane adds into copy lane % RS_REP
+    __shared__ __attribute__((aligned(16))) u32 sums[RS_SLOTS][4][RS_REP];
     __shared__ u32 lhist[LUMA ? 2 : 1][LUMA ? 256 : 1];
     __shared__ int srows[64];           // clamped source rows of this tile: slot 2 * lr + k
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -307,7 +383,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         for (int i = tid; i < 256; i += RS_WG) { lut_s[i] = p.lut[i]; lut_h[i] = p.lut[256 + i]; }
     }
     if (HSV || LUMA) {
-        for (int i = tid; i < RS_SLOTS * 4; i += RS_WG) (&sums[0][0])[i] = 0;
+        for (int i = tid; i < RS_SLOTS * 4 * RS_REP; i += RS_WG) (&sums[0][0][0])[i] = 0;
     }
     if (LUMA) {
         for (int i = tid; i < 2 * 256; i += RS_WG) (&lhist[0][0])[i] = 0;
@@ -316,22 +392,31 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         const YTap y = p.yt[r0 + (tid >> 1)];
         srows[tid] = p.area2 ? 2 * (r0 + (tid >> 1)) + (tid & 1) : ((tid & 1) ? y.s1 : y.s0);
     }
-    // this thread's destination pixels: p = g * 256 + tid over the tile's nrows * dw pixels
-    int lrow[G], o0[G], o1[G], a01[G], b01[G];
+    // this thread's destination pixels: p = g * 256 + tid over the tile's nrows * dw pixels.  A slot beyond the tile's pixels
+    // (`dead`) reads the tile's first taps with ALL coefficients zero: its pixel is (0, 0, 0) in every frame, so it adds nothing
+    // to the SADs and the byte sum, and its histogram increment is 0 -- no branch around it.
+    RsPx px[G];
     bool live[G];
+    u32 dst_off[G];                     // STORE: byte offset of the pixel inside a destination frame
     const int npx = nrows * p.dw;
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        const int px = g * RS_WG + tid;
-        live[g] = px < npx;
-        const int lr = live[g] ? px / p.dw : 0, col = live[g] ? px - lr * p.dw : 0;
-        lrow[g] = lr;
+        const int q = g * RS_WG + tid;
+        live[g] = q < npx;
+        const int lr = live[g] ? q / p.dw : 0, col = live[g] ? q - lr * p.dw : 0;
+        dst_off[g] = (u32)(((r0 + lr) * p.dw + col) * 3);
         if (p.area2) {
-            o0[g] = 6 * col; o1[g] = 6 * col + 3; a01[g] = 0; b01[g] = 0;
+            px[g].off = (u32)(2 * lr * p.row_pad + 6 * col);
+            px[g].a4 = live[g] ? 0x00010001u : 0u;
+            px[g].b80 = px[g].b81 = 0;
         } else {
             const XTap x = p.xt[col];
-            o0[g] = x.o0; o1[g] = x.o1; a01[g] = x.a;
-            b01[g] = p.yt[r0 + lr].b;
+            const u32 b = (u32)p.yt[r0 + lr].b;
+            px[g].off = (u32)(2 * lr * p.row_pad + x.o0);
+            // (coefficients are in [0, 2048]: << 4 fits the 16-bit halves the dot product reads)
+            px[g].a4 = live[g] ? (((u32)x.a & 0xffffu) << 4) | (((u32)x.a >> 16) << 20) : 0u;
+            px[g].b80 = live[g] ? (b & 0xffffu) << 8 : 0u;
+            px[g].b81 = live[g] ? (b >> 16) << 8 : 0u;
         }
     }
     __syncthreads();
@@ -379,15 +464,16 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     // the frame in front of the chunk only feeds the HSV carry
     const bool halo = HSV && (t0 > 0 || p.prev != nullptr);
     const int tb = halo ? t0 - 1 : t0;
-    u32 prev_hsv[G];
+    u32 ph[HSV ? G : 1], ps[HSV ? G : 1], pv[HSV ? G : 1];         // the previous frame's H, S, V of this thread's pixels
 #pragma unroll
-    for (int g = 0; g < G; g++) prev_hsv[g] = 0;
+    for (int g = 0; g < (HSV ? G : 1); g++) ph[g] = ps[g] = pv[g] = 0;
     bool have_prev = false;
     // this wave's LDS-DMA instructions per frame (the same every frame): with three buffers the rows of frame t+1 may
     // still be in flight when frame t is taken (DMA completes in order, so "at most that many outstanding" means
     // frame t has landed)
     const int mine = (pieces * 2 * nrows - wave + RS_NW - 1) / RS_NW;
     const int ahead = p.depth - 1;             // frames in flight beyond the current one
+    const u32 rep = (u32)(tid & (RS_REP - 1));
     if (tb < t1) issue(frame_ptr(tb), 0);
     if (ahead > 1 && tb + 1 < t1) issue(frame_ptr(tb + 1), 1);
     // Clip-start flag of the NEXT frame to be stepped.  It is requested behind that frame's DMA issue and turned into an SGPR at
@@ -413,7 +499,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (LUMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's hidden histogram increments of frame t-1
+        if (HSV || LUMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's hidden LDS increments of frame t-1
         u32 flag_now = 0;
         if constexpr (SEG) {
             flag_now = __builtin_amdgcn_readfirstlane(seg_next);
@@ -428,8 +514,16 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         if ((HSV || LUMA) && rel >= 8 && (rel & 7) == 0 && tid < 32) {
             // frames rel-8 .. rel-1 are complete (all waves added them before this frame's barrier)
             const int f = rel - 8 + (tid >> 2), q = tid & 3;
-            const u32 v = sums[f & (RS_SLOTS - 1)][q];
-            sums[f & (RS_SLOTS - 1)][q] = 0;
+            u32* cell = sums[f & (RS_SLOTS - 1)][q];
+            u32 v = 0;
+#pragma unroll
+            for (int k = 0; k < RS_REP; k += 4) {
+                const uint4 w = *reinterpret_cast<const uint4*>(cell + k);
+                v += w.x + w.y + w.z + w.w;
+            }
+            // (cleared with stores the compiler does not see: a visible LDS store would wait for the staging issued a few lines up)
+#pragma unroll
+            for (int k = 0; k < RS_REP; k += 2) asm volatile("ds_write_b64 %0, %1" ::"v"((u32)(uintptr_t)(cell + k)), "v"(0ull) : "memory");
             psd_frame_scores* rec = p.out + t0 + f;
             if (v) atomicAdd(q == 0 ? (unsigned long long*)&rec->sad_h : q == 1 ? (unsigned long long*)&rec->sad_s
                              : q == 2 ? (unsigned long long*)&rec->sad_v : (unsigned long long*)&rec->byte_sum, (unsigned long long)v);
@@ -449,74 +543,67 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         const bool count_luma = LUMA && t >= t0;           // (the halo frame only feeds the HSV carry)
         u32* hcur = lhist[LUMA ? (rel & 1) : 0];
         const bool chain = have_prev && !(SEG && flag_now != 0);
+        constexpr int C = G < 4 ? G : 4;        // pixels whose taps are in flight together (six dwords each)
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            if (!live[g]) continue;
-            const uint8_t* ra = base + (size_t)(2 * lrow[g]) * p.row_pad;
-            const uint8_t* rb = ra + p.row_pad;
-            u32 c[3];
-            if (p.area2) {
+        for (int g0 = 0; g0 < G; g0 += C) {
+            RsTaps taps[C];
+            u32 addr[C];
 #pragma unroll
-                for (int k = 0; k < 3; k++) c[k] = ((u32)ra[o0[g] + k] + ra[o1[g] + k] + rb[o0[g] + k] + rb[o1[g] + k] + 2) >> 2;
-            } else {
-                const int a0 = (short)(a01[g] & 0xffff), a1 = a01[g] >> 16, b0 = (short)(b01[g] & 0xffff), b1 = b01[g] >> 16;
+            for (int i = 0; i < C; i++) addr[i] = ((u32)(uintptr_t)base + px[g0 + i].off) & ~3u;
+            rs_taps_load<C>(addr, (u32)p.row_pad, taps);
 #pragma unroll
-                for (int k = 0; k < 3; k++) c[k] = interp(ra[o0[g] + k], ra[o1[g] + k], rb[o0[g] + k], rb[o1[g] + k], a0, a1, b0, b1);
-            }
-            if (STORE && t >= t0) {
-                uint8_t* d = p.dst + (size_t)t * p.dstride + ((size_t)(r0 + lrow[g]) * p.dw + (g * RS_WG + tid - lrow[g] * p.dw)) * 3;
-                d[0] = (uint8_t)c[0]; d[1] = (uint8_t)c[1]; d[2] = (uint8_t)c[2];
-            }
-            if (LUMA) {
-                if (count_luma) {
-                    // BT.601 luma in OpenCV's 14-bit fixed point (color_yuv.simd.hpp: 1868 B + 9617 G + 4899 R, + 8192 >> 14)
-                    const u32 y = (mul_u24(c[0], 1868u) + mul_u24(c[1], 9617u) + mul_u24(c[2], 4899u) + 8192u) >> 14;
-                    rs_lds_add(&hcur[y], 1u);
-                    bsum += c[0] + c[1] + c[2];
+            for (int i = 0; i < C; i++) {
+                const int g = g0 + i;
+                u32 c[3];
+                // (the staging buffers start 16-byte aligned and are multiples of 1024 bytes long: the tap's byte shift is off & 3)
+                if (p.area2) rs_interp<true>(taps[i], px[g].off, px[g], c);
+                else rs_interp<false>(taps[i], px[g].off, px[g], c);
+                if (STORE && t >= t0 && live[g]) {
+                    uint8_t* d = p.dst + (size_t)t * p.dstride + dst_off[g];
+                    d[0] = (uint8_t)c[0]; d[1] = (uint8_t)c[1]; d[2] = (uint8_t)c[2];
                 }
-            }
-            if (HSV) {
-                u32 h, s, v;
-                hsv_px(c[0], c[1], c[2], lut_s, lut_h, h, s, v);
-                const u32 cur = h | (s << 8) | (v << 16);
-                if (chain) {
-                    const u32 pv = prev_hsv[g];
-                    sh += (u32)abs((int)h - (int)(pv & 0xffu));
-                    ss += (u32)abs((int)s - (int)((pv >> 8) & 0xffu));
-                    sv += (u32)abs((int)v - (int)(pv >> 16));
+                if (LUMA) {
+                    if (count_luma) {
+                        // BT.601 luma in OpenCV's 14-bit fixed point (color_yuv.simd.hpp: 1868 B + 9617 G + 4899 R, + 8192 >> 14)
+                        const u32 y = (c[0] * 1868u + c[1] * 9617u + c[2] * 4899u + 8192u) >> 14;
+                        rs_lds_add(&hcur[y], live[g] ? 1u : 0u);
+                        bsum += c[0] + c[1] + c[2];
+                    }
                 }
-                prev_hsv[g] = cur;
+                if (HSV) {
+                    u32 h, s, v;
+                    rs_hsv(c[0], c[1], c[2], lut_s, lut_h, h, s, v);
+                    if (chain) {
+                        sh = __builtin_amdgcn_sad_u16(h, ph[g], sh);      // |h - ph| + sh on the 16-bit halves (the upper ones are 0)
+                        ss = __builtin_amdgcn_sad_u16(s, ps[g], ss);
+                        sv = __builtin_amdgcn_sad_u16(v, pv[g], sv);
+                    }
+                    ph[g] = h; ps[g] = s; pv[g] = v;
+                }
             }
         }
+        u32* s4 = &sums[rel & (RS_SLOTS - 1)][0][0] + rep;
         if (HSV) {
             if (chain) {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    sh += __shfl_xor(sh, o); ss += __shfl_xor(ss, o); sv += __shfl_xor(sv, o);
-                }
-                if (lane == 0) {
-                    u32* s4 = sums[rel & (RS_SLOTS - 1)];
-                    atomicAdd(&s4[0], sh); atomicAdd(&s4[1], ss); atomicAdd(&s4[2], sv);
-                }
+                rs_lds_add(s4, sh); rs_lds_add(s4 + RS_REP, ss); rs_lds_add(s4 + 2 * RS_REP, sv);
             }
             have_prev = true;
         }
         if (LUMA) {
-            if (count_luma) {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) bsum += __shfl_xor(bsum, o);
-                if (lane == 0) atomicAdd(&sums[rel & (RS_SLOTS - 1)][3], bsum);
-            }
+            if (count_luma) rs_lds_add(s4 + 3 * RS_REP, bsum);
         }
     }
     if (HSV || LUMA) {
-        if (LUMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
         // the periodic flush took frames [0, 8 * floor((done - 1) / 8)); at most 8 are left
         const int done = t1 - t0;
         const int f = (done > 0 ? ((done - 1) & ~7) : 0) + (tid >> 2), q = tid & 3;
         if (tid < 32 && f < done) {
-            const u32 v = sums[f & (RS_SLOTS - 1)][q];
+            const u32* cell = sums[f & (RS_SLOTS - 1)][q];
+            u32 v = 0;
+#pragma unroll
+            for (int k = 0; k < RS_REP; k++) v += cell[k];
             psd_frame_scores* rec = p.out + t0 + f;
             if (v) atomicAdd(q == 0 ? (unsigned long long*)&rec->sad_h : q == 1 ? (unsigned long long*)&rec->sad_s
                              : q == 2 ? (unsigned long long*)&rec->sad_v : (unsigned long long*)&rec->byte_sum, (unsigned long long)v);
@@ -646,6 +733,15 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     if (R > 16) R = 16;
     while (R > 1 && (R * dst_w + RS_WG - 1) / RS_WG > 8) R--;
     if (R > dst_h) R = dst_h;
+    if (rows_env <= 0) {
+        // pixel slots per thread come in powers of two (the G instances): six pixels per thread -- 640 x 360 -> 256 x 144, R = 6 --
+        // ran the 8-slot instance with a quarter of its slots dead.  Take the largest R' in (R / 2, R] whose tile fills its slots.
+        for (int r = R; 2 * r > R; r--) {
+            const int px = r * dst_w;
+            const int per = px / RS_WG;
+            if (px % RS_WG == 0 && per >= 1 && per <= 8 && (per & (per - 1)) == 0) { R = r; break; }
+        }
+    }
     const int per_thread = (R * dst_w + RS_WG - 1) / RS_WG;
     if (per_thread > 8) {   // destination rows wider than 2048 pixels: not a downscale for scoring; plain kernel
         if (d_out) { psd_set_error("destination rows of %d pixels are too wide for the fused downscale + score", dst_w); return PSD_ERR_UNSUPPORTED; }
@@ -666,7 +762,7 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     if (chunks < 1) chunks = 1;
     p.frames_per_chunk = (n + chunks - 1) / chunks;
     chunks = (n + p.frames_per_chunk - 1) / p.frames_per_chunk;
-    const size_t lds = (size_t)p.depth * 2 * R * p.row_pad;
+    const size_t lds = (size_t)p.depth * 2 * R * p.row_pad + 16;      // (+ 16: a tap read of 8 bytes at the end of the last staged row)
     const int grid = p.n_tiles * chunks;
     if (want_hsv) note_walk_geometry(p.frames_per_chunk, p.n_tiles);
     if (want_luma) {
