@@ -106,6 +106,79 @@ def downscaled_size(h: int, w: int, downscale: str) -> tuple[int, int, float]:
     return max(1, round(h / factor)), max(1, round(w / factor)), factor
 
 
+class SmiPoll:
+    """Socket power and shader clock of the GPU while the timed steps run (amdgpu hwmon sysfs, 50 Hz, a daemon thread that only
+    reads two small files): what the box was doing goes INTO the record, so that a line read on a slow box can be told from a
+    regression (round-5 review: the driver's box read 4 - 6 % under the builder's, and nothing in BENCH_r05 said why).
+    The HSV pass sits at the package power cap: its clock is what the firmware leaves it."""
+
+    def __init__(self, device_index: int = 0):
+        import glob
+
+        def first(pattern):
+            for path in sorted(glob.glob(pattern)):
+                try:
+                    open(path).read()
+                    return path
+                except OSError:
+                    pass
+            return None
+
+        # (one GPU per process: the first card that answers -- the pool's boxes show one; an 8-GPU node's ranks each see theirs
+        #  through ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES only for compute, so take the card with the rank's index if it exists)
+        base = "/sys/class/drm/card*/device/hwmon/hwmon*/"
+        cards = sorted({pth.split("/device/")[0] for pth in glob.glob(base + "freq1_input")})
+        pick = cards[device_index] + "/device/hwmon/hwmon*/" if device_index < len(cards) else base
+        self.pw = first(pick + "power1_average") or first(pick + "power1_input")
+        self.fq = first(pick + "freq1_input")
+        self.cap = first(pick + "power1_cap")
+        self.samples, self._stop, self._thread = [], False, None
+
+    def _run(self):
+        while not self._stop:
+            row = {}
+            try:
+                if self.pw:
+                    row["w"] = int(open(self.pw).read()) / 1e6
+                if self.fq:
+                    row["mhz"] = int(open(self.fq).read()) / 1e6
+            except (OSError, ValueError):
+                pass
+            if row:
+                self.samples.append(row)
+            time.sleep(0.02)
+
+    def __enter__(self):
+        import threading
+
+        if self.pw or self.fq:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+
+    def summary(self) -> dict | None:
+        if not self.samples:
+            return None
+        ws = sorted(r["w"] for r in self.samples if "w" in r)
+        fs = sorted(r["mhz"] for r in self.samples if "mhz" in r)
+        out = {"samples": len(self.samples), "source": "amdgpu hwmon sysfs, 50 Hz, during the timed steps"}
+        if ws:
+            out.update(socket_power_w_median=round(ws[len(ws) // 2], 1), socket_power_w_max=round(ws[-1], 1))
+        if fs:
+            out.update(shader_clock_mhz_median=round(fs[len(fs) // 2]), shader_clock_mhz_min=round(fs[0]), shader_clock_mhz_max=round(fs[-1]))
+        if self.cap:
+            try:
+                out["power_cap_w"] = int(open(self.cap).read()) / 1e6
+            except (OSError, ValueError):
+                pass
+        return out
+
+
 def parity_runs(n: int, k: int, walk: int = 0, frame_bytes: int = 0) -> list[tuple[int, int]]:
     """Frame ranges [a, b) a parity sample looks at: the first, the middle and the last k frames of the batch, both sides
     of every boundary between two time walks of the launch (`walk` frames each: psd_last_walk_geometry -- a workgroup starts
@@ -244,6 +317,8 @@ class Workload:
         return self.n * self.h * self.w * per_px
 
     def kernel_name(self) -> str:
+        if self.downscale and self.detector == "edges":
+            return "psd::resize_walk_kernel<STORE> into the engine's buffer + V-mode HSV pass + edge pipeline on the resized frames"
         if self.downscale:
             return "psd::resize_walk_kernel"
         return {"content": "psd::score_frames_dma_kernel", "all": "psd::score_frames_dma_kernel", "hist": "psd::luma_hist_kernel",
@@ -404,6 +479,16 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
     attempt("default_pipeline_downscale_auto_all_four", f"all four detectors behind SceneManager's default downscale ({w}x{h} -> 256 wide), {n} frames: "
             "resize + HSV + luma histogram + byte sum in ONE kernel, the small frame never exists in memory; roofline counts the source rows "
             "that carry taps", lambda: quick_measure(Workload(eng, batch, "all", "auto", epilogue, E), steps=20, warmup=5))
+    def run_ds_edges():
+        # the reference's default pipeline WITH a StatsManager (content_detector.py:158: the edge term is computed whenever one is
+        # attached): resize to 256 wide into the engine's buffer, then HSV + Canny / dilate / XOR on the small frames, k = 5
+        bt = make_batch(frames_small, "T", 20250921, device, h, w)
+        r = quick_measure(Workload(eng, bt, "edges", "auto", epilogue, E), steps=10, warmup=3)
+        del bt
+        return r
+    attempt("default_pipeline_downscale_auto_edges", f"ContentDetector with the edge term (weights 1,1,1,1: what a StatsManager makes the reference "
+            f"compute) behind SceneManager's default downscale ({w}x{h} -> 256 wide), {frames_small} frames with objects; roofline counts "
+            "the source rows that carry taps", run_ds_edges)
     attempt("hash_detector_1080p", f"HashDetector (thumbnail kernel + DCT epilogue), {n} x {w}x{h}",
             lambda: quick_measure(Workload(eng, batch, "hash", None, epilogue, E), steps=3, warmup=1))
     for dist, label in (("S", "shot-like content (64-frame shots, hard cuts)"), ("K", "constant frames (one histogram bin per frame)")):
@@ -510,9 +595,15 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
             t0 = time.perf_counter()
             cuts_stats, _vals = run(eng, clip, True)
             best_stats = min(best_stats, time.perf_counter() - t0)
-        r = {"value": round(len(clip) / best, 1), "unit": "frames/s", "pcie_inclusive": True, "frames": len(clip),
+        # `value` keeps the definition of rounds 1-4 -- WITH a StatsManager (per-frame metrics kept, the edge term computed) -- so that the
+        # line compares across rounds (round 5 had silently made the no-StatsManager run the value: ADVICE r05); the reference's default
+        # `detect()` (no StatsManager, scenedetect/__init__.py:208-210) is reported under its own key
+        r = {"value": round(len(clip) / best_stats, 1), "unit": "frames/s", "pcie_inclusive": True, "frames": len(clip),
              "distinct_frames": len(host),
+             "definition": "SceneManager.detect_scenes WITH a StatsManager over %d frames (%d distinct ones, cycled), thread on the GPU's NUMA "
+                           "node; best of 2" % (len(clip), len(host)),
              "with_stats_manager_frames_per_s": round(len(clip) / best_stats, 1),
+             "without_stats_manager_frames_per_s": round(len(clip) / best, 1),
              "source_rows_uploaded_per_frame": int(len(rows)), "source_rows_per_frame": h,
              "frames_per_upload_call": psd.scene_manager._DeviceFeeder.FEED_BATCH, "cuts_found": len(cuts),
              "host_to_device_GBps": round(len(rows) * w * 3 * len(clip) / best / 1e9, 2)}
@@ -1155,10 +1246,11 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
     if args.warmup > 0:
         run(args.warmup, False)
     barrier()
-    t0 = time.perf_counter()
-    run(args.steps, True)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with SmiPoll(local_rank if on_gpu else 0) as smi:
+        t0 = time.perf_counter()
+        run(args.steps, True)
+        barrier()
+        elapsed = time.perf_counter() - t0
     if use_dist:
         import torch.distributed as dist
 
@@ -1231,6 +1323,8 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "limiter": "package power: the HSV pass holds the 1400 W cap and the shader clock falls to 1.9-2.1 GHz "
                            "(profiles/r02_a_power_and_clock_by_build.txt)" if headline else None,
+                # what THIS box did during the timed steps (power-bound passes read 4 - 6 % apart between boxes of the pool)
+                "box": smi.summary(),
             },
             "cuts_found": len(wl.state["cuts"]),
         }

@@ -49,7 +49,8 @@ extern "C" {
                             *    threads and frame buffers themselves);
                             * 7: additive over 6 (psd_score_segments_downscaled_device: MANY clips packed into one batch behind the
                             *    reference's default downscale -- what `detect(path, detector_cls())` of benchmark/__main__.py:44-61
-                            *    computes per video, for a whole shard of videos in one launch) */
+                            *    computes per video, for a whole shard of videos in one launch; psd_allgather_host: the exchange step for
+                            *    records a rank already holds on the host) */
 
 typedef enum psd_status {
     PSD_OK = 0,
@@ -174,6 +175,14 @@ int psd_comm_create(psd_engine* e, int n_ranks, int rank, const void* id128, psd
 void psd_comm_destroy(psd_comm* c);
 int psd_allgather_scores(psd_comm* c, const psd_frame_scores* d_local, int n_local, const int* counts,
                          psd_frame_scores* h_all);
+/* The same exchange for records that are already on the HOST: after a corpus pass a rank holds the records of its clips from
+ * several submissions (one per resolution, pieces of long runs, collected as they finished), usually as psd_frame_sums.
+ * n_local elements of elem_bytes each (sizeof(psd_frame_sums) or sizeof(psd_frame_scores)) -> page-locked staging -> ONE
+ * ncclAllGather of padded per-rank blocks -> h_all: counts[r] elements of every rank r in rank order.  counts as above: the
+ * same array on every rank, counts[rank] == n_local -- the sharded flow derives it from the plan every rank computes alike
+ * (clips greedy longest-first), so the exchange is this one collective and nothing else.  A rank with a local argument error
+ * still takes part (zero-filled) and reports afterwards, like psd_allgather_scores. */
+int psd_allgather_host(psd_comm* c, const void* h_local, int n_local, size_t elem_bytes, const int* counts, void* h_all);
 
 /* Device time (ms, HIP events on the launch stream) spent in the scoring kernels of the most
  * recently *collected* submission, and the number of kernel launches it took. */

@@ -172,3 +172,127 @@ int psd_hash_thumbs(psd_engine* e, const uint8_t* h_frames, int n, int height, i
     free(gray);
     return PSD_OK;
 }
+
+/* ---- the exchange step (psd_comm_* / psd_allgather_host / psd_allgather_scores) without RCCL ----------------------------------------
+ * A stand-in communicator over POSIX shared memory, so that the code path a multi-GPU run takes -- distributed.native_comm_for ->
+ * NativeComm -> psd_allgather_host, instead of torch.distributed -- can be executed at world sizes 2 ... 8 in the CPU suite
+ * (tests/test_distributed.py).  Same contract as the RCCL implementation in pyscenedetect_amd/csrc/psd_comm.cpp: counts identical on
+ * every rank, ragged blocks padded to the largest, a rank with a local argument error still takes part (zero-filled) and reports
+ * afterwards.  The unique id names the segment; a two-phase counter barrier (arrive / leave) orders writes and reads. */
+#include <fcntl.h>
+#include <stdatomic.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#define PSD_SHM_BYTES ((size_t)256 << 20)      /* sparse: only touched pages exist */
+
+typedef struct {
+    _Atomic int arrived, left;
+    _Atomic unsigned generation;
+} shm_head;
+
+struct psd_comm {
+    int n_ranks, rank, fd;
+    char name[64];
+    uint8_t* base;
+};
+
+int psd_comm_unique_id(void* id128)
+{
+    if (!id128) { snprintf(g_err, sizeof g_err, "psd_comm_unique_id: null argument"); return PSD_ERR_INVALID; }
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    memset(id128, 0, 128);
+    snprintf((char*)id128, 64, "/psd_comm_%d_%ld_%ld", (int)getpid(), (long)ts.tv_sec, (long)ts.tv_nsec);
+    return PSD_OK;
+}
+
+int psd_comm_create(psd_engine* e, int n_ranks, int rank, const void* id128, psd_comm** out)
+{
+    if (!e || !id128 || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) {
+        snprintf(g_err, sizeof g_err, "psd_comm_create: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    psd_comm* c = (psd_comm*)calloc(1, sizeof *c);
+    if (!c) return PSD_ERR_NOMEM;
+    c->n_ranks = n_ranks; c->rank = rank;
+    memcpy(c->name, id128, 63);
+    c->fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+    if (c->fd < 0 || ftruncate(c->fd, (off_t)PSD_SHM_BYTES) != 0) {
+        snprintf(g_err, sizeof g_err, "psd_comm_create: shared memory segment %s unavailable", c->name);
+        if (c->fd >= 0) close(c->fd);
+        free(c);
+        return PSD_ERR_HIP;
+    }
+    c->base = (uint8_t*)mmap(NULL, PSD_SHM_BYTES, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0);
+    if (c->base == MAP_FAILED) { close(c->fd); free(c); snprintf(g_err, sizeof g_err, "psd_comm_create: mmap failed"); return PSD_ERR_HIP; }
+    *out = c;      /* (a fresh segment is zero: the counters start at 0 whoever arrives first) */
+    return PSD_OK;
+}
+
+void psd_comm_destroy(psd_comm* c)
+{
+    if (!c) return;
+    munmap(c->base, PSD_SHM_BYTES);
+    close(c->fd);
+    if (c->rank == 0) shm_unlink(c->name);
+    free(c);
+}
+
+static void shm_barrier(psd_comm* c, _Atomic int* counter)
+{
+    shm_head* h = (shm_head*)c->base;
+    const unsigned gen = atomic_load(&h->generation);
+    if (atomic_fetch_add(counter, 1) + 1 == c->n_ranks) {
+        atomic_store(counter, 0);
+        atomic_fetch_add(&h->generation, 1);
+    } else {
+        while (atomic_load(&h->generation) == gen) { struct timespec ts = {0, 50000}; nanosleep(&ts, NULL); }
+    }
+}
+
+int psd_allgather_host(psd_comm* c, const void* h_local, int n_local, size_t elem_bytes, const int* counts, void* h_all)
+{
+    if (!c || !counts || elem_bytes == 0) { snprintf(g_err, sizeof g_err, "psd_allgather_host: invalid argument"); return PSD_ERR_INVALID; }
+    char local_msg[160] = "";
+    int local_error = 0;
+    if (n_local < 0 || (n_local > 0 && !h_local)) {
+        snprintf(local_msg, sizeof local_msg, "psd_allgather_host: invalid local records (n_local = %d)", n_local);
+        local_error = 1; n_local = 0;
+    } else if (counts[c->rank] != n_local) {
+        snprintf(local_msg, sizeof local_msg, "psd_allgather_host: counts[%d] = %d but this rank contributes %d records", c->rank,
+                 counts[c->rank], n_local);
+        local_error = 1;
+        if (counts[c->rank] >= 0 && n_local > counts[c->rank]) n_local = counts[c->rank];
+    }
+    size_t cap = 1, total = 0;
+    for (int i = 0; i < c->n_ranks; i++) {
+        if (counts[i] < 0) { snprintf(g_err, sizeof g_err, "psd_allgather_host: negative count"); return PSD_ERR_INVALID; }
+        if ((size_t)counts[i] > cap) cap = (size_t)counts[i];
+        total += (size_t)counts[i];
+    }
+    const size_t block = cap * elem_bytes;
+    if (total > 0 && !h_all) { snprintf(g_err, sizeof g_err, "psd_allgather_host: null output"); return PSD_ERR_INVALID; }
+    if (4096 + block * (size_t)c->n_ranks > PSD_SHM_BYTES) { snprintf(g_err, sizeof g_err, "psd_allgather_host: stand-in segment too small"); return PSD_ERR_NOMEM; }
+    shm_head* h = (shm_head*)c->base;
+    uint8_t* data = c->base + 4096;
+    memset(data + (size_t)c->rank * block, 0, block);
+    if (n_local > 0) memcpy(data + (size_t)c->rank * block, h_local, (size_t)n_local * elem_bytes);
+    shm_barrier(c, &h->arrived);                 /* every block is written */
+    size_t off = 0;
+    for (int i = 0; i < c->n_ranks && !local_error; i++) {
+        memcpy((uint8_t*)h_all + off, data + (size_t)i * block, (size_t)counts[i] * elem_bytes);
+        off += (size_t)counts[i] * elem_bytes;
+    }
+    shm_barrier(c, &h->left);                    /* every block is read: the segment may be reused */
+    if (local_error) { snprintf(g_err, sizeof g_err, "%s (the collective was completed with zero-filled records)", local_msg); return PSD_ERR_INVALID; }
+    return PSD_OK;
+}
+
+/* records that sit "on the device" (host memory here) */
+int psd_allgather_scores(psd_comm* c, const psd_frame_scores* d_local, int n_local, const int* counts, psd_frame_scores* h_all)
+{
+    return psd_allgather_host(c, d_local, n_local, sizeof(psd_frame_scores), counts, h_all);
+}

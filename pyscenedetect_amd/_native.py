@@ -124,6 +124,7 @@ SYMBOLS = {
     "psd_comm_create": (_i, [_vp, _i, _i, _vp, _P(_vp)]),
     "psd_comm_destroy": (None, [_vp]),
     "psd_allgather_scores": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "psd_allgather_host": (_i, [_vp, _vp, _i, _sz, _vp, _vp]),
     "psd_last_records_device": (_i, [_vp, _P(_vp), _P(_i)]),
     "psd_last_kernel_ms": (_i, [_vp, _P(_f), _P(_i)]),
     "psd_device_alloc": (_i, [_vp, _sz, _P(_vp)]),

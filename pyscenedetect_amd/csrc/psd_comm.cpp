@@ -211,4 +211,68 @@ int psd_allgather_scores(psd_comm* c, const psd_frame_scores* d_local, int n_loc
     return PSD_OK;
 }
 
+// The same exchange for records that are already on the HOST -- what a rank holds after a corpus pass: its clips were scored in
+// several submissions (one per resolution, pieces of long runs) and collected as they finished, so no single device buffer has
+// them.  n_local elements of elem_bytes each (40: psd_frame_sums; 1064: psd_frame_scores) go through a page-locked staging
+// buffer to the device, ONE ncclAllGather of padded per-rank blocks, and back; h_all receives counts[r] elements of every rank
+// r in rank order.  counts must be the same array on every rank -- in the sharded flow every rank derives it from the plan
+// (distributed.assign_clips is deterministic and every rank knows every clip's length), so no collective is spent on it.
+int psd_allgather_host(psd_comm* c, const void* h_local, int n_local, size_t elem_bytes, const int* counts, void* h_all)
+{
+    if (!c || !counts || elem_bytes == 0) { psd_set_error("psd_allgather_host: invalid argument"); return PSD_ERR_INVALID; }
+    bool local_error = false;
+    char local_msg[160] = "";
+    if (n_local < 0 || (n_local > 0 && !h_local)) {
+        snprintf(local_msg, sizeof local_msg, "psd_allgather_host: invalid local records (n_local = %d)", n_local);
+        local_error = true; n_local = 0;
+    } else if (counts[c->rank] != n_local) {
+        snprintf(local_msg, sizeof local_msg, "psd_allgather_host: counts[%d] = %d but this rank contributes %d records",
+                 c->rank, counts[c->rank], n_local);
+        local_error = true;
+        if (counts[c->rank] >= 0 && n_local > counts[c->rank]) n_local = counts[c->rank];
+    }
+    Rccl* r = rccl();
+    if (!r) { psd_set_error("RCCL (librccl.so) is not available: %s", g_rccl_why.c_str()); return PSD_ERR_UNSUPPORTED; }
+    size_t cap_el = 1, total = 0;
+    for (int i = 0; i < c->n_ranks; i++) {
+        if (counts[i] < 0) { psd_set_error("psd_allgather_host: negative count"); return PSD_ERR_INVALID; }
+        if ((size_t)counts[i] > cap_el) cap_el = (size_t)counts[i];
+        total += (size_t)counts[i];
+    }
+    if (total > 0 && !h_all) { psd_set_error("psd_allgather_host: null output"); return PSD_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(psd::engine_device(c->engine)));
+    hipStream_t stream = psd::engine_stream(c->engine);
+    // (the buffers are sized in records of the widest kind: a block of cap_el elements fits cap records whenever
+    //  cap * sizeof(psd_frame_scores) >= cap_el * elem_bytes)
+    const size_t rec = sizeof(psd_frame_scores);
+    const size_t block = cap_el * elem_bytes;
+    const size_t cap = (block + rec - 1) / rec;
+    if (c->cap < cap) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (c->d_send) HIP_TRY(hipFree(c->d_send));
+        if (c->d_recv) HIP_TRY(hipFree(c->d_recv));
+        if (c->h_recv) HIP_TRY(hipHostFree(c->h_recv));
+        c->d_send = c->d_recv = c->h_recv = nullptr; c->cap = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_send, cap * rec));
+        HIP_TRY(hipMalloc((void**)&c->d_recv, cap * rec * c->n_ranks));
+        HIP_TRY(hipHostMalloc((void**)&c->h_recv, cap * rec * c->n_ranks, hipHostMallocDefault));
+        c->cap = cap;
+    }
+    // this rank's block travels through the front of the pinned mirror (it is overwritten by the gathered blocks afterwards)
+    memset(c->h_recv, 0, block);
+    if (n_local > 0) memcpy(c->h_recv, h_local, (size_t)n_local * elem_bytes);
+    HIP_TRY(hipMemcpyAsync(c->d_send, c->h_recv, block, hipMemcpyHostToDevice, stream));
+    const int rc = r->all_gather(c->d_send, c->d_recv, block, 0 /* ncclChar */, c->comm, stream);
+    if (rc != 0) return rccl_fail(r, "ncclAllGather", rc);
+    HIP_TRY(hipMemcpyAsync(c->h_recv, c->d_recv, block * c->n_ranks, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (local_error) { psd_set_error("%s (the collective was completed with zero-filled records)", local_msg); return PSD_ERR_INVALID; }
+    size_t off = 0;
+    for (int i = 0; i < c->n_ranks; i++) {
+        memcpy((uint8_t*)h_all + off, c->h_recv + (size_t)i * block, (size_t)counts[i] * elem_bytes);
+        off += (size_t)counts[i] * elem_bytes;
+    }
+    return PSD_OK;
+}
+
 }  // extern "C"

@@ -638,12 +638,23 @@ static hipError_t wait_done(hipEvent_t ev, int n)
     static const int spin_n = [] { const char* v = getenv("PSD_SPIN_N"); return v ? atoi(v) : 16; }();
     if (n <= spin_n && spin_us > 0) {
         const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
+        bool polled_not_ready = false;
         do {
             const hipError_t q = hipEventQuery(ev);
-            // (hipErrorNotReady lands in HIP's last-error slot like any failure: clear it, or the next launch check reports it)
-            if (q != hipErrorNotReady) { (void)hipGetLastError(); return q; }
+            if (q != hipErrorNotReady) {
+                // hipErrorNotReady lands in HIP's last-error slot like any failure: clear it, or the next launch check reports it --
+                // but ONLY when this loop put it there (an unrelated error pending on this thread is not ours to discard)
+                if (polled_not_ready) (void)hipGetLastError();
+                return q;
+            }
+            polled_not_ready = true;
+            // (a pause between two queries: the poll shares its core's issue slots with whatever else the host runs -- many engines
+            //  or threads on the per-frame API -- and 400 us of back-to-back driver calls per collect is what it would otherwise burn)
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
         } while (std::chrono::steady_clock::now() < until);
-        (void)hipGetLastError();
+        (void)hipGetLastError();      // (only reached behind at least one hipErrorNotReady)
     }
     return hipEventSynchronize(ev);
 }

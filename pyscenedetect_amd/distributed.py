@@ -44,12 +44,14 @@ def device_records_tensor(ptr: int, n: int, device):
     return torch.as_tensor(_View(), device=device)
 
 
-def all_gather_records(local: np.ndarray, group=None, device_records: tuple[int, int] | None = None) -> list[np.ndarray]:
+def all_gather_records(local: np.ndarray, group=None, device_records: tuple[int, int] | None = None, counts=None) -> list[np.ndarray]:
     """All-gather ragged per-rank record arrays; returns one array per rank, in rank order.
 
-    Two collectives: the counts (tiny) and one padded byte tensor.  With the ``nccl`` backend the
-    payload travels GPU-to-GPU (RCCL); the records are KBs-MBs, so this is latency-bound and a
-    single fused all-gather is the cheapest pattern on the point-to-point xGMI mesh.
+    One padded byte tensor -- and, unless the caller knows them, the counts (tiny) in front of it.  ``counts``: the number of
+    records of every rank when all ranks can work it out alike (the sharded corpus flow: the plan is deterministic and every
+    clip's length is known everywhere); that saves the first collective and its device -> host synchronisation.  With the
+    ``nccl`` backend the payload travels GPU-to-GPU (RCCL); the records are KBs-MBs, so this is latency-bound and a single
+    fused all-gather is the cheapest pattern on the point-to-point xGMI mesh.
     ``device_records = engine.last_records_device()`` hands over the records where the kernels left them, so the
     send buffer is filled by one device-to-device copy instead of a host -> device upload (SURVEY.md 8b / 8e);
     ``local`` (the host copy the engine returned anyway) is then only used for its length.
@@ -63,10 +65,15 @@ def all_gather_records(local: np.ndarray, group=None, device_records: tuple[int,
     world = dist.get_world_size(group)
     on_gpu = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    mine = torch.tensor([len(local)], dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, mine, group=group)
-    counts = counts.cpu().tolist()
+    if counts is None:
+        counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        mine = torch.tensor([len(local)], dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(counts, mine, group=group)
+        counts = counts.cpu().tolist()
+    else:
+        counts = [int(c) for c in counts]
+        if len(counts) != world or counts[dist.get_rank(group)] != len(local):
+            raise ValueError("counts must hold one entry per rank, this rank's equal to its number of records")
     cap = max(max(counts), 1) * dtype.itemsize
     if on_gpu and device_records is not None and device_records[1] == len(local) and len(local):
         send = torch.zeros(cap, dtype=torch.uint8, device=dev)
@@ -124,7 +131,15 @@ def score_clips_distributed(engine, clips, flags: int, edge_kernel: int = 0, gro
     #  records to an all-gather of 40-byte ones: found by the world-8 gloo test of the resized corpus.)
     sums = not (flags & SCORE_LUMA_HIST)
     local = np.concatenate(mine) if mine else np.zeros(0, SUMS_DTYPE if sums else RECORD_DTYPE)
-    parts = all_gather_records(local, group)
+    # every rank can count every rank's records: the plan is deterministic and a clip's length is known wherever its shape is
+    counts = [sum(int(clips[i].shape[0]) for i in plan[r]) for r in range(world)]
+    comm = native_comm_for(engine, group)
+    if comm is not None:
+        # the exchange the C-ABI advertises (psd_comm_* / psd_allgather_host): RCCL loaded by libpsd_hip.so, one ncclAllGather, no
+        # torch tensors staged, no counts collective
+        parts = comm.all_gather_host(local, counts)
+    else:
+        parts = all_gather_records(local, group, counts=counts)
     out: list = [None] * len(clips)
     for r in range(world):
         off = 0
@@ -134,42 +149,117 @@ def score_clips_distributed(engine, clips, flags: int, edge_kernel: int = 0, gro
     return out
 
 
+_native_comms: dict = {}      # (id(engine), id(group)) -> NativeComm | None: one communicator per engine and process group
+
+
+def native_comm_for(engine, group=None, lib=None):
+    """The ``NativeComm`` of ``engine`` over ``group``, made on first use, or ``None`` where the flow keeps to
+    ``torch.distributed``: the group's backend is not ``nccl`` (CPU tests over gloo), the engine is not the HIP engine,
+    ``PSD_NATIVE_EXCHANGE=0``, or RCCL could not be loaded / initialised on SOME rank (the ranks agree on the outcome through one
+    all-reduce, once per group: a communicator only some ranks hold would hang the first collective).  ``lib``: tests hand in the
+    CPU stand-in of the C-ABI (``oracle/libpsd_oracle_abi.so``) to run this path over gloo."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    key = (id(engine), id(group))
+    if key in _native_comms:
+        return _native_comms[key]
+    comm = None
+    wanted = os.environ.get("PSD_NATIVE_EXCHANGE", "1") != "0" and getattr(engine, "_h", None) is not None and \
+        (lib is not None or dist.get_backend(group) == "nccl")
+    if wanted:      # (every rank evaluates `wanted` alike: same environment, same kind of engine, same backend)
+        try:
+            comm = NativeComm.from_process_group(engine, group, lib=lib)
+            ok = 1
+        except Exception:  # noqa: BLE001 -- no RCCL, an initialisation error: this rank votes for the torch path
+            ok = 0
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        vote = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
+        if int(vote.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+    _native_comms[key] = comm
+    return comm
+
+
 class NativeComm:
     """The exchange step through the C-ABI itself (``psd_comm_*`` / ``psd_allgather_scores``): RCCL loaded by
     ``libpsd_hip.so``, no torch in the data path.  ``unique_id`` (128 bytes from :meth:`make_unique_id` on rank 0) reaches
     the other ranks by whatever means the host has; :meth:`from_process_group` uses an existing ``torch.distributed``
     group (any backend) just for that hand-over."""
 
-    def __init__(self, engine, n_ranks: int, rank: int, unique_id: bytes):
+    def __init__(self, engine, n_ranks: int, rank: int, unique_id: bytes, lib=None):
         import ctypes
 
         from pyscenedetect_amd import _native
 
         if len(unique_id) != 128:
             raise ValueError("unique_id must be the 128 bytes of psd_comm_unique_id")
-        self._engine, self._lib, self.n_ranks, self.rank = engine, _native.load(), int(n_ranks), int(rank)
+        self._engine, self._lib, self.n_ranks, self.rank = engine, lib if lib is not None else _native.load(), int(n_ranks), int(rank)
+        self.exchanges = 0
         h = ctypes.c_void_p()
         buf = ctypes.create_string_buffer(unique_id, 128)
-        _native.check(self._lib.psd_comm_create(engine._h, self.n_ranks, self.rank, buf, ctypes.byref(h)))
+        self._check(self._lib.psd_comm_create(engine._h, self.n_ranks, self.rank, buf, ctypes.byref(h)))
         self._h = h
 
+    def _check(self, rc: int) -> None:
+        from pyscenedetect_amd import _native
+
+        if rc != 0 and self._lib is not _native._lib:        # (a stand-in library keeps its own error text)
+            msg = (self._lib.psd_last_error() or b"").decode("utf-8", "replace")
+            raise (ValueError if rc == _native.PSD_ERR_INVALID else NotImplementedError if rc == _native.PSD_ERR_UNSUPPORTED else RuntimeError)(msg)
+        _native.check(rc)
+
     @staticmethod
-    def make_unique_id() -> bytes:
+    def make_unique_id(lib=None) -> bytes:
         import ctypes
 
         from pyscenedetect_amd import _native
 
         buf = ctypes.create_string_buffer(128)
-        _native.check(_native.load().psd_comm_unique_id(buf))
+        if lib is None:
+            _native.check(_native.load().psd_comm_unique_id(buf))
+        elif lib.psd_comm_unique_id(buf) != 0:
+            raise RuntimeError((lib.psd_last_error() or b"").decode("utf-8", "replace"))
         return buf.raw
 
     @classmethod
-    def from_process_group(cls, engine, group=None) -> "NativeComm":
+    def from_process_group(cls, engine, group=None, lib=None) -> "NativeComm":
         import torch.distributed as dist
 
-        box = [cls.make_unique_id() if dist.get_rank(group) == 0 else None]
+        box = [cls.make_unique_id(lib) if dist.get_rank(group) == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
-        return cls(engine, dist.get_world_size(group), dist.get_rank(group), box[0])
+        return cls(engine, dist.get_world_size(group), dist.get_rank(group), box[0], lib=lib)
+
+    def all_gather_host(self, local: np.ndarray, counts) -> list[np.ndarray]:
+        """Every rank's records, in rank order, from records this rank holds on the HOST (``psd_allgather_host``): what a
+        corpus pass leaves -- several submissions' worth, ``SUMS_DTYPE`` or ``RECORD_DTYPE``, the same on every rank.
+        ``counts[r]`` = number of records of rank r, the same list on every rank (the sharded flow derives it from its plan).
+        Whatever is wrong with ``local`` on THIS rank, the rank still enters the collective (the library zero-fills) and
+        raises afterwards."""
+        import ctypes
+
+        local = np.ascontiguousarray(local)
+        dtype = local.dtype
+        assert dtype in (RECORD_DTYPE, SUMS_DTYPE)
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        if counts.shape != (self.n_ranks,):
+            raise ValueError("counts must hold one entry per rank")     # (the same array everywhere: every rank raises)
+        out = np.zeros(int(counts.sum()), dtype)
+        rc = self._lib.psd_allgather_host(self._h, ctypes.c_void_p(local.ctypes.data if len(local) else None), len(local),
+                                          ctypes.c_size_t(dtype.itemsize), ctypes.c_void_p(counts.ctypes.data),
+                                          ctypes.c_void_p(out.ctypes.data if len(out) else None))
+        self._check(rc)
+        self.exchanges += 1
+        parts, off = [], 0
+        for c in counts:
+            parts.append(out[off:off + int(c)])
+            off += int(c)
+        return parts
 
     def all_gather_records(self, counts, local: np.ndarray | None = None, device_records: tuple[int, int] | None = None) -> list[np.ndarray]:
         """Every rank's records, in rank order.  ``counts[r]`` = number of records of rank r (the same list on every

@@ -94,6 +94,30 @@ def get_scenes_from_cuts(cut_list, start_pos, end_pos):
     return list(zip(bounds[:-1], bounds[1:]))
 
 
+def _scaled_shape(shape, factor) -> tuple[int, int]:
+    """(height, width) of a frame of ``shape`` as the detectors see it behind a downscale by ``factor`` (scene_manager.py:670-678)."""
+    if factor > 1.0:
+        return max(1, round(shape[0] / factor)), max(1, round(shape[1] / factor))
+    return int(shape[0]), int(shape[1])
+
+
+def _patch_first_record(engine, plan, result, seam) -> None:
+    """The first record of a batch scored against ``seam[0]`` -- the previous call's last frame AS ITS detectors saw it -- where
+    the two calls reach the same size by different downscales (``detect_scenes``): ``seam[1]`` is the batch's first frame as seen."""
+    prev_small, cur_small = seam
+    flags = plan["flags"] & 9
+    if not flags or result.get("records") is None:
+        return
+    kernels = plan["kernels"] if plan["flags"] & 8 else [0]
+    for k in kernels:
+        rec = engine.score_host(cur_small[None], prev=prev_small, flags=flags, edge_kernel=k)
+        if k == kernels[0]:
+            for name in ("sad_h", "sad_s", "sad_v", "edge_xor"):
+                result["records"][name][0] = rec[name][0]
+        if plan["flags"] & 8 and k in result.get("edge_xor", {}):
+            result["edge_xor"][k][0] = rec["edge_xor"][0]
+
+
 def _score_flags(detector) -> int:
     """The ``PSD_SCORE_*`` terms a detector wants from the device; 0 for a detector that only knows the plug-in API (one written
     against the reference's ``scenedetect.SceneDetector`` has none of this package's extension methods)."""
@@ -138,7 +162,8 @@ class SceneManager:
         self._frame_buffer: list[tuple] = []
         self._frame_buffer_size = 0
         self._crop = None
-        self._carry_frame = None     # the last frame of the previous detect_scenes() call (see there)
+        self._carry_frame = None     # the last frame of the previous detect_scenes() call (see there): this manager's own copy
+        self._carry_scale = None     # ... and the (downscale factor, interpolation) it was scored behind
         self._roles: list[tuple] = []  # (detector, score flags, thumbnail size, edge kernel) per registered detector (_dispatch)
 
     # -- configuration (reference :265-335) ---------------------------------------------------------
@@ -221,6 +246,7 @@ class SceneManager:
     def clear_detectors(self) -> None:
         self._detector_list.clear()
         self._carry_frame = None     # (the reference's detectors own this state: scene_manager.py:372-375 drops them)
+        self._carry_scale = None
 
     # -- results -----------------------------------------------------------------------------------
     def _get_cutting_list(self) -> list[FrameTimecode]:
@@ -390,8 +416,8 @@ class SceneManager:
 
         # (every timecode a stream hands over becomes one of this package's: the stream may be one of the reference's backends)
         self._base_timecode = FrameTimecode(video.base_timecode)
-        if self._stats_manager is not None:
-            self._stats_manager._base_timecode = self._base_timecode
+        # (the StatsManager is NOT told the base timecode: since round 5 its save_to_csv skips rows keyed by a bare frame number
+        #  like the reference's, and a time base planted here would have been state nobody reads)
         start_frame_num = video.frame_number
         if end_time is not None:
             end_time = self._base_timecode + end_time
@@ -428,6 +454,7 @@ class SceneManager:
         # Here the previous frame belongs to the manager's shared pass: it survives the call, until clear() / clear_detectors()
         # (a detector added in between still starts without a predecessor: each detector has its own "seen a frame" flag).
         last_frame = self._carry_frame
+        carry_scale = self._carry_scale if last_frame is not None else None
         # ... and the detectors know better where they have been in the meantime: fed by hand through process_frame(), or run under
         # ANOTHER manager (which left its last frame with them, below) -- the frame a detector saw last is the predecessor then
         if engine is not None:
@@ -436,6 +463,8 @@ class SceneManager:
                 if _score_flags(detector) & 9 and scorer is not None and hasattr(scorer, "last_frame"):
                     seen = scorer.last_frame()
                     if seen is not None:
+                        if seen is not last_frame:
+                            carry_scale = None      # (a frame fed by hand: as the stream delivered it)
                         last_frame = seen
                         break
         if feeder and last_frame is not None:
@@ -449,20 +478,35 @@ class SceneManager:
                 frames, positions, slot = batch
                 result = None
                 if engine is not None:
-                    if last_frame is not None and last_frame.shape != frames[0].shape:
-                        # frames of another size than the one a detector saw last: the reference's ContentDetector compares the planes it
-                        # kept with the new ones behind `assert left.shape == right.shape` (content_detector.py:29-36) -- a second video
-                        # of another size without clear(), a manager taking over from process_frame() calls on other frames
-                        for detector in self._detector_list:
-                            if _score_flags(detector) & 9 and getattr(detector, "_have_last", False):
-                                raise AssertionError("frame size changed from %dx%d to %dx%d" % (
-                                    last_frame.shape[1], last_frame.shape[0], frames[0].shape[1], frames[0].shape[0]))
+                    seam = None
+                    if last_frame is not None and (last_frame.shape != frames[0].shape or
+                                                   (carry_scale is not None and carry_scale != (factor, interp))):
+                        # The frame a detector saw last is of another size, or was scored behind another downscale.  The reference's
+                        # ContentDetector compares the planes it KEPT -- downscaled as they were -- with the new frame's behind
+                        # `assert left.shape == right.shape` (content_detector.py:29-36): what decides is the size the detectors see.
+                        # (Until round 6 the raw shapes were compared: 512 x 288 at factor 2 followed by 256 x 144 at factor 1 raised
+                        # here and not in the reference, and a changed `downscale` on frames of one size went unnoticed.)
+                        old_f, old_i = carry_scale if carry_scale is not None else (factor, interp)
+                        seen = _scaled_shape(last_frame.shape, old_f)
+                        now = _scaled_shape(frames[0].shape, factor)
+                        users = [d for d in self._detector_list if _score_flags(d) & 9 and getattr(d, "_have_last", False)]
+                        if seen != now:
+                            if users:      # a second video of another size without clear(), a manager taking over from other frames
+                                raise AssertionError("frame size changed from %dx%d to %dx%d" % (seen[1], seen[0], now[1], now[0]))
+                        elif users:
+                            # same size for the detectors, another path to it: the first record of this call is scored on the two small
+                            # frames themselves (each behind its own downscale), the batch itself without a predecessor
+                            seam = (engine.downscale_host(np.asarray(last_frame)[None], old_f, old_i)[0],
+                                    engine.downscale_host(np.asarray(frames[0])[None], factor, interp)[0])
                         last_frame = None
                         if feeder:
                             feeder.forget_halo()
+                    carry_scale = None
                     if slot is not None:
                         slot["prev"] = feeder.halo_ptr(slot)
                     result = self._score_batch(engine, plan, frames, factor, last_frame, slot, interp)
+                    if seam is not None:
+                        _patch_first_record(engine, plan, result, seam)
                     if slot is not None:
                         feeder.release(slot, keep_last=len(frames))
                     last_frame = frames[-1]
@@ -492,7 +536,13 @@ class SceneManager:
         if self._exception_info is not None:
             exc = self._exception_info[1]
             raise exc.with_traceback(self._exception_info[2])
+        if last_frame is not None:
+            # this manager's (and its detectors' scorers') OWN copy: `frames[-1]` of an ArrayVideoStream is a view of the caller's
+            # array -- holding it kept the whole clip alive until clear(), and a stream that reuses its read buffer, or a caller
+            # who edits the array between two calls, changed the predecessor under the manager.  One frame per call.
+            last_frame = np.array(last_frame, copy=True)
         self._carry_frame = last_frame
+        self._carry_scale = (factor, interp) if last_frame is not None else None
         if last_frame is not None:      # (the other way round: process_frame() on one of these detectors goes on from this frame)
             for detector in self._detector_list:
                 scorer = getattr(detector, "_scorer", None)

@@ -213,3 +213,108 @@ def test_four_and_eight_ranks_equal_one(tmp_path, world):
         assert json.load(open(tmp_path / f"nohist{r}.json")) == nohist
         assert json.load(open(tmp_path / f"nohist_one{r}.json")) == nohist[:1]
     _check_wide(tmp_path, world, eng)
+
+
+# ---- the exchange step through the C-ABI (psd_comm_* / psd_allgather_host) instead of torch.distributed ---------------------------
+class AbiEngine:
+    """The oracle engine with a handle of the CPU build of the C-ABI (oracle/libpsd_oracle_abi.so): what NativeComm needs."""
+
+    def __init__(self, lib):
+        import ctypes
+
+        from oracle.detectors_np import OracleEngine
+
+        self._oracle = OracleEngine()
+        h = ctypes.c_void_p()
+        assert lib.psd_create(0, ctypes.byref(h)) == 0
+        self._h = h
+
+    def score_host(self, *a, **kw):
+        return self._oracle.score_host(*a, **kw)
+
+
+def _abi_lib():
+    import ctypes
+    import subprocess
+
+    from pyscenedetect_amd import _native
+
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "libpsd_oracle_abi.so"])
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libpsd_oracle_abi.so"))
+    for name in ("psd_create", "psd_last_error", "psd_comm_unique_id", "psd_comm_create", "psd_comm_destroy", "psd_allgather_host",
+                 "psd_allgather_scores"):
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = _native.SYMBOLS[name]
+    return lib
+
+
+def _native_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import json
+
+    from pyscenedetect_amd import corpus
+    from pyscenedetect_amd._native import RECORD_DTYPE, SUMS_DTYPE
+    from pyscenedetect_amd.synth import make_clip
+
+    lib = _abi_lib() if rank == 0 else None
+    dist.barrier()                                      # (one rank builds the library, the others load it)
+    lib = lib or _abi_lib()
+    eng = AbiEngine(lib)
+    assert D.native_comm_for(eng, None) is None         # gloo and no stand-in handed in: the flow keeps to torch.distributed
+    D._native_comms.clear()
+    comm = D.native_comm_for(eng, None, lib=lib)
+    assert comm is not None and D.native_comm_for(eng, None) is comm and comm.n_ranks == world
+    # ragged blocks of both kinds, a rank with nothing
+    for dtype in (SUMS_DTYPE, RECORD_DTYPE):
+        counts = [0 if r == 1 else 3 + 2 * r for r in range(world)]
+        mine = np.zeros(counts[rank], dtype)
+        mine["sad_v"] = np.arange(counts[rank]) + 1000 * rank
+        parts = comm.all_gather_host(mine, counts)
+        assert [len(x) for x in parts] == counts and all(x.dtype == dtype for x in parts)
+        assert all(parts[r]["sad_v"].tolist() == list(range(1000 * r, 1000 * r + counts[r])) for r in range(world))
+    # a rank whose records do not match the counts: everybody completes the collective, that rank raises afterwards
+    counts = [4] * world
+    mine = np.zeros(3 if rank == world - 1 else 4, SUMS_DTYPE)
+    try:
+        comm.all_gather_host(mine, counts)
+        assert rank != world - 1
+    except ValueError as ex:
+        assert rank == world - 1 and "contributes 3" in str(ex)
+    # the sharded flows through it: default pipeline on the resized corpus, the small corpus, fewer clips than ranks
+    before = comm.exchanges
+    wide = [make_clip(80 + i, n, h, w, shot_len=(9, 14), noise=12.0)[0] for i, (n, h, w) in enumerate(CORPUS_WIDE)]
+    small = [make_clip(60 + i, n, h, w, shot_len=(16, 24))[0] for i, (n, h, w) in enumerate(CORPUS)]
+    res = {"wide_all_four": corpus.detect_corpus(eng, wide, 25.0, ALL_FOUR), "wide_sums": corpus.detect_corpus(eng, wide, 25.0, NO_HIST),
+           "small": corpus.detect_corpus(eng, small, 25.0, ALL_FOUR), "one": corpus.detect_corpus(eng, small[:1], 25.0, NO_HIST)}
+    assert comm.exchanges == before + 4                 # every flow took the native exchange, once
+    with open(os.path.join(tmp, f"native{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_native_exchange_over_the_c_abi_stand_in(tmp_path, world):
+    """``score_clips_distributed`` with the exchange the C-ABI advertises -- ``NativeComm`` over ``psd_comm_*`` / ``psd_allgather_host``,
+    counts from the plan, one collective -- executed over the shared-memory stand-in of ``oracle/abi_cpu.c`` (the RCCL implementation
+    needs GPUs): every rank's cut lists == one process."""
+    import json
+
+    from oracle.detectors_np import OracleEngine
+    from pyscenedetect_amd import corpus
+    from pyscenedetect_amd.synth import make_clip
+
+    port = 33500 + world * 16 + (os.getpid() % 1500)
+    mp.spawn(_native_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    eng = OracleEngine()
+    wide = [make_clip(80 + i, n, h, w, shot_len=(9, 14), noise=12.0)[0] for i, (n, h, w) in enumerate(CORPUS_WIDE)]
+    small = [make_clip(60 + i, n, h, w, shot_len=(16, 24))[0] for i, (n, h, w) in enumerate(CORPUS)]
+    single = {"wide_all_four": corpus.detect_corpus(eng, wide, 25.0, ALL_FOUR), "wide_sums": corpus.detect_corpus(eng, wide, 25.0, NO_HIST),
+              "small": corpus.detect_corpus(eng, small, 25.0, ALL_FOUR), "one": corpus.detect_corpus(eng, small[:1], 25.0, NO_HIST)}
+    for r in range(world):
+        assert json.load(open(tmp_path / f"native{r}.json")) == single

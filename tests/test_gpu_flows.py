@@ -139,7 +139,9 @@ def test_benchmark_harness_through_hip(tmp_path, hip_engine, oracle_engine):
 
 def test_detect_corpus_under_a_one_rank_rccl_group():
     """The sharded flow on the GPU with a real RCCL process group (one rank: the only size a 1-GPU box offers): plan,
-    packed scoring, all-gather of the records over nccl, decisions == the same call without a process group."""
+    packed scoring, all-gather of the records, decisions == the same call without a process group.  Round 6: the exchange is the
+    one the C-ABI advertises (``psd_comm_*`` / ``psd_allgather_host``: RCCL loaded by ``libpsd_hip.so``, counts from the plan, one
+    collective, no torch staging); ``PSD_NATIVE_EXCHANGE=0`` keeps ``torch.distributed``'s."""
     code = r'''
 import os, sys, json
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tools"))
@@ -156,8 +158,18 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 flags = corpus.required_flags(spec)
 recs = D.score_clips_distributed(eng, clips, flags)
 ok = all((a[f] == b[f]).all() for a, b in zip(recs, corpus.score_clips(eng, clips, flags)) for f in ("sad_h", "sad_s", "sad_v", "byte_sum", "hist"))
+comm = D.native_comm_for(eng, None)                      # the exchange went through psd_allgather_host (RCCL loaded by libpsd_hip.so)
+native = comm is not None and comm.exchanges == 1
+grouped = corpus.detect_corpus(eng, clips, 25.0, spec)   # the whole flow under the group: default pipeline, 1064-byte records
+sums = corpus.detect_corpus(eng, clips, 25.0, {"adaptive": {"min_scene_len": 6}})     # ... and 40-byte sums
+native = native and comm.exchanges == 3
+os.environ["PSD_NATIVE_EXCHANGE"] = "0"                  # the torch.distributed path stays selectable
+D._native_comms.clear()
+torch_path = corpus.detect_corpus(eng, clips, 25.0, spec)
+assert D.native_comm_for(eng, None) is None
 dist.destroy_process_group()
-print("RESULT " + json.dumps({"same_records": bool(ok), "plain": plain, "cuts": sum(len(v) for r in plain for v in r.values())}))
+print("RESULT " + json.dumps({"same_records": bool(ok), "native": bool(native), "same_cuts": grouped == plain == torch_path,
+                              "sums": sums == [{"adaptive": r["adaptive"]} for r in plain], "cuts": sum(len(v) for r in plain for v in r.values())}))
 ''' % (ROOT, ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -166,6 +178,7 @@ print("RESULT " + json.dumps({"same_records": bool(ok), "plain": plain, "cuts": 
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     res = json.loads(line[7:])
     assert res["same_records"] and res["cuts"] > 0
+    assert res["native"] and res["same_cuts"] and res["sums"]
 
 
 # ---- thicker oracle samples on BASELINE's own configurations ----------------------------------------------------------

@@ -363,6 +363,13 @@ def test_native_rccl_all_gather_of_device_records_one_rank(hip_engine):
     assert comm.all_gather_records([5], local=recs2)[0].tobytes() == recs2.tobytes()      # smaller than the buffers: reuse
     with pytest.raises(ValueError):
         comm.all_gather_records([6])
+    # records a rank holds on the host (psd_allgather_host): both kinds, an empty contribution, a count that disagrees
+    for local in (recs, E._sums_of(recs), recs[:0]):
+        got = comm.all_gather_host(local, [len(local)])
+        assert len(got) == 1 and got[0].dtype == local.dtype and got[0].tobytes() == local.tobytes()
+    with pytest.raises(ValueError):
+        comm.all_gather_host(recs[:4], [5])
+    assert comm.all_gather_host(recs2, [5])[0].tobytes() == recs2.tobytes()              # ... and the communicator is still usable
     comm.close()
     buf.free()
 

@@ -587,3 +587,78 @@ def test_a_manager_taking_over_frames_of_another_size_raises_like_the_reference(
         for side, engine in (("mirror", oracle_engine), ("mirror", fuzz.sim_engine(oracle_engine)), ("plug", oracle_engine)):
             b = fuzz.outcome(lambda: fuzz.run_side(side, frames, 25.0, dets, cfg, engine))
             assert fuzz.differ(a, b, cfg) is None, (dets, side, fuzz.differ(a, b, cfg))
+
+
+def test_manager_reuse_compares_the_sizes_the_detectors_see(fuzz, oracle_engine):
+    """One manager on a second video without ``clear()``: the reference's detectors keep the DOWNSCALED planes of the
+    last frame, so what must agree between the two calls is the size behind crop and downscale -- 512 x 288 at factor 2 followed by a
+    256 x 144 crop of such frames at factor 1 goes on (the seam is scored on the two small frames themselves), the same frames behind
+    another factor raise.  (A second video of another DECODED size never gets that far: the manager remembers the first video's
+    size until ``clear()`` and skips every frame of another one, scene_manager.py:646-664 -- the crop is how the sizes part.)"""
+    import scenedetect as ref
+    from oracle.gen_golden import MemoryStream
+
+    import pyscenedetect_amd as psd
+    from pyscenedetect_amd.synth import make_clip
+
+    big, _ = make_clip(21, 30, 288, 512, shot_len=(10, 14))
+    other, _ = make_clip(22, 30, 288, 512, shot_len=(10, 14))
+
+    def run(side, second_factor, crop=None, interp=None):
+        # (no StatsManager: with one, the reference answers the second video's frames from the metrics cached under the same frame
+        #  numbers by the first; min_scene_len = 0: a cut wherever the score reaches the threshold, also at the seam)
+        if side == "ref":
+            sm = ref.SceneManager()
+            det = ref.ContentDetector(min_scene_len=0)
+            streams = [MemoryStream(big, 25.0), MemoryStream(other, 25.0)]
+        else:
+            sm = psd.SceneManager(engine=oracle_engine, batch_frames=7)
+            det = psd.ContentDetector(min_scene_len=0, engine=oracle_engine)
+            streams = [psd.ArrayVideoStream(big, 25.0), psd.ArrayVideoStream(other, 25.0)]
+        sm.auto_downscale = False
+        sm.add_detector(det)
+        sm.downscale = 2
+        sm.detect_scenes(streams[0])
+        first = [c.frame_num for c in sm.get_cut_list(show_warning=False)]
+        sm.downscale = second_factor
+        if crop is not None:
+            sm.crop = crop
+        if interp is not None:
+            sm.interpolation = (ref.common.Interpolation if side == "ref" else psd.Interpolation)[interp]
+        sm.detect_scenes(streams[1])
+        return first, [c.frame_num for c in sm.get_cut_list(show_warning=False)]
+
+    # the detectors see 256 x 144 both times (half-size frames, then a full-size crop): no assertion, frame 0 of the second video is
+    # scored against the first's last -- another shot, a cut
+    a, b = run("ref", 1, crop=(100, 60, 355, 203)), run("mirror", 1, crop=(100, 60, 355, 203))
+    assert a == b and 0 in b[1] and 0 not in b[0]
+    # the same size behind the same factor but another interpolation: the seam frame is resized by each call's own mode
+    a, b = run("ref", 2, interp="NEAREST"), run("mirror", 2, interp="NEAREST")
+    assert a == b and 0 in b[1]
+    # another factor: 256 x 144 planes against 128 x 72 ones
+    for side in ("ref", "mirror"):
+        with pytest.raises(AssertionError):
+            run(side, 4)
+
+
+def test_the_carried_frame_is_the_managers_own_copy(oracle_engine):
+    """the predecessor a manager keeps between two ``detect_scenes()`` calls must not alias the caller's array."""
+    import pyscenedetect_amd as psd
+    from pyscenedetect_amd.synth import make_clip
+
+    frames, _ = make_clip(23, 24, 36, 64, shot_len=(8, 10))
+    work = frames.copy()
+    sm = psd.SceneManager(engine=oracle_engine)
+    sm.auto_downscale = False
+    sm.add_detector(psd.ContentDetector(min_scene_len=2, engine=oracle_engine))
+    video = psd.ArrayVideoStream(work, 25.0)
+    sm.detect_scenes(video, duration=12)
+    assert sm._carry_frame is not None and not np.shares_memory(sm._carry_frame, work)
+    work[11] = 255 - work[11]                     # the caller reuses its buffer between the calls
+    sm.detect_scenes(video)
+    got = [c.frame_num for c in sm.get_cut_list(show_warning=False)]
+    one = psd.SceneManager(engine=oracle_engine)
+    one.auto_downscale = False
+    one.add_detector(psd.ContentDetector(min_scene_len=2, engine=oracle_engine))
+    one.detect_scenes(psd.ArrayVideoStream(frames, 25.0))
+    assert got == [c.frame_num for c in one.get_cut_list(show_warning=False)]
