@@ -332,9 +332,14 @@ __device__ __forceinline__ void sobel_phase1_quads(const uint8_t (*sv)[N2_SVW], 
     }
 }
 
-// grid = (tiles_x * tiles_y, frames).  (Handing the tiles out so that every XCD walks one contiguous run of them -- the
-// 128-byte lines a tile shares with its left / right neighbour then hit in that XCD's L2 -- measured no difference: 299.5 k
-// vs 299-301 k frames/s on 2048 x 1080p; the 2 MB V plane of a frame sits in the Infinity Cache either way.)
+// grid = (tiles_x * tiles_y, frames).  Workgroups are dealt to the eight XCDs round-robin by their linear id, so with the tile
+// taken straight from blockIdx.x every tile's neighbours -- which share its halo: 4 of 36 rows above / below, and the 128-byte
+// lines left / right of which it needs four bytes -- sit in seven OTHER L2s and every halo line is fetched over the fabric
+// again: FETCH_SIZE 3.17 GB per 1024 x 1080p frames for a 2.12 GB plane (profiles/hbm_traffic.json, round 5).  Round 6: the
+// workgroups k = r, r + 8, r + 16 ... of a frame (one XCD: the frame's first workgroup has linear id tiles * frame, a constant
+// rotation of r) take one CONTIGUOUS run of tiles, row-major, about four tile rows at 1080p, so halo lines hit in that XCD's
+// L2.  (Round 3 had tried this for TIME and measured none -- 299.5 k vs 299-301 k frames/s: the kernel is instruction-bound
+// and the Infinity Cache absorbs the re-fetches -- and did not count the traffic.)
 // `dirty` (zeroed by the caller): one flag per 64x64 hysteresis tile, set where this tile leaves a weak pixel -- the first
 // hysteresis launch then only looks at tiles that can change at all (a natural frame has few of them).
 // tiles_x_magic = ceil(2^32 / tiles_x): tile / tiles_x as one multiply-high (exact for tile < 2^20).
@@ -352,7 +357,10 @@ __global__ __launch_bounds__(256) void sobel_nms_bits_kernel(const uint8_t* vpla
     static_assert(N2_H * (N2_W / 8) == 512, "the sparse / dense rule below counts (thread, step) pairs of eight pixels");
     __shared__ int ncand, npos;   // candidates of the tile; list positions handed out (two words: nobody resets one the others still read)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = blockIdx.x, j = blockIdx.y;
+    const int j = blockIdx.y;
+    // XCD-contiguous runs (above): residue class r = k % 8 holds ceil((T - r) / 8) workgroups and starts at r (T / 8) + min(r, T % 8)
+    const int k = blockIdx.x, T = gridDim.x;
+    const int tile = T >= 16 ? (k & 7) * (T >> 3) + min(k & 7, T & 7) + (k >> 3) : k;
     const int ty = tiles_x == 1 ? tile : (int)__umulhi((u32)tile, tiles_x_magic), tx = tile - ty * tiles_x;
     const uint8_t* V = vplane + (size_t)j * g.npix;
     const int x0 = tx * N2_W, y0 = ty * N2_H, H = g.height, W = g.width;
