@@ -232,3 +232,37 @@ def test_live_reference_behind_its_resize_slice():
     finally:
         logging.disable(level)
     assert resized >= 30
+
+
+def _bbc_layout(tmp_path, names):
+    """The golden clips `names` as a dataset in the BBC layout (benchmark/dataset.py:77-106), annotations = the generator's shot starts."""
+    os.makedirs(tmp_path / "videos")
+    os.makedirs(tmp_path / "fixed")
+    for i, name in enumerate(names):
+        frames = corpus_clip(name)
+        np.save(tmp_path / "videos" / f"bbc_{i + 1:02d}.npy", frames)
+        bounds = [0, *corpus_golden()["clips"][name]["shot_starts"], len(frames)]
+        with open(tmp_path / "fixed" / f"{i + 1:02d}-scenes.txt", "w") as f:
+            for a, b in zip(bounds[:-1], bounds[1:]):
+                f.write(f"{a}\t{b - 1}\n")
+
+
+def test_benchmark_harness_packed_equals_one_manager_per_video(tmp_path, oracle_engine):
+    """SURVEY 8 f2 meets the packed flow: ``tools/bbc_harness.run_predictions`` is the reference's ``_run_predictions``
+    (benchmark/__main__.py:44-61: one default detector per video through a default SceneManager); ``run_predictions_packed`` hands the
+    whole dataset to ``detect_corpus`` -- and returns the same predictions, which are also the reference's own (the goldens)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bbc_harness as H
+
+    names = ["bbc_a", "bbc_b", "bbc_c", "noisy_a"]
+    _bbc_layout(tmp_path, names)
+    samples = H.bbc_samples(str(tmp_path))
+    for det, key in H.PACKED.items():
+        one = H.run_predictions(samples, det, engine=oracle_engine)
+        packed = H.run_predictions_packed(samples, det, oracle_engine)
+        assert [r["predicted_cuts"] for r in packed] == [r["predicted_cuts"] for r in one], det
+        # (the goldens' adaptive line spells out window_width = 2, min_content_val = 15: the constructor's defaults)
+        for name, r in zip(names, packed):
+            c = corpus_golden()["clips"][name]
+            cuts = c["cuts"][key]
+            assert r["predicted_cuts"] == (cuts + [c["n"]] if cuts else []), (det, name)

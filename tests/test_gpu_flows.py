@@ -133,6 +133,9 @@ def test_benchmark_harness_through_hip(tmp_path, hip_engine, oracle_engine):
         got = H.run_predictions(samples, det, engine=hip_engine)
         want = H.run_predictions(samples, det, engine=oracle_engine)
         assert [r["predicted_cuts"] for r in got] == [r["predicted_cuts"] for r in want], det
+        if det in H.PACKED:      # the whole dataset in shared device batches (detect_corpus behind the default downscale): the same predictions
+            packed = H.run_predictions_packed(samples, det, hip_engine)
+            assert [r["predicted_cuts"] for r in packed] == [r["predicted_cuts"] for r in want], det
         if det in ("detect-adaptive", "detect-content"):
             assert all(len(r["predicted_cuts"]) > 1 for r in got), det
 

@@ -82,6 +82,35 @@ def run_predictions(samples, detector_name: str, open_stream=None, engine=None) 
     return records
 
 
+#: the reference's table entries the packed flow decides (corpus.DETECTORS; HashDetector is scored per video)
+PACKED = {"detect-adaptive": "adaptive", "detect-content": "content", "detect-hist": "hist", "detect-threshold": "threshold"}
+
+
+def run_predictions_packed(samples, detector_name: str, engine, open_frames=None, fps: float = 25.0) -> list[dict]:
+    """The same records from the PACKED flow (``corpus.detect_corpus``: every video of the dataset -- or of this rank's shard
+    under ``torch.distributed`` -- in shared device batches behind the reference's default downscale,
+    ``psd_score_segments_downscaled_device``, native decisions): what ``run_predictions`` computes one SceneManager at a time.
+    ``elapsed`` is the whole call divided by the number of videos (the videos are not scored one after the other).
+    ``open_frames(sample)`` returns ``uint8[N,H,W,3]`` (default: the sample's .npy file, memory-mapped)."""
+    from pyscenedetect_amd import corpus
+
+    name = PACKED[detector_name]
+    open_frames = open_frames or (lambda sample: np.load(sample["video_file"], mmap_mode="r"))
+    start = time.time()
+    clips = [open_frames(sample) for sample in samples]
+    results = corpus.detect_corpus(engine, clips, fps, {name: {}})
+    each = (time.time() - start) / max(1, len(samples))
+    records = []
+    for sample, clip, res in zip(samples, clips, results):
+        cuts = [int(c) for c in res[name]]
+        # detect() returns the scene list with start_in_scene=False: no cuts, no scenes (scene_manager.py:397-400); otherwise every
+        # scene's end, the last one the end of the video (:394-396)
+        ends = cuts + [int(clip.shape[0])] if cuts else []
+        records.append({"video_file": str(sample["video_file"]), "predicted_cuts": ends, "hard_cuts": [int(c) for c in sample["hard_cuts"]],
+                        "elapsed": each})
+    return records
+
+
 def dump(records, path: str, **meta) -> None:
     with open(path, "w") as f:
         json.dump({"format": "psd-benchmark-predictions/1", **meta, "videos": records}, f)
@@ -92,7 +121,12 @@ if __name__ == "__main__":
     ap.add_argument("--dataset-dir", required=True)
     ap.add_argument("--detector", default="detect-adaptive", choices=sorted(DETECTORS))
     ap.add_argument("--out", default="predictions.json")
+    ap.add_argument("--packed", action="store_true", help="all videos in shared device batches (corpus.detect_corpus) instead of one "
+                                                          "SceneManager per video; the same predictions")
     a = ap.parse_args()
-    recs = run_predictions(bbc_samples(a.dataset_dir), a.detector)
+    if a.packed:
+        recs = run_predictions_packed(bbc_samples(a.dataset_dir), a.detector, psd.engine.default_engine())
+    else:
+        recs = run_predictions(bbc_samples(a.dataset_dir), a.detector)
     dump(recs, a.out, detector=a.detector, dataset=a.dataset_dir)
     print("wrote", a.out, len(recs), "videos")
