@@ -304,7 +304,7 @@ class Workload:
         self.sh, self.sw = self.h, self.w                  # size the detectors see
         if downscale:
             self.sh, self.sw, self.factor = downscaled_size(self.h, self.w, downscale)
-        self.state = {"cuts": [], "recs": None, "thumbs": None}
+        self.state = {"cuts": [], "recs": None, "bits": None}
         self.walk = 0        # frames per time walk of this workload's launch (0: the kernel does not walk / not known)
 
     # bytes one launch has to read: every BGR byte once; with the edge term 5 B/px; behind the default
@@ -322,7 +322,7 @@ class Workload:
         if self.downscale:
             return "psd::resize_walk_kernel"
         return {"content": "psd::score_frames_dma_kernel", "all": "psd::score_frames_dma_kernel", "hist": "psd::luma_hist_kernel",
-                "hash": "psd::gray_area_dma_kernel", "edges": "psd::score_frames_dma_kernel<V mode> + psd::sobel_nms_bits_kernel (edge pipeline)"}[self.detector]
+                "hash": "psd::gray_area_dma_kernel + psd::hash_bits_kernel", "edges": "psd::score_frames_dma_kernel<V mode> + psd::sobel_nms_bits_kernel (edge pipeline)"}[self.detector]
 
     def submit(self):
         if self.downscale:
@@ -354,35 +354,20 @@ class Workload:
             ep.adaptive_cuts(sc["content_val"], 25.0)
         return ms
 
-    def run_hash_step(self) -> float:
-        # HashDetector: grey INTER_AREA thumbnails on the device, DCT / median / Hamming distance / decision on the host
-        thumbs = self.eng.hash_thumbs_device(self.ptr, self.n, self.h, self.w, 16)
-        ms = self.eng.last_kernel_ms()[0]
-        self.hash_decide(thumbs)
-        return ms
-
-    def hash_decide(self, thumbs) -> None:
-        bits = self.ep.hash_bits(thumbs, 8)
-        self.state["cuts"] = self.ep.hash_cuts(bits, 25.0, threshold=0.35, min_scene_len=15)[0]
-        self.state["thumbs"] = thumbs
+    # HashDetector with the reference's defaults (hash_detector.py:68-77: size = 16, lowpass = 2): 32 x 32 grey thumbnails, the
+    # 16 x 16 lowest DCT frequencies, 256 hash bits per frame.  (Rounds 3-5 timed size = 8: 16 x 16 thumbnails, 64 bits.)
+    HASH_SIZE, HASH_LOWPASS = 16, 2
 
     def run_hash_steps(self, k: int, sink: list) -> None:
-        """k HashDetector steps with two in flight, like every other workload: the thumbnail call is synchronous, so the host
-        epilogue of step i (a DCT per frame: 1.1 ms for 4096 frames on 16 threads) runs on a second thread while the device
-        makes the thumbnails of step i + 1 (both are native calls that release the GIL).  Serial, the GPU idled a fifth of
-        the step: 744 k frames/s whole-step against 941 k for the kernel alone."""
-        from concurrent.futures import ThreadPoolExecutor
-
-        with ThreadPoolExecutor(1) as ex:
-            pending = None
-            for _ in range(k):
-                thumbs = self.eng.hash_thumbs_device(self.ptr, self.n, self.h, self.w, 16)
-                sink.append(self.eng.last_kernel_ms()[0])
-                if pending is not None:
-                    pending.result()
-                pending = ex.submit(self.hash_decide, thumbs)
-            if pending is not None:
-                pending.result()
+        """k HashDetector steps.  Round 6: thumbnails, DCT, median and bits are ONE device call (psd_hash_bits_device: 256 bytes
+        per frame come back), then the native decisions; until round 5 the step ended in the DCT on the host (1.1 ms per 4096
+        frames on 16 threads, hidden behind the next step's kernel by a second thread: 865 k frames/s, 744 k without that)."""
+        im = self.HASH_SIZE * self.HASH_LOWPASS
+        for _ in range(k):
+            bits = self.eng.hash_bits_device(self.ptr, self.n, self.h, self.w, im, self.HASH_SIZE)
+            sink.append(self.eng.last_kernel_ms()[0])
+            self.state["cuts"] = self.ep.hash_cuts(bits, 25.0, threshold=0.35, min_scene_len=15)[0]
+            self.state["bits"] = bits
 
 
 def parity_sample(wl: Workload, k: int) -> str:
@@ -393,9 +378,18 @@ def parity_sample(wl: Workload, k: int) -> str:
     threads = os.cpu_count() or 1
     if wl.detector == "hash":
         k = min(k, wl.n)
-        frames = wl.batch[:k].cpu().numpy()
-        ok = np.array_equal(wl.state["thumbs"][:k], orc.hash_thumbs(frames, 16))
-        return ("thumbnails of the first %d frames identical to the oracle" % k) if ok else "MISMATCH vs oracle in thumbnails (first %d frames)" % k
+        im, hs = wl.HASH_SIZE * wl.HASH_LOWPASS, wl.HASH_SIZE
+        bad = []
+        for a in sorted({0, max(0, wl.n // 2 - k // 2), wl.n - k}):      # the first, the middle and the last k frames
+            frames = wl.batch[a:a + k].cpu().numpy()
+            want_thumbs = orc.hash_thumbs(frames, im)
+            _, thumbs = wl.eng.hash_bits_device(wl.ptr + a * wl.h * wl.w * 3, k, wl.h, wl.w, im, hs, want_thumbs=True)
+            if not np.array_equal(thumbs, want_thumbs):
+                bad.append("thumbnails of frames %d-%d" % (a, a + k - 1))
+            if not np.array_equal(wl.state["bits"][a:a + k], orc.hash_bits(want_thumbs, hs).reshape(k, -1)):
+                bad.append("hash bits of frames %d-%d" % (a, a + k - 1))
+        what = "%d x %d thumbnails and %d hash bits of the first, middle and last %d frames" % (im, im, hs * hs, k)
+        return (what + " identical to the oracle") if not bad else "MISMATCH vs oracle: " + ", ".join(bad)
     edges = wl.detector == "edges"
     # (the edge term's oracle is two orders of magnitude slower than the sums: walk boundaries only for the cheap terms)
     runs = parity_runs(wl.n, k, 0 if edges else wl.walk, 0 if wl.downscale else wl.h * wl.w * 3)
@@ -489,8 +483,9 @@ def secondary_runs(eng, batch, E, epilogue, device, frames_small: int, args) -> 
     attempt("default_pipeline_downscale_auto_edges", f"ContentDetector with the edge term (weights 1,1,1,1: what a StatsManager makes the reference "
             f"compute) behind SceneManager's default downscale ({w}x{h} -> 256 wide), {frames_small} frames with objects; roofline counts "
             "the source rows that carry taps", run_ds_edges)
-    attempt("hash_detector_1080p", f"HashDetector (thumbnail kernel + DCT epilogue), {n} x {w}x{h}",
-            lambda: quick_measure(Workload(eng, batch, "hash", None, epilogue, E), steps=3, warmup=1))
+    attempt("hash_detector_1080p", f"HashDetector with the reference's defaults (32 x 32 thumbnails, 256 bits): thumbnail kernel + DCT / median / bits "
+            f"on the device (psd_hash_bits_device), {n} x {w}x{h}",
+            lambda: quick_measure(Workload(eng, batch, "hash", None, epilogue, E), steps=5, warmup=2))
     for dist, label in (("S", "shot-like content (64-frame shots, hard cuts)"), ("K", "constant frames (one histogram bin per frame)")):
         def run_dist(dist=dist):
             # shot-like content at the headline's batch length (the fraction of the roofline moves with the length of a
@@ -1333,13 +1328,12 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
 
             sample = batch[: min(64, n)].cpu().numpy()
             t0 = time.perf_counter()
-            ref = orc.hash_thumbs(sample, 16)
+            ref = orc.hash_bits(orc.hash_thumbs(sample, wl.HASH_SIZE * wl.HASH_LOWPASS), wl.HASH_SIZE)
             dt = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": round(len(sample) / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": "%d frames of the same batch through oracle/cv2_restate.c (grey + INTER_AREA), "
+                                   "sample": "%d frames of the same batch through oracle/cv2_restate.c (grey + INTER_AREA + DCT + median), "
                                              "one thread; real OpenCV is not installed" % len(sample)}
-            out["parity_sample"] = ("thumbnails of the first %d frames identical to the oracle" % len(sample)
-                                    if np.array_equal(wl.state["thumbs"][: len(sample)], ref) else "MISMATCH vs oracle")
+            out["parity_sample"] = parity_sample(wl, min(16, n))
         elif not args.no_cpu_baseline and world == 1 and not args.downscale and args.detector != "edges":
             sample = batch[: args.cpu_sample].cpu().numpy()
             cb = cpu_baseline(sample, wl.flags & 7, os.cpu_count() or 1)

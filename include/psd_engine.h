@@ -50,7 +50,7 @@ extern "C" {
                             * 7: additive over 6 (psd_score_segments_downscaled_device: MANY clips packed into one batch behind the
                             *    reference's default downscale -- what `detect(path, detector_cls())` of benchmark/__main__.py:44-61
                             *    computes per video, for a whole shard of videos in one launch; psd_allgather_host: the exchange step for
-                            *    records a rank already holds on the host) */
+                            *    records a rank already holds on the host; psd_hash_bits_device: HashDetector's DCT / median on the device) */
 
 typedef enum psd_status {
     PSD_OK = 0,
@@ -326,6 +326,14 @@ int psd_hash_thumbs_device(psd_engine* e, const uint8_t* d_frames, int n, int he
                            size_t row_stride, size_t frame_stride, int size, uint8_t* h_thumbs);
 int psd_hash_thumbs(psd_engine* e, const uint8_t* h_frames, int n, int height, int width,
                     size_t row_stride, size_t frame_stride, int size, uint8_t* h_thumbs);
+/* HashDetector.hash_frame as a whole for n device-resident frames (hash_detector.py:125-151): the thumbnails above and then, still
+ * on the device, psd_epilogue_hash_bits -- scaling by the maximum, the 2-D DCT-II in float64 (the same sums in the same order),
+ * one rounding to float32, the float32 median, bits = coefficient > median.  h_bits: uint8[n][hash_size^2] of 0 / 1, identical to
+ * psd_epilogue_hash_bits(thumbs); h_thumbs: uint8[n][size][size] as well, or NULL.  256 instead of 1024 bytes per frame leave the
+ * device and the step does not end in host arithmetic.  size <= 64 or so (the transform works in a workgroup's LDS): larger ones
+ * return PSD_ERR_UNSUPPORTED -- take psd_hash_thumbs_device + psd_epilogue_hash_bits.  Kernel time: psd_last_kernel_ms(). */
+int psd_hash_bits_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
+                         size_t frame_stride, int size, int hash_size, uint8_t* h_bits, uint8_t* h_thumbs);
 
 /* ---- host epilogues (no device involved) -------------------------------------------------
  * Frame positions are frame numbers first_frame .. first_frame+n-1 at a constant frame rate

@@ -154,6 +154,7 @@ SYMBOLS = {
     "psd_resize_linear_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _vp, _i, _i, _sz, _vp]),
     "psd_hash_thumbs_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp]),
     "psd_hash_thumbs": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp]),
+    "psd_hash_bits_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _i, _vp, _vp]),
     "psd_epilogue_content_scores": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "psd_epilogue_content_scores_sums": (_i, [_vp, _sz, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "psd_epilogue_threshold_cuts_sums": (_i, [_vp, _sz, _i, _i, _i, _i64, _i64, _i64, _P(ThresholdParams), _vp, _vp, _P(_i)]),

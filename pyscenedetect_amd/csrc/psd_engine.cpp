@@ -69,6 +69,11 @@ void feed_release(psd_engine* e);
 // psd_hash_kernels.hip
 int hash_thumbs(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
                 int size, uint8_t* d_thumbs, hipStream_t stream, hipEvent_t ev_start);
+int hash_bits(const uint8_t* d_thumbs, int n, int S, int K, const double* d_basis, uint8_t* d_bits, hipStream_t stream);
+size_t hash_bits_lds(int S, int K);
+void hash_dct_basis(int size, int keep, double* c);
+bool table_find(psd_engine* e, int kind, int sh, int sw, int dh, int dw, DevTable* out);
+int table_store(psd_engine* e, int kind, int sh, int sw, int dh, int dw, const void* host, size_t bytes, int mode, float inv_area, DevTable* out);
 }  // namespace psd
 
 struct psd_feed;   // psd_feed.cpp
@@ -107,6 +112,8 @@ struct psd_engine {
     size_t edge_ws_bytes = 0;
     uint8_t* d_hash = nullptr;  // thumbnails of psd_hash_thumbs*
     size_t hash_bytes = 0;
+    uint8_t* d_hbits = nullptr; // hash bits of psd_hash_bits_device
+    size_t hbits_bytes = 0;
     hipEvent_t ev_hash[2] = {nullptr, nullptr};
     void* resize_cache = nullptr;   // coefficient tables per (src, dst) shape of every resize mode + the hash thumbnails, owned by psd_resize_kernels.hip
     uint8_t* d_small = nullptr;     // resized frames of psd_score_downscaled_* when the terms need them in memory
@@ -252,6 +259,7 @@ void psd_destroy(psd_engine* e)
     }
     for (auto& d : e->d_stage) if (d) (void)hipFree(d);
     if (e->d_hash) (void)hipFree(e->d_hash);
+    if (e->d_hbits) (void)hipFree(e->d_hbits);
     for (auto& ev : e->ev_hash) if (ev) (void)hipEventDestroy(ev);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
@@ -916,6 +924,63 @@ int psd_hash_thumbs_device(psd_engine* e, const uint8_t* d_frames, int n, int he
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ev_hash[0], e->ev_hash[1]));
     e->last_launches = (n + 32767) / 32768;
+    return PSD_OK;
+}
+
+// grows one of the engine's device buffers on demand (the stream is drained first: queued kernels may still use the old one)
+static int grow_buffer(psd_engine* e, uint8_t** buf, size_t* have, size_t need)
+{
+    need = (need + 255) & ~(size_t)255;
+    if (*have >= need) return PSD_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr; *have = 0;
+    hipError_t err = hipMalloc((void**)buf, need);
+    if (err != hipSuccess) {
+        psd_set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(err));
+        (void)hipGetLastError();
+        return err == hipErrorOutOfMemory ? PSD_ERR_NOMEM : PSD_ERR_HIP;
+    }
+    *have = need;
+    return PSD_OK;
+}
+
+int psd_hash_bits_device(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride, size_t frame_stride,
+                         int size, int hash_size, uint8_t* h_bits, uint8_t* h_thumbs)
+{
+    if (!e) { psd_set_error("null engine"); return PSD_ERR_INVALID; }
+    int rc = validate_hash(d_frames, n, height, width, row_stride, frame_stride, size, h_bits);
+    if (rc != PSD_OK) return rc;
+    if (hash_size <= 0 || hash_size > size) { psd_set_error("hash_size must be in 1 .. %d, got %d", size, hash_size); return PSD_ERR_INVALID; }
+    if (!psd::hash_bits_lds(size, hash_size)) {
+        psd_set_error("hash bits on the device: a %d x %d transform of a %d x %d thumbnail does not fit a workgroup's LDS "
+                      "(psd_hash_thumbs_device + psd_epilogue_hash_bits take any size)", hash_size, hash_size, size, size);
+        return PSD_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return PSD_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    rc = grow_buffer(e, &e->d_hash, &e->hash_bytes, (size_t)n * size * size);
+    if (rc != PSD_OK) return rc;
+    rc = grow_buffer(e, &e->d_hbits, &e->hbits_bytes, (size_t)n * hash_size * hash_size);
+    if (rc != PSD_OK) return rc;
+    psd::DevTable basis;
+    if (!psd::table_find(e, psd::kTabHashBasis, size, size, hash_size, hash_size, &basis)) {
+        std::vector<double> c((size_t)hash_size * size);
+        psd::hash_dct_basis(size, hash_size, c.data());      // (the host epilogue's own table: the same doubles)
+        rc = psd::table_store(e, psd::kTabHashBasis, size, size, hash_size, hash_size, c.data(), c.size() * sizeof(double), 0, 0.f, &basis);
+        if (rc != PSD_OK) return rc;
+    }
+    if (!e->ev_hash[0]) { HIP_TRY(hipEventCreate(&e->ev_hash[0])); HIP_TRY(hipEventCreate(&e->ev_hash[1])); }
+    rc = psd::hash_thumbs(e, d_frames, n, height, width, row_stride, frame_stride, size, e->d_hash, e->stream, e->ev_hash[0]);
+    if (rc != PSD_OK) return rc;
+    rc = psd::hash_bits(e->d_hash, n, size, hash_size, static_cast<const double*>(basis.ptr), e->d_hbits, e->stream);
+    if (rc != PSD_OK) return rc;
+    HIP_TRY(hipEventRecord(e->ev_hash[1], e->stream));
+    HIP_TRY(hipMemcpyAsync(h_bits, e->d_hbits, (size_t)n * hash_size * hash_size, hipMemcpyDeviceToHost, e->stream));
+    if (h_thumbs) HIP_TRY(hipMemcpyAsync(h_thumbs, e->d_hash, (size_t)n * size * size, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ev_hash[0], e->ev_hash[1]));
+    e->last_launches = (n + 32767) / 32768 + (n + 65534) / 65535;
     return PSD_OK;
 }
 

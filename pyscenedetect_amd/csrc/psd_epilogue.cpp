@@ -372,6 +372,19 @@ int psd_epilogue_threshold_cuts(const psd_frame_scores* recs, int n, int height,
                                             fps_den, p, average_rgb, cuts, n_cuts);
 }
 
+extern "C++" {
+namespace psd {
+// orthonormal DCT-II basis, rows 0 .. keep-1 of the size-point transform: c[k][j] (shared with the device form, psd_hash_bits_device)
+void hash_dct_basis(int size, int keep, double* c)
+{
+    for (int k = 0; k < keep; k++)
+        for (int j = 0; j < size; j++)
+            c[(size_t)k * size + j] = k == 0 ? std::sqrt(1.0 / size)
+                                             : std::sqrt(2.0 / size) * std::cos(3.14159265358979323846 * (2 * j + 1) * k / (2.0 * size));
+}
+}  // namespace psd
+}  // extern "C++"
+
 int psd_epilogue_hash_bits(const uint8_t* thumbs, int n, int size, int hash_size, uint8_t* bits)
 {
     if (n < 0 || size <= 0 || hash_size <= 0 || hash_size > size || (n > 0 && (!thumbs || !bits))) {
@@ -379,12 +392,8 @@ int psd_epilogue_hash_bits(const uint8_t* thumbs, int n, int size, int hash_size
         return PSD_ERR_INVALID;
     }
     const int keep = hash_size;
-    // orthonormal DCT-II basis, rows 0..keep-1
     std::vector<double> c((size_t)keep * size);
-    for (int k = 0; k < keep; k++)
-        for (int j = 0; j < size; j++)
-            c[(size_t)k * size + j] = k == 0 ? std::sqrt(1.0 / size)
-                                             : std::sqrt(2.0 / size) * std::cos(3.14159265358979323846 * (2 * j + 1) * k / (2.0 * size));
+    psd::hash_dct_basis(size, keep, c.data());
     // frames are independent: split long clips over a few host threads (results do not depend on the split)
     auto work = [&](int t_begin, int t_end) {
         std::vector<double> tmp((size_t)keep * size);

@@ -420,4 +420,89 @@ int hash_thumbs(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
     return PSD_OK;
 }
 
+// ---- HashDetector.hash_frame, back half, on the device (hash_detector.py:131-151) -------------------------------------------
+// One workgroup per frame takes the S x S grey thumbnail where gray_area_dma_kernel left it and produces the K x K hash bits:
+// scale by the maximum (float32 division, as numpy's), the orthonormal 2-D DCT-II restricted to the K lowest frequencies per
+// axis in FLOAT64 -- the very sums of psd_epilogue_hash_bits (psd_epilogue.cpp), in the same order, every product and sum rounded
+// on its own (-ffp-contract=off: v_mul_f64 + v_add_f64), so the bits equal the host epilogue's -- one rounding to float32, the
+// float32 median numpy.median computes (middle element, or the float32 mean of the two middle ones) by rank counting, and
+// bit = coefficient > median.  268 M double multiply-adds per 4096 frames: nothing beside the 25 GB the thumbnails were made
+// from, and the step no longer ends in 1.1 ms of host arithmetic on sixteen threads.
+// Dynamic LDS: x float[S * S] | c double[K * S] | tmp double[K * S] | low float[K * K] | scratch.
+constexpr int kBitsWG = 256;
+
+__global__ __launch_bounds__(kBitsWG) void hash_bits_kernel(const uint8_t* __restrict__ thumbs, const double* __restrict__ basis, int S, int K,
+                                                            uint8_t* __restrict__ bits)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t hb_lds[];
+    double* c = reinterpret_cast<double*>(hb_lds);                       // [K][S]
+    double* tmp = c + (size_t)K * S;                                      // [K][S]
+    float* x = reinterpret_cast<float*>(tmp + (size_t)K * S);             // [S][S]
+    float* low = x + (size_t)S * S;                                       // [K][K]
+    __shared__ int s_max;
+    __shared__ float s_mid[2];
+    const int tid = threadIdx.x, t = blockIdx.x;
+    const uint8_t* th = thumbs + (size_t)t * S * S;
+    if (tid == 0) s_max = 0;
+    for (int i = tid; i < K * S; i += kBitsWG) c[i] = basis[i];
+    __syncthreads();
+    int mx = 0;
+    for (int i = tid; i < S * S; i += kBitsWG) mx = max(mx, (int)th[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) atomicMax(&s_max, mx);
+    __syncthreads();
+    const float fmx = (float)(s_max == 0 ? 1 : s_max);                    // hash_detector.py:132-135
+    for (int i = tid; i < S * S; i += kBitsWG) x[i] = __fdiv_rn((float)th[i], fmx);
+    __syncthreads();
+    // tmp[u][xx] = sum over y (ascending) of c[u][y] * x[y][xx]
+    for (int i = tid; i < K * S; i += kBitsWG) {
+        const int u = i / S, xx = i - u * S;
+        double acc = 0.0;
+        for (int y = 0; y < S; y++) acc = __dadd_rn(acc, __dmul_rn(c[(size_t)u * S + y], (double)x[(size_t)y * S + xx]));
+        tmp[i] = acc;
+    }
+    __syncthreads();
+    // low[u][v] = (float) sum over xx (ascending) of tmp[u][xx] * c[v][xx]
+    for (int i = tid; i < K * K; i += kBitsWG) {
+        const int u = i / K, v = i - u * K;
+        double acc = 0.0;
+        for (int xx = 0; xx < S; xx++) acc = __dadd_rn(acc, __dmul_rn(tmp[(size_t)u * S + xx], c[(size_t)v * S + xx]));
+        low[i] = (float)acc;
+    }
+    __syncthreads();
+    // the two middle order statistics by rank counting: value low[i] occupies the sorted positions [#less, #less-or-equal)
+    const int m = K * K, ia = (m - 1) / 2, ib = m / 2;
+    for (int i = tid; i < m; i += kBitsWG) {
+        const float v = low[i];
+        int lt = 0, le = 0;
+        for (int j = 0; j < m; j++) { const float w = low[j]; lt += w < v; le += w <= v; }
+        if (lt <= ia && ia < le) s_mid[0] = v;      // (every thread whose value sits there writes the same value)
+        if (lt <= ib && ib < le) s_mid[1] = v;
+    }
+    __syncthreads();
+    const float med = (m & 1) ? s_mid[1] : __fdiv_rn(__fadd_rn(s_mid[0], s_mid[1]), 2.0f);
+    uint8_t* b = bits + (size_t)t * m;
+    for (int i = tid; i < m; i += kBitsWG) b[i] = low[i] > med ? 1 : 0;
+}
+
+// LDS the kernel needs for thumbnails of S x S and a K x K hash, or 0 if that exceeds what a workgroup may have
+size_t hash_bits_lds(int S, int K)
+{
+    const size_t need = 2 * (size_t)K * S * sizeof(double) + (size_t)S * S * sizeof(float) + (size_t)K * K * sizeof(float);
+    return need <= 60 * 1024 ? need : 0;
+}
+
+int hash_bits(const uint8_t* d_thumbs, int n, int S, int K, const double* d_basis, uint8_t* d_bits, hipStream_t stream)
+{
+    const size_t lds = hash_bits_lds(S, K);
+    if (!lds) { psd_set_error("hash bits on the device: a %d x %d transform of a %d x %d thumbnail does not fit a workgroup's LDS", K, K, S, S); return PSD_ERR_UNSUPPORTED; }
+    for (int t0 = 0; t0 < n; t0 += 65535)
+        hipLaunchKernelGGL(hash_bits_kernel, dim3(std::min(65535, n - t0)), dim3(kBitsWG), lds, stream, d_thumbs + (size_t)t0 * S * S, d_basis, S, K,
+                           d_bits + (size_t)t0 * K * K);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) { psd_set_error("hash_bits_kernel launch: %s", hipGetErrorString(err)); return PSD_ERR_HIP; }
+    return PSD_OK;
+}
+
 }  // namespace psd

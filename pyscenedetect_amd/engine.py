@@ -442,6 +442,21 @@ class ScoringEngine(TapRowPolicy):
                                                        frame_stride, int(size), out.ctypes.data if n else None))
         return out
 
+    def hash_bits_device(self, d_frames: int, n: int, height: int, width: int, size: int, hash_size: int,
+                         row_stride: int | None = None, frame_stride: int | None = None, want_thumbs: bool = False):
+        """``HashDetector.hash_frame`` as a whole for n frames resident in HBM (``psd_hash_bits_device``): thumbnails, DCT, median
+        and bits on the device.  Returns ``uint8[n, hash_size**2]`` of 0 / 1 -- what ``epilogue.hash_bits(hash_thumbs_device(...))``
+        returns -- or ``(bits, thumbs)``.  ``NotImplementedError`` for transforms that do not fit a workgroup's LDS (size > 64 or so):
+        use the two-step form then."""
+        row_stride = width * 3 if row_stride is None else row_stride
+        frame_stride = height * row_stride if frame_stride is None else frame_stride
+        bits = np.zeros((n, hash_size * hash_size), np.uint8)
+        thumbs = np.zeros((n, size, size), np.uint8) if want_thumbs else None
+        _native.check(self._lib.psd_hash_bits_device(self._h, d_frames, int(n), int(height), int(width), row_stride, frame_stride, int(size),
+                                                     int(hash_size), bits.ctypes.data if n else None,
+                                                     thumbs.ctypes.data if (want_thumbs and n) else None))
+        return (bits, thumbs) if want_thumbs else bits
+
     def hash_thumbs_host(self, frames: np.ndarray, size: int, downscale: float = 1.0, interpolation: int = 1) -> np.ndarray:
         """Same for frames uint8[N,H,W,3] in host memory (staged in bounded chunks by the engine)."""
         frames = np.asarray(frames)
@@ -818,7 +833,7 @@ def _locked(fn):
 
 # the synchronous calls hold the engine's lock from their first step to their last (the submit_* / collect pairs of the
 # pipelined API stay the caller's to serialise)
-for _name in ("score_host", "_score_host_downscaled", "analyze_frames", "hash_thumbs_device", "hash_thumbs_host", "score_device",
+for _name in ("score_host", "_score_host_downscaled", "analyze_frames", "hash_thumbs_device", "hash_bits_device", "hash_thumbs_host", "score_device",
               "score_device_downscaled", "score_device_segments", "score_device_segments_downscaled", "score_clips", "edge_map",
               "resize_device"):
     setattr(ScoringEngine, _name, _locked(getattr(ScoringEngine, _name)))

@@ -163,16 +163,20 @@ recs = D.score_clips_distributed(eng, clips, flags)
 ok = all((a[f] == b[f]).all() for a, b in zip(recs, corpus.score_clips(eng, clips, flags)) for f in ("sad_h", "sad_s", "sad_v", "byte_sum", "hist"))
 comm = D.native_comm_for(eng, None)                      # the exchange went through psd_allgather_host (RCCL loaded by libpsd_hip.so)
 native = comm is not None and comm.exchanges == 1
-grouped = corpus.detect_corpus(eng, clips, 25.0, spec)   # the whole flow under the group: default pipeline, 1064-byte records
-sums = corpus.detect_corpus(eng, clips, 25.0, {"adaptive": {"min_scene_len": 6}})     # ... and 40-byte sums
-native = native and comm.exchanges == 3
+def same(a, b, fields):
+    return all((x[f] == y[f]).all() for x, y in zip(a, b) for f in fields)
+sums = D.score_clips_distributed(eng, clips, E.SCORE_HSV_SAD, downscale="auto")      # 40-byte sums behind the default downscale
+native = native and comm.exchanges == 2 and sums[0].dtype.itemsize == 40
+ok_sums = same(sums, corpus.score_clips(eng, clips, E.SCORE_HSV_SAD, downscale="auto"), ("sad_h", "sad_s", "sad_v"))
 os.environ["PSD_NATIVE_EXCHANGE"] = "0"                  # the torch.distributed path stays selectable
 D._native_comms.clear()
-torch_path = corpus.detect_corpus(eng, clips, 25.0, spec)
+recs_torch = D.score_clips_distributed(eng, clips, flags)
 assert D.native_comm_for(eng, None) is None
+same_cuts = same(recs_torch, recs, ("sad_h", "sad_s", "sad_v", "byte_sum", "hist"))
+grouped = corpus.detect_corpus(eng, clips, 25.0, spec)   # (one rank: detect_corpus keeps to its single-process path)
 dist.destroy_process_group()
-print("RESULT " + json.dumps({"same_records": bool(ok), "native": bool(native), "same_cuts": grouped == plain == torch_path,
-                              "sums": sums == [{"adaptive": r["adaptive"]} for r in plain], "cuts": sum(len(v) for r in plain for v in r.values())}))
+print("RESULT " + json.dumps({"same_records": bool(ok), "native": bool(native), "same_cuts": bool(same_cuts) and grouped == plain,
+                              "sums": bool(ok_sums), "cuts": sum(len(v) for r in plain for v in r.values())}))
 ''' % (ROOT, ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -17,6 +17,13 @@ NOEDGE = E.SCORE_HSV_SAD | E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM
 FIELDS = ("sad_h", "sad_s", "sad_v", "byte_sum", "hist")
 
 
+def device_copy(engine, frames):
+    """frames uint8[N,H,W,3] copied into a fresh device buffer of the engine"""
+    buf = engine.alloc(frames.nbytes)
+    buf.upload(np.ascontiguousarray(frames).reshape(-1))
+    return buf
+
+
 def same(a, b, fields=FIELDS):
     for f in fields:
         assert np.array_equal(a[f], b[f]), f"field {f} differs: {np.argwhere(a[f] != b[f])[:4].tolist()}"
@@ -584,3 +591,42 @@ def test_hash_thumbs_host_batches_larger_than_one_staging_chunk(hip_engine):
     one_by_one = np.stack([hip_engine.hash_thumbs_host(frames[i : i + 1], 16)[0] for i in (0, 42, 43, 46)])
     assert np.array_equal(got[[0, 42, 43, 46]], one_by_one)
     assert np.array_equal(got[-1], orc.hash_thumbs(frames[-1:], 16)[0])
+
+
+@pytest.mark.parametrize("size,hash_size", [(32, 16), (16, 8), (64, 16), (12, 3), (48, 11), (8, 8)])
+def test_hash_bits_on_the_device_equal_the_host_epilogue(hip_engine, size, hash_size):
+    """``psd_hash_bits_device`` (round 6: HashDetector's scaling, float64 DCT, float32 median and threshold on the device, beside the
+    thumbnail kernel) == ``psd_epilogue_hash_bits`` of the thumbnails == the oracle, bit for bit: shot-like frames, uniform noise,
+    constant frames (every AC coefficient rounding noise: the bits only agree if every sum runs in the same order), all-black frames
+    (the maximum replaced by 1, hash_detector.py:132-135), odd hash sizes (an odd count's median is one element) and transforms of
+    12 ... 64 points."""
+    from oracle import lib as orc
+    from pyscenedetect_amd import epilogue
+    from pyscenedetect_amd.synth import make_clip
+
+    rng = np.random.default_rng(size * 100 + hash_size)
+    clip, _ = make_clip(size + hash_size, 24, 90, 160, shot_len=(5, 9))
+    frames = np.concatenate([clip, rng.integers(0, 256, (8, 90, 160, 3), dtype=np.uint8),
+                             np.full((3, 90, 160, 3), 137, np.uint8), np.zeros((2, 90, 160, 3), np.uint8),
+                             np.clip(rng.integers(-1, 2, (6, 90, 160, 3)) + 60, 0, 255).astype(np.uint8)])
+    n = len(frames)
+    buf = device_copy(hip_engine, frames)
+    bits, thumbs = hip_engine.hash_bits_device(buf.ptr, n, 90, 160, size, hash_size, want_thumbs=True)
+    assert np.array_equal(thumbs, hip_engine.hash_thumbs_device(buf.ptr, n, 90, 160, size))
+    assert np.array_equal(thumbs, orc.hash_thumbs(frames, size))
+    host = epilogue.hash_bits(thumbs, hash_size)
+    assert bits.shape == (n, hash_size * hash_size) and np.array_equal(bits, host.reshape(n, -1))
+    assert np.array_equal(bits, orc.hash_bits(thumbs, hash_size).reshape(n, -1).astype(np.uint8))
+    assert np.array_equal(hip_engine.hash_bits_device(buf.ptr, n, 90, 160, size, hash_size), bits)       # bits alone
+    buf.free()
+
+
+def test_hash_bits_on_the_device_refuse_what_does_not_fit(hip_engine):
+    frames = np.zeros((2, 300, 300, 3), np.uint8)
+    buf = device_copy(hip_engine, frames)
+    with pytest.raises(NotImplementedError):
+        hip_engine.hash_bits_device(buf.ptr, 2, 300, 300, 128, 64)          # a 128-point transform: the two-step form takes it
+    with pytest.raises(ValueError):
+        hip_engine.hash_bits_device(buf.ptr, 2, 300, 300, 16, 17)           # more frequencies than points
+    assert hip_engine.hash_bits_device(buf.ptr, 2, 300, 300, 16, 8).shape == (2, 64)
+    buf.free()
