@@ -256,6 +256,16 @@ __device__ __forceinline__ u32 interp(u32 p00, u32 p01, u32 p10, u32 p11, int a0
 }
 
 constexpr int RS_WG = 256, RS_NW = 4, RS_SLOTS = 16, RS_REP = 16;
+// copies of a tile's luma histogram (lane l counts into copy l % RS_HREP).  Neighbouring pixels of a natural frame share their
+// luma, and the lanes of ONE ds_add_u32 that hit the same word are served one after the other -- which cost the score kernels up
+// to 40 % on constant frames until they got 16 copies (psd_score_kernels.hip, round 4).  Not here: 1 / 4 / 8 copies measure the
+// same on uniform, shot-like and object frames (1.18-1.29 / 1.20-1.22 / 1.20-1.32 ms per 4096 x 1080p, all four detectors;
+// profiles/r06_j_ab_resize_hist_replicas.txt) -- a lane adds 2-8 pixels per frame between barriers, the atomics are not what
+// the step waits for -- and one copy has the cheapest flush.
+#ifndef PSD_RS_HREP
+#define PSD_RS_HREP 1
+#endif
+constexpr int RS_HREP = PSD_RS_HREP;
 
 // LDS increment the compiler does not see as an LDS store: hipcc orders every LDS store / atomic behind ALL outstanding LDS-DMA
 // (s_waitcnt vmcnt(0)), i.e. behind the staging of the NEXT frame, which would serialise the prefetch with this frame's
@@ -372,7 +382,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     __shared__ u32 lut_s[HSV ? 256 : 1], lut_h[HSV ? 256 : 1];
     // per-frame sums (sad_h, sad_s, sad_v, byte_sum), RS_REP copies each: a lane adds into copy lane % RS_REP
     __shared__ __attribute__((aligned(16))) u32 sums[RS_SLOTS][4][RS_REP];
-    __shared__ u32 lhist[LUMA ? 2 : 1][LUMA ? 256 : 1];
+    __shared__ __attribute__((aligned(16))) u32 lhist[LUMA ? 2 : 1][LUMA ? RS_HREP * 256 : 1];     // [slot][copy][bin]
     __shared__ int srows[64];           // clamped source rows of this tile: slot 2 * lr + k
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x % p.n_tiles, chunk = blockIdx.x / p.n_tiles;
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         for (int i = tid; i < RS_SLOTS * 4 * RS_REP; i += RS_WG) (&sums[0][0][0])[i] = 0;
     }
     if (LUMA) {
-        for (int i = tid; i < 2 * 256; i += RS_WG) (&lhist[0][0])[i] = 0;
+        for (int i = tid; i < 2 * RS_HREP * 256; i += RS_WG) (&lhist[0][0])[i] = 0;
     }
     if (tid < 2 * nrows) {
         const YTap y = p.yt[r0 + (tid >> 1)];
@@ -531,17 +541,21 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         if (LUMA && rel >= 1 && tid < 128) {
             // frame rel-1's histogram of this tile is complete: out as 128 packed words, and the slot is free for frame rel+1
             u32* hs = lhist[(rel - 1) & 1];
-            const u32 lo = hs[2 * tid], hi = hs[2 * tid + 1];
-            // (cleared with a store the compiler does not see, for the reason given at rs_lds_add: a visible LDS store here would
-            //  make these two waves wait for the NEXT frame's staging, issued a few lines up; the read above is of a different
-            //  object than the staging buffers and is not held back)
-            asm volatile("ds_write_b64 %0, %1" ::"v"((u32)(uintptr_t)&hs[2 * tid]), "v"(0ull) : "memory");
+            u32 lo = 0, hi = 0;
+#pragma unroll
+            for (int r = 0; r < RS_HREP; r++) {
+                lo += hs[r * 256 + 2 * tid]; hi += hs[r * 256 + 2 * tid + 1];
+                // (cleared with a store the compiler does not see, for the reason given at rs_lds_add: a visible LDS store here would
+                //  make these two waves wait for the NEXT frame's staging, issued a few lines up; the reads above are of a different
+                //  object than the staging buffers and are not held back)
+                asm volatile("ds_write_b64 %0, %1" ::"v"((u32)(uintptr_t)&hs[r * 256 + 2 * tid]), "v"(0ull) : "memory");
+            }
             p.hpart[((size_t)(t - 1) * p.n_tiles + tile) * 128 + tid] = lo | (hi << 16);
         }
         const uint8_t* base = rs_stage + (size_t)buf * buf_bytes;
         u32 sh = 0, ss = 0, sv = 0, bsum = 0;
         const bool count_luma = LUMA && t >= t0;           // (the halo frame only feeds the HSV carry)
-        u32* hcur = lhist[LUMA ? (rel & 1) : 0];
+        u32* hcur = lhist[LUMA ? (rel & 1) : 0] + (LUMA ? (tid & (RS_HREP - 1)) * 256 : 0);
         const bool chain = have_prev && !(SEG && flag_now != 0);
         constexpr int C = G < 4 ? G : 4;        // pixels whose taps are in flight together (six dwords each)
 #pragma unroll
@@ -610,7 +624,10 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         }
         if (LUMA && done > 0 && tid < 128) {   // the chunk's last frame
             const u32* hs = lhist[(done - 1) & 1];
-            p.hpart[((size_t)(t1 - 1) * p.n_tiles + tile) * 128 + tid] = hs[2 * tid] | (hs[2 * tid + 1] << 16);
+            u32 lo = 0, hi = 0;
+#pragma unroll
+            for (int r = 0; r < RS_HREP; r++) { lo += hs[r * 256 + 2 * tid]; hi += hs[r * 256 + 2 * tid + 1]; }
+            p.hpart[((size_t)(t1 - 1) * p.n_tiles + tile) * 128 + tid] = lo | (hi << 16);
         }
     }
 }

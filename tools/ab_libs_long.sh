@@ -1,0 +1,8 @@
+#!/bin/bash
+# like tools/ab_libs.sh, with runs long enough for ~1 ms kernels (40 timed steps after 10 warm-up steps) and the variants
+# interleaved ROUNDS times, so that drifts of the box (clock, neighbours' power) show as spread instead of as a difference
+# usage: tools/ab_libs_long.sh "<bench args>" ROUNDS name1 name2 ...     (name "default" = the in-tree library)
+R=${GRAFT_REPO_ROOT:-$PWD}; ARGS="$1"; ROUNDS=$2; shift 2
+t() { if [ "$1" = default ]; then L=$R/pyscenedetect_amd/libpsd_hip.so; else L=$R/pyscenedetect_amd/csrc/build/abl/libpsd_$1.so; fi
+  PSD_LIB_PATH=$L python bench.py --no-cpu-baseline --no-secondary --steps 40 --warmup 10 $ARGS 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-12s' % '$1', d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['value'])"; }
+for i in $(seq $ROUNDS); do for v in "$@"; do t $v; done; done
