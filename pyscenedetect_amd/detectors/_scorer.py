@@ -26,15 +26,34 @@ class FrameScorer:
             self._engine = default_engine()
         return self._engine
 
-    def seed(self, frame: np.ndarray) -> None:
+    def seed(self, frame: np.ndarray, scale=None) -> None:
         """``frame`` precedes whatever is scored next: a SceneManager's shared pass saw it on this detector's behalf (the reference's
         detector would hold the planes it derived from it, ``content_detector.py:189``), so a caller who goes on with
-        ``process_frame()`` on the same detector gets the score against it."""
-        # (a reference, not a copy: the manager's own carried frame is one too -- frames a stream hands out are not written to again,
-        #  the decode queue of the reference and the batches here both rest on that)
+        ``process_frame()`` on the same detector gets the score against it.
+
+        ``scale = (downscale factor, interpolation)`` the manager scored it behind.  The reference's detector holds the DOWNSCALED
+        planes then, so the frames it accepts by hand afterwards are downscaled ones; the frame kept here is the one the stream
+        delivered (making the small one at the end of every ``detect_scenes`` call would put a device round trip on the default
+        pipeline), and :meth:`score` makes the small one the moment a frame of that size arrives -- a frame of the stream's own
+        size is scored against the frame as delivered, as before (round 6; until then only the latter worked)."""
+        # (the manager hands over its own copy of the frame, scene_manager.py: nothing else writes to it)
         self._last = self._seed = np.asarray(frame)
         self._last_shape = self._last.shape
+        self._seed_scale = scale if scale is not None and scale[0] > 1.0 else None
         self.scored_since_seed = False
+
+    def _seed_as_seen(self, shape) -> None:
+        """A frame of ``shape`` follows a seed that was scored behind a downscale: if ``shape`` is the size the detectors saw, the seed
+        becomes the frame they saw (``cv2.resize`` on the device, like every frame of that pass)."""
+        scale = getattr(self, "_seed_scale", None)
+        if self._seed is None or scale is None or tuple(shape) == tuple(self._seed.shape):
+            return
+        factor, interp = scale
+        h, w = self._seed.shape[:2]
+        if tuple(shape[:2]) == (max(1, round(h / factor)), max(1, round(w / factor))):
+            self._last = self._seed = self.engine.downscale_host(self._seed[None], factor, interp)[0]
+            self._last_shape = self._last.shape
+            self._seed_scale = None
 
     def last_frame(self):
         """The frame scored last through this scorer (None before the first), for a SceneManager that takes over from direct
@@ -55,6 +74,7 @@ class FrameScorer:
         # A frame of another size than the one before: the reference's ContentDetector compares the planes it kept with the new
         # ones behind `assert len(left.shape) == 2 and left.shape == right.shape` (content_detector.py:29-36); the terms that
         # compare nothing across frames on the device (histogram, byte sum, thumbnails) go on, as in the reference.
+        self._seed_as_seen(frame.shape)
         last_shape = getattr(self, "_last_shape", None)
         if last_shape is not None and last_shape != frame.shape and (flags & 9):      # HSV SAD | edges
             raise AssertionError("frame size changed from %dx%d to %dx%d" % (last_shape[1], last_shape[0], frame.shape[1], frame.shape[0]))

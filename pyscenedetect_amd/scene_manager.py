@@ -486,7 +486,9 @@ class SceneManager:
                         # `assert left.shape == right.shape` (content_detector.py:29-36): what decides is the size the detectors see.
                         # (Until round 6 the raw shapes were compared: 512 x 288 at factor 2 followed by 256 x 144 at factor 1 raised
                         # here and not in the reference, and a changed `downscale` on frames of one size went unnoticed.)
-                        old_f, old_i = carry_scale if carry_scale is not None else (factor, interp)
+                        # (no scale on record: the frame was fed BY HAND -- the reference's detector holds it as given, i.e. a caller
+                        #  who follows the reference's rules fed frames of the size the detectors see: factor 1 on that side)
+                        old_f, old_i = carry_scale if carry_scale is not None else (1.0, interp)
                         seen = _scaled_shape(last_frame.shape, old_f)
                         now = _scaled_shape(frames[0].shape, factor)
                         users = [d for d in self._detector_list if _score_flags(d) & 9 and getattr(d, "_have_last", False)]
@@ -547,7 +549,10 @@ class SceneManager:
             for detector in self._detector_list:
                 scorer = getattr(detector, "_scorer", None)
                 if scorer is not None and hasattr(scorer, "seed") and _score_flags(detector) & 9:
-                    scorer.seed(last_frame)
+                    try:
+                        scorer.seed(last_frame, scale=(factor, interp))
+                    except TypeError:      # (a scorer of the caller's own with the older signature)
+                        scorer.seed(last_frame)
         self._last_pos = FrameTimecode(video.position)
         for detector in self._detector_list:
             if isinstance(detector, SceneDetector):

@@ -310,6 +310,8 @@ def draw_case(rng):
         sm["manager_first"] = bool(rng.integers(0, 2))
         if rng.integers(0, 3) == 0:
             sm["two_managers"] = True
+        if rng.integers(0, 2):      # round 6: behind the manager's downscale too -- by hand the detectors then get DOWNSCALED frames,
+            sm["mixed_downscale"] = True      # which is what the reference's detectors hold after a manager's pass (its rule, both sides)
         sm.pop("pts", None)
     if WIDE and "chunks" in sm and rng.integers(0, 3) == 0:
         sm["add_between"] = draw_detector(rng)            # a detector that joins after the first piece
@@ -486,9 +488,12 @@ def run_side(side, frames, fps, dets, cfg, engine):
             return {"scenes": [[a.frame_num, b.frame_num] for a, b in scenes], "csv": text,
                     "stream": [video.frame_number, video.position.frame_num]}
     if cfg.get("mode") == "mixed":
-        # (both halves must see frames of one size: no downscale, no crop; no aborted runs)
-        cfg = {k: v for k, v in cfg.items() if k not in ("downscale", "crop", "frame_skip", "fail_at", "odd_frames", "end_time", "duration")}
-        cfg["auto_downscale"] = False
+        # (both halves must see frames of one size: no crop; no aborted runs; a downscale only with `mixed_downscale`, where the by-hand
+        #  half is fed the frames the manager's half scored -- resized by the manager's own factor and interpolation)
+        keep_ds = bool(cfg.get("mixed_downscale"))
+        cfg = {k: v for k, v in cfg.items() if k not in ("crop", "frame_skip", "fail_at", "odd_frames", "end_time", "duration") and (keep_ds or k != "downscale")}
+        if not keep_ds:
+            cfg["auto_downscale"] = False
         # SceneManager.detect_scenes on one half of the clip, SceneDetector.process_frame by hand on the other, the SAME detector objects:
         # what a detector derived from the last frame it saw goes with it (reference content_detector.py:189)
         built = configure(sm)
@@ -496,10 +501,21 @@ def run_side(side, frames, fps, dets, cfg, engine):
         tc_cls = ref.FrameTimecode if side in ("ref", "plug") else psd.FrameTimecode
         emitted = []
 
+        hh, ww = frames[0].shape[:2]
+        ds_factor = (psd.compute_downscale_factor(max(ww, hh)) if sm.auto_downscale else sm.downscale)
+        ds_interp = int(sm.interpolation.value)
+
+        def as_scored(f):
+            if not ds_factor > 1.0:
+                return f
+            import cv2  # the oracle's shim
+
+            return cv2.resize(f, (max(1, round(ww / ds_factor)), max(1, round(hh / ds_factor))), interpolation=ds_interp)
+
         def by_hand(lo, hi):
             for i in range(lo, hi):
                 for j, d in enumerate(built):
-                    got = d.process_frame(tc_cls(i, fps), frames[i])
+                    got = d.process_frame(tc_cls(i, fps), as_scored(frames[i]))
                     if got:
                         emitted.append([i, j, [c.frame_num for c in got]])
 
@@ -507,7 +523,10 @@ def run_side(side, frames, fps, dets, cfg, engine):
             n = sm.detect_scenes(video, duration=half)
             other = (RefSceneManager(stats) if side in ("ref", "plug")
                      else psd.SceneManager(stats, engine=engine, batch_frames=int(cfg.get("batch_frames", 64))))
-            other.auto_downscale = False
+            other.auto_downscale = sm.auto_downscale
+            if not sm.auto_downscale:
+                other.downscale = sm.downscale
+            other.interpolation = sm.interpolation
             for d in built:
                 other.add_detector(d)
             n += other.detect_scenes(video)
@@ -795,6 +814,8 @@ def main():
                     cfg["two_managers"] = True
                 if f == "mixed":
                     cfg.pop("pts", None)
+                    if cases % 2 == 0:
+                        cfg["mixed_downscale"] = True
             elif f == "pts" and "pts" not in cfg:
                 steps = rng.choice([20, 40, 40, 40, 40, 60, 80], size=len(frames) - 1)
                 cfg["pts"] = [0] + [int(x) for x in np.cumsum(steps)]
