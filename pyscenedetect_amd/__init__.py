@@ -7,7 +7,7 @@ path): :class:`SceneManager`, :class:`ContentDetector`, :class:`AdaptiveDetector
 (whole-clip native decisions) are the batch face underneath.
 """
 
-from pyscenedetect_amd import engine, epilogue  # noqa: F401  (submodules of the public surface; the library loads on first use)
+from pyscenedetect_amd import corpus, engine, epilogue  # noqa: F401  (submodules of the public surface; the library loads on first use)
 from pyscenedetect_amd.detector import FlashFilter, SceneDetector
 from pyscenedetect_amd.detectors import AdaptiveDetector, ContentDetector, HashDetector, HistogramDetector, ThresholdDetector
 from pyscenedetect_amd.scene_manager import (Interpolation, SceneManager, compute_downscale_factor, expand_scenes_to_bounds,
