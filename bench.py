@@ -124,17 +124,33 @@ class SmiPoll:
                     pass
             return None
 
-        # (one GPU per process: the first card that answers -- the pool's boxes show one; an 8-GPU node's ranks each see theirs
-        #  through ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES only for compute, so take the card with the rank's index if it exists)
-        base = "/sys/class/drm/card*/device/hwmon/hwmon*/"
-        cards = sorted({pth.split("/device/")[0] for pth in glob.glob(base + "freq1_input")})
-        pick = cards[device_index] + "/device/hwmon/hwmon*/" if device_index < len(cards) else base
-        self.pw = first(pick + "power1_average") or first(pick + "power1_input")
+        # The sysfs node of the device THIS process computes on, by its PCI address (a container may see the hwmon entries of other
+        # tenants' GPUs of the node -- the first one that answers read 239 W / 105 MHz through eight seconds of this kernel,
+        # tools/probe_power_ramp.py): no address or no readable node -> no record, rather than somebody else's GPU.
+        pick = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            if glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*/" % bdf):
+                pick = "/sys/bus/pci/devices/%s/hwmon/hwmon*/" % bdf
+            self.bdf = bdf
+        except Exception:  # noqa: BLE001
+            self.bdf = None
+        if pick is None:
+            self.pw = self.fq = self.cap = self.dpm = None
+            self.samples, self._stop, self._thread = [], False, None
+            return
+        self.pw = first(pick + "power1_input") or first(pick + "power1_average")     # (instantaneous where the driver has it)
         self.fq = first(pick + "freq1_input")
         self.cap = first(pick + "power1_cap")
+        # no hwmon clock on this driver: the DPM table marks the current shader-clock level with '*'
+        dev = pick.split("/hwmon/")[0]
+        self.dpm = None if self.fq else first(dev + "/pp_dpm_sclk")
         self.samples, self._stop, self._thread = [], False, None
 
     def _run(self):
+        import re
+
         while not self._stop:
             row = {}
             try:
@@ -142,6 +158,10 @@ class SmiPoll:
                     row["w"] = int(open(self.pw).read()) / 1e6
                 if self.fq:
                     row["mhz"] = int(open(self.fq).read()) / 1e6
+                elif self.dpm:
+                    m = re.search(r"(\d+)\s*[Mm][Hh]z\s*\*", open(self.dpm).read())
+                    if m:
+                        row["mhz"] = float(m.group(1))
             except (OSError, ValueError):
                 pass
             if row:
@@ -151,7 +171,7 @@ class SmiPoll:
     def __enter__(self):
         import threading
 
-        if self.pw or self.fq:
+        if self.pw or self.fq or self.dpm:
             self._thread = threading.Thread(target=self._run, daemon=True)
             self._thread.start()
         return self
@@ -164,9 +184,12 @@ class SmiPoll:
     def summary(self) -> dict | None:
         if not self.samples:
             return None
-        ws = sorted(r["w"] for r in self.samples if "w" in r)
-        fs = sorted(r["mhz"] for r in self.samples if "mhz" in r)
-        out = {"samples": len(self.samples), "source": "amdgpu hwmon sysfs, 50 Hz, during the timed steps"}
+        # (the sensors average over hundreds of milliseconds: the steady state is the second half of the samples)
+        half = self.samples[len(self.samples) // 2:]
+        ws = sorted(r["w"] for r in half if "w" in r)
+        fs = sorted(r["mhz"] for r in half if "mhz" in r)
+        out = {"samples": len(self.samples), "pci": self.bdf,
+               "source": "amdgpu sysfs of this device (hwmon power, hwmon / DPM shader clock), 50 Hz, second half of the probe"}
         if ws:
             out.update(socket_power_w_median=round(ws[len(ws) // 2], 1), socket_power_w_max=round(ws[-1], 1))
         if fs:
@@ -1251,11 +1274,23 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
     if args.warmup > 0:
         run(args.warmup, False)
     barrier()
-    with SmiPoll(local_rank if on_gpu else 0) as smi:
-        t0 = time.perf_counter()
-        run(args.steps, True)
-        barrier()
-        elapsed = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # What this box does under this workload, OUTSIDE the timed region: the same steps back to back for about a second and a half
+    # while a thread samples socket power and shader clock (the sensors are moving averages: the 0.1 s of the timed steps still
+    # show the idle value).  Rank 0 only, and not in the CPU dry run.
+    smi = SmiPoll(local_rank if on_gpu else 0)
+    if on_gpu and rank == 0 and args.detector != "hash" and elapsed > 0:
+        probe_steps = int(min(2000, max(args.steps, 1.5 / (elapsed / args.steps))))
+        with smi:
+            wl.submit()                       # (the workload's own steps, two in flight, without the launcher's exchange)
+            for _ in range(probe_steps - 1):
+                wl.submit()
+                wl.finish()
+            wl.finish()
+            torch.cuda.synchronize(device)
     if use_dist:
         import torch.distributed as dist
 
@@ -1328,7 +1363,8 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "limiter": "package power: the HSV pass holds the 1400 W cap and the shader clock falls to 1.9-2.1 GHz "
                            "(profiles/r02_a_power_and_clock_by_build.txt)" if headline else None,
-                # what THIS box did during the timed steps (power-bound passes read 4 - 6 % apart between boxes of the pool)
+                # what THIS box does under this workload (power-bound passes read 4 - 6 % apart between boxes of the pool): sampled
+                # during ~1.5 s of the same steps run again behind the timed region
                 "box": smi.summary(),
             },
             "cuts_found": len(wl.state["cuts"]),
