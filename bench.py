@@ -348,10 +348,15 @@ class Workload:
                 "hash": "psd::gray_area_dma_kernel + psd::hash_bits_kernel", "edges": "psd::score_frames_dma_kernel<V mode> + psd::sobel_nms_bits_kernel (edge pipeline)"}[self.detector]
 
     def submit(self):
+        stream = self.stream
+        alt = getattr(self, "alt_streams", None)
+        if alt:      # --alt-streams (experiment): consecutive submissions on two streams, so that one launch's tail and the next one's ramp overlap
+            self._k = getattr(self, "_k", 0) + 1
+            stream = alt[self._k & 1]
         if self.downscale:
-            self.eng.submit_device_downscaled(self.ptr, self.n, self.h, self.w, self.sh, self.sw, flags=self.flags, stream=self.stream)
-        elif self.stream is not None:
-            self.eng.submit_device(self.ptr, self.n, self.h, self.w, flags=self.flags, stream=self.stream)
+            self.eng.submit_device_downscaled(self.ptr, self.n, self.h, self.w, self.sh, self.sw, flags=self.flags, stream=stream)
+        elif stream is not None:
+            self.eng.submit_device(self.ptr, self.n, self.h, self.w, flags=self.flags, stream=stream)
         else:
             self.eng.submit_device(self.ptr, self.n, self.h, self.w, flags=self.flags)
         if not self.walk and (self.flags & 1) and hasattr(self.eng, "last_walk_geometry"):
@@ -1085,6 +1090,7 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
     ap.add_argument("--workload", default="headline", choices=["headline", "corpus", "bbc"],
                     help="headline = one resident batch (BASELINE configs[1], or what --detector/--res/--downscale select); "
                          "corpus = configs[4] (mixed 1080p/4K clips, four detectors, sharded by clip); bbc = configs[3]")
+    ap.add_argument("--alt-streams", action="store_true", help=argparse.SUPPRESS)   # experiment: consecutive submissions alternate between two streams
     ap.add_argument("--flow-pipeline", default="default", choices=["default", "full"],
                     help="--workload corpus|bbc: default = every clip behind the reference's auto-downscale (what detect() scores); "
                          "full = full-resolution frames (auto_downscale off; the form rounds 2-5 timed)")
@@ -1157,6 +1163,9 @@ def main(argv=None, engine_factory=None, cpu_dry_run: bool = False) -> None:
     deferred = use_dist and args.exchange == "default"
     xstream = torch.cuda.Stream(device) if (on_gpu and use_dist and args.exchange in ("stream", "inline")) else None
     wl = Workload(eng, batch, args.detector, args.downscale, epilogue, E, stream=xstream.cuda_stream if inline else None)
+    if args.alt_streams and on_gpu:
+        keep_alt = [torch.cuda.Stream(device), torch.cuda.Stream(device)]
+        wl.alt_streams = [st.cuda_stream for st in keep_alt]
 
     kernel_ms: list[float] = []
     state = {"pending_gather": None, "gathered": None, "copies": [], "pinned": [], "held": [], "exchanges": 0}
