@@ -137,3 +137,80 @@ def test_busy_sobel_tiles_select_their_neighbours_without_branching(tmp_path):
     branches = sum(1 for l in body if l.startswith(("s_cbranch", "s_branch")))
     selects = sum(1 for l in body if l.startswith("v_cndmask"))
     assert len(body) < 650 and branches <= 16 and selects >= 40, (len(body), branches, selects)
+
+
+def _frame_loop(lines, marker="v_dot2_u32_u16"):
+    """The smallest loop that holds every `marker` instruction: the per-frame step of a time-walking kernel."""
+    at = [i for i, l in enumerate(lines) if marker in l]
+    assert at, "no " + marker
+    spans = [s for s in _loops(lines) if s[0] <= at[0] and s[1] >= at[-1]]
+    assert spans
+    a, b = min(spans, key=lambda s: s[1] - s[0])
+    return lines[a:b + 1]
+
+
+def test_fused_downscale_kernel_reads_its_taps_as_dwords(tmp_path):
+    """Round 6: the pixel path of resize_walk_kernel.  Per destination pixel and frame: two `ds_read2_b32` + two
+    `ds_read_b32` for the four taps (no byte-wide LDS reads: the kernel it replaces issued sixteen, and an unaligned `ds_read_b64`
+    per row -- what hipcc makes of the obvious source -- runs on a slow path of the LDS), six `v_dot2_u32_u16` and six
+    `v_mul_hi_u32_u24` for the interpolation, no exec-mask branch per pixel slot."""
+    bodies = kernel_bodies(device_asm("psd_resize_kernels", tmp_path))
+    checked = 0
+    for name, lines in bodies.items():
+        m = re.search(r"resize_walk_kernelILb([01])ELb([01])ELi(\d)ELb([01])ELb([01])E", name)
+        if not m:
+            continue
+        store, hsv, g, luma, seg = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5))
+        # (hipcc may unswitch the frame loop on the uniform "exact 2 x 2 decimation" flag: the general copy is the one with the
+        #  vertical products)
+        body = [l.strip() for l in _frame_loop(lines, "v_mul_hi_u32_u24") if l.startswith("\t") and l.strip()]
+        whole = [l.strip() for l in lines if l.startswith("\t") and l.strip()]
+        count = lambda op, where=body: sum(1 for l in where if l.split()[0].startswith(op))      # noqa: E731
+        # no byte-wide or unaligned-wide LDS reads anywhere in the kernel (the only 8-byte LDS read left is the luma instances'
+        # aligned read of two histogram bins in the per-frame flush)
+        assert count("ds_read_u8", whole) == 0 and count("ds_read_u16", whole) == 0 and count("ds_read_b96", whole) == 0, name
+        assert count("ds_read_b64", whole) <= (2 if luma else 0), (name, count("ds_read_b64", whole))
+        # (per copy of the step -- one, or two where the loop was unswitched: 2 G paired dword reads, 6 G dot products, 4 G realignments;
+        #  the vertical products only exist in the general copy)
+        copies = count("v_dot2_u32_u16", whole) // (6 * g)
+        assert copies in (1, 2) and count("v_dot2_u32_u16", whole) == 6 * g * copies, (name, count("v_dot2_u32_u16", whole))
+        assert count("ds_read2_b32", whole) == 2 * g * copies and count("v_alignbyte_b32", whole) == 4 * g * copies, name
+        assert count("v_mul_hi_u32_u24", whole) == 6 * g, name
+        valu = sum(1 for l in body if l.startswith("v_"))
+        # (set-up and flushes are amortised over the slots: the narrow instances carry them on few pixels)
+        limit = {1: 150, 2: 120, 4: 100, 8: 95}[g] + (15 if luma else 0) + (10 if store else 0)
+        assert valu / g <= limit, (name, valu / g)
+        checked += 1
+    assert checked == 32
+
+
+def test_fused_downscale_seg_instance_reads_the_flag_behind_the_dma_issue(tmp_path):
+    """The clip-start flag of the next frame is requested BEHIND that frame's LDS-DMA issue and consumed at the top of its own step:
+    between the issue and the end of the step the compiler must not wait for global memory (an `s_waitcnt vmcnt(0)` there drains
+    the prefetch the wave has just started: psd_score_kernels.hip found that out in round 5)."""
+    bodies = kernel_bodies(device_asm("psd_resize_kernels", tmp_path))
+    checked = 0
+    for name, lines in bodies.items():
+        if not re.search(r"resize_walk_kernelILb[01]ELb1ELi\dELb[01]ELb1E", name):
+            continue
+        loops = _loops(lines)
+        in_loop = 0
+        for i, l in enumerate(lines):
+            if "global_load_ubyte" not in l:
+                continue
+            spans = [sp for sp in loops if sp[0] <= i <= sp[1]]
+            if not spans:
+                continue                      # the first frame's flag, requested in front of the walk
+            in_loop += 1
+            a, b = max(spans, key=lambda sp: sp[1] - sp[0])      # the frame loop (the kernel's only outer loop): one step of the walk
+            step = [x.strip() for x in lines[a:b + 1] if x.startswith("\t") and x.strip()]
+            at = next(k for k, x in enumerate(step) if x.startswith("global_load_ubyte"))
+            # DMA issues in front of it in the step, no wait for global memory behind it
+            assert any(x.startswith("global_load_lds_dwordx4") for x in step[:at]), name
+            assert not any(x.startswith("s_waitcnt") and "vmcnt(0)" in x for x in step[at:]), name
+            # ... and the flag becomes an SGPR in front of the step's barrier (right behind the step's own wait)
+            bar = next(k for k, x in enumerate(step) if x.startswith("s_barrier"))
+            assert any(x.startswith("v_readfirstlane_b32") for x in step[:bar]), name
+        assert in_loop in (1, 2), (name, in_loop)     # (two where the frame loop was unswitched)
+        checked += 1
+    assert checked == 12
