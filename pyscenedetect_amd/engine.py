@@ -686,10 +686,19 @@ class ScoringEngine(TapRowPolicy):
                     ready(batch[0], out[batch[0]])
                     continue
                 buf = self._scratch("clips", frames * stride)
+                # behind a downscale only the source rows that carry taps cross PCIe (288 of 1080 for the default 1080p -> 256 x 144),
+                # like SceneManager's feeder: the rows in between keep whatever the buffer held, nothing reads them
+                rows = self.tap_rows(h, w, factor, interpolation) if factor > 1.0 else None
                 first, off = [], 0
                 for j in batch:
                     c = np.ascontiguousarray(clips[j], dtype=np.uint8)
-                    buf.upload(c.reshape(-1), off * stride)
+                    if rows is not None:
+                        # the clip as one tall frame of n * h rows: where the row pattern continues across frames the whole clip is
+                        # a few strided copies (_score_host_downscaled)
+                        tall = (rows[None, :] + (np.arange(c.shape[0], dtype=np.int32) * h)[:, None]).reshape(-1)
+                        buf.upload_rows(c.reshape(c.shape[0] * h, w, 3), off * stride, tall)
+                    else:
+                        buf.upload(c.reshape(-1), off * stride)
                     first.append(off)
                     off += c.shape[0]
                 if factor > 1.0:

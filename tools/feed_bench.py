@@ -34,6 +34,14 @@ out["psd_score_batch_pinned_fps"] = round(N / best_of(lambda: eng.score_host(pin
 # the same entry point behind the default downscale (1080p -> 256 x 144): the stacked array travels as tap rows only
 out["score_host_downscaled_pageable_fps"] = round(N / best_of(lambda: eng.score_host(hf, flags=E.SCORE_HSV_SAD, downscale=7.5)), 1)
 out["score_host_downscaled_pinned_fps"] = round(N / best_of(lambda: eng.score_host(pinned, flags=E.SCORE_HSV_SAD, downscale=7.5)), 1)
+# round 6: the packed flow on clips in HOST memory (corpus.detect_corpus: three clips of 128 frames, AdaptiveDetector), behind the reference's
+# default downscale -- tap rows only -- and at full resolution (whole frames)
+from pyscenedetect_amd import corpus  # noqa: E402
+
+host_clips = [hf[0:128], hf[128:256], hf[256:384]]
+for name, auto in (("auto_downscale", True), ("full_res", False)):
+    out[f"detect_corpus_host_clips_{name}_pageable_fps"] = round(
+        N / best_of(lambda: corpus.detect_corpus(eng, host_clips, 25.0, {"adaptive": {}}, auto_downscale=auto)), 1)
 buf = eng.alloc(hf.nbytes)
 
 
