@@ -78,6 +78,8 @@ def score_clip(engine, clip, flags: int, edge_kernel: int = 0, downscale=None, i
     from pyscenedetect_amd.engine import downscale_size
 
     n, h, w, c = clip.shape
+    if n == 0:
+        return np.zeros(0, _native.RECORD_DTYPE)
     factor, dh, dw = downscale_size(h, w, downscale)
     if hasattr(clip, "data_ptr"):
         if c != 3 or not clip.is_contiguous():

@@ -266,3 +266,14 @@ def test_benchmark_harness_packed_equals_one_manager_per_video(tmp_path, oracle_
             c = corpus_golden()["clips"][name]
             cuts = c["cuts"][key]
             assert r["predicted_cuts"] == (cuts + [c["n"]] if cuts else []), (det, name)
+
+
+def test_empty_and_one_frame_clips(oracle_engine):
+    """A corpus may hold clips without frames and clips of one frame, behind the downscale as without it."""
+    rng = np.random.default_rng(0)
+    clips = [np.zeros((0, 360, 640, 3), np.uint8), rng.integers(0, 256, (3, 360, 640, 3), dtype=np.uint8),
+             rng.integers(0, 256, (1, 100, 100, 3), dtype=np.uint8)]
+    assert corpus.detect_corpus(oracle_engine, [], 25.0, CORPUS_DETECTORS) == []
+    for auto in (True, False):
+        res = corpus.detect_corpus(oracle_engine, clips, [25.0, 30.0, 24.0], CORPUS_DETECTORS, auto_downscale=auto)
+        assert res[0] == res[2] == {"content": [], "adaptive": [], "hist": [], "threshold": []} and set(res[1]) == set(CORPUS_DETECTORS)
