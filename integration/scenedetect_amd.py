@@ -16,6 +16,11 @@ stays the reference's code.  Only the C-ABI is touched: ``psd_create``, ``psd_sc
 host copy of the frame -- the reference keeps three HSV planes per detector for the same purpose, content_detector.py:189)
 on whatever shared library ``lib_path`` names (``pyscenedetect_amd/libpsd_hip.so`` on a machine with an MI355X).
 Nothing of ``pyscenedetect_amd`` is imported.
+
+``detect_many()`` is the batch front end of INTEGRATION.md B: what ``for video in dataset: detect(video, detector_cls())``
+(``benchmark/__main__.py:44-61``) computes, for decoded videos of one size packed into ONE device batch --
+``psd_score_segments_downscaled_device`` resizes every frame the way the reference's SceneManager does by default and scores it --
+with the decisions still taken by the reference's own detector objects, fed from the records through the same three seams.
 """
 
 import ctypes
@@ -48,9 +53,13 @@ class Binding:
                                                ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         lib.psd_hash_thumbs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
                                         ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        lib.psd_score_segments_downscaled_device.argtypes = [
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         self._lib = lib
         self._engine = ctypes.c_void_p()
         self._pairs = []
+        self.current = None      # replay mode (detect_many): (record, has a predecessor) of the frame the seams are asked about
         if lib.psd_create(device, ctypes.byref(self._engine)) != 0:
             raise RuntimeError(lib.psd_last_error().decode())
 
@@ -86,6 +95,42 @@ class Binding:
             raise (ValueError if rc == -1 else RuntimeError)(self._lib.psd_last_error().decode())
         return rec
 
+
+    def score_videos_downscaled(self, videos, dst_h: int, dst_w: int, flags: int, kernel: int = 0):
+        """Records of several decoded videos of ONE size (``uint8[n_i, H, W, 3]`` each), every frame resized to ``dst_w x dst_h`` with
+        INTER_LINEAR first: the videos are packed back to back into one device buffer and scored by ONE
+        ``psd_score_segments_downscaled_device`` call; returns one ``FrameScores`` array per video."""
+        h, w = videos[0].shape[1:3]
+        if any(v.dtype != np.uint8 or v.ndim != 4 or v.shape[1:] != (h, w, 3) for v in videos):
+            raise ValueError("videos must be uint8[n, H, W, 3] of one size")
+        stride = h * w * 3
+        counts = [int(v.shape[0]) for v in videos]
+        total = sum(counts)
+        first = np.cumsum([0] + counts[:-1]).astype(np.int32)
+        first = first[[c > 0 for c in counts]]                     # (a video without frames has no first frame)
+        first = np.ascontiguousarray(np.unique(first))
+        out = (FrameScores * max(total, 1))()
+        if total == 0:
+            return [out[0:0] for _ in videos]
+        d = ctypes.c_void_p()
+        self._check(self._lib.psd_device_alloc(self._engine, total * stride, ctypes.byref(d)))
+        try:
+            off = 0
+            for v in videos:
+                if v.shape[0]:
+                    v = np.ascontiguousarray(v)
+                    self._check(self._lib.psd_memcpy_h2d(self._engine, d.value + off * stride, v.ctypes.data, v.nbytes))
+                    off += v.shape[0]
+            self._check(self._lib.psd_score_segments_downscaled_device(
+                self._engine, d, total, h, w, stride, first.ctypes.data, len(first), int(dst_h), int(dst_w), 1, flags, kernel,
+                ctypes.byref(out), None))
+        finally:
+            self._lib.psd_device_free(self._engine, d)
+        parts, off = [], 0
+        for c in counts:
+            parts.append(out[off:off + c])
+            off += c
+        return parts
 
     def hash_thumb(self, frame: np.ndarray, size: int) -> np.ndarray:
         """``cv2.resize(cv2.cvtColor(frame, BGR2GRAY), (size, size), INTER_AREA)`` from the device (``psd_hash_thumbs``)."""
@@ -155,7 +200,7 @@ class _NumpyWithDeviceMean:
 
     def mean(self, a, *args, **kwargs):
         if not args and not kwargs and isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3:
-            rec = self._b.score(a, None, BYTE_SUM)
+            rec = self._b.current[0] if self._b.current is not None else self._b.score(a, None, BYTE_SUM)
             return np.float64(rec.byte_sum) / np.float64(a.size)        # integer-exact sum, one float64 divide
         return np.mean(a, *args, **kwargs)
 
@@ -174,10 +219,13 @@ def install(binding: Binding):
     def _calculate_frame_score(self, timecode, frame_img):
         calculate_edges = (self._weights.delta_edges > 0.0) or self.stats_manager is not None
         pair = getattr(self, "_amd_pair", None)
-        if pair is None:
+        if pair is None and binding.current is None:
             pair = self._amd_pair = binding.frame_pair()        # this detector's previous frame lives in HBM
         kernel = int(self._kernel.shape[0]) if self._kernel is not None else 0
-        rec, had_prev = pair.score_next(frame_img, HSV_SAD | (EDGES if calculate_edges else 0), kernel)
+        if binding.current is not None:      # detect_many: the record was computed with the batch
+            rec, had_prev = binding.current
+        else:
+            rec, had_prev = pair.score_next(frame_img, HSV_SAD | (EDGES if calculate_edges else 0), kernel)
         if not had_prev:
             return 0.0
         n = float(frame_img.shape[0] * frame_img.shape[1])
@@ -194,7 +242,7 @@ def install(binding: Binding):
         return frame_score
 
     def calculate_histogram(frame_img, bins: int = 256, normalize: bool = True):
-        rec = binding.score(frame_img, None, LUMA_HIST)
+        rec = binding.current[0] if binding.current is not None else binding.score(frame_img, None, LUMA_HIST)
         counts = np.frombuffer(rec.hist, dtype=np.uint32)
         # cv2.calcHist with `bins` uniform bins over [0, 256): value v falls into bin floor(v * bins / 256)
         lut = np.floor(np.arange(256) * (bins / 256.0)).astype(np.int64)
@@ -228,3 +276,46 @@ def install(binding: Binding):
         _ = content_detector, histogram_detector
 
     return uninstall
+
+
+def detect_many(binding: Binding, videos, make_detector, fps=25.0):
+    """Cut lists of several decoded videos of one size, computed as the reference's benchmark computes them one by one --
+    ``detect(video, detector_cls())`` (``benchmark/__main__.py:44-61``): a default SceneManager, i.e. every frame resized by
+    ``compute_downscale_factor(max(frame_size))`` (``scene_manager.py:123-140,525-528,666-678``), no StatsManager -- from ONE device batch.
+    ``install(binding)`` must be in effect.  The pixel work is one ``psd_score_segments_downscaled_device`` call; every decision is
+    taken by a fresh detector of the reference (``make_detector()``) fed frame by frame through ``process_frame`` / ``post_process``,
+    whose seams answer from the records.  Returns ``[[cut frame numbers], ...]`` as ``SceneManager.get_cut_list`` orders them."""
+    from scenedetect import FrameTimecode
+    from scenedetect.detectors import AdaptiveDetector, ContentDetector, HistogramDetector, ThresholdDetector
+    from scenedetect.scene_manager import compute_downscale_factor
+
+    h, w = videos[0].shape[1:3]
+    factor = compute_downscale_factor(max(w, h))
+    dst_h, dst_w = (max(1, round(h / factor)), max(1, round(w / factor))) if factor > 1.0 else (h, w)
+    probe = make_detector()
+    if isinstance(probe, (ContentDetector, AdaptiveDetector)):
+        flags = HSV_SAD | (EDGES if probe._weights.delta_edges > 0.0 else 0)
+        kernel = int(probe._kernel.shape[0]) if probe._kernel is not None else 0
+    elif isinstance(probe, HistogramDetector):
+        flags, kernel = LUMA_HIST, 0
+    elif isinstance(probe, ThresholdDetector):
+        flags, kernel = BYTE_SUM, 0
+    else:
+        raise TypeError("detect_many drives Content / Adaptive / Histogram / Threshold detectors")
+    records = binding.score_videos_downscaled(videos, dst_h, dst_w, flags, kernel)
+    seen = np.empty((dst_h, dst_w, 3), np.uint8)       # what a detector is handed: only its shape and dtype are looked at (the seams answer)
+    out = []
+    try:
+        for video, recs in zip(videos, records):
+            det = make_detector()
+            cuts, tc = [], None
+            for t in range(video.shape[0]):
+                binding.current = (recs[t], t > 0)
+                tc = FrameTimecode(t, fps)
+                cuts += det.process_frame(tc, seen)
+            if tc is not None:
+                cuts += det.post_process(tc)
+            out.append(sorted({int(c.frame_num) for c in cuts}))
+    finally:
+        binding.current = None
+    return out

@@ -296,3 +296,41 @@ int psd_allgather_scores(psd_comm* c, const psd_frame_scores* d_local, int n_loc
 {
     return psd_allgather_host(c, d_local, n_local, sizeof(psd_frame_scores), counts, h_all);
 }
+
+/* ---- many clips packed in one batch behind the downscale (psd_score_segments_downscaled_device), on the oracle --------------------
+ * cv2.resize(frame, (dst_w, dst_h), INTER_LINEAR) per frame (oracle restatement), then the terms per clip with no predecessor for
+ * a clip's first frame: what n_seg SceneManagers with auto_downscale compute (scene_manager.py:666-678 + the detectors).  The CPU
+ * build of the entry point the batch front end of INTEGRATION.md B binds; INTER_LINEAR only (the reference's default). */
+void orc_resize_linear_u8(const uint8_t* src, size_t sstep, int sh, int sw, int cn, uint8_t* dst, size_t dstep, int dh, int dw);
+
+int psd_score_segments_downscaled_device(psd_engine* e, const uint8_t* d_frames, int n, int src_h, int src_w, size_t frame_stride,
+                                         const int32_t* seg_first, int n_seg, int dst_h, int dst_w, int interpolation, uint32_t flags,
+                                         int edge_kernel, psd_frame_scores* out, void* stream)
+{
+    (void)stream;
+    if (!e || n < 0 || src_h <= 0 || src_w <= 0 || dst_h <= 0 || dst_w <= 0 || (n > 0 && (!d_frames || !out)) || n_seg < 0 ||
+        (n_seg > 0 && !seg_first) || flags == 0 || (flags & ~(uint32_t)PSD_SCORE_ALL)) {
+        snprintf(g_err, sizeof g_err, "psd_score_segments_downscaled_device: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    for (int i = 0; i < n_seg; i++)
+        if (seg_first[i] < 0 || seg_first[i] >= n || (i > 0 && seg_first[i] <= seg_first[i - 1])) {
+            snprintf(g_err, sizeof g_err, "segment table must hold ascending frame indices inside the batch (entry %d = %d, n = %d)", i, seg_first[i], n);
+            return PSD_ERR_INVALID;
+        }
+    if (interpolation != PSD_INTER_LINEAR) { snprintf(g_err, sizeof g_err, "the CPU build resizes with INTER_LINEAR only"); return PSD_ERR_UNSUPPORTED; }
+    if (n == 0) return PSD_OK;
+    const size_t small = (size_t)dst_h * dst_w * 3;
+    uint8_t* buf = (uint8_t*)malloc(small * (size_t)n);
+    if (!buf) return PSD_ERR_NOMEM;
+    for (int t = 0; t < n; t++)
+        orc_resize_linear_u8(d_frames + (size_t)t * frame_stride, (size_t)src_w * 3, src_h, src_w, 3, buf + (size_t)t * small, (size_t)dst_w * 3, dst_h, dst_w);
+    int rc = PSD_OK, a = 0;
+    for (int i = 0; i <= n_seg && rc == PSD_OK; i++) {      /* clips: [0, first[0]), [first[0], first[1]), ... (frame 0 starts one either way) */
+        const int b = i < n_seg ? seg_first[i] : n;
+        if (b > a) rc = psd_score_batch(e, buf + (size_t)a * small, b - a, dst_h, dst_w, (size_t)dst_w * 3, small, NULL, flags, edge_kernel, out + a);
+        a = b;
+    }
+    free(buf);
+    return rc;
+}

@@ -56,3 +56,28 @@ def test_same_records_through_the_same_binding():
     gpu.close()
     cpu.close()
     assert ctypes.sizeof(B.FrameScores) == 1064
+
+
+def test_batch_front_end_gets_the_same_records_from_both_libraries():
+    """INTEGRATION.md B's batch front end (``Binding.score_videos_downscaled`` -> ``psd_score_segments_downscaled_device``): the golden
+    corpus' videos of one size packed into one device batch behind the reference's default downscale -- byte-identical records from
+    ``libpsd_hip.so`` and from the oracle-backed build, which is the library ``tests/test_reference_binding.py`` drives under the
+    unmodified reference in the build container (there the decisions come out as the reference's own cut lists)."""
+    sys.path.insert(0, os.path.join(ROOT, "integration"))
+    import scenedetect_amd as B
+
+    from tests._helpers import corpus_clip
+
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "libpsd_oracle_abi.so"])
+    gpu = B.Binding(os.path.join(ROOT, "pyscenedetect_amd", "libpsd_hip.so"))
+    cpu = B.Binding(os.path.join(ROOT, "oracle", "libpsd_oracle_abi.so"))
+    for group, (dh, dw) in ((("bbc_a", "bbc_b", "bbc_c", "noisy_a"), (144, 256)), (("hd_b",), (144, 256)), (("odd_a",), (142, 256)),
+                            (("small_a",), (120, 200))):
+        videos = [corpus_clip(k) for k in group] + [np.zeros((0,) + corpus_clip(group[0]).shape[1:], np.uint8)]     # ... and one without frames
+        for flags in (B.HSV_SAD, B.LUMA_HIST, B.BYTE_SUM, B.HSV_SAD | B.LUMA_HIST | B.BYTE_SUM):
+            a, b = gpu.score_videos_downscaled(videos, dh, dw, flags), cpu.score_videos_downscaled(videos, dh, dw, flags)
+            assert [len(x) for x in a] == [len(v) for v in videos]
+            for k, (x, y) in enumerate(zip(a, b)):
+                assert len(x) == len(y) and all(bytes(p) == bytes(q) for p, q in zip(x, y)), (group, flags, k)
+    gpu.close()
+    cpu.close()

@@ -48,6 +48,7 @@ def patched_reference():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gen_golden  # the reference-side MemoryStream / run() that produced the goldens
 
+    gen_golden.amd = (scenedetect_amd, binding)      # (for the tests that drive the binding's own entry points)
     yield gen_golden
     undo()
     binding.close()
@@ -151,3 +152,33 @@ def test_bound_hash_detector_takes_its_thumbnails_from_the_c_abi(patched_referen
         assert len(calls) == n_calls                       # the plain run did not touch the binding
         assert bound == plain and len(bound[0]) >= 2, kw
         calls.clear()
+
+
+@pytest.mark.parametrize("group", [("bbc_a", "bbc_b", "bbc_c", "noisy_a"), ("qhd_a",), ("odd_a",), ("portrait_a",), ("small_a",), ("edge_a",)])
+def test_batch_front_end_over_the_c_abi_gives_the_references_cut_lists(patched_reference, group):
+    """INTEGRATION.md B's batch front end, executed: ``scenedetect_amd.detect_many`` packs decoded videos of one size into one device
+    batch, takes their records from ONE ``psd_score_segments_downscaled_device`` call (every frame resized as the reference's
+    SceneManager does by default) and lets the UNMODIFIED reference's own detector objects decide from them -- and returns the cut
+    lists ``detect(video, detector_cls())`` returned for every video (``tests/golden/corpus_default_pipeline.json``, generated by the
+    unpatched reference), for all four detectors: 640 x 360 (four videos in one batch), 960 x 540, 486 x 270, portrait, a size that is
+    not resized at all and one that is resized by 0.4 %."""
+    from scenedetect.detectors import AdaptiveDetector, ContentDetector, HistogramDetector, ThresholdDetector
+
+    from tests._helpers import corpus_clip, corpus_golden
+
+    amd, binding = patched_reference.amd
+    videos = [corpus_clip(k) for k in group]
+    makers = {"content": ContentDetector, "adaptive": lambda: AdaptiveDetector(window_width=2, min_content_val=15.0),
+              "hist": HistogramDetector, "threshold": ThresholdDetector}
+    for key, make in makers.items():
+        got = amd.detect_many(binding, videos, make, fps=25.0)
+        for name, cuts in zip(group, got):
+            assert cuts == corpus_golden()["clips"][name]["cuts"][key], (key, name)
+    assert binding.current is None
+    # ... and the per-frame seams still work afterwards (the replay mode is off again)
+    import scenedetect
+
+    sm = scenedetect.SceneManager()
+    sm.add_detector(ContentDetector())
+    sm.detect_scenes(patched_reference.MemoryStream(videos[0], 25.0))
+    assert [c.frame_num for c in sm.get_cut_list(show_warning=False)] == corpus_golden()["clips"][group[0]]["cuts"]["content"]
