@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <vector>
 
@@ -255,7 +256,16 @@ __device__ __forceinline__ u32 interp(u32 p00, u32 p01, u32 p10, u32 p11, int a0
     return (u32)(((mul_i24(b0, h0 >> 4) >> 16) + (mul_i24(b1, h1 >> 4) >> 16) + 2) >> 2) & 0xffu;
 }
 
-constexpr int RS_WG = 256, RS_NW = 4, RS_SLOTS = 16, RS_REP = 16;
+#ifndef PSD_RS_WG
+#define PSD_RS_WG 256
+#endif
+#ifndef PSD_RS_SWAP
+#define PSD_RS_SWAP 0
+#endif
+#ifndef PSD_RS_HUE_SELECT
+#define PSD_RS_HUE_SELECT 0
+#endif
+constexpr int RS_WG = PSD_RS_WG, RS_NW = RS_WG / 64, RS_SLOTS = 16, RS_REP = 16;
 // copies of a tile's luma histogram (lane l counts into copy l % RS_HREP).  Neighbouring pixels of a natural frame share their
 // luma, and the lanes of ONE ds_add_u32 that hit the same word are served one after the other -- which cost the score kernels up
 // to 40 % on constant frames until they got 16 copies (psd_score_kernels.hip, round 4).  Not here: 1 / 4 / 8 copies measure the
@@ -360,7 +370,16 @@ __device__ __forceinline__ void rs_hsv(u32 b, u32 g, u32 r, const u32* lut_s, co
     __builtin_assume(ls < (1u << 24) && lh < (1u << 21) && diff <= 255u);  // (24-bit factors: v_mad_u32_u24 / v_mad_i32_i24)
     s = (diff * ls + (2048u << 4)) >> 16;
     const int d = (int)diff;
+#if PSD_RS_HUE_SELECT
+    // without branches: hipcc turns the nested ?: into two divergent branches per pixel (all three arms run in any wave that
+    // holds all three cases, plus eight scalar exec-mask instructions)
+    const int c0 = (int)g - (int)b, c1 = (int)b - (int)r + 2 * d, c2 = (int)r - (int)g + 4 * d;
+    int c12, hraw;
+    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %4, vcc" : "=v"(c12) : "v"(v), "v"(g), "v"(c2), "v"(c1) : "vcc");
+    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %4, vcc" : "=v"(hraw) : "v"(v), "v"(r), "v"(c12), "v"(c0) : "vcc");
+#else
     const int hraw = v == r ? (int)g - (int)b : v == g ? (int)b - (int)r + 2 * d : (int)r - (int)g + 4 * d;
+#endif
     __builtin_assume(hraw >= -2048 && hraw < 2048);                        // (|hraw| <= 1275)
     const int hh = (hraw * (int)lh + (2048 << 4)) >> 16;
     h = min((u32)hh, (u32)(hh + 180));                                     // hh in [-90, 179]: the negative ones wrap by + 180
@@ -494,7 +513,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     if constexpr (SEG) {
         if (tb < t1 && tb >= 0) seg_next = p.seg[tb];
     }
-    for (int t = tb; t < t1; t++) {
+    auto frame_step = [&](const int t, const auto& ph, const auto& ps, const auto& pv, auto& nh, auto& ns, auto& nv) {
         const int step = t - tb;
         const int buf = ahead > 1 ? step % 3 : (step & 1);
         if (ahead > 1 && t + 1 < t1) {
@@ -592,7 +611,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
                         ss = __builtin_amdgcn_sad_u16(s, ps[g], ss);
                         sv = __builtin_amdgcn_sad_u16(v, pv[g], sv);
                     }
-                    ph[g] = h; ps[g] = s; pv[g] = v;
+                    nh[g] = h; ns[g] = s; nv[g] = v;
                 }
             }
         }
@@ -606,7 +625,21 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         if (LUMA) {
             if (count_luma) rs_lds_add(s4 + 3 * RS_REP, bsum);
         }
+    };
+#if PSD_RS_SWAP
+    // two steps per trip with the two H, S, V register sets swapped: "previous = current" is a renaming instead of 3 G v_mov_b32 per
+    // frame (hipcc does not rotate registers across the back edge of a loop that holds inline asm and a barrier; psd_score_kernels.hip,
+    // round 3)
+    u32 qh[HSV ? G : 1], qs[HSV ? G : 1], qv[HSV ? G : 1];
+#pragma unroll
+    for (int g = 0; g < (HSV ? G : 1); g++) qh[g] = qs[g] = qv[g] = 0;
+    for (int t = tb; t < t1; t += 2) {
+        frame_step(t, ph, ps, pv, qh, qs, qv);
+        if (t + 1 < t1) frame_step(t + 1, qh, qs, qv, ph, ps, pv);
     }
+#else
+    for (int t = tb; t < t1; t++) frame_step(t, ph, ps, pv, ph, ps, pv);
+#endif
     if (HSV || LUMA) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
@@ -679,24 +712,39 @@ __global__ __launch_bounds__(256) void resize_linear_generic_kernel(const uint8_
 }
 
 template <bool STORE, bool HSV, bool LUMA, bool SEG>
-static void launch_walk_g(const RsParams& p, int g, int grid, size_t lds, hipStream_t stream)
+static const void* walk_fn_g(int g)
 {
     switch (g) {
-    case 1: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 1, LUMA, SEG>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
-    case 2: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 2, LUMA, SEG>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
-    case 4: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 4, LUMA, SEG>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
-    default: hipLaunchKernelGGL((resize_walk_kernel<STORE, HSV, 8, LUMA, SEG>), dim3(grid), dim3(RS_WG), lds, stream, p); break;
+    case 1: return reinterpret_cast<const void*>(&resize_walk_kernel<STORE, HSV, 1, LUMA, SEG>);
+    case 2: return reinterpret_cast<const void*>(&resize_walk_kernel<STORE, HSV, 2, LUMA, SEG>);
+    case 4: return reinterpret_cast<const void*>(&resize_walk_kernel<STORE, HSV, 4, LUMA, SEG>);
+    default: return reinterpret_cast<const void*>(&resize_walk_kernel<STORE, HSV, 8, LUMA, SEG>);
     }
 }
 
 template <bool STORE, bool HSV, bool LUMA = false>
-static void launch_walk(const RsParams& p, int g, int grid, size_t lds, hipStream_t stream)
+static const void* walk_fn(bool seg, int g)
 {
     // (the clip-start flags only matter to the HSV carry: instances without the HSV term have no SEG form)
     if constexpr (HSV) {
-        if (p.seg != nullptr) { launch_walk_g<STORE, HSV, LUMA, true>(p, g, grid, lds, stream); return; }
+        if (seg) return walk_fn_g<STORE, HSV, LUMA, true>(g);
     }
-    launch_walk_g<STORE, HSV, LUMA, false>(p, g, grid, lds, stream);
+    return walk_fn_g<STORE, HSV, LUMA, false>(g);
+}
+
+// Resident workgroups per CU of one instance with `lds` bytes of staging (the runtime's own occupancy figure: registers, LDS
+// -- static + dynamic -- and wave slots), asked once per (instance, lds).
+static int walk_blocks_per_cu(const void* fn, size_t lds)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void*, size_t>, int> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = seen.find({fn, lds});
+    if (it != seen.end()) return it->second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, RS_WG, lds) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+    seen[{fn, lds}] = nb;
+    return nb;
 }
 
 // cv2.resize(INTER_LINEAR) of n frames and / or the HSV term of the resized frames.
@@ -771,15 +819,32 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     const int g = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : per_thread <= 4 ? 4 : 8;
     p.rows_per_tile = R;
     p.n_tiles = (dst_h + R - 1) / R;
-    // time chunks: enough workgroups for every CU several times over, walks long enough that the halo frame stays small
-    const int target = engine_num_cus(e) * 12;
-    int chunks = (target + p.n_tiles - 1) / p.n_tiles;
+    const size_t lds = (size_t)p.depth * 2 * R * p.row_pad + 16;      // (+ 16: a tap read of 8 bytes at the end of the last staged row)
+    const bool seg = d_seg != nullptr;
+    const void* fn = (d_dst && want_hsv) ? walk_fn<true, true>(seg, g) : (want_hsv && want_luma) ? walk_fn<false, true, true>(seg, g)
+                     : want_luma ? walk_fn<false, false, true>(seg, g) : want_hsv ? walk_fn<false, true>(seg, g) : walk_fn<true, false>(seg, g);
+    // Time chunks.  The workgroups of a launch all take about the same time, so it runs in ROUNDS of as many workgroups as the
+    // chip holds at once (CUs x the instance's occupancy), and a last round that is 2 % full takes as long as a full one.  Until
+    // round 6 the count was "12 workgroups per CU" rounded UP to whole chunks per tile: 3096 workgroups for 3072 slots at 640 x
+    // 360 (4 per CU, 3.02 rounds) and 6.05 rounds at 1080p (2 per CU) -- a nearly empty round at the end of every launch.  Now:
+    // whole rounds, rounded DOWN to whole chunks per tile; walks long enough that the halo frame stays small.
+    const int capacity = engine_num_cus(e) * walk_blocks_per_cu(fn, lds);
+    static const int rounds_env = [] { const char* v = getenv("PSD_RESIZE_ROUNDS"); return v ? atoi(v) : -1; }();   // experiments; 0 = the old rule
+    int chunks;
+    if (rounds_env == 0) {
+        const int target = engine_num_cus(e) * 12;
+        chunks = (target + p.n_tiles - 1) / p.n_tiles;
+    } else {
+        // six rounds: 640 x 360 (4 workgroups per CU) 0.64-0.66 of peak under the old rule, 0.69-0.70 with 3 whole rounds, 0.71 with
+        // 6, 0.72 with 8; 1080p (2 per CU) 0.79 / 0.80 / 0.82 / 0.80-0.81 (profiles/r06_r_ab_resize_whole_rounds.txt)
+        const int rounds = rounds_env > 0 ? rounds_env : 6;
+        chunks = (int)(((long)rounds * capacity) / p.n_tiles);
+    }
     if (want_hsv) { const int by_walk = (n + 31) / 32; if (chunks > by_walk) chunks = by_walk; }
     if (chunks > n) chunks = n;
     if (chunks < 1) chunks = 1;
     p.frames_per_chunk = (n + chunks - 1) / chunks;
     chunks = (n + p.frames_per_chunk - 1) / p.frames_per_chunk;
-    const size_t lds = (size_t)p.depth * 2 * R * p.row_pad + 16;      // (+ 16: a tap read of 8 bytes at the end of the last staged row)
     const int grid = p.n_tiles * chunks;
     if (want_hsv) note_walk_geometry(p.frames_per_chunk, p.n_tiles);
     if (want_luma) {
@@ -788,11 +853,10 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
         if (rc != PSD_OK) return rc;
         p.hpart = static_cast<u32*>(scratch);
     }
-    if (d_dst && want_hsv) launch_walk<true, true>(p, g, grid, lds, stream);
-    else if (want_hsv && want_luma) launch_walk<false, true, true>(p, g, grid, lds, stream);
-    else if (want_luma) launch_walk<false, false, true>(p, g, grid, lds, stream);
-    else if (want_hsv) launch_walk<false, true>(p, g, grid, lds, stream);
-    else launch_walk<true, false>(p, g, grid, lds, stream);
+    {
+        void* args[] = {&p};
+        HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3(RS_WG), args, lds, stream));
+    }
     HIP_TRY(hipGetLastError());
     if (launches) *launches += 1;
     if (want_luma) {
