@@ -239,6 +239,7 @@ struct RsParams {
     const YTap* yt;
     int n, rows_per_tile, n_tiles, frames_per_chunk, row_pad;
     int area2;
+    int store_vec;           // STORE: a tile's pixels leave through LDS as 16-byte stores (whole, 16-byte aligned tiles), else byte stores
     int depth;               // staging buffers: 2 = one frame ahead, 3 = two frames ahead
     u32* hpart;              // LUMA: per (frame, tile) partial luma histograms, 128 words of two 16-bit counts (bins 2i | 2i+1 << 16)
 };
@@ -403,6 +404,14 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     __shared__ __attribute__((aligned(16))) u32 sums[RS_SLOTS][4][RS_REP];
     __shared__ __attribute__((aligned(16))) u32 lhist[LUMA ? 2 : 1][LUMA ? RS_HREP * 256 : 1];     // [slot][copy][bin]
     __shared__ int srows[64];           // clamped source rows of this tile: slot 2 * lr + k
+    // STORE: the tile's resized pixels of frame t (whole destination rows: ONE contiguous run of the frame) collect here and leave
+    // one barrier later as 16-byte stores, two slots taking turns: a third of the store instructions of three byte stores per pixel,
+    // 1 % of the kernel's time.  What makes the storing instance 40 % slower than the one that converts to HSV and scores (1.40
+    // against 1.02 ms per 4096 x 1080p -> 256 x 144; 0.96 ms with the stores taken out) is the WRITE TRAFFIC ITSELF: 453 MB in 295 k
+    // runs of 1.5 KB between 6.8 GB of streaming reads cost 0.44 ms whatever the instruction (bytes, dwordx4) and cache policy (nt,
+    // sc0, sc1, sc0 sc1: 1.34-1.41 ms) -- about 1 ms per GB written, where the 2 MB-per-frame V plane of the full-resolution edge
+    // front end costs 0.08 (profiles/r06_u_resize_store_cost.txt).
+    __shared__ __attribute__((aligned(16))) uint8_t obuf[STORE ? 2 : 1][STORE ? RS_WG * G * 3 : 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x % p.n_tiles, chunk = blockIdx.x / p.n_tiles;
     const int r0 = tile * p.rows_per_tile;
@@ -513,6 +522,11 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     if constexpr (SEG) {
         if (tb < t1 && tb >= 0) seg_next = p.seg[tb];
     }
+    auto store_tile = [&](int t, int slot) {
+        const uint4* from = reinterpret_cast<const uint4*>(obuf[slot]);
+        uint4* to = reinterpret_cast<uint4*>(p.dst + (size_t)t * p.dstride + (size_t)r0 * p.dw * 3);
+        for (int i = tid; i < (npx * 3) >> 4; i += RS_WG) to[i] = from[i];
+    };
     auto frame_step = [&](const int t, const auto& ph, const auto& ps, const auto& pv, auto& nh, auto& ns, auto& nv) {
         const int step = t - tb;
         const int buf = ahead > 1 ? step % 3 : (step & 1);
@@ -528,7 +542,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        if (HSV || LUMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's hidden LDS increments of frame t-1
+        if (HSV || LUMA || STORE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's hidden LDS increments / pixel bytes of frame t-1
         u32 flag_now = 0;
         if constexpr (SEG) {
             flag_now = __builtin_amdgcn_readfirstlane(seg_next);
@@ -571,6 +585,9 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             }
             p.hpart[((size_t)(t - 1) * p.n_tiles + tile) * 128 + tid] = lo | (hi << 16);
         }
+        if (STORE && rel >= 1) {
+            if (p.store_vec) store_tile(t - 1, (rel - 1) & 1);       // frame t-1's pixels are complete (every wave wrote them before this barrier)
+        }
         const uint8_t* base = rs_stage + (size_t)buf * buf_bytes;
         u32 sh = 0, ss = 0, sv = 0, bsum = 0;
         const bool count_luma = LUMA && t >= t0;           // (the halo frame only feeds the HSV carry)
@@ -592,8 +609,15 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
                 if (p.area2) rs_interp<true>(taps[i], px[g].off, px[g], c);
                 else rs_interp<false>(taps[i], px[g].off, px[g], c);
                 if (STORE && t >= t0 && live[g]) {
-                    uint8_t* d = p.dst + (size_t)t * p.dstride + dst_off[g];
-                    d[0] = (uint8_t)c[0]; d[1] = (uint8_t)c[1]; d[2] = (uint8_t)c[2];
+                    if (p.store_vec) {
+                        // (stores the compiler does not see, like rs_lds_add: a visible LDS store waits for the next frame's staging)
+                        const u32 o = (u32)(uintptr_t)&obuf[rel & 1][(g * RS_WG + tid) * 3];
+                        asm volatile("ds_write_b8 %0, %1\n\tds_write_b8 %0, %2 offset:1\n\tds_write_b8 %0, %3 offset:2"
+                                     ::"v"(o), "v"(c[0]), "v"(c[1]), "v"(c[2]) : "memory");
+                    } else {
+                        uint8_t* d = p.dst + (size_t)t * p.dstride + dst_off[g];
+                        d[0] = (uint8_t)c[0]; d[1] = (uint8_t)c[1]; d[2] = (uint8_t)c[2];
+                    }
                 }
                 if (LUMA) {
                     if (count_luma) {
@@ -640,6 +664,13 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
 #else
     for (int t = tb; t < t1; t++) frame_step(t, ph, ps, pv, ph, ps, pv);
 #endif
+    if (STORE) {
+        if (p.store_vec && t1 > t0) {                  // the chunk's last frame
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            store_tile(t1 - 1, (t1 - 1 - t0) & 1);
+        }
+    }
     if (HSV || LUMA) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
@@ -817,6 +848,9 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
         return PSD_OK;
     }
     const int g = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : per_thread <= 4 ? 4 : 8;
+    // (every tile is whole rows, so it is one run of the frame; 16-byte stores when every such run starts and ends on 16 bytes)
+    static const int store_env = [] { const char* v = getenv("PSD_RESIZE_STORE_VEC"); return v ? atoi(v) : 1; }();
+    p.store_vec = (d_dst && store_env && (dst_w * 3) % 16 == 0 && (uintptr_t)d_dst % 16 == 0 && (dst_frame_stride % 16 == 0 || n == 1)) ? 1 : 0;
     p.rows_per_tile = R;
     p.n_tiles = (dst_h + R - 1) / R;
     const size_t lds = (size_t)p.depth * 2 * R * p.row_pad + 16;      // (+ 16: a tap read of 8 bytes at the end of the last staged row)
