@@ -629,6 +629,89 @@ void orc_resize_nearest_u8(const uint8_t* src, size_t sstep, int sh, int sw, int
     }
 }
 
+/* ---------------------------------------------------------------------------
+ * cv2.resize(INTER_LANCZOS4), 8-bit, cn channels (scene_manager.py:670-678 with Interpolation.LANCZOS4, common.py:148-160).
+ * resize.cpp, the generic path (lanczos4_tab[CV_8U] = resizeGeneric_<HResizeLanczos4<uchar, int, short>,
+ * VResizeLanczos4<uchar, int, short, FixedPtCast<int, uchar, INTER_RESIZE_COEF_BITS * 2>, VResizeNoVec>>): everything behind the
+ * coefficients is INTEGER arithmetic -- no SIMD vertical pass (VResizeNoVec; unlike INTER_CUBIC, whose 8-bit vertical pass is
+ * float32 SIMD and which x86 wheels hand to IPP) and no IPP branch (ipp_resize takes NEAREST / LINEAR / CUBIC / AREA only):
+ *   fx = (float)((dx + 0.5) * scale_x - 0.5);  sx = cvFloor(fx);  fx -= sx;          (the taps are source columns sx-3 .. sx+4)
+ *   interpolateLanczos4(fx, cbuf);  ialpha[k] = saturate_cast<short>(cbuf[k] * 2048)  (cvRound: to nearest even)
+ *   rows likewise from fy;  a tap outside the image is the nearest pixel inside (HResizeLanczos4's while loops, clip() on rows);
+ *   D = sum_j S[sx - 3 + j] * alpha[j]  (int);   dst = saturate_cast<uchar>((sum_k D_k * beta[k] + (1 << 21)) >> 22).
+ * interpolateLanczos4 (imgproc/src/resize.cpp / imgwarp.cpp, OpenCV 4.x): the eight weights are sin(y) sin(y / 4) / y^2-shaped
+ * values at the taps' distances, y = -(x + 3 - i) pi / 4, evaluated through the angle-sum table cs[][] from ONE sin / cos pair in
+ * double, cast to float, a tap at distance < 1e-6 takes the weight 1e30 (so it becomes 1 after the normalisation), normalised by
+ * their float sum.  (OpenCV 3.x returned (0,0,0,1,0,0,0,0) for x < FLT_EPSILON instead: the same shorts.)
+ * ------------------------------------------------------------------------- */
+static void lanczos4_coeffs(float x, float* coeffs)
+{
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    const double pi = 3.1415926535897932384626433832795;
+    float sum = 0;
+    double y0 = -(x + 3) * pi * 0.25, s0 = sin(y0), c0 = cos(y0);
+    for (int i = 0; i < 8; i++) {
+        float y0_ = (x + 3 - i);
+        if (fabsf(y0_) >= 1e-6f) {
+            double y = -y0_ * pi * 0.25;
+            coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        } else {
+            coeffs[i] = 1e30f;
+        }
+        sum += coeffs[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++) coeffs[i] *= sum;
+}
+
+/* the taps of one axis: first[d] = s - 3 (not clamped), coef[8 d .. 8 d + 7] */
+void orc_lanczos4_taps(int ssize, int dsize, int* first, short* coef)
+{
+    double scale = 1. / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        float cbuf[8];
+        lanczos4_coeffs(f, cbuf);
+        first[d] = s - 3;
+        for (int k = 0; k < 8; k++) coef[8 * d + k] = sat_s16_round(cbuf[k] * 2048);
+    }
+}
+
+void orc_resize_lanczos4_u8(const uint8_t* src, size_t sstep, int sh, int sw, int cn, uint8_t* dst, size_t dstep, int dh, int dw)
+{
+    int* xf = (int*)malloc(sizeof(int) * dw);
+    int* yf = (int*)malloc(sizeof(int) * dh);
+    short* xa = (short*)malloc(sizeof(short) * 8 * dw);
+    short* yb = (short*)malloc(sizeof(short) * 8 * dh);
+    orc_lanczos4_taps(sw, dw, xf, xa);
+    orc_lanczos4_taps(sh, dh, yf, yb);
+    int* rows = (int*)malloc(sizeof(int) * 8 * (size_t)dw * cn);
+    for (int dy = 0; dy < dh; dy++) {
+        for (int k = 0; k < 8; k++) {
+            const uint8_t* S = src + (size_t)clampi(yf[dy] + k, 0, sh - 1) * sstep;
+            int* D = rows + (size_t)k * dw * cn;
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    int v = 0;
+                    for (int j = 0; j < 8; j++) v += S[(size_t)clampi(xf[dx] + j, 0, sw - 1) * cn + c] * xa[8 * dx + j];
+                    D[dx * cn + c] = v;
+                }
+        }
+        uint8_t* D = dst + (size_t)dy * dstep;
+        for (int x = 0; x < dw * cn; x++) {
+            /* (unsigned: the sum of the eight products may pass 2^31 on the way; what OpenCV's int arithmetic leaves is the low 32 bits) */
+            uint32_t v = 0;
+            for (int k = 0; k < 8; k++) v += (uint32_t)rows[(size_t)k * dw * cn + x] * (uint32_t)(int32_t)yb[8 * dy + k];
+            int r = ((int32_t)(v + (1u << 21))) >> 22;
+            D[x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+        }
+    }
+    free(rows); free(xf); free(yf); free(xa); free(yb);
+}
+
 /* Orthonormal 2-D DCT-II of an n x n float32 block: out = C * in * C^T,
  * C[0][j] = sqrt(1/n), C[k][j] = sqrt(2/n) * cos(pi*(2j+1)*k/(2n)).  Only the top-left keep x keep block is produced. */
 void orc_dct2d_f32(const float* in, int n, int keep, float* out)

@@ -137,8 +137,12 @@ def resize(src, dsize, interpolation=INTER_LINEAR):
     if interpolation == INTER_NEAREST:
         _orc.lib().orc_resize_nearest_u8(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw)
         return dst
+    if interpolation == INTER_LANCZOS4:
+        _orc.lib().orc_resize_lanczos4_u8(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw)
+        return dst
     if interpolation != INTER_LINEAR:
-        raise NotImplementedError("cv2 shim: INTER_LINEAR, INTER_NEAREST and INTER_AREA only")
+        raise NotImplementedError("cv2 shim: INTER_LINEAR, INTER_NEAREST, INTER_AREA and INTER_LANCZOS4 only (INTER_CUBIC's 8-bit "
+                                  "result depends on the OpenCV build: IPP on x86 wheels, float32 SIMD elsewhere)")
     dst = np.empty((dh, dw) + (() if src.ndim == 2 else (cn,)), np.uint8)
     _orc.lib().orc_resize_linear_u8(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw)
     return dst

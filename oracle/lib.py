@@ -75,6 +75,10 @@ def lib() -> ctypes.CDLL:
         L.orc_resize_area_u8.argtypes = [vp, sz, i, i, vp, sz, i, i]
         L.orc_resize_area_u8_cn.argtypes = [vp, sz, i, i, i, vp, sz, i, i]
         L.orc_resize_nearest_u8.argtypes = [vp, sz, i, i, i, vp, sz, i, i]
+        L.orc_resize_lanczos4_u8.restype = None
+        L.orc_resize_lanczos4_u8.argtypes = [vp, sz, i, i, i, vp, sz, i, i]
+        L.orc_lanczos4_taps.restype = None
+        L.orc_lanczos4_taps.argtypes = [i, i, vp, vp]
         L.orc_dct2d_f32.argtypes = [vp, i, i, vp]
         L.orc_score_batch.argtypes = [vp, i, i, i, sz, sz, vp, vp]
         L.orc_score_batch_flags.argtypes = [vp, i, i, i, sz, sz, vp, vp, ctypes.c_uint]

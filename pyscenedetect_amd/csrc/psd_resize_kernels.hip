@@ -1019,24 +1019,115 @@ static void nearest_offsets(int src_h, int src_w, int dst_h, int dst_w, int* ofs
     for (int y = 0; y < dst_h; y++) ofs[dst_w + y] = std::min((int)floor(y * scale_y), src_h - 1);
 }
 
-// interpolation: 0 = INTER_NEAREST, 3 = INTER_AREA that shrinks along both axes (cv2's values)
+// ---- cv2.resize(INTER_LANCZOS4), 8-bit (Interpolation.LANCZOS4, common.py:148-160) -----------------------------------------
+// OpenCV's generic path for this filter is integer arithmetic behind the coefficient tables (resize.cpp: lanczos4_tab[CV_8U] =
+// HResizeLanczos4<uchar, int, short> + VResizeLanczos4<..., FixedPtCast<int, uchar, 22>, VResizeNoVec>; no IPP branch, no SIMD
+// vertical pass -- which is what keeps INTER_CUBIC refused: its 8-bit result depends on the build), so the device result is the
+// reference's: eight taps per axis at source positions s - 3 .. s + 4 (s = floor of (d + 0.5) * scale - 0.5 in float32), a tap
+// outside the image replaced by the nearest pixel inside, 11-bit coefficients
+//   D_k = sum_j S[row_k][col_j] * alpha[j]  (int32),   dst = saturate_u8((sum_k D_k * beta[k] + 2^21) >> 22)  (low 32 bits).
+struct LzTap { int first; short a[8]; };      // first = s - 3 (not clamped)
+
+// interpolateLanczos4 (OpenCV 4.x), the same float / double steps: the weights through the angle-sum table from one sin / cos pair
+// in double, cast to float, 1e30 for a tap at distance < 1e-6, normalised by their float32 sum
+static void lanczos4_coeffs(float x, float* coeffs)
+{
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    const double pi = 3.1415926535897932384626433832795;
+    float sum = 0;
+    const double y0 = -(x + 3) * pi * 0.25, s0 = sin(y0), c0 = cos(y0);
+    for (int i = 0; i < 8; i++) {
+        const float d = (x + 3 - i);
+        if (fabsf(d) >= 1e-6f) {
+            const double y = -d * pi * 0.25;
+            coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        } else {
+            coeffs[i] = 1e30f;
+        }
+        sum += coeffs[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++) coeffs[i] *= sum;
+}
+
+static void lanczos4_taps(int ssize, int dsize, LzTap* t)
+{
+    const double scale = 1. / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        const int s = (int)floorf(f);
+        f -= s;
+        float cbuf[8];
+        lanczos4_coeffs(f, cbuf);
+        t[d].first = s - 3;
+        for (int k = 0; k < 8; k++) t[d].a[k] = sat_s16_round(cbuf[k] * 2048);
+    }
+}
+
+// one destination pixel per thread: 8 x 8 taps x 3 channels.  Behind a 7.5-fold downscale neighbouring pixels share no taps, so
+// there is nothing to stage; the lanes of a wave read runs 22.5 bytes apart of the same eight source rows (whole cache lines).
+__global__ __launch_bounds__(kOtherWG) void resize_lanczos4_kernel(const uint8_t* src, int sh, int sw, size_t sstride, uint8_t* dst, int dh, int dw,
+                                                                   size_t dstride, const LzTap* xtab, const LzTap* ytab)
+{
+    const int p = blockIdx.x * kOtherWG + threadIdx.x;
+    if (p >= dh * dw) return;
+    const int dy = p / dw, dx = p - dy * dw;
+    const LzTap X = xtab[dx], Y = ytab[dy];
+    const uint8_t* S = src + (size_t)blockIdx.y * sstride;
+    const bool inner = X.first >= 0 && X.first + 7 < sw;
+    u32 acc[3] = {0u, 0u, 0u};      // (unsigned: the running sum may pass 2^31; OpenCV's int arithmetic keeps the low 32 bits as well)
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        const uint8_t* row = S + (size_t)min(max(Y.first + k, 0), sh - 1) * sw * 3;
+        int h[3] = {0, 0, 0};
+        if (inner) {
+            const uint8_t* q = row + (size_t)X.first * 3;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                h[0] += (int)q[3 * j] * X.a[j]; h[1] += (int)q[3 * j + 1] * X.a[j]; h[2] += (int)q[3 * j + 2] * X.a[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint8_t* q = row + (size_t)min(max(X.first + j, 0), sw - 1) * 3;
+                h[0] += (int)q[0] * X.a[j]; h[1] += (int)q[1] * X.a[j]; h[2] += (int)q[2] * X.a[j];
+            }
+        }
+        const u32 b = (u32)(int)Y.a[k];
+        acc[0] += (u32)h[0] * b; acc[1] += (u32)h[1] * b; acc[2] += (u32)h[2] * b;
+    }
+    uint8_t* D = dst + (size_t)blockIdx.y * dstride + (size_t)p * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int r = ((int)(acc[c] + (1u << 21))) >> 22;
+        D[c] = (uint8_t)min(255, max(0, r));
+    }
+}
+
+// interpolation: 0 = INTER_NEAREST, 3 = INTER_AREA that shrinks along both axes, 4 = INTER_LANCZOS4 (cv2's values)
 int resize_other(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
                  int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream)
 {
     if (n == 0) return PSD_OK;
-    if (interpolation != PSD_INTER_NEAREST && interpolation != PSD_INTER_AREA) {
-        psd_set_error("interpolation %d is not implemented on the device (0 = NEAREST, 1 = LINEAR, 3 = AREA)", interpolation);
+    if (interpolation != PSD_INTER_NEAREST && interpolation != PSD_INTER_AREA && interpolation != PSD_INTER_LANCZOS4) {
+        psd_set_error("interpolation %d is not implemented on the device (0 = NEAREST, 1 = LINEAR, 3 = AREA, 4 = LANCZOS4)", interpolation);
         return PSD_ERR_UNSUPPORTED;
     }
     if (interpolation == PSD_INTER_AREA && (dst_w > src_w || dst_h > src_h)) {
         psd_set_error("INTER_AREA run tables are for decimation (%dx%d -> %dx%d)", src_w, src_h, dst_w, dst_h);
         return PSD_ERR_UNSUPPORTED;
     }
-    const int kind = interpolation == PSD_INTER_NEAREST ? kTabNearest : kTabArea;
+    const int kind = interpolation == PSD_INTER_NEAREST ? kTabNearest : interpolation == PSD_INTER_LANCZOS4 ? kTabLanczos4 : kTabArea;
     DevTable tab;
     if (!table_find(e, kind, src_h, src_w, dst_h, dst_w, &tab)) {
         int rc;
-        if (kind == kTabNearest) {
+        if (kind == kTabLanczos4) {
+            std::vector<LzTap> t((size_t)dst_w + dst_h);
+            lanczos4_taps(src_w, dst_w, t.data());
+            lanczos4_taps(src_h, dst_h, t.data() + dst_w);
+            rc = table_store(e, kind, src_h, src_w, dst_h, dst_w, t.data(), t.size() * sizeof(LzTap), 0, 0.f, &tab);
+        } else if (kind == kTabNearest) {
             std::vector<int> ofs((size_t)dst_w + dst_h);
             nearest_offsets(src_h, src_w, dst_h, dst_w, ofs.data());
             rc = table_store(e, kind, src_h, src_w, dst_h, dst_w, ofs.data(), ofs.size() * sizeof(int), 0, 0.f, &tab);
@@ -1054,7 +1145,10 @@ int resize_other(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_
         const int cnt = n - t0 < 32768 ? n - t0 : 32768;
         const uint8_t* S = d_src + (size_t)t0 * src_frame_stride;
         uint8_t* D = d_dst + (size_t)t0 * dst_frame_stride;
-        if (kind == kTabNearest)
+        if (kind == kTabLanczos4)
+            hipLaunchKernelGGL(resize_lanczos4_kernel, dim3(blocks, cnt), dim3(kOtherWG), 0, stream, S, src_h, src_w, src_frame_stride, D, dst_h,
+                               dst_w, dst_frame_stride, (const LzTap*)tab.ptr, (const LzTap*)tab.ptr + dst_w);
+        else if (kind == kTabNearest)
             hipLaunchKernelGGL(resize_nearest_kernel, dim3(blocks, cnt), dim3(kOtherWG), 0, stream, S, src_w, src_frame_stride, D, dst_h,
                                dst_w, dst_frame_stride, (const int*)tab.ptr, (const int*)tab.ptr + dst_w);
         else
@@ -1088,8 +1182,13 @@ int resize_source_rows(int src_h, int src_w, int dst_h, int dst_w, int interpola
         area_tables(src_h, src_w, dst_h, dst_w, t.data(), &mode, &inv_area);
         for (int dy = 0; dy < dst_h; dy++)
             for (int j = 0; j < t[dst_w + dy].count; j++) used[std::min(src_h - 1, t[dst_w + dy].first + j)] = 1;
+    } else if (interpolation == PSD_INTER_LANCZOS4) {
+        std::vector<LzTap> t((size_t)dst_h);
+        lanczos4_taps(src_h, dst_h, t.data());
+        for (int dy = 0; dy < dst_h; dy++)
+            for (int k = 0; k < 8; k++) used[std::min(src_h - 1, std::max(0, t[dy].first + k))] = 1;
     } else {
-        psd_set_error("interpolation %d is not implemented on the device (0 = NEAREST, 1 = LINEAR, 3 = AREA)", interpolation);
+        psd_set_error("interpolation %d is not implemented on the device (0 = NEAREST, 1 = LINEAR, 3 = AREA, 4 = LANCZOS4)", interpolation);
         return PSD_ERR_UNSUPPORTED;
     }
     int k = 0;

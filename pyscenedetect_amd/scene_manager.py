@@ -59,9 +59,10 @@ DEFAULT_BATCH_FRAMES: int = 64
 
 class Interpolation(Enum):
     """Resize filters of the reference (``scenedetect/common.py:148-160``, values = OpenCV's ``INTER_*``).
-    LINEAR (the reference's default), NEAREST and AREA are implemented on the device.  CUBIC and LANCZOS4 are refused:
-    OpenCV's 8-bit vertical pass for them is float32 SIMD whose lane count, scalar tail and fused multiply-add use depend
-    on the build, so a device result could not be bit-identical to "the" reference."""
+    LINEAR (the reference's default), NEAREST, AREA and LANCZOS4 are implemented on the device (LANCZOS4 since round 6: OpenCV's
+    8-bit path for it is integer arithmetic behind its coefficient tables, so it has ONE result).  CUBIC is refused: OpenCV's
+    8-bit vertical pass for it is float32 SIMD whose lane count, scalar tail and fused multiply-add use depend on the build,
+    and x86 wheels hand it to IPP -- a device result could not be bit-identical to "the" reference."""
 
     NEAREST = 0
     LINEAR = 1
@@ -198,7 +199,7 @@ class SceneManager:
     @interpolation.setter
     def interpolation(self, value: Interpolation):
         value = Interpolation(value)
-        if value not in (Interpolation.LINEAR, Interpolation.NEAREST, Interpolation.AREA):
+        if value is Interpolation.CUBIC:
             raise NotImplementedError(f"Interpolation.{value.name} is not implemented on the device")
         self._interpolation = value
 

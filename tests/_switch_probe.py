@@ -60,6 +60,15 @@ def main():
     got = eng.score_device_downscaled(buf.ptr, len(big), 360, 640, 144, 256, flags=E.SCORE_ALL & ~E.SCORE_EDGES)
     same(got, w2, FIELDS[:4], "downscaled all")
     assert np.array_equal(got["hist"], w2["hist"]), "downscaled hist"
+    # ... with the edge term: the resized frames go through the engine's buffer (the storing instance of the downscale kernel)
+    w3 = oracle_score(small, edges=True)
+    same(eng.score_device_downscaled(buf.ptr, len(big), 360, 640, 144, 256, flags=E.SCORE_HSV_SAD | E.SCORE_EDGES), w3, FIELDS[:3] + ("edge_xor",),
+         "downscaled hsv + edges")
+    out = eng.alloc(small.nbytes)
+    eng.resize_device(buf.ptr, len(big), 360, 640, out.ptr, 144, 256)
+    eng.synchronize()
+    assert np.array_equal(out.download(small.nbytes).reshape(small.shape), small), "resize_device"
+    out.free()
     buf.free()
     # submissions with LARGE record sets, two in flight (the packed-heads form of >= 256 records, the whole-record copy): 320
     # records with histograms (340 KB), 7000 without (280 KB of heads)

@@ -193,8 +193,8 @@ def test_scene_manager_feeds_tap_rows_and_decides_like_the_oracle(golden, hip_en
 
 
 def test_reference_runs_on_larger_frames_through_the_row_feeder(golden, hip_engine):
-    """golden["downscale_rows"]: the UNMODIFIED reference over whole 960 x 540 frames (auto downscale to 256 x 144, LINEAR and
-    NEAREST, six detector configurations) against the HIP path whose feeder uploaded 288 (144) of the 540 rows of every frame:
+    """golden["downscale_rows"]: the UNMODIFIED reference over whole 960 x 540 frames (auto downscale to 256 x 144, LINEAR,
+    NEAREST and LANCZOS4, six detector configurations) against the HIP path whose feeder uploaded 288 (144) of the 540 rows of every frame:
     same cuts, same per-frame metrics."""
     from pyscenedetect_amd import scene_manager as smod
     from tests._helpers import assert_same_run, run_config
@@ -216,7 +216,8 @@ def test_reference_runs_on_larger_frames_through_the_row_feeder(golden, hip_engi
                 del seen[:]
                 got = run_config(frames, cls_name, kwargs, with_stats, hip_engine, auto_downscale=True, interpolation=mode)
                 assert_same_run(got, want, f"big_e/{mode}/{name}")
-                assert seen == [288 if mode == "LINEAR" else 144] * len(frames), (mode, name, seen[:3])
+                # (LANCZOS4: eight taps per destination row over 3.75 source rows -- every row carries taps, whole frames travel)
+                assert seen == [{"LINEAR": 288, "NEAREST": 144, "LANCZOS4": 0}[mode]] * len(frames), (mode, name, seen[:3])
     finally:
         smod._DeviceFeeder.put = original
 

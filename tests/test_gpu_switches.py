@@ -26,6 +26,9 @@ SWITCHES = [
     {"PSD_RESIZE_DEPTH": "3"},            # downscale kernel with two frames in flight
     {"PSD_RESIZE_ROWS": "1"},             # ... one destination row per workgroup
     {"PSD_RESIZE_ROWS": "5", "PSD_RESIZE_DEPTH": "3"},
+    {"PSD_RESIZE_STORE_VEC": "0"},        # ... its storing instance with byte stores instead of 16-byte stores through LDS
+    {"PSD_RESIZE_ROUNDS": "0"},           # ... time chunks by the rule of rounds 4-5 (12 workgroups per CU, rounded up)
+    {"PSD_RESIZE_ROUNDS": "1"},           # ... one round: every workgroup resident at once, the longest walks
 ]
 
 
