@@ -205,8 +205,18 @@ def test_fused_downscale_seg_instance_reads_the_flag_behind_the_dma_issue(tmp_pa
             a, b = max(spans, key=lambda sp: sp[1] - sp[0])      # the frame loop (the kernel's only outer loop): one step of the walk
             step = [x.strip() for x in lines[a:b + 1] if x.startswith("\t") and x.strip()]
             at = next(k for k, x in enumerate(step) if x.startswith("global_load_ubyte"))
-            # DMA issues in front of it in the step, no wait for global memory behind it
-            assert any(x.startswith("global_load_lds_dwordx4") for x in step[:at]), name
+            # DMA issues in front of it in the step -- in the text, or in blocks hipcc placed out of line (the instance that also stores
+            # its pixels: the issue sits behind the loop body and is entered by branches from in front of the flag's load) --, no wait
+            # for global memory behind it
+            dma_blocks, label = set(), None
+            for x in lines:               # (the whole kernel: such blocks may sit behind the loop's back edge)
+                m = re.match(r"^(\.LBB\d+_\d+):", x)
+                if m:
+                    label = m.group(1)
+                elif x.strip().startswith("global_load_lds_dwordx4") and label:
+                    dma_blocks.add(label)
+            enters = any(x.startswith("s_cbranch") and x.split()[-1] in dma_blocks for x in step[:at])
+            assert any(x.startswith("global_load_lds_dwordx4") for x in step[:at]) or enters, name
             assert not any(x.startswith("s_waitcnt") and "vmcnt(0)" in x for x in step[at:]), name
             # ... and the flag becomes an SGPR in front of the step's barrier (right behind the step's own wait)
             bar = next(k for k, x in enumerate(step) if x.startswith("s_barrier"))
