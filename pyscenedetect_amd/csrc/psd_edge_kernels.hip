@@ -1039,15 +1039,32 @@ static void threshold_table(int2* tab)
 // hsv != nullptr: the chunk's real frames get their V plane and V histogram from the HSV pass in V mode (one read of the
 // frames for both terms, psd_score_kernels.hip); only a predecessor frame standing in as virtual frame 0 still goes
 // through the V-plane kernel.
+// down != nullptr (with hsv: its `out` / `seg` of the chunk): the chunk's frames are FULL-SIZE frames behind the default downscale;
+// the fused downscale kernel's VOUT instance is the front end (psd_resize_kernels.hip), for the predecessor frame as well.
 static int edge_chunk(psd_engine* e, const EdgeGeom& g, const ChunkSrc& src, int count, const EdgeBuffers& b, hipStream_t stream,
-                      const ScoreParams* hsv = nullptr, int target_blocks = 0, int* launches = nullptr)
+                      const ScoreParams* hsv = nullptr, int target_blocks = 0, int* launches = nullptr, const DownSrc* down = nullptr)
 {
     HIP_TRY(hipMemsetAsync(b.zero_begin, 0, b.zero_bytes, stream));   // histograms, XOR counters, tile flags
     // packed 16-byte aligned frames with a multiple of 16 pixels take the LDS-DMA streaming variant
     const bool vp_dma = g.row_stride == (size_t)g.width * 3 && (g.npix & 15) == 0 && (g.frame_stride & 15) == 0 &&
                         ((uintptr_t)src.frames & 15) == 0 && (!src.first_is_prev || ((uintptr_t)src.prev & 15) == 0);
-    const int vp_count = hsv ? (src.first_is_prev ? 1 : 0) : count;   // virtual frames the V-plane kernel converts
-    if (vp_count > 0 && vp_dma) {
+    const int vp_count = down ? 0 : hsv ? (src.first_is_prev ? 1 : 0) : count;   // virtual frames the V-plane kernel converts
+    if (down) {
+        const int fp = src.first_is_prev;
+        int rc = PSD_OK;
+        // (the predecessor alone: no SADs -- it has no predecessor of its own -- only its V plane and histogram, virtual frame 0)
+        if (fp) rc = resize_linear_score_vplane(e, down->prev, 1, down->src_h, down->src_w, down->frame_stride, nullptr, g.height, g.width, hsv->out,
+                                                stream, launches, nullptr, b.vplane, b.hist);
+        if (rc != PSD_OK) return rc;
+        const int cnt = count - fp;
+        if (cnt > 0) {
+            const uint8_t* first = down->frames + (size_t)src.start * down->frame_stride;
+            const uint8_t* before = src.start == 0 ? down->prev : first - down->frame_stride;
+            rc = resize_linear_score_vplane(e, first, cnt, down->src_h, down->src_w, down->frame_stride, before, g.height, g.width, hsv->out, stream,
+                                            launches, hsv->seg, b.vplane + (fp ? (size_t)g.npix : 0), b.hist + (fp ? 256 : 0));
+            if (rc != PSD_OK) return rc;
+        }
+    } else if (vp_count > 0 && vp_dma) {
         const int n_groups = (int)(g.npix >> 4);
         const int cap = VD_STEP * (vp_count >= 32 ? VD_STEPS_PER_TILE : 1);
         const int tiles = (n_groups + cap - 1) / cap;
@@ -1057,7 +1074,7 @@ static int edge_chunk(psd_engine* e, const EdgeGeom& g, const ChunkSrc& src, int
         hipLaunchKernelGGL(value_plane_hist_kernel, dim3((unsigned)((g.npix + 1024 * VP_ITER - 1) / (1024 * VP_ITER)), vp_count), dim3(256), 0, stream, src, g,
                            b.vplane, b.hist);
     }
-    if (hsv) HIP_TRY(launch_score_frames(*hsv, true, false, true, target_blocks, stream, launches));
+    if (hsv && !down) HIP_TRY(launch_score_frames(*hsv, true, false, true, target_blocks, stream, launches));
     hipLaunchKernelGGL(median_thresholds_kernel, dim3(count), dim3(256), 0, stream, b.hist, g.npix, b.thr_tab, b.thr);
     const int htx = (g.width + HT - 1) / HT, hty = (g.height + HT - 1) / HT;
     {
@@ -1124,10 +1141,18 @@ static EdgeGeom make_geom(int height, int width, size_t row_stride, size_t frame
     return g;
 }
 
+// down != nullptr: d_frames / d_prev / row_stride / frame_stride are not used -- height x width is the RESIZED size, the frames are
+// down->frames at full size, and the HSV term comes with the front end (d_out gets its SADs; d_seg as always).
 int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
                 size_t frame_stride, const uint8_t* d_prev, int edge_kernel, psd_frame_scores* d_out,
-                hipStream_t stream, const uint8_t* d_seg, const ScoreParams* hsv, int target_blocks, int* launches)
+                hipStream_t stream, const uint8_t* d_seg, const ScoreParams* hsv, int target_blocks, int* launches, const DownSrc* down)
 {
+    ScoreParams down_hsv{};
+    if (down) {
+        d_prev = down->prev;                      // (only its presence counts below)
+        down_hsv.out = d_out; down_hsv.seg = d_seg;
+        hsv = &down_hsv;
+    }
     const EdgeGeom g = make_geom(height, width, row_stride, frame_stride);
     const int k = edge_kernel ? edge_kernel : estimated_kernel_size(width, height);
     const int total = n + (d_prev ? 1 : 0);
@@ -1169,7 +1194,7 @@ int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
             // the LDS increments cost the same wherever they sit; profiles/r04_f_vmode_front_end_experiments.txt.)
             cp.vhist = b.hist + (src.first_is_prev ? 256 : 0);
         }
-        rc = edge_chunk(e, g, src, count, b, stream, hsv ? &cp : nullptr, target_blocks, launches);
+        rc = edge_chunk(e, g, src, count, b, stream, hsv ? &cp : nullptr, target_blocks, launches, down);
         if (rc != PSD_OK) return rc;
         rc = launch_dilate_xor(g, k, count, b, have_carry ? b.carry : nullptr, nullptr, stream);
         if (rc != PSD_OK) return rc;

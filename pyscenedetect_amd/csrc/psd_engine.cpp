@@ -51,7 +51,7 @@ namespace psd {
 int edges_score(psd_engine* e, const uint8_t* d_frames, int n, int height, int width, size_t row_stride,
                 size_t frame_stride, const uint8_t* d_prev, int edge_kernel, psd_frame_scores* d_out,
                 hipStream_t stream, const uint8_t* d_seg, const ScoreParams* hsv = nullptr, int target_blocks = 0,
-                int* launches = nullptr);
+                int* launches = nullptr, const DownSrc* down = nullptr);
 int edges_map(psd_engine* e, const uint8_t* d_frame, int height, int width, size_t row_stride,
               int edge_kernel, uint8_t* h_edges);
 void edges_release(psd_engine* e);
@@ -557,6 +557,19 @@ static int downscaled_submit(psd_engine* e, const uint8_t* d_frames, int n, int 
             // frame never leaves the CU (only the edge term needs it in memory)
             rc = psd::resize_linear_score(e, d_frames, n, src_h, src_w, (size_t)src_w * 3, frame_stride, d_prev, nullptr, dst_h, dst_w, 0,
                                           s->d_recs, stream, &s->launches, d_seg, false, flags);
+            if (rc == PSD_OK) done = true;
+            else if (rc != PSD_ERR_UNSUPPORTED) return rc;
+        }
+        static const bool fuse_edges = [] { const char* v = getenv("PSD_EDGE_FUSE_DOWNSCALE"); return !v || atoi(v) != 0; }();
+        if (!done && interpolation == PSD_INTER_LINEAR && flags == (PSD_SCORE_HSV_SAD | PSD_SCORE_EDGES) && fuse_edges &&
+            !(dst_h == src_h && dst_w == src_w) && psd::resize_vplane_available(d_frames, src_w, frame_stride, d_prev, dst_w, n)) {
+            // ContentDetector with the edge term (weights.delta_edges or a StatsManager) behind the default downscale: the fused
+            // kernel's VOUT instance is the edge term's front end -- HSV SADs, and of the resized frame only its V plane and V
+            // histogram in memory (round 6; until then the frame was resized into the buffer below and read again by the V-mode
+            // pass: 453 MB of scattered writes per 4096 frames that cost 0.44 ms, psd_resize_kernels.hip)
+            const psd::DownSrc down{d_frames, d_prev, src_h, src_w, frame_stride};
+            rc = psd::edges_score(e, nullptr, n, dst_h, dst_w, (size_t)dst_w * 3, (size_t)dst_h * dst_w * 3, nullptr, edge_kernel, s->d_recs, stream, d_seg,
+                                  nullptr, e->num_cus * 8, &s->launches, &down);
             if (rc == PSD_OK) done = true;
             else if (rc != PSD_ERR_UNSUPPORTED) return rc;
         }

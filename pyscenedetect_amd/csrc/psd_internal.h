@@ -58,6 +58,20 @@ bool score_v_mode_available(long npix);
 // every launcher of a time-walking kernel leaves how it cut the batch (psd_last_walk_geometry; thread-local, psd_engine.cpp)
 void note_walk_geometry(int frames_per_chunk, int n_tiles);
 
+// The edge term behind the default downscale (psd_resize_kernels.hip): cv2.resize(INTER_LINEAR) + the HSV term + the resized
+// frames' V planes and V histograms from one pass over the full-size frames -- the resized frame itself never exists.
+// DownSrc: where the full-size frames of a submission are (edges_score takes it in place of small frames).
+struct DownSrc {
+    const uint8_t* frames;   // n full-size packed BGR frames, frame_stride apart
+    const uint8_t* prev;     // full-size frame preceding frame 0, or null
+    int src_h, src_w;
+    size_t frame_stride;
+};
+int resize_linear_score_vplane(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, const uint8_t* d_prev,
+                               int dst_h, int dst_w, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg,
+                               uint8_t* d_vout, uint32_t* d_vhist);
+bool resize_vplane_available(const uint8_t* d_src, int src_w, size_t src_frame_stride, const uint8_t* d_prev, int dst_w, int n);
+
 // OpenCV's computeResizeAreaTab for one destination index in run-length form: `count` consecutive source cells from
 // `first`, the first / last of them with their own weight (hash thumbnails and cv2.resize(INTER_AREA) share it).
 struct AreaRun {

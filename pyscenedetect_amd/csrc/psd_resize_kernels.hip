@@ -241,7 +241,8 @@ struct RsParams {
     int area2;
     int store_vec;           // STORE: a tile's pixels leave through LDS as 16-byte stores (whole, 16-byte aligned tiles), else byte stores
     int depth;               // staging buffers: 2 = one frame ahead, 3 = two frames ahead
-    u32* hpart;              // LUMA: per (frame, tile) partial luma histograms, 128 words of two 16-bit counts (bins 2i | 2i+1 << 16)
+    uint8_t* vout;           // VOUT: the resized frame's V plane (max(B, G, R), one byte per pixel), frame t at vout + t * dh * dw
+    u32* hpart;              // LUMA / VOUT: per (frame, tile) partial luma (V) histograms, 128 words of two 16-bit counts (bins 2i | 2i+1 << 16)
 };
 
 // 24-bit multiplies (v_mul_lo_u32 issues at a quarter of their rate; hipcc does not pick them for `>> 4`-ed or table operands)
@@ -395,14 +396,20 @@ __device__ __forceinline__ void rs_hsv(u32 b, u32 g, u32 r, const u32* lut_s, co
 // frame from every XCD -- would cost more than the pixels.)  The byte sum rides with the three SADs.
 // SEG: the instance for batches of packed clips (p.seg != nullptr; psd_score_segments_downscaled_device): a frame that starts
 // a clip has no predecessor.  The plain instances carry none of the flag's code.
-template <bool STORE, bool HSV, int G, bool LUMA = false, bool SEG = false>
+// VOUT (with HSV, without LUMA / STORE): the front end of the edge term behind the default downscale -- ContentDetector with
+// weights.delta_edges or a StatsManager, content_detector.py:155-174 on what scene_manager.py:666-678 hands it.  The HSV term as
+// always, and of the resized frame only what cv2.Canny needs leaves the CU: its V plane (a third of the frame's bytes, through
+// LDS as 16-byte stores) and its V histogram (the luma instances' machinery counting V: numpy.median for the thresholds).
+template <bool STORE, bool HSV, int G, bool LUMA = false, bool SEG = false, bool VOUT = false>
 __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
 {
+    static_assert(!VOUT || (HSV && !LUMA && !STORE), "VOUT rides on the HSV conversion");
+    constexpr bool HIST = LUMA || VOUT;
     extern __shared__ __attribute__((aligned(16))) uint8_t rs_stage[];
     __shared__ u32 lut_s[HSV ? 256 : 1], lut_h[HSV ? 256 : 1];
     // per-frame sums (sad_h, sad_s, sad_v, byte_sum), RS_REP copies each: a lane adds into copy lane % RS_REP
     __shared__ __attribute__((aligned(16))) u32 sums[RS_SLOTS][4][RS_REP];
-    __shared__ __attribute__((aligned(16))) u32 lhist[LUMA ? 2 : 1][LUMA ? RS_HREP * 256 : 1];     // [slot][copy][bin]
+    __shared__ __attribute__((aligned(16))) u32 lhist[HIST ? 2 : 1][HIST ? RS_HREP * 256 : 1];     // [slot][copy][bin]
     __shared__ int srows[64];           // clamped source rows of this tile: slot 2 * lr + k
     // STORE: the tile's resized pixels of frame t (whole destination rows: ONE contiguous run of the frame) collect here and leave
     // one barrier later as 16-byte stores, two slots taking turns: a third of the store instructions of three byte stores per pixel,
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     // runs of 1.5 KB between 6.8 GB of streaming reads cost 0.44 ms whatever the instruction (bytes, dwordx4) and cache policy (nt,
     // sc0, sc1, sc0 sc1: 1.34-1.41 ms) -- about 1 ms per GB written, where the 2 MB-per-frame V plane of the full-resolution edge
     // front end costs 0.08 (profiles/r06_u_resize_store_cost.txt).
-    __shared__ __attribute__((aligned(16))) uint8_t obuf[STORE ? 2 : 1][STORE ? RS_WG * G * 3 : 16];
+    __shared__ __attribute__((aligned(16))) uint8_t obuf[(STORE || VOUT) ? 2 : 1][STORE ? RS_WG * G * 3 : VOUT ? RS_WG * G : 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = blockIdx.x % p.n_tiles, chunk = blockIdx.x / p.n_tiles;
     const int r0 = tile * p.rows_per_tile;
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     if (HSV || LUMA) {
         for (int i = tid; i < RS_SLOTS * 4 * RS_REP; i += RS_WG) (&sums[0][0][0])[i] = 0;
     }
-    if (LUMA) {
+    if (HIST) {
         for (int i = tid; i < 2 * RS_HREP * 256; i += RS_WG) (&lhist[0][0])[i] = 0;
     }
     if (tid < 2 * nrows) {
@@ -524,8 +531,9 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     }
     auto store_tile = [&](int t, int slot) {
         const uint4* from = reinterpret_cast<const uint4*>(obuf[slot]);
-        uint4* to = reinterpret_cast<uint4*>(p.dst + (size_t)t * p.dstride + (size_t)r0 * p.dw * 3);
-        for (int i = tid; i < (npx * 3) >> 4; i += RS_WG) to[i] = from[i];
+        constexpr int BPP = VOUT ? 1 : 3;          // bytes per pixel that leave: the V plane or the BGR frame
+        uint4* to = reinterpret_cast<uint4*>(VOUT ? p.vout + ((size_t)t * p.dh + r0) * p.dw : p.dst + (size_t)t * p.dstride + (size_t)r0 * p.dw * 3);
+        for (int i = tid; i < (npx * BPP) >> 4; i += RS_WG) to[i] = from[i];
     };
     auto frame_step = [&](const int t, const auto& ph, const auto& ps, const auto& pv, auto& nh, auto& ns, auto& nv) {
         const int step = t - tb;
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             if (v) atomicAdd(q == 0 ? (unsigned long long*)&rec->sad_h : q == 1 ? (unsigned long long*)&rec->sad_s
                              : q == 2 ? (unsigned long long*)&rec->sad_v : (unsigned long long*)&rec->byte_sum, (unsigned long long)v);
         }
-        if (LUMA && rel >= 1 && tid < 128) {
+        if (HIST && rel >= 1 && tid < 128) {
             // frame rel-1's histogram of this tile is complete: out as 128 packed words, and the slot is free for frame rel+1
             u32* hs = lhist[(rel - 1) & 1];
             u32 lo = 0, hi = 0;
@@ -585,13 +593,13 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             }
             p.hpart[((size_t)(t - 1) * p.n_tiles + tile) * 128 + tid] = lo | (hi << 16);
         }
-        if (STORE && rel >= 1) {
+        if ((STORE || VOUT) && rel >= 1) {
             if (p.store_vec) store_tile(t - 1, (rel - 1) & 1);       // frame t-1's pixels are complete (every wave wrote them before this barrier)
         }
         const uint8_t* base = rs_stage + (size_t)buf * buf_bytes;
         u32 sh = 0, ss = 0, sv = 0, bsum = 0;
-        const bool count_luma = LUMA && t >= t0;           // (the halo frame only feeds the HSV carry)
-        u32* hcur = lhist[LUMA ? (rel & 1) : 0] + (LUMA ? (tid & (RS_HREP - 1)) * 256 : 0);
+        const bool count_luma = HIST && t >= t0;           // (the halo frame only feeds the HSV carry)
+        u32* hcur = lhist[HIST ? (rel & 1) : 0] + (HIST ? (tid & (RS_HREP - 1)) * 256 : 0);
         const bool chain = have_prev && !(SEG && flag_now != 0);
         constexpr int C = G < 4 ? G : 4;        // pixels whose taps are in flight together (six dwords each)
 #pragma unroll
@@ -636,6 +644,18 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
                         sv = __builtin_amdgcn_sad_u16(v, pv[g], sv);
                     }
                     nh[g] = h; ns[g] = s; nv[g] = v;
+                    if (VOUT) {
+                        if (count_luma) {
+                            rs_lds_add(&hcur[v], live[g] ? 1u : 0u);
+                            if (live[g]) {
+                                if (p.store_vec) {
+                                    asm volatile("ds_write_b8 %0, %1" ::"v"((u32)(uintptr_t)&obuf[rel & 1][g * RS_WG + tid]), "v"(v) : "memory");
+                                } else {
+                                    p.vout[((size_t)t * p.dh + r0) * p.dw + g * RS_WG + tid] = (uint8_t)v;
+                                }
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -664,7 +684,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
 #else
     for (int t = tb; t < t1; t++) frame_step(t, ph, ps, pv, ph, ps, pv);
 #endif
-    if (STORE) {
+    if (STORE || VOUT) {
         if (p.store_vec && t1 > t0) {                  // the chunk's last frame
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();
@@ -686,7 +706,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             if (v) atomicAdd(q == 0 ? (unsigned long long*)&rec->sad_h : q == 1 ? (unsigned long long*)&rec->sad_s
                              : q == 2 ? (unsigned long long*)&rec->sad_v : (unsigned long long*)&rec->byte_sum, (unsigned long long)v);
         }
-        if (LUMA && done > 0 && tid < 128) {   // the chunk's last frame
+        if (HIST && done > 0 && tid < 128) {   // the chunk's last frame
             const u32* hs = lhist[(done - 1) & 1];
             u32 lo = 0, hi = 0;
 #pragma unroll
@@ -698,7 +718,8 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
 
 // rec[t].hist = sum over the tiles of frame t of their packed partial histograms.  grid = frames; 128 threads (one per packed
 // word) or a multiple: the tiles are split over blockDim / 128 groups of threads and joined in LDS.
-__global__ __launch_bounds__(512) void hist_reduce_kernel(const u32* hpart, int n_tiles, psd_frame_scores* out)
+// out_words + t * stride_words = the 256 bins of frame t (a record's `hist`, or a row of the edge term's V histograms).
+__global__ __launch_bounds__(512) void hist_reduce_kernel(const u32* hpart, int n_tiles, u32* out_words, size_t stride_words)
 {
     __shared__ u32 part[3][256];
     const int t = blockIdx.x, i = threadIdx.x & 127, q = threadIdx.x >> 7, nq = blockDim.x >> 7;
@@ -713,8 +734,8 @@ __global__ __launch_bounds__(512) void hist_reduce_kernel(const u32* hpart, int 
     __syncthreads();
     if (q == 0) {
         for (int r = 0; r + 1 < nq; r++) { lo += part[r][2 * i]; hi += part[r][2 * i + 1]; }
-        out[t].hist[2 * i] = lo;
-        out[t].hist[2 * i + 1] = hi;
+        out_words[(size_t)t * stride_words + 2 * i] = lo;
+        out_words[(size_t)t * stride_words + 2 * i + 1] = hi;
     }
 }
 
@@ -742,25 +763,25 @@ __global__ __launch_bounds__(256) void resize_linear_generic_kernel(const uint8_
     for (int c = 0; c < 3; c++) D[c] = (uint8_t)interp(ra[x.o0 + c], ra[x.o1 + c], rb[x.o0 + c], rb[x.o1 + c], a0, a1, b0, b1);
 }
 
-template <bool STORE, bool HSV, bool LUMA, bool SEG>
+template <bool STORE, bool HSV, bool LUMA, bool SEG, bool VOUT>
 static const void* walk_fn_g(int g)
 {
     switch (g) {
-    case 1: return reinterpret_cast<const void*>(&resize_walk_kernel<STORE, HSV, 1, LUMA, SEG>);
-    case 2: return reinterpret_cast<const void*>(&resize_walk_kernel<STORE, HSV, 2, LUMA, SEG>);
-    case 4: return reinterpret_cast<const void*>(&resize_walk_kernel<STORE, HSV, 4, LUMA, SEG>);
-    default: return reinterpret_cast<const void*>(&resize_walk_kernel<STORE, HSV, 8, LUMA, SEG>);
+    case 1: return reinterpret_cast<const void*>(&resize_walk_kernel<STORE, HSV, 1, LUMA, SEG, VOUT>);
+    case 2: return reinterpret_cast<const void*>(&resize_walk_kernel<STORE, HSV, 2, LUMA, SEG, VOUT>);
+    case 4: return reinterpret_cast<const void*>(&resize_walk_kernel<STORE, HSV, 4, LUMA, SEG, VOUT>);
+    default: return reinterpret_cast<const void*>(&resize_walk_kernel<STORE, HSV, 8, LUMA, SEG, VOUT>);
     }
 }
 
-template <bool STORE, bool HSV, bool LUMA = false>
+template <bool STORE, bool HSV, bool LUMA = false, bool VOUT = false>
 static const void* walk_fn(bool seg, int g)
 {
     // (the clip-start flags only matter to the HSV carry: instances without the HSV term have no SEG form)
     if constexpr (HSV) {
-        if (seg) return walk_fn_g<STORE, HSV, LUMA, true>(g);
+        if (seg) return walk_fn_g<STORE, HSV, LUMA, true, VOUT>(g);
     }
-    return walk_fn_g<STORE, HSV, LUMA, false>(g);
+    return walk_fn_g<STORE, HSV, LUMA, false, VOUT>(g);
 }
 
 // Resident workgroups per CU of one instance with `lds` bytes of staging (the runtime's own occupancy figure: registers, LDS
@@ -784,12 +805,16 @@ static int walk_blocks_per_cu(const void* fn, size_t lds)
 //   terms   with d_out: PSD_SCORE_HSV_SAD (sad_h / sad_s / sad_v) and / or PSD_SCORE_LUMA_HIST | PSD_SCORE_BYTE_SUM (hist and
 //           byte_sum, always both); the luma terms only without d_dst
 //   d_prev  source-size frame preceding frame 0 (HSV carry), or null
-int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_row_stride,
-                        size_t src_frame_stride, const uint8_t* d_prev, uint8_t* d_dst, int dst_h, int dst_w,
-                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg,
-                        bool area_mode, uint32_t terms)
+//   d_vout / d_vhist (both or neither; with the HSV term alone, without d_dst): the resized frames' V planes (dst_h * dst_w bytes
+//           per frame, packed) and V histograms (256 words per frame) for the edge term -- the VOUT instances
+static int resize_linear_impl(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_row_stride,
+                              size_t src_frame_stride, const uint8_t* d_prev, uint8_t* d_dst, int dst_h, int dst_w,
+                              size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg,
+                              bool area_mode, uint32_t terms, uint8_t* d_vout, u32* d_vhist)
 {
     const bool want_hsv = d_out && (terms & PSD_SCORE_HSV_SAD), want_luma = d_out && (terms & (PSD_SCORE_LUMA_HIST | PSD_SCORE_BYTE_SUM));
+    const bool want_v = d_vout != nullptr;
+    if (want_v && (!d_vhist || !want_hsv || want_luma || d_dst)) { psd_set_error("fused downscale: the V plane rides on the HSV term alone"); return PSD_ERR_INVALID; }
     if (d_out && !want_hsv && !want_luma) return PSD_OK;
     if (want_luma && d_dst) { psd_set_error("fused downscale: the luma terms do not combine with storing the resized frames"); return PSD_ERR_UNSUPPORTED; }
     if (n == 0 || (!d_dst && !d_out)) return PSD_OK;
@@ -851,11 +876,13 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     // (every tile is whole rows, so it is one run of the frame; 16-byte stores when every such run starts and ends on 16 bytes)
     static const int store_env = [] { const char* v = getenv("PSD_RESIZE_STORE_VEC"); return v ? atoi(v) : 1; }();
     p.store_vec = (d_dst && store_env && (dst_w * 3) % 16 == 0 && (uintptr_t)d_dst % 16 == 0 && (dst_frame_stride % 16 == 0 || n == 1)) ? 1 : 0;
+    if (want_v) p.store_vec = (store_env && dst_w % 16 == 0 && (uintptr_t)d_vout % 16 == 0 && ((size_t)dst_h * dst_w % 16 == 0 || n == 1)) ? 1 : 0;
+    p.vout = d_vout;
     p.rows_per_tile = R;
     p.n_tiles = (dst_h + R - 1) / R;
     const size_t lds = (size_t)p.depth * 2 * R * p.row_pad + 16;      // (+ 16: a tap read of 8 bytes at the end of the last staged row)
     const bool seg = d_seg != nullptr;
-    const void* fn = (d_dst && want_hsv) ? walk_fn<true, true>(seg, g) : (want_hsv && want_luma) ? walk_fn<false, true, true>(seg, g)
+    const void* fn = want_v ? walk_fn<false, true, false, true>(seg, g) : (d_dst && want_hsv) ? walk_fn<true, true>(seg, g) : (want_hsv && want_luma) ? walk_fn<false, true, true>(seg, g)
                      : want_luma ? walk_fn<false, false, true>(seg, g) : want_hsv ? walk_fn<false, true>(seg, g) : walk_fn<true, false>(seg, g);
     // Time chunks.  The workgroups of a launch all take about the same time, so it runs in ROUNDS of as many workgroups as the
     // chip holds at once (CUs x the instance's occupancy), and a last round that is 2 % full takes as long as a full one.  Until
@@ -881,7 +908,7 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     chunks = (n + p.frames_per_chunk - 1) / p.frames_per_chunk;
     const int grid = p.n_tiles * chunks;
     if (want_hsv) note_walk_geometry(p.frames_per_chunk, p.n_tiles);
-    if (want_luma) {
+    if (want_luma || want_v) {
         void* scratch = nullptr;
         rc = engine_hist_scratch(e, (size_t)n * p.n_tiles * 128 * sizeof(u32), stream, &scratch);
         if (rc != PSD_OK) return rc;
@@ -893,16 +920,46 @@ int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, i
     }
     HIP_TRY(hipGetLastError());
     if (launches) *launches += 1;
-    if (want_luma) {
+    if (want_luma || want_v) {
         // (one quarter-less pass of 128 threads per frame: in the pipelined flow the small workgroups slip in beside the next
         //  submission's kernels -- 1.29-1.30 ms per 4096 frames against 1.31-1.32 with 512 threads, which are faster alone)
+        u32* words = want_v ? d_vhist : reinterpret_cast<u32*>(&d_out[0].hist[0]);
+        const size_t stride = want_v ? 256 : sizeof(psd_frame_scores) / sizeof(u32);
         for (int t0 = 0; t0 < n; t0 += 65535)
             hipLaunchKernelGGL(hist_reduce_kernel, dim3(std::min(65535, n - t0)), dim3(128), 0, stream, p.hpart + (size_t)t0 * p.n_tiles * 128,
-                               p.n_tiles, d_out + t0);
+                               p.n_tiles, words + (size_t)t0 * stride, stride);
         HIP_TRY(hipGetLastError());
         if (launches) *launches += 1;
     }
     return PSD_OK;
+}
+
+int resize_linear_score(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_row_stride,
+                        size_t src_frame_stride, const uint8_t* d_prev, uint8_t* d_dst, int dst_h, int dst_w,
+                        size_t dst_frame_stride, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg,
+                        bool area_mode, uint32_t terms)
+{
+    return resize_linear_impl(e, d_src, n, src_h, src_w, src_row_stride, src_frame_stride, d_prev, d_dst, dst_h, dst_w, dst_frame_stride, d_out, stream,
+                              launches, d_seg, area_mode, terms, nullptr, nullptr);
+}
+
+// cv2.resize(INTER_LINEAR) + the HSV term + the resized frames' V planes and V histograms, nothing else in memory: the front end of
+// the edge term behind the default downscale (psd_edge_kernels.hip).  PSD_ERR_UNSUPPORTED where the fused kernel does not apply
+// (source rows not 16-byte aligned, very wide targets): the caller resizes into a buffer instead.
+int resize_linear_score_vplane(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, const uint8_t* d_prev,
+                               int dst_h, int dst_w, psd_frame_scores* d_out, hipStream_t stream, int* launches, const uint8_t* d_seg,
+                               uint8_t* d_vout, uint32_t* d_vhist)
+{
+    return resize_linear_impl(e, d_src, n, src_h, src_w, (size_t)src_w * 3, src_frame_stride, d_prev, nullptr, dst_h, dst_w, 0, d_out, stream, launches,
+                              d_seg, false, PSD_SCORE_HSV_SAD, d_vout, d_vhist);
+}
+
+// whether resize_linear_score_vplane would take the fused kernel for this shape (the edge term decides its route up front)
+bool resize_vplane_available(const uint8_t* d_src, int src_w, size_t src_frame_stride, const uint8_t* d_prev, int dst_w, int n)
+{
+    const int row_bytes = src_w * 3;
+    return row_bytes % 16 == 0 && (uintptr_t)d_src % 16 == 0 && (src_frame_stride % 16 == 0 || n == 1) && (!d_prev || (uintptr_t)d_prev % 16 == 0) &&
+           row_bytes <= 16384 && dst_w <= 2048;
 }
 
 // ---- cv2.resize(INTER_NEAREST) and cv2.resize(INTER_AREA), 8-bit, 3 channels ---------------------------------------

@@ -29,6 +29,8 @@ SWITCHES = [
     {"PSD_RESIZE_STORE_VEC": "0"},        # ... its storing instance with byte stores instead of 16-byte stores through LDS
     {"PSD_RESIZE_ROUNDS": "0"},           # ... time chunks by the rule of rounds 4-5 (12 workgroups per CU, rounded up)
     {"PSD_RESIZE_ROUNDS": "1"},           # ... one round: every workgroup resident at once, the longest walks
+    {"PSD_EDGE_FUSE_DOWNSCALE": "0"},     # HSV + edges behind the downscale: resize into the buffer and read it again (the route until round 6)
+    {"PSD_EDGE_FUSE_DOWNSCALE": "1", "PSD_EDGE_WS_MB": "1"},    # ... the fused front end over many small chunks
 ]
 
 

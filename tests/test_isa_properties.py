@@ -157,10 +157,11 @@ def test_fused_downscale_kernel_reads_its_taps_as_dwords(tmp_path):
     bodies = kernel_bodies(device_asm("psd_resize_kernels", tmp_path))
     checked = 0
     for name, lines in bodies.items():
-        m = re.search(r"resize_walk_kernelILb([01])ELb([01])ELi(\d)ELb([01])ELb([01])E", name)
+        m = re.search(r"resize_walk_kernelILb([01])ELb([01])ELi(\d)ELb([01])ELb([01])ELb([01])E", name)
         if not m:
             continue
         store, hsv, g, luma, seg = int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5))
+        luma |= int(m.group(6))        # (the V-plane instances count V with the luma instances' histogram machinery)
         # (hipcc may unswitch the frame loop on the uniform "exact 2 x 2 decimation" flag: the general copy is the one with the
         #  vertical products)
         body = [l.strip() for l in _frame_loop(lines, "v_mul_hi_u32_u24") if l.startswith("\t") and l.strip()]
@@ -181,7 +182,7 @@ def test_fused_downscale_kernel_reads_its_taps_as_dwords(tmp_path):
         limit = {1: 150, 2: 120, 4: 100, 8: 95}[g] + (15 if luma else 0) + (10 if store else 0)
         assert valu / g <= limit, (name, valu / g)
         checked += 1
-    assert checked == 32
+    assert checked == 40
 
 
 def test_fused_downscale_seg_instance_reads_the_flag_behind_the_dma_issue(tmp_path):
@@ -223,4 +224,4 @@ def test_fused_downscale_seg_instance_reads_the_flag_behind_the_dma_issue(tmp_pa
             assert any(x.startswith("v_readfirstlane_b32") for x in step[:bar]), name
         assert in_loop in (1, 2), (name, in_loop)     # (two where the frame loop was unswitched)
         checked += 1
-    assert checked == 12
+    assert checked == 16      # (HSV | HSV + store | HSV + luma | HSV + V plane) x four pixel-slot counts
