@@ -294,7 +294,10 @@ __global__ __launch_bounds__(kHashWG) void gray_area_dma_kernel(const HashGeom g
     }
 }
 
-constexpr int kHashDmaG = 2;
+// 16-pixel groups per lane and step of the DMA kernel.  Round 6: 1 (was 2) -- half the staging (12 KiB), 12 fewer registers, and with
+// the row buffer sized for it SIX workgroups per CU instead of three: 4.58-4.68 -> 4.03-4.05 ms per 4096 x 1080p (0.68-0.69 -> 0.79
+// of peak; 4 groups: 16 ms, the registers spill) -- profiles/r06_aa_ab_hash_kernel_occupancy.txt
+constexpr int kHashDmaG = 1;
 
 // ---- frames SMALLER than the thumbnail along an axis (a 24-row frame, 32 x 32 thumbnails) -----------------------------------
 // cv2.resize(INTER_AREA) that does not shrink along both axes is OpenCV's bilinear kernel with area-mode coefficients
@@ -391,10 +394,11 @@ int hash_thumbs(psd_engine* e, const uint8_t* d_frames, int n, int height, int w
     const bool fast = (width % 16 == 0) && (row_stride % 16 == 0) && (frame_stride % 16 == 0) && ((uintptr_t)d_frames % 16 == 0);
     static const bool no_dma = [] { const char* e = getenv("PSD_HASH_DIRECT"); return e && atoi(e) != 0; }();
     const bool dma = fast && row_stride == (size_t)width * 3 && !no_dma;
-    // LDS per workgroup: staging (DMA path) + R grey rows + R*size partials + the x run table.  Three workgroups
-    // per CU (160 KiB) keep enough loads in flight; the register path has no staging and may use up to 60 KiB.
+    // LDS per workgroup: staging (DMA path) + R grey rows + R*size partials + the x run table.  The register path has no
+    // staging and may use up to 60 KiB.
     const size_t fixed = (size_t)size * sizeof(AreaRun) + (dma ? (size_t)kHashDmaG * (kHashWG / 64) * 3072 : 0);
-    const size_t budget = dma ? 52 * 1024 : 60 * 1024;
+    // (DMA path: six workgroups per CU -- 6 rows of a 1080p frame per batch; eight rows, five workgroups: 0.78; five rows: 0.75)
+    const size_t budget = dma ? 26 * 1024 : 60 * 1024;
     int R = kHashWG / size;
     while (R > 1 && (size_t)R * g.wpad + (size_t)R * size * 4 + fixed > budget) R--;
     const size_t lds = (size_t)R * g.wpad + (size_t)R * size * 4 + fixed;
