@@ -341,7 +341,8 @@ class Workload:
 
     def kernel_name(self) -> str:
         if self.downscale and self.detector == "edges":
-            return "psd::resize_walk_kernel<STORE> into the engine's buffer + V-mode HSV pass + edge pipeline on the resized frames"
+            return ("psd::resize_walk_kernel<VOUT> (fused downscale + HSV term; of the resized frame only its V plane and V histogram leave the CU) "
+                    "+ the edge pipeline (Sobel / NMS, hysteresis, dilation + XOR) on the V planes")
         if self.downscale:
             return "psd::resize_walk_kernel"
         return {"content": "psd::score_frames_dma_kernel", "all": "psd::score_frames_dma_kernel", "hist": "psd::luma_hist_kernel",

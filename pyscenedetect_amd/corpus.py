@@ -168,13 +168,43 @@ def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: 
         records = score_clips_distributed(engine, clips, flags, edge_kernel, group, downscale=ds, interpolation=interpolation)
     fps_list = fps if isinstance(fps, (list, tuple)) else [fps] * len(clips)
     sizes = [scored_size(c.shape[1], c.shape[2], ds) for c in clips]       # what the detectors see (and divide by)
+    # (worker threads only where a decision is mostly native code: the histogram epilogue takes 0.2 us per frame with the GIL released;
+    #  the others are microseconds per clip, and handing THEM to a pool costs a GIL hand-over per clip -- the BBC flow lost 15 %)
+    pool = _decide_pool() if "hist" in detectors else None
     if not use_dist:
-        # one process: a clip is decided as soon as its records are on the host, while the batches behind it are still on the GPU
+        # one process: a clip is decided as soon as its records are on the host, while the batches behind it are still on the GPU --
+        # and (round 6) on a worker thread, several clips at a time: the native epilogues release the GIL, and behind the default
+        # downscale the kernels of a pass are as short as the histogram epilogue of its clips on one core
         result: list = [None] * len(clips)
 
         def decide_now(i, recs):
-            result[i] = decide(recs, sizes[i][0], sizes[i][1], fps_list[i], detectors)
+            if pool is None:
+                result[i] = decide(recs, sizes[i][0], sizes[i][1], fps_list[i], detectors)
+            else:
+                result[i] = pool.submit(decide, recs, sizes[i][0], sizes[i][1], fps_list[i], detectors)
 
         score_clips(engine, clips, flags, edge_kernel, on_ready=decide_now, downscale=ds, interpolation=interpolation)
-        return result
-    return [decide(r, hw[0], hw[1], f, detectors) for r, hw, f in zip(records, sizes, fps_list)]
+        return result if pool is None else [f.result() for f in result]
+    if pool is None:
+        return [decide(r, hw[0], hw[1], f, detectors) for r, hw, f in zip(records, sizes, fps_list)]
+    return list(pool.map(lambda a: decide(a[0], a[1][0], a[1][1], a[2], detectors), zip(records, sizes, fps_list)))
+
+
+_POOL = None
+
+
+def _decide_pool():
+    """Worker threads for the per-clip decisions of ``detect_corpus`` (``PSD_DECIDE_THREADS``: 0 or 1 = decide inline; default
+    min(8, cores)); one pool per process."""
+    global _POOL
+    import os
+
+    want = os.environ.get("PSD_DECIDE_THREADS")
+    n = int(want) if want is not None else min(8, os.cpu_count() or 1)
+    if n <= 1:
+        return None
+    if _POOL is None or _POOL._max_workers != n:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _POOL = ThreadPoolExecutor(max_workers=n, thread_name_prefix="psd-decide")
+    return _POOL

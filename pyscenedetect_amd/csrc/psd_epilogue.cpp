@@ -264,24 +264,49 @@ int psd_epilogue_hist_cuts(const psd_frame_scores* recs, int n, const psd_frame_
         int idx = (int)std::floor(j * (p->bins / 256.0));
         lut[j] = idx < 0 ? 0 : (idx > p->bins - 1 ? p->bins - 1 : idx);
     }
-    std::vector<float> a((size_t)p->bins), b((size_t)p->bins);
-    float* last = a.data();
-    float* cur = b.data();
-    bool have_last = false;
-    if (prev_rec) { normalized_hist(prev_rec->hist, p->bins, lut, last); have_last = true; }
+    // hist_diff[t] of every frame first -- the normalisation and the correlation of a frame pair depend on nothing but the two
+    // records, so frame ranges go to a few threads (round 6: behind the default downscale the packed flows' kernels take 2 ms per
+    // pass and this loop, 0.22 us per frame on one core, had become as long as they are) -- then the cuts in order.
+    std::vector<double> own;
+    double* diff = hist_diff;
+    if (!diff) { own.resize((size_t)n); diff = own.data(); }
+    const int bins = p->bins;
+    auto range = [&](int t_begin, int t_end) {
+        std::vector<float> a((size_t)bins), b((size_t)bins);
+        float* last = a.data();
+        float* cur = b.data();
+        bool have_last = false;
+        if (t_begin > 0) { normalized_hist(recs[t_begin - 1].hist, bins, lut, last); have_last = true; }
+        else if (prev_rec) { normalized_hist(prev_rec->hist, bins, lut, last); have_last = true; }
+        for (int t = t_begin; t < t_end; t++) {
+            normalized_hist(recs[t].hist, bins, lut, cur);
+            diff[t] = have_last ? correl(last, cur, bins) : NAN;
+            float* tmp = last; last = cur; cur = tmp;
+            have_last = true;
+        }
+    };
+    static const int max_threads = [] {
+        const char* v = getenv("PSD_EPILOGUE_THREADS");
+        const int hw = (int)std::thread::hardware_concurrency();
+        const int t = v ? atoi(v) : (hw > 16 ? 8 : hw > 1 ? hw / 2 : 1);
+        return t < 1 ? 1 : t > 64 ? 64 : t;
+    }();
+    const int nt = std::min(max_threads, n / 1024);     // (a thread costs ~0.1 ms to start and join: not for short clips)
+    if (nt > 1) {
+        std::vector<std::thread> pool;
+        pool.reserve((size_t)nt - 1);
+        for (int k = 1; k < nt; k++) pool.emplace_back(range, (int)((long)n * k / nt), (int)((long)n * (k + 1) / nt));
+        range(0, (int)((long)n / nt));
+        for (auto& th : pool) th.join();
+    } else {
+        range(0, n);
+    }
     int nc = 0;
     int64_t last_cut = first_frame - (prev_rec ? 1 : 0);
     for (int t = 0; t < n; t++) {
         const int64_t tc = first_frame + t;
-        normalized_hist(recs[t].hist, p->bins, lut, cur);
-        double d = NAN;
-        if (have_last) {
-            d = correl(last, cur, p->bins);
-            if (d <= thr && len.met(tc, last_cut)) { cuts[nc++] = tc; last_cut = tc; }
-        }
-        if (hist_diff) hist_diff[t] = d;
-        float* tmp = last; last = cur; cur = tmp;
-        have_last = true;
+        const double d = diff[t];
+        if ((t > 0 || prev_rec) && d <= thr && len.met(tc, last_cut)) { cuts[nc++] = tc; last_cut = tc; }
     }
     *n_cuts = nc;
     return PSD_OK;

@@ -277,3 +277,49 @@ def test_empty_and_one_frame_clips(oracle_engine):
     for auto in (True, False):
         res = corpus.detect_corpus(oracle_engine, clips, [25.0, 30.0, 24.0], CORPUS_DETECTORS, auto_downscale=auto)
         assert res[0] == res[2] == {"content": [], "adaptive": [], "hist": [], "threshold": []} and set(res[1]) == set(CORPUS_DETECTORS)
+
+
+def test_decisions_on_worker_threads_equal_the_inline_ones(monkeypatch):
+    """``detect_corpus`` decides clips on worker threads when a HistogramDetector is among the detectors (its native epilogue is most of
+    the host time of a pass behind the default downscale) and ``psd_epilogue_hist_cuts`` splits long clips over native threads: the same
+    cut lists and ``hist_diff`` values, to the bit, as one thread does inline."""
+    import numpy as np
+
+    from pyscenedetect_amd import _native, corpus, epilogue
+
+    rng = np.random.default_rng(11)
+    n = 5000
+    recs = np.zeros(n, _native.RECORD_DTYPE)
+    base = rng.integers(0, 400, (8, 256))
+    for t in range(n):
+        recs["hist"][t] = base[(t // 700) % 8] + rng.integers(0, 6, 256)          # shots of 700 frames with a little noise
+    recs["byte_sum"] = recs["hist"].sum(axis=1) * 3
+    runs = {}
+    for threads in ("1", "2", "5"):
+        # (the library reads PSD_EPILOGUE_THREADS once per process: each setting in its own interpreter)
+        import json
+        import os
+        import subprocess
+        import sys
+
+        code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from pyscenedetect_amd import epilogue, _native;"
+                "recs = np.load(sys.argv[1]); c, d = epilogue.hist_cuts(recs, 25.0); print(json.dumps([c, np.nan_to_num(d, nan=-1.0).tobytes().hex()]))"
+                % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "psd_hist_recs_%d.npy" % os.getpid())
+        np.save(path, recs)
+        out = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=dict(os.environ, PSD_EPILOGUE_THREADS=threads))
+        os.unlink(path)
+        assert out.returncode == 0, out.stderr[-800:]
+        runs[threads] = json.loads(out.stdout.strip().splitlines()[-1])
+    assert runs["1"] == runs["2"] == runs["5"] and len(runs["1"][0]) >= 6
+    # the Python-level pool: a stand-in engine that hands out prepared records
+    class Eng:
+        def score_host(self, frames, prev=None, flags=7, edge_kernel=0, downscale=1.0, interpolation=1):
+            return recs[: len(frames)]
+    clips = [np.zeros((k, 8, 8, 3), np.uint8) for k in (4000, 1200, 0, 1, 2600)]
+    spec = {"hist": {}, "threshold": {}}
+    monkeypatch.setenv("PSD_DECIDE_THREADS", "0")
+    inline = corpus.detect_corpus(Eng(), clips, 25.0, spec, auto_downscale=False)
+    monkeypatch.setenv("PSD_DECIDE_THREADS", "4")
+    pooled = corpus.detect_corpus(Eng(), clips, 25.0, spec, auto_downscale=False)
+    assert pooled == inline and inline[0]["hist"] and corpus._POOL is not None
