@@ -266,13 +266,16 @@ int psd_edge_map_device(psd_engine* e, const uint8_t* d_frame, int height, int w
 
 /* cv2.resize(src, (dst_w, dst_h), interpolation) for n device-resident BGR frames (packed rows): the downscale
  * SceneManager applies in front of the detectors (scene_manager.py:666-678).  `interpolation` takes cv2's values
- * as the reference's Interpolation enum does (common.py:148-160): NEAREST, LINEAR (the default), AREA and LANCZOS4 are
- * implemented (AREA that does not shrink along both axes is, as in OpenCV, bilinear with area-mode coefficients; LANCZOS4 is
- * OpenCV's integer path for 8-bit images -- HResizeLanczos4 / VResizeLanczos4 with FixedPtCast<int, uchar, 22> and no vector
- * pass -- so it has one result, reproduced here byte for byte).
- * CUBIC returns PSD_ERR_UNSUPPORTED on purpose: OpenCV's 8-bit vertical pass for it runs in float32 SIMD whose lane count,
- * scalar tail and use of fused multiply-add depend on the build, and x86 wheels route it to IPP, so no restatement can be
- * bit-exact. */
+ * as the reference's Interpolation enum does (common.py:148-160), and all five are implemented: NEAREST, LINEAR (the default),
+ * AREA (when it does not shrink along both axes it is, as in OpenCV, bilinear with area-mode coefficients), LANCZOS4 (OpenCV's
+ * integer path for 8-bit images -- HResizeLanczos4 / VResizeLanczos4 with FixedPtCast<int, uchar, 22> and no vector pass -- so it
+ * has one result, reproduced here byte for byte) and CUBIC.
+ * CUBIC has no single 8-bit result in OpenCV: its vertical pass (VResizeCubicVec_32s8u) runs in float32 on groups of 8 elements
+ * with a fixed-point scalar tail, fused or unfused by build, is absent from builds without CV_SIMD, and x86-64 PyPI wheels hand the
+ * filter to IPP.  The environment variable PSD_CUBIC_FORM (read once per process) names the form reproduced byte for byte:
+ * "sse" (default: OpenCV 4.x without IPP on an SSE2/SSE3 baseline, every product and sum rounded to float32), "fma" (fused
+ * multiply-adds: aarch64, FMA baselines), "fixed" (FixedPtCast everywhere).  They differ in about one byte per 50,000.  Any other
+ * value: PSD_ERR_INVALID from the first CUBIC call.  An `interpolation` outside 0..4: PSD_ERR_UNSUPPORTED. */
 enum psd_interpolation { PSD_INTER_NEAREST = 0, PSD_INTER_LINEAR = 1, PSD_INTER_CUBIC = 2, PSD_INTER_AREA = 3, PSD_INTER_LANCZOS4 = 4 };
 int psd_resize_device(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w,
                       size_t src_frame_stride, uint8_t* d_dst, int dst_h, int dst_w,

@@ -17,7 +17,7 @@
  *   cv2.calcHist                    scenedetect/detectors/histogram_detector.py:159
  *   cv2.normalize                   scenedetect/detectors/histogram_detector.py:163
  *   cv2.compareHist(CORREL)         scenedetect/detectors/histogram_detector.py:98
- *   cv2.resize(INTER_LINEAR | INTER_NEAREST | INTER_AREA)   scenedetect/scene_manager.py:670-678 (Interpolation, common.py:148-160)
+ *   cv2.resize(INTER_LINEAR | INTER_NEAREST | INTER_AREA | INTER_CUBIC | INTER_LANCZOS4)   scenedetect/scene_manager.py:670-678 (Interpolation, common.py:148-160)
  *   cv2.cvtColor(BGR2GRAY) / cv2.resize(INTER_AREA) / cv2.dct   scenedetect/detectors/hash_detector.py:125,129,139
  *
  * PARITY UNPINNED at the cv2 boundary: no real cv2 build and none of the
@@ -705,6 +705,106 @@ void orc_resize_lanczos4_u8(const uint8_t* src, size_t sstep, int sh, int sw, in
             /* (unsigned: the sum of the eight products may pass 2^31 on the way; what OpenCV's int arithmetic leaves is the low 32 bits) */
             uint32_t v = 0;
             for (int k = 0; k < 8; k++) v += (uint32_t)rows[(size_t)k * dw * cn + x] * (uint32_t)(int32_t)yb[8 * dy + k];
+            int r = ((int32_t)(v + (1u << 21))) >> 22;
+            D[x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+        }
+    }
+    free(rows); free(xf); free(yf); free(xa); free(yb);
+}
+
+/* ---------------------------------------------------------------------------
+ * cv2.resize(INTER_CUBIC), 8-bit, cn channels (scene_manager.py:670-678 with Interpolation.CUBIC, common.py:148-160).
+ * resize.cpp, the generic path: cubic_tab[CV_8U] = resizeGeneric_<HResizeCubic<uchar, int, short>, VResizeCubic<uchar, int,
+ * short, FixedPtCast<int, uchar, INTER_RESIZE_COEF_BITS * 2>, VResizeCubicVec_32s8u>>.
+ *   fx = (float)((dx + 0.5) * scale_x - 0.5);  sx = cvFloor(fx);  fx -= sx;          (the taps are source columns sx-1 .. sx+2)
+ *   interpolateCubic(fx, cbuf)  (A = -0.75, float32);  ialpha[k] = saturate_cast<short>(cbuf[k] * 2048)
+ *   rows likewise;  a tap outside the image is the nearest pixel inside;  D = sum_j S[sx - 1 + j] * alpha[j]  (int)
+ * The VERTICAL pass is where OpenCV builds differ, and `form` says which one is restated:
+ *   form 0 ("sse": a build whose baseline is SSE2/SSE3 and that has no IPP -- distribution packages, conda-forge, source builds
+ *           with WITH_IPP=OFF): VResizeCubicVec_32s8u takes the row in whole groups of v_int16's 8 lanes,
+ *             dst = pack_u8(pack_s16(cvtps2dq( S0*b0 + (S1*b1 + (S2*b2 + S3*b3)) )))   with b_k = beta[k] * 2^-22 in float32,
+ *           every product and every sum ROUNDED to float32 (v_muladd is mul + add without FMA), cvtps2dq to nearest even; the
+ *           width % 8 elements left over go through the scalar FixedPtCast: (S0*b0 + S1*b1 + S2*b2 + S3*b3 + 2^21) >> 22;
+ *   form 1 ("fma": a baseline with fused multiply-add -- aarch64 NEON wheels, x86 builds with an AVX2 baseline and 8 lanes kept
+ *           here; v_muladd = one rounding per step), same groups of 8, same tail;
+ *   form 2 ("fixed": CV_SIMD off, or OpenCV before the vector pass existed): the scalar FixedPtCast everywhere.
+ * The x86-64 PyPI wheels do neither: they carry IPP and ipp_resize takes 8-bit CUBIC (closed source; "results differ from the
+ * OpenCV implementation" is OpenCV's own comment on it), so no form here claims to be theirs.
+ * ------------------------------------------------------------------------- */
+static void cubic_coeffs(float x, float* coeffs)
+{
+    const float A = -0.75f;
+    coeffs[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    coeffs[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    coeffs[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    coeffs[3] = 1.f - coeffs[0] - coeffs[1] - coeffs[2];
+}
+
+/* the taps of one axis: first[d] = s - 1 (not clamped), coef[4 d .. 4 d + 3] */
+void orc_cubic_taps(int ssize, int dsize, int* first, short* coef)
+{
+    double scale = 1. / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        float cbuf[4];
+        cubic_coeffs(f, cbuf);
+        first[d] = s - 1;
+        for (int k = 0; k < 4; k++) coef[4 * d + k] = sat_s16_round(cbuf[k] * 2048);
+    }
+}
+
+void orc_resize_cubic_u8(const uint8_t* src, size_t sstep, int sh, int sw, int cn, uint8_t* dst, size_t dstep, int dh, int dw, int form)
+{
+    int* xf = (int*)malloc(sizeof(int) * dw);
+    int* yf = (int*)malloc(sizeof(int) * dh);
+    short* xa = (short*)malloc(sizeof(short) * 4 * dw);
+    short* yb = (short*)malloc(sizeof(short) * 4 * dh);
+    orc_cubic_taps(sw, dw, xf, xa);
+    orc_cubic_taps(sh, dh, yf, yb);
+    const int width = dw * cn;
+    const int vec_end = form == 2 ? 0 : width - width % 8;
+    const float scale = 1.f / (2048 * 2048);
+    int* rows = (int*)malloc(sizeof(int) * 4 * (size_t)width);
+    for (int dy = 0; dy < dh; dy++) {
+        for (int k = 0; k < 4; k++) {
+            const uint8_t* S = src + (size_t)clampi(yf[dy] + k, 0, sh - 1) * sstep;
+            int* D = rows + (size_t)k * width;
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    int v = 0;
+                    for (int j = 0; j < 4; j++) v += S[(size_t)clampi(xf[dx] + j, 0, sw - 1) * cn + c] * xa[4 * dx + j];
+                    D[dx * cn + c] = v;
+                }
+        }
+        const int *S0 = rows, *S1 = rows + width, *S2 = rows + 2 * (size_t)width, *S3 = rows + 3 * (size_t)width;
+        const short* beta = yb + 4 * dy;
+        const float b0 = beta[0] * scale, b1 = beta[1] * scale, b2 = beta[2] * scale, b3 = beta[3] * scale;
+        uint8_t* D = dst + (size_t)dy * dstep;
+        int x = 0;
+        for (; x < vec_end; x++) {
+            float t;
+            if (form == 1) {
+                t = (float)S3[x] * b3;
+                t = fmaf((float)S2[x], b2, t);
+                t = fmaf((float)S1[x], b1, t);
+                t = fmaf((float)S0[x], b0, t);
+            } else {
+                /* (volatile: each product and each sum is a float32 of its own whatever the compiler would like to contract) */
+                volatile float p3 = (float)S3[x] * b3, p2 = (float)S2[x] * b2, p1 = (float)S1[x] * b1, p0 = (float)S0[x] * b0;
+                volatile float s2 = p2 + p3;
+                volatile float s1 = p1 + s2;
+                t = p0 + s1;
+            }
+            long r = lrintf(t);                      /* cvtps2dq: to nearest even */
+            if (r > 32767) r = 32767;                /* v_pack: int32 -> int16, saturating */
+            if (r < -32768) r = -32768;
+            D[x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);   /* v_pack_u: int16 -> uint8, saturating */
+        }
+        for (; x < width; x++) {
+            uint32_t v = (uint32_t)S0[x] * (uint32_t)(int32_t)beta[0] + (uint32_t)S1[x] * (uint32_t)(int32_t)beta[1] +
+                         (uint32_t)S2[x] * (uint32_t)(int32_t)beta[2] + (uint32_t)S3[x] * (uint32_t)(int32_t)beta[3];
             int r = ((int32_t)(v + (1u << 21))) >> 22;
             D[x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
         }

@@ -10,6 +10,8 @@ PARITY UNPINNED: this is a restatement of OpenCV's published 8-bit algorithms, n
 Only the functions the hot path calls are provided.
 """
 
+import os
+
 import numpy as np
 
 from oracle import lib as _orc
@@ -22,6 +24,7 @@ INTER_LINEAR = 1
 INTER_CUBIC = 2
 INTER_AREA = 3
 INTER_LANCZOS4 = 4
+CUBIC_FORMS = {"sse": 0, "fma": 1, "fixed": 2}      # (the shim's own: which OpenCV build's INTER_CUBIC is restated)
 COLOR_BGR2RGB = 4
 COLOR_BGR2GRAY = 6
 COLOR_BGR2HSV = 40
@@ -140,9 +143,14 @@ def resize(src, dsize, interpolation=INTER_LINEAR):
     if interpolation == INTER_LANCZOS4:
         _orc.lib().orc_resize_lanczos4_u8(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw)
         return dst
+    if interpolation == INTER_CUBIC:
+        # the 8-bit vertical pass of INTER_CUBIC depends on the OpenCV build (cv2_restate.c: orc_resize_cubic_u8); PSD_CUBIC_FORM names the
+        # one restated, as it does for the device library: sse (default) | fma | fixed
+        form = CUBIC_FORMS[os.environ.get("PSD_CUBIC_FORM", "sse")]
+        _orc.lib().orc_resize_cubic_u8(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw, form)
+        return dst
     if interpolation != INTER_LINEAR:
-        raise NotImplementedError("cv2 shim: INTER_LINEAR, INTER_NEAREST, INTER_AREA and INTER_LANCZOS4 only (INTER_CUBIC's 8-bit "
-                                  "result depends on the OpenCV build: IPP on x86 wheels, float32 SIMD elsewhere)")
+        raise NotImplementedError("cv2 shim: INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA and INTER_LANCZOS4 only")
     dst = np.empty((dh, dw) + (() if src.ndim == 2 else (cn,)), np.uint8)
     _orc.lib().orc_resize_linear_u8(src.ctypes.data, sw * cn, sh, sw, cn, dst.ctypes.data, dw * cn, dh, dw)
     return dst

@@ -291,7 +291,7 @@ def main():
     # the non-default downscale filters the device implements (scene_manager.py:265-272, common.py:148-160)
     frames, _ = make_clip(*CLIPS["wide_d"][:4], **CLIPS["wide_d"][4])
     golden["interp"] = {}
-    for mode in ("NEAREST", "AREA", "LANCZOS4"):
+    for mode in ("NEAREST", "AREA", "LANCZOS4", "CUBIC"):     # (CUBIC: the shim's default form, "sse")
         golden["interp"][mode] = {}
         for cname in ("content_stats", "hist_default", "hash_default"):
             cls_name, kwargs, with_stats = CONFIGS[cname]
@@ -303,7 +303,7 @@ def main():
     frames, truth = make_clip(seed, n, h, w, **kw)
     golden["downscale_rows"] = {"clip": {"seed": seed, "n": n, "h": h, "w": w, "kwargs": kw, "true_cuts": truth,
                                          "sum_all": int(frames.sum())}, "results": {}}
-    for mode in ("LINEAR", "NEAREST", "LANCZOS4"):
+    for mode in ("LINEAR", "NEAREST", "LANCZOS4", "CUBIC"):
         golden["downscale_rows"]["results"][mode] = {}
         for cname in ("content_stats", "content_edges", "adaptive_default", "hist_default", "hash_default", "threshold_default"):
             cls_name, kwargs, with_stats = CONFIGS[cname]

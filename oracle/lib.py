@@ -79,6 +79,10 @@ def lib() -> ctypes.CDLL:
         L.orc_resize_lanczos4_u8.argtypes = [vp, sz, i, i, i, vp, sz, i, i]
         L.orc_lanczos4_taps.restype = None
         L.orc_lanczos4_taps.argtypes = [i, i, vp, vp]
+        L.orc_resize_cubic_u8.restype = None
+        L.orc_resize_cubic_u8.argtypes = [vp, sz, i, i, i, vp, sz, i, i, i]
+        L.orc_cubic_taps.restype = None
+        L.orc_cubic_taps.argtypes = [i, i, vp, vp]
         L.orc_dct2d_f32.argtypes = [vp, i, i, vp]
         L.orc_score_batch.argtypes = [vp, i, i, i, sz, sz, vp, vp]
         L.orc_score_batch_flags.argtypes = [vp, i, i, i, sz, sz, vp, vp, ctypes.c_uint]

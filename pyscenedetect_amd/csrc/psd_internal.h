@@ -87,7 +87,7 @@ void area_tables(int src_h, int src_w, int dst_h, int dst_w, AreaRun* tab, int* 
 
 // Coefficient tables stay on the device for as long as the engine does, one per (kind, src shape, dst shape): built and
 // uploaded on the first call with a shape, found again afterwards (no allocation or synchronisation on the call path).
-enum TableKind { kTabNearest = 2, kTabArea = 3, kTabHashArea = 4, kTabHashBasis = 5, kTabLanczos4 = 6 };
+enum TableKind { kTabNearest = 2, kTabArea = 3, kTabHashArea = 4, kTabHashBasis = 5, kTabLanczos4 = 6, kTabCubic = 7 };
 struct DevTable {
     const void* ptr = nullptr;
     int mode = 0;

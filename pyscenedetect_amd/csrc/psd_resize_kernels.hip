@@ -1079,7 +1079,7 @@ static void nearest_offsets(int src_h, int src_w, int dst_h, int dst_w, int* ofs
 // ---- cv2.resize(INTER_LANCZOS4), 8-bit (Interpolation.LANCZOS4, common.py:148-160) -----------------------------------------
 // OpenCV's generic path for this filter is integer arithmetic behind the coefficient tables (resize.cpp: lanczos4_tab[CV_8U] =
 // HResizeLanczos4<uchar, int, short> + VResizeLanczos4<..., FixedPtCast<int, uchar, 22>, VResizeNoVec>; no IPP branch, no SIMD
-// vertical pass -- which is what keeps INTER_CUBIC refused: its 8-bit result depends on the build), so the device result is the
+// vertical pass -- unlike INTER_CUBIC below, whose 8-bit result depends on the build), so the device result is the
 // reference's: eight taps per axis at source positions s - 3 .. s + 4 (s = floor of (d + 0.5) * scale - 0.5 in float32), a tap
 // outside the image replaced by the nearest pixel inside, 11-bit coefficients
 //   D_k = sum_j S[row_k][col_j] * alpha[j]  (int32),   dst = saturate_u8((sum_k D_k * beta[k] + 2^21) >> 22)  (low 32 bits).
@@ -1162,20 +1162,136 @@ __global__ __launch_bounds__(kOtherWG) void resize_lanczos4_kernel(const uint8_t
     }
 }
 
-// interpolation: 0 = INTER_NEAREST, 3 = INTER_AREA that shrinks along both axes, 4 = INTER_LANCZOS4 (cv2's values)
+// ---- cv2.resize(INTER_CUBIC), 8-bit (Interpolation.CUBIC, common.py:148-160) -----------------------------------------------
+// Four taps per axis at s - 1 .. s + 2 (s as for LANCZOS4), interpolateCubic's float32 weights (A = -0.75) as 11-bit shorts, the
+// horizontal pass in int -- and a VERTICAL pass that OpenCV builds compute differently (resize.cpp: VResizeCubic<..., FixedPtCast<int,
+// uchar, 22>, VResizeCubicVec_32s8u>).  PSD_CUBIC_FORM picks the build that is reproduced byte for byte:
+//   sse (default)  OpenCV 4.x without IPP on an SSE2/SSE3 baseline: whole groups of 8 elements (v_int16x8) of a destination row go through
+//                  float32 -- S0*b0 + (S1*b1 + (S2*b2 + S3*b3)), b_k = beta[k] * 2^-22, every product and every sum rounded, cvtps2dq
+//                  (to nearest even), saturating packs -- and the width*3 % 8 elements at the end of a row through the scalar fixed point;
+//   fma            the same with fused multiply-adds (v_muladd on aarch64 NEON / FMA baselines);
+//   fixed          the scalar FixedPtCast everywhere: (sum_k D_k * beta[k] + 2^21) >> 22 (CV_SIMD off).
+// The forms differ in about one byte per 50,000 (products that land within float32 rounding of .5).  x86-64 PyPI wheels hand 8-bit
+// CUBIC to IPP, whose arithmetic is not published: no form claims to be theirs.
+struct CbTap { int first; short a[4]; };      // first = s - 1 (not clamped)
+enum CubicForm { kCubicSse = 0, kCubicFma = 1, kCubicFixed = 2 };
+
+static int cubic_form()
+{
+    static const int form = [] {
+        const char* v = getenv("PSD_CUBIC_FORM");
+        if (!v || !strcmp(v, "sse")) return (int)kCubicSse;
+        if (!strcmp(v, "fma")) return (int)kCubicFma;
+        if (!strcmp(v, "fixed")) return (int)kCubicFixed;
+        return -1;
+    }();
+    return form;
+}
+
+// interpolateCubic (OpenCV 4.x), float32 step by step (no contraction: an x86 baseline build has no FMA to contract into)
+static void cubic_coeffs(float x, float* coeffs)
+{
+#pragma clang fp contract(off)
+    const float A = -0.75f;
+    coeffs[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    coeffs[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    coeffs[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    coeffs[3] = 1.f - coeffs[0] - coeffs[1] - coeffs[2];
+}
+
+static void cubic_taps(int ssize, int dsize, CbTap* t)
+{
+    const double scale = 1. / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        const int s = (int)floorf(f);
+        f -= s;
+        float cbuf[4];
+        cubic_coeffs(f, cbuf);
+        t[d].first = s - 1;
+        for (int k = 0; k < 4; k++) t[d].a[k] = sat_s16_round(cbuf[k] * 2048);
+    }
+}
+
+// one destination pixel per thread: 4 x 4 taps x 3 channels; vec_end = the elements of a destination row (3 per pixel) in front of the
+// scalar tail, 0 for the fixed form
+template <bool FMA>
+__global__ __launch_bounds__(kOtherWG) void resize_cubic_kernel(const uint8_t* src, int sh, int sw, size_t sstride, uint8_t* dst, int dh, int dw,
+                                                                size_t dstride, const CbTap* xtab, const CbTap* ytab, int vec_end)
+{
+    const int p = blockIdx.x * kOtherWG + threadIdx.x;
+    if (p >= dh * dw) return;
+    const int dy = p / dw, dx = p - dy * dw;
+    const CbTap X = xtab[dx], Y = ytab[dy];
+    const uint8_t* S = src + (size_t)blockIdx.y * sstride;
+    const bool inner = X.first >= 0 && X.first + 3 < sw;
+    int h[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint8_t* row = S + (size_t)min(max(Y.first + k, 0), sh - 1) * sw * 3;
+        h[k][0] = h[k][1] = h[k][2] = 0;
+        if (inner) {
+            const uint8_t* q = row + (size_t)X.first * 3;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                h[k][0] += (int)q[3 * j] * X.a[j]; h[k][1] += (int)q[3 * j + 1] * X.a[j]; h[k][2] += (int)q[3 * j + 2] * X.a[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint8_t* q = row + (size_t)min(max(X.first + j, 0), sw - 1) * 3;
+                h[k][0] += (int)q[0] * X.a[j]; h[k][1] += (int)q[1] * X.a[j]; h[k][2] += (int)q[2] * X.a[j];
+            }
+        }
+    }
+    const float scale = 1.f / (2048 * 2048);
+    const float b0 = (float)Y.a[0] * scale, b1 = (float)Y.a[1] * scale, b2 = (float)Y.a[2] * scale, b3 = (float)Y.a[3] * scale;   // (exact)
+    uint8_t* D = dst + (size_t)blockIdx.y * dstride + (size_t)p * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int r;
+        if (dx * 3 + c < vec_end) {
+            // |h| < 2^20: the conversions are exact; the _rn intrinsics keep hipcc from contracting the unfused form
+            float t = __fmul_rn((float)h[3][c], b3);
+            if (FMA) {
+                t = __fmaf_rn((float)h[2][c], b2, t);
+                t = __fmaf_rn((float)h[1][c], b1, t);
+                t = __fmaf_rn((float)h[0][c], b0, t);
+            } else {
+                t = __fadd_rn(__fmul_rn((float)h[2][c], b2), t);
+                t = __fadd_rn(__fmul_rn((float)h[1][c], b1), t);
+                t = __fadd_rn(__fmul_rn((float)h[0][c], b0), t);
+            }
+            r = __float2int_rn(t);
+        } else {
+            const u32 acc = (u32)h[0][c] * (u32)(int)Y.a[0] + (u32)h[1][c] * (u32)(int)Y.a[1] + (u32)h[2][c] * (u32)(int)Y.a[2] +
+                            (u32)h[3][c] * (u32)(int)Y.a[3];
+            r = ((int)(acc + (1u << 21))) >> 22;
+        }
+        D[c] = (uint8_t)min(255, max(0, r));
+    }
+}
+
+// interpolation: 0 = INTER_NEAREST, 2 = INTER_CUBIC, 3 = INTER_AREA that shrinks along both axes, 4 = INTER_LANCZOS4 (cv2's values)
 int resize_other(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_w, size_t src_frame_stride, uint8_t* d_dst, int dst_h,
                  int dst_w, size_t dst_frame_stride, int interpolation, hipStream_t stream)
 {
     if (n == 0) return PSD_OK;
-    if (interpolation != PSD_INTER_NEAREST && interpolation != PSD_INTER_AREA && interpolation != PSD_INTER_LANCZOS4) {
-        psd_set_error("interpolation %d is not implemented on the device (0 = NEAREST, 1 = LINEAR, 3 = AREA, 4 = LANCZOS4)", interpolation);
+    if (interpolation != PSD_INTER_NEAREST && interpolation != PSD_INTER_AREA && interpolation != PSD_INTER_LANCZOS4 &&
+        interpolation != PSD_INTER_CUBIC) {
+        psd_set_error("interpolation %d is not one of cv2's filters the reference offers (0 = NEAREST, 1 = LINEAR, 2 = CUBIC, 3 = AREA, 4 = LANCZOS4)", interpolation);
         return PSD_ERR_UNSUPPORTED;
     }
     if (interpolation == PSD_INTER_AREA && (dst_w > src_w || dst_h > src_h)) {
         psd_set_error("INTER_AREA run tables are for decimation (%dx%d -> %dx%d)", src_w, src_h, dst_w, dst_h);
         return PSD_ERR_UNSUPPORTED;
     }
-    const int kind = interpolation == PSD_INTER_NEAREST ? kTabNearest : interpolation == PSD_INTER_LANCZOS4 ? kTabLanczos4 : kTabArea;
+    if (interpolation == PSD_INTER_CUBIC && cubic_form() < 0) {
+        psd_set_error("PSD_CUBIC_FORM=%s: the forms of OpenCV's 8-bit INTER_CUBIC are sse (default), fma and fixed", getenv("PSD_CUBIC_FORM"));
+        return PSD_ERR_INVALID;
+    }
+    const int kind = interpolation == PSD_INTER_NEAREST ? kTabNearest : interpolation == PSD_INTER_LANCZOS4 ? kTabLanczos4 :
+                     interpolation == PSD_INTER_CUBIC ? kTabCubic : kTabArea;
     DevTable tab;
     if (!table_find(e, kind, src_h, src_w, dst_h, dst_w, &tab)) {
         int rc;
@@ -1184,6 +1300,11 @@ int resize_other(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_
             lanczos4_taps(src_w, dst_w, t.data());
             lanczos4_taps(src_h, dst_h, t.data() + dst_w);
             rc = table_store(e, kind, src_h, src_w, dst_h, dst_w, t.data(), t.size() * sizeof(LzTap), 0, 0.f, &tab);
+        } else if (kind == kTabCubic) {
+            std::vector<CbTap> t((size_t)dst_w + dst_h);
+            cubic_taps(src_w, dst_w, t.data());
+            cubic_taps(src_h, dst_h, t.data() + dst_w);
+            rc = table_store(e, kind, src_h, src_w, dst_h, dst_w, t.data(), t.size() * sizeof(CbTap), 0, 0.f, &tab);
         } else if (kind == kTabNearest) {
             std::vector<int> ofs((size_t)dst_w + dst_h);
             nearest_offsets(src_h, src_w, dst_h, dst_w, ofs.data());
@@ -1205,7 +1326,15 @@ int resize_other(psd_engine* e, const uint8_t* d_src, int n, int src_h, int src_
         if (kind == kTabLanczos4)
             hipLaunchKernelGGL(resize_lanczos4_kernel, dim3(blocks, cnt), dim3(kOtherWG), 0, stream, S, src_h, src_w, src_frame_stride, D, dst_h,
                                dst_w, dst_frame_stride, (const LzTap*)tab.ptr, (const LzTap*)tab.ptr + dst_w);
-        else if (kind == kTabNearest)
+        else if (kind == kTabCubic) {
+            const int form = cubic_form(), vec_end = form == kCubicFixed ? 0 : dst_w * 3 - dst_w * 3 % 8;
+            if (form == kCubicFma)
+                hipLaunchKernelGGL(resize_cubic_kernel<true>, dim3(blocks, cnt), dim3(kOtherWG), 0, stream, S, src_h, src_w, src_frame_stride, D,
+                                   dst_h, dst_w, dst_frame_stride, (const CbTap*)tab.ptr, (const CbTap*)tab.ptr + dst_w, vec_end);
+            else
+                hipLaunchKernelGGL(resize_cubic_kernel<false>, dim3(blocks, cnt), dim3(kOtherWG), 0, stream, S, src_h, src_w, src_frame_stride, D,
+                                   dst_h, dst_w, dst_frame_stride, (const CbTap*)tab.ptr, (const CbTap*)tab.ptr + dst_w, vec_end);
+        } else if (kind == kTabNearest)
             hipLaunchKernelGGL(resize_nearest_kernel, dim3(blocks, cnt), dim3(kOtherWG), 0, stream, S, src_w, src_frame_stride, D, dst_h,
                                dst_w, dst_frame_stride, (const int*)tab.ptr, (const int*)tab.ptr + dst_w);
         else
@@ -1239,13 +1368,18 @@ int resize_source_rows(int src_h, int src_w, int dst_h, int dst_w, int interpola
         area_tables(src_h, src_w, dst_h, dst_w, t.data(), &mode, &inv_area);
         for (int dy = 0; dy < dst_h; dy++)
             for (int j = 0; j < t[dst_w + dy].count; j++) used[std::min(src_h - 1, t[dst_w + dy].first + j)] = 1;
+    } else if (interpolation == PSD_INTER_CUBIC) {
+        std::vector<CbTap> t((size_t)dst_h);
+        cubic_taps(src_h, dst_h, t.data());
+        for (int dy = 0; dy < dst_h; dy++)
+            for (int k = 0; k < 4; k++) used[std::min(src_h - 1, std::max(0, t[dy].first + k))] = 1;
     } else if (interpolation == PSD_INTER_LANCZOS4) {
         std::vector<LzTap> t((size_t)dst_h);
         lanczos4_taps(src_h, dst_h, t.data());
         for (int dy = 0; dy < dst_h; dy++)
             for (int k = 0; k < 8; k++) used[std::min(src_h - 1, std::max(0, t[dy].first + k))] = 1;
     } else {
-        psd_set_error("interpolation %d is not implemented on the device (0 = NEAREST, 1 = LINEAR, 3 = AREA, 4 = LANCZOS4)", interpolation);
+        psd_set_error("interpolation %d is not one of cv2's filters the reference offers (0 = NEAREST, 1 = LINEAR, 2 = CUBIC, 3 = AREA, 4 = LANCZOS4)", interpolation);
         return PSD_ERR_UNSUPPORTED;
     }
     int k = 0;

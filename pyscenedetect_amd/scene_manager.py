@@ -58,11 +58,12 @@ DEFAULT_BATCH_FRAMES: int = 64
 
 
 class Interpolation(Enum):
-    """Resize filters of the reference (``scenedetect/common.py:148-160``, values = OpenCV's ``INTER_*``).
-    LINEAR (the reference's default), NEAREST, AREA and LANCZOS4 are implemented on the device (LANCZOS4 since round 6: OpenCV's
-    8-bit path for it is integer arithmetic behind its coefficient tables, so it has ONE result).  CUBIC is refused: OpenCV's
-    8-bit vertical pass for it is float32 SIMD whose lane count, scalar tail and fused multiply-add use depend on the build,
-    and x86 wheels hand it to IPP -- a device result could not be bit-identical to "the" reference."""
+    """Resize filters of the reference (``scenedetect/common.py:148-160``, values = OpenCV's ``INTER_*``), all five on the device.
+    LINEAR (the reference's default), NEAREST, AREA and LANCZOS4 have ONE 8-bit result in OpenCV (integer arithmetic behind the
+    coefficient tables).  CUBIC does not: its 8-bit vertical pass is float32 SIMD on most builds, fused or not, scalar fixed point on
+    others, and the x86-64 PyPI wheels hand it to IPP.  The device reproduces, byte for byte, the form ``PSD_CUBIC_FORM`` names --
+    ``sse`` (default: OpenCV 4.x without IPP on an SSE baseline), ``fma`` (aarch64 / FMA baselines), ``fixed`` (no vector pass);
+    they differ in about one byte per 50,000."""
 
     NEAREST = 0
     LINEAR = 1
@@ -198,10 +199,7 @@ class SceneManager:
 
     @interpolation.setter
     def interpolation(self, value: Interpolation):
-        value = Interpolation(value)
-        if value is Interpolation.CUBIC:
-            raise NotImplementedError(f"Interpolation.{value.name} is not implemented on the device")
-        self._interpolation = value
+        self._interpolation = Interpolation(value)
 
     @property
     def downscale(self) -> int:

@@ -70,6 +70,30 @@ def main():
     assert np.array_equal(out.download(small.nbytes).reshape(small.shape), small), "resize_device"
     out.free()
     buf.free()
+    # INTER_CUBIC in the form PSD_CUBIC_FORM names (the shim reads the same switch): noise that tells the three forms apart, a destination
+    # width whose rows end in a scalar tail
+    noise = np.random.default_rng(11).integers(0, 256, (8, 360, 640, 3), dtype=np.uint8)
+    form = cv2.CUBIC_FORMS[os.environ.get("PSD_CUBIC_FORM", "sse")]
+    nbuf = eng.alloc(noise.nbytes)
+    nbuf.upload(noise.reshape(-1))
+    told_apart = set()
+    for dh, dw in ((144, 256), (143, 255)):
+        forms = []
+        for f in range(3):
+            o = np.empty((len(noise), dh, dw, 3), np.uint8)
+            for i in range(len(noise)):
+                orc.lib().orc_resize_cubic_u8(noise[i].ctypes.data, 640 * 3, 360, 640, 3, o[i].ctypes.data, dw * 3, dh, dw, f)
+            forms.append(o)
+        told_apart |= {(a, b) for a, b in ((0, 1), (0, 2), (1, 2)) if not np.array_equal(forms[a], forms[b])}
+        out = eng.alloc(forms[0].nbytes)
+        eng.resize_device(nbuf.ptr, len(noise), 360, 640, out.ptr, dh, dw, interpolation=cv2.INTER_CUBIC)
+        eng.synchronize()
+        got = out.download(forms[0].nbytes).reshape(forms[0].shape)
+        assert np.array_equal(got, forms[form]), ("INTER_CUBIC", form, dh, dw, int(np.count_nonzero(got != forms[form])))
+        assert np.array_equal(got[0], cv2.resize(noise[0], (dw, dh), interpolation=cv2.INTER_CUBIC)), "the shim follows the same switch"
+        out.free()
+    assert len(told_apart) == 3, ("the input must tell the three forms apart", told_apart)
+    nbuf.free()
     # submissions with LARGE record sets, two in flight (the packed-heads form of >= 256 records, the whole-record copy): 320
     # records with histograms (340 KB), 7000 without (280 KB of heads)
     many = np.random.default_rng(3).integers(0, 256, (7000, 16, 32, 3), dtype=np.uint8)

@@ -28,7 +28,7 @@ def source_rows(h, w, dh, dw, interp):
 SHAPES = [(1080, 1920, 7.0), (720, 1280, 5.0), (480, 854, 3.0), (270, 481, 1.5), (96, 128, 2.0), (97, 131, 2.0), (33, 47, 4.2)]
 
 
-@pytest.mark.parametrize("interp", [NEAREST, LINEAR, AREA])
+@pytest.mark.parametrize("interp", [NEAREST, LINEAR, AREA, 2, 4])       # (2 = CUBIC, 4 = LANCZOS4)
 @pytest.mark.parametrize("h,w,factor", SHAPES)
 def test_rows_not_listed_never_reach_the_resized_frame(h, w, factor, interp):
     import cv2  # the oracle's shim (tests/conftest.py puts it on the path)
@@ -68,8 +68,8 @@ def test_source_rows_argument_errors():
     n = ctypes.c_int(0)
     assert lib.psd_resize_source_rows(0, 16, 4, 4, LINEAR, rows.ctypes.data, ctypes.addressof(n)) == _native.PSD_ERR_INVALID
     assert lib.psd_resize_source_rows(16, 16, 4, 4, LINEAR, None, ctypes.addressof(n)) == _native.PSD_ERR_INVALID
-    assert lib.psd_resize_source_rows(16, 16, 4, 4, 2, rows.ctypes.data, ctypes.addressof(n)) == _native.PSD_ERR_UNSUPPORTED  # CUBIC
-    assert "not implemented" in _native.last_error()
+    assert lib.psd_resize_source_rows(16, 16, 4, 4, 5, rows.ctypes.data, ctypes.addressof(n)) == _native.PSD_ERR_UNSUPPORTED  # (no such filter)
+    assert "not one of cv2's filters" in _native.last_error()
     assert lib.psd_upload_rows(None, None, None, 16, 16, None, 0) == _native.PSD_ERR_INVALID
 
 
@@ -252,7 +252,9 @@ def test_row_policy_per_shape():
     assert e.tap_rows(1080, 1920, 1.0, LINEAR) is None            # no downscale: every row is scored
     assert e.tap_rows(270, 481, 1.5, LINEAR) is None              # most rows carry taps
     assert e.tap_rows(1080, 1920, 7.0, AREA) is None              # every row carries weight
-    assert e.tap_rows(1080, 1920, 7.0, 2) is None                 # CUBIC: the scoring call refuses
+    assert len(e.tap_rows(1080, 1920, 7.0, 2)) == 4 * 154         # CUBIC: four of every seven rows
+    assert len(e.tap_rows(1080, 1920, 7.5, 2)) == 4 * 144         # ... the default pipeline's 7.5: 53 % of the rows
+    assert e.tap_rows(1080, 1920, 7.0, 5) is None                 # no such filter: the scoring call reports it
     assert e.tap_rows(1080, 1920, 4.3, LINEAR) is None            # ~70 copies per frame: not worth it
     # the feeder asks the engine; an engine without the policy gets whole frames
     assert len(_DeviceFeeder(e, 4, factor=7.5, interpolation=LINEAR)._rows_of(1080, 1920)) == 288

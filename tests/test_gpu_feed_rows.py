@@ -13,7 +13,7 @@ from tests.conftest import golden_clip
 
 pytestmark = pytest.mark.gpu
 
-NEAREST, LINEAR = 0, 1
+NEAREST, LINEAR, CUBIC = 0, 1, 2
 
 
 def _poisoned(engine, nbytes):
@@ -27,16 +27,19 @@ def _analyze(engine, buf, n, h, w, factor, interp, flags, hash_sizes=()):
                                  hash_sizes=hash_sizes, want_frames=True)
 
 
-@pytest.mark.parametrize("interp", [LINEAR, NEAREST])
-@pytest.mark.parametrize("h,w,factor,n", [(1080, 1920, 7.5, 6), (1080, 1920, 7.0, 2), (2160, 3840, 15.0, 3), (270, 480, 3.0, 9), (97, 131, 3.0, 5),
-                                          (720, 1280, 5.0, 4)])
+_ROW_SHAPES = [(1080, 1920, 7.5, 6), (1080, 1920, 7.0, 2), (2160, 3840, 15.0, 3), (270, 480, 3.0, 9), (97, 131, 3.0, 5), (720, 1280, 5.0, 4),
+               (270, 480, 6.0, 9)]
+
+
+# (CUBIC: four taps per destination row -- below a factor of 6 nearly every source row carries one and whole frames travel)
+@pytest.mark.parametrize("h,w,factor,n,interp", [s + (i,) for i in (LINEAR, NEAREST, CUBIC) for s in _ROW_SHAPES if i != CUBIC or s[2] >= 6])
 def test_tap_rows_only_equal_the_full_upload(hip_engine, oracle_engine, h, w, factor, n, interp):
     rng = np.random.default_rng(h + w + interp)
     frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
     frames[n // 2:, : h // 3] //= 4
     dw, dh = max(1, round(w / factor)), max(1, round(h / factor))
     rows = hip_engine.downscale_source_rows(h, w, dh, dw, interp)
-    assert len(rows) <= 2 * dh < 0.7 * h
+    assert len(rows) <= {LINEAR: 2, NEAREST: 1, CUBIC: 4}[interp] * dh < 0.7 * h
     stride = h * w * 3
     sparse, full = _poisoned(hip_engine, n * stride), hip_engine.alloc(n * stride)
     for t in range(n):
@@ -194,7 +197,7 @@ def test_scene_manager_feeds_tap_rows_and_decides_like_the_oracle(golden, hip_en
 
 def test_reference_runs_on_larger_frames_through_the_row_feeder(golden, hip_engine):
     """golden["downscale_rows"]: the UNMODIFIED reference over whole 960 x 540 frames (auto downscale to 256 x 144, LINEAR,
-    NEAREST and LANCZOS4, six detector configurations) against the HIP path whose feeder uploaded 288 (144) of the 540 rows of every frame:
+    NEAREST, LANCZOS4 and CUBIC, six detector configurations) against the HIP path whose feeder uploaded 288 (144) of the 540 rows of every frame:
     same cuts, same per-frame metrics."""
     from pyscenedetect_amd import scene_manager as smod
     from tests._helpers import assert_same_run, run_config
@@ -216,8 +219,8 @@ def test_reference_runs_on_larger_frames_through_the_row_feeder(golden, hip_engi
                 del seen[:]
                 got = run_config(frames, cls_name, kwargs, with_stats, hip_engine, auto_downscale=True, interpolation=mode)
                 assert_same_run(got, want, f"big_e/{mode}/{name}")
-                # (LANCZOS4: eight taps per destination row over 3.75 source rows -- every row carries taps, whole frames travel)
-                assert seen == [{"LINEAR": 288, "NEAREST": 144, "LANCZOS4": 0}[mode]] * len(frames), (mode, name, seen[:3])
+                # (LANCZOS4 / CUBIC: eight / four taps per destination row over 3.75 source rows -- every row carries taps, whole frames travel)
+                assert seen == [{"LINEAR": 288, "NEAREST": 144, "LANCZOS4": 0, "CUBIC": 0}[mode]] * len(frames), (mode, name, seen[:3])
     finally:
         smod._DeviceFeeder.put = original
 

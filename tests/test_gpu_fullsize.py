@@ -265,19 +265,19 @@ def test_downscale_then_all_four_constant_frames_and_headline_size(hip_engine):
 
 
 def test_downscale_then_score_other_terms_and_modes(hip_engine):
-    """Edges and the NEAREST / AREA modes go through the resize-then-score path of the same entry point."""
+    """Edges and the NEAREST / AREA / LANCZOS4 / CUBIC modes go through the resize-then-score path of the same entry point."""
     import cv2  # the oracle shim
 
     n, sh, sw, dh, dw = 5, 360, 640, 144, 256
     frames = shots_with_objects(77, n, sh, sw)
     buf = device_copy(hip_engine, frames)
-    for interpolation in (1, 0, 3):
+    for interpolation in (1, 0, 3, 4, 2):       # (cv2's values: LINEAR, NEAREST, AREA, LANCZOS4, CUBIC)
         small = np.stack([cv2.resize(f, (dw, dh), interpolation=interpolation) for f in frames])
         want = oracle_score(small, edges=True)
         got = hip_engine.score_device_downscaled(buf.ptr, n, sh, sw, dh, dw, flags=E.SCORE_ALL, interpolation=interpolation)
         same(got, want, FIELDS + ("edge_xor",))
     with pytest.raises(NotImplementedError):
-        hip_engine.score_device_downscaled(buf.ptr, n, sh, sw, dh, dw, interpolation=2)
+        hip_engine.score_device_downscaled(buf.ptr, n, sh, sw, dh, dw, interpolation=5)
     buf.free()
 
 

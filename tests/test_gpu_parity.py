@@ -522,12 +522,12 @@ def test_hash_thumbs_randomised_shapes(hip_engine):
 @pytest.mark.parametrize("shape", [((180, 320), (144, 256)), ((200, 300), (100, 150)), ((97, 131), (41, 77)),
                                    ((64, 96), (32, 32)), ((1080, 1920), (144, 256)), ((90, 120), (30, 40)),
                                    ((50, 70), (50, 70))])
-@pytest.mark.parametrize("mode", ["NEAREST", "AREA", "LANCZOS4"])
+@pytest.mark.parametrize("mode", ["NEAREST", "AREA", "LANCZOS4", "CUBIC"])
 def test_resize_nearest_and_area_match_oracle(hip_engine, shape, mode):
     import cv2  # the oracle shim
 
     (sh, sw), (dh, dw) = shape
-    inter = {"NEAREST": cv2.INTER_NEAREST, "AREA": cv2.INTER_AREA, "LANCZOS4": cv2.INTER_LANCZOS4}[mode]
+    inter = {"NEAREST": cv2.INTER_NEAREST, "AREA": cv2.INTER_AREA, "LANCZOS4": cv2.INTER_LANCZOS4, "CUBIC": cv2.INTER_CUBIC}[mode]
     rng = np.random.default_rng(sh * 3 + dw)
     src = rng.integers(0, 256, (2, sh, sw, 3), dtype=np.uint8)
     src[1, : sh // 2] = 255
@@ -544,18 +544,20 @@ def test_resize_nearest_and_area_match_oracle(hip_engine, shape, mode):
 def test_resize_unsupported_modes(hip_engine):
     a = hip_engine.alloc(64 * 64 * 3)
     b = hip_engine.alloc(128 * 128 * 3)
-    with pytest.raises(NotImplementedError):
-        hip_engine.resize_device(a.ptr, 1, 64, 64, b.ptr, 32, 32, interpolation=2)     # CUBIC (build-dependent in OpenCV itself)
-    with pytest.raises(NotImplementedError):
-        hip_engine.resize_device(a.ptr, 1, 64, 64, b.ptr, 32, 32, interpolation=5)     # (no such filter)
+    for interp in (5, -1, 7):                                                          # (no such filter: cv2's 0 .. 4 are all there)
+        with pytest.raises(NotImplementedError):
+            hip_engine.resize_device(a.ptr, 1, 64, 64, b.ptr, 32, 32, interpolation=interp)
 
 
 @pytest.mark.parametrize("shape", [((64, 64), (128, 128)), ((45, 80), (90, 160)), ((37, 53), (55, 80)), ((72, 128), (36, 256)), ((9, 5), (3, 2)),
                                    ((4, 4), (31, 17)), ((2160, 3840), (144, 256))])
-def test_resize_lanczos4_enlarging_and_extreme_shapes(hip_engine, shape):
-    """cv2.resize(INTER_LANCZOS4) where most taps fall outside the image (tiny sources: every tap clamped), enlargements, mixed
+@pytest.mark.parametrize("mode", ["LANCZOS4", "CUBIC"])
+def test_resize_lanczos4_enlarging_and_extreme_shapes(hip_engine, shape, mode):
+    """cv2.resize(INTER_LANCZOS4 / INTER_CUBIC) where most taps fall outside the image (tiny sources: every tap clamped), enlargements, mixed
     directions and the 15-fold reduction of a 4K frame -- OpenCV's integer arithmetic, byte for byte."""
     import cv2  # the oracle shim
+
+    inter = {"LANCZOS4": cv2.INTER_LANCZOS4, "CUBIC": cv2.INTER_CUBIC}[mode]       # (CUBIC: the default form, PSD_CUBIC_FORM unset)
 
     (sh, sw), (dh, dw) = shape
     rng = np.random.default_rng(sh * 7 + dw)
@@ -564,12 +566,13 @@ def test_resize_lanczos4_enlarging_and_extreme_shapes(hip_engine, shape):
     a = hip_engine.alloc(src.nbytes)
     a.upload(src.reshape(-1))
     b = hip_engine.alloc(2 * dh * dw * 3)
-    hip_engine.resize_device(a.ptr, 2, sh, sw, b.ptr, dh, dw, interpolation=cv2.INTER_LANCZOS4)
+    hip_engine.resize_device(a.ptr, 2, sh, sw, b.ptr, dh, dw, interpolation=inter)
     got = b.download().reshape(2, dh, dw, 3)
     for i in range(2):
-        want = cv2.resize(src[i], (dw, dh), interpolation=cv2.INTER_LANCZOS4)
-        assert np.array_equal(got[i], want), f"LANCZOS4 {sh}x{sw}->{dh}x{dw}: {np.count_nonzero(got[i] != want)} bytes differ"
-    assert got.min() == 0 and got.max() == 255
+        want = cv2.resize(src[i], (dw, dh), interpolation=inter)
+        assert np.array_equal(got[i], want), f"{mode} {sh}x{sw}->{dh}x{dw}: {np.count_nonzero(got[i] != want)} bytes differ"
+    if mode == "LANCZOS4" or dh * dw > 100:
+        assert got.min() == 0 and got.max() == 255
 
 
 @pytest.mark.parametrize("shape", [((64, 64), (128, 128)), ((45, 80), (90, 160)), ((37, 53), (55, 80)), ((72, 128), (36, 256)),

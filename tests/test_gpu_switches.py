@@ -31,6 +31,8 @@ SWITCHES = [
     {"PSD_RESIZE_ROUNDS": "1"},           # ... one round: every workgroup resident at once, the longest walks
     {"PSD_EDGE_FUSE_DOWNSCALE": "0"},     # HSV + edges behind the downscale: resize into the buffer and read it again (the route until round 6)
     {"PSD_EDGE_FUSE_DOWNSCALE": "1", "PSD_EDGE_WS_MB": "1"},    # ... the fused front end over many small chunks
+    {"PSD_CUBIC_FORM": "fma"},            # Interpolation.CUBIC as OpenCV builds with fused multiply-adds compute it (aarch64)
+    {"PSD_CUBIC_FORM": "fixed"},          # ... as builds without the vector pass do (the scalar fixed point everywhere)
 ]
 
 

@@ -163,7 +163,7 @@ def test_stats_manager_fuzz_slice_and_what_it_found(tmp_path):
 def test_api_surface_fuzz_slice():
     """``tools/fuzz_api_vs_reference.py``: constructor arguments of every kind, SceneManager property assignments, the module helpers
     (1.1 M cases clean after one fix: an odd FLOAT ``kernel_size`` passes the range check and is a TypeError in the reference, where
-    it builds the kernel).  Two documented differences are not drawn: CUBIC is refused, and a non-Interpolation value is
+    it builds the kernel).  One documented difference is not drawn: a non-Interpolation value is
     refused at the assignment instead of at its first use."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_api_vs_reference as A

@@ -191,8 +191,8 @@ def test_auto_downscale_matches_reference(golden, oracle_engine):
 
 
 def test_downscale_interpolation_modes_match_reference(golden, oracle_engine):
-    """SceneManager.interpolation = NEAREST / AREA (reference scene_manager.py:265-272): the downscale in front of the
-    detectors uses the requested cv2.resize filter."""
+    """SceneManager.interpolation = NEAREST / AREA / LANCZOS4 / CUBIC (reference scene_manager.py:265-272): the downscale in front of
+    the detectors uses the requested cv2.resize filter (CUBIC: the default form of PSD_CUBIC_FORM, which is what the goldens were made with)."""
     frames = golden_clip(golden, "wide_d")
     for mode, runs in golden["interp"].items():
         for name, want in runs.items():
@@ -200,10 +200,11 @@ def test_downscale_interpolation_modes_match_reference(golden, oracle_engine):
             got = run_config(frames, cls_name, kwargs, with_stats, oracle_engine, auto_downscale=True, interpolation=mode)
             assert_same_run(got, want, f"wide_d/{mode}/{name}")
     sm = psd.SceneManager(engine=oracle_engine)
-    with pytest.raises(NotImplementedError):
-        sm.interpolation = psd.Interpolation.CUBIC             # (its 8-bit result depends on the OpenCV build: DESIGN.md 7)
-    sm.interpolation = psd.Interpolation.LANCZOS4
-    assert sm.interpolation is psd.Interpolation.LANCZOS4
+    for mode in psd.Interpolation:                             # (all five filters of the reference's enum are accepted)
+        sm.interpolation = mode
+        assert sm.interpolation is mode
+    with pytest.raises(ValueError):
+        sm.interpolation = 5
 
 
 def big_clip(golden):

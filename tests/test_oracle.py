@@ -272,7 +272,96 @@ def test_nearest_and_multichannel_area_resize():
             assert np.array_equal(area[..., c], cv2.resize(np.ascontiguousarray(img[..., c]), (dw, dh), interpolation=cv2.INTER_AREA))
     assert cv2.resize(img, (200, 200), interpolation=cv2.INTER_AREA).shape == (200, 200, 3)   # enlargement: bilinear emulation
     with pytest.raises(NotImplementedError):
-        cv2.resize(img, (50, 50), interpolation=cv2.INTER_CUBIC)
+        cv2.resize(img, (50, 50), interpolation=7)
+
+
+def _cubic_numpy(img, dh, dw, form):
+    """cv2.resize(INTER_CUBIC) for 8-bit images written a second time, in numpy: resize.cpp's HResizeCubic in int32, then the vertical pass in
+    the form asked for -- float32 arrays (numpy rounds every product and every sum: the unfused form; the fused one through float64, in
+    which a float32 product is exact and one rounding is left) or FixedPtCast."""
+    def taps(ssize, dsize):
+        d = np.arange(dsize)
+        f = ((d + 0.5) * (1.0 / (dsize / ssize)) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        x = (f - s.astype(np.float32)).astype(np.float32)
+        A, one = np.float32(-0.75), np.float32(1)
+        c0 = ((A * (x + one) - np.float32(5) * A) * (x + one) + np.float32(8) * A) * (x + one) - np.float32(4) * A
+        c1 = ((A + np.float32(2)) * x - (A + np.float32(3))) * x * x + one
+        c2 = ((A + np.float32(2)) * (one - x) - (A + np.float32(3))) * (one - x) * (one - x) + one
+        c3 = one - c0 - c1 - c2
+        c = np.stack([c0, c1, c2, c3], 1)
+        assert c.dtype == np.float32
+        return s - 1, np.rint(c * np.float32(2048)).astype(np.int64)
+    sh, sw = img.shape[:2]
+    xf, xa = taps(sw, dw)
+    yf, yb = taps(sh, dh)
+    cols = np.clip(xf[:, None] + np.arange(4), 0, sw - 1)                     # (dw, 4)
+    hor = (img.astype(np.int64)[:, cols, :] * xa[None, :, :, None]).sum(2)    # (sh, dw, 3)
+    rows = np.clip(yf[:, None] + np.arange(4), 0, sh - 1)                     # (dh, 4)
+    S = hor[rows].reshape(dh, 4, dw * 3)                                      # (dh, 4, width)
+    fixed = np.clip(((S * yb[:, :, None]).sum(1) + (1 << 21)) >> 22, 0, 255)
+    if form == 2:
+        return fixed.astype(np.uint8).reshape(dh, dw, 3)
+    b = (yb.astype(np.float32) * np.float32(1.0 / (2048 * 2048)))[:, :, None]
+    Sf = S.astype(np.float32)
+    if form == 0:
+        t = Sf[:, 3] * b[:, 3]
+        for k in (2, 1, 0):
+            t = Sf[:, k] * b[:, k] + t
+            assert t.dtype == np.float32
+    else:
+        t = (Sf[:, 3] * b[:, 3]).astype(np.float64)
+        for k in (2, 1, 0):     # (a float32 product is exact in float64: what is rounded to float32 is product + t, as fmaf does)
+            t = (Sf[:, k].astype(np.float64) * b[:, k].astype(np.float64) + t).astype(np.float32).astype(np.float64)
+    vec = np.clip(np.rint(t), 0, 255)
+    width = dw * 3
+    out = np.where(np.arange(width)[None, :] < width - width % 8, vec, fixed)
+    return out.astype(np.uint8).reshape(dh, dw, 3)
+
+
+@pytest.mark.parametrize("shape", [((97, 131), (41, 77)), ((360, 640), (144, 256)), ((540, 960), (143, 255)), ((9, 5), (3, 2)), ((4, 4), (31, 17)),
+                                   ((50, 70), (50, 70)), ((45, 80), (90, 161))])
+def test_cubic_resize_forms_against_a_second_restatement(shape):
+    """orc_resize_cubic_u8 (C) against the numpy restatement above in all three forms, on noise with saturated halves; what the forms have
+    in common (identity at equal sizes, constants stay constant, never more than one level apart)."""
+    from oracle import lib as orc
+
+    (sh, sw), (dh, dw) = shape
+    rng = np.random.default_rng(sh * 5 + dw)
+    img = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+    img[:, : max(1, sw // 3)] = (255, 0, 255)
+    outs = []
+    for form in range(3):
+        got = np.empty((dh, dw, 3), np.uint8)
+        orc.lib().orc_resize_cubic_u8(img.ctypes.data, sw * 3, sh, sw, 3, got.ctypes.data, dw * 3, dh, dw, form)
+        want = _cubic_numpy(img, dh, dw, form)
+        assert np.array_equal(got, want), (form, int(np.count_nonzero(got != want)))
+        outs.append(got.astype(int))
+    assert max(np.abs(outs[0] - outs[1]).max(), np.abs(outs[0] - outs[2]).max()) <= 1
+    if dh * dw > 1000:
+        assert outs[0].min() == 0 and outs[0].max() == 255
+    if (sh, sw) == (dh, dw):
+        assert all(np.array_equal(o, img) for o in outs)
+    flat = np.full((sh, sw, 3), 201, np.uint8)
+    got = np.empty((dh, dw, 3), np.uint8)
+    orc.lib().orc_resize_cubic_u8(flat.ctypes.data, sw * 3, sh, sw, 3, got.ctypes.data, dw * 3, dh, dw, 0)
+    assert np.all(np.abs(got.astype(int) - 201) <= 1)       # (the 11-bit weights of a tap set need not sum to 2048 exactly)
+
+
+def test_cubic_form_switch_of_the_shim(monkeypatch):
+    import cv2  # the oracle shim
+    from oracle import lib as orc
+
+    img = np.random.default_rng(3).integers(0, 256, (360, 640, 3), dtype=np.uint8)
+    for name, form in cv2.CUBIC_FORMS.items():
+        monkeypatch.setenv("PSD_CUBIC_FORM", name)
+        want = np.empty((143, 255, 3), np.uint8)
+        orc.lib().orc_resize_cubic_u8(img.ctypes.data, 640 * 3, 360, 640, 3, want.ctypes.data, 255 * 3, 143, 255, form)
+        assert np.array_equal(cv2.resize(img, (255, 143), interpolation=cv2.INTER_CUBIC), want)
+    monkeypatch.delenv("PSD_CUBIC_FORM")
+    monkeypatch.setenv("PSD_CUBIC_FORM", "ipp")
+    with pytest.raises(KeyError):
+        cv2.resize(img, (255, 143), interpolation=cv2.INTER_CUBIC)
 
 
 def test_fp32_formulation_of_the_hsv_pass_is_exact_on_all_triples():

@@ -257,6 +257,8 @@ def draw_case(rng):
         sm["downscale"] = int(rng.integers(1, 4))
     if rng.integers(0, 3) == 0:
         sm["interpolation"] = ["LINEAR", "NEAREST", "AREA", "LANCZOS4"][int(rng.integers(0, 4))]
+        if sm["interpolation"] == "LANCZOS4" and (w + h) % 2:      # (CUBIC, accepted since round 6, without another draw: earlier seeds keep their cases)
+            sm["interpolation"] = "CUBIC"
     if rng.integers(0, 5) == 0 and w > 40 and h > 30:
         x0, y0 = int(rng.integers(0, w // 3)), int(rng.integers(0, h // 3))
         sm["crop"] = (x0, y0, int(rng.integers(x0 + 17, w)), int(rng.integers(y0 + 17, h)))
