@@ -190,7 +190,7 @@ def run(seed: int, seconds: float, max_cases: int, verbose: bool = False, engine
                 diff = compare(got, want, fields)
             elif entry == "downscale":
                 factor = float(rng.choice([1.25, 1.5, 2.0, 2.5, 3.0, 4.0, 7.5, rng.uniform(1.05, 9.0)]))
-                interp = int(rng.choice([1, 1, 1, 0, 3]))       # INTER_LINEAR, NEAREST, AREA
+                interp = int(rng.choice([1, 1, 1, 0, 3, 4, 2]))       # INTER_LINEAR, NEAREST, AREA, LANCZOS4, CUBIC (the default form)
                 flags = int(rng.integers(1, 8))
                 frames = draw_content(rng, n, h, w)
                 prev = draw_content(rng, 1, h, w)[0] if rng.integers(0, 2) else None
@@ -212,7 +212,7 @@ def run(seed: int, seconds: float, max_cases: int, verbose: bool = False, engine
                 ds, interp = None, 1
                 if rng.integers(0, 2):
                     ds = "auto" if rng.integers(0, 2) else float(rng.choice([1.25, 1.5, 2.0, 2.5, 3.0, 7.5, rng.uniform(1.05, 6.0)]))
-                    interp = int(rng.choice([1, 1, 1, 0, 3]))
+                    interp = int(rng.choice([1, 1, 1, 0, 3, 4, 2]))
                     if rng.integers(0, 5) == 0:
                         flags |= 8
                 clips, wants = [], []
