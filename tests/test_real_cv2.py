@@ -85,3 +85,28 @@ def test_hash_detector_primitives_and_other_resize_modes(seed):
     low = np.empty((16, 16), np.float32)
     orc.lib().orc_dct2d_f32(np.ascontiguousarray(x).ctypes.data, 32, 16, low.ctypes.data)
     assert np.abs(cv2.dct(x)[:16, :16] - low).max() <= 1e-5
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_lanczos4_and_cubic(seed):
+    """INTER_LANCZOS4 has one 8-bit result in OpenCV (integer arithmetic) and must match; INTER_CUBIC has several: the
+    installed build must be ONE of the three restated forms byte for byte -- or, on a build with IPP (x86-64 PyPI wheels; cv2.ipp.useIPP()),
+    within one level of the `sse` form, which is all that can be said of a closed implementation.  The form found is printed: that is the
+    value PSD_CUBIC_FORM should have next to this cv2."""
+    img = np.random.default_rng(100 + seed).integers(0, 256, (360, 640, 3), dtype=np.uint8)
+    img[:, :200] = (255, 0, 255)
+    found = set(range(3))
+    for dw, dh in ((256, 144), (255, 143), (700, 380)):
+        got = np.empty((dh, dw, 3), np.uint8)
+        orc.lib().orc_resize_lanczos4_u8(img.ctypes.data, 640 * 3, 360, 640, 3, got.ctypes.data, dw * 3, dh, dw)
+        assert np.array_equal(got, cv2.resize(img, (dw, dh), interpolation=cv2.INTER_LANCZOS4)), (dw, dh)
+        want = cv2.resize(img, (dw, dh), interpolation=cv2.INTER_CUBIC)
+        for form in range(3):
+            orc.lib().orc_resize_cubic_u8(img.ctypes.data, 640 * 3, 360, 640, 3, got.ctypes.data, dw * 3, dh, dw, form)
+            if not np.array_equal(got, want):
+                found.discard(form)
+            if form == 0:
+                assert np.abs(got.astype(int) - want).max() <= 1, (dw, dh)
+    ipp = bool(getattr(getattr(cv2, "ipp", None), "useIPP", lambda: False)())
+    print("INTER_CUBIC of this cv2 is form(s)", sorted(found), "of (sse, fma, fixed); IPP in use:", ipp)
+    assert found or ipp

@@ -38,6 +38,9 @@ def main():
         out[f"resize_{seed}"] = cv2.resize(img, (64, 48), interpolation=cv2.INTER_LINEAR)
         out[f"resize_nearest_{seed}"] = cv2.resize(img, (64, 48), interpolation=cv2.INTER_NEAREST)
         out[f"resize_area_{seed}"] = cv2.resize(img, (64, 48), interpolation=cv2.INTER_AREA)
+        out[f"resize_lanczos4_{seed}"] = cv2.resize(img, (64, 48), interpolation=cv2.INTER_LANCZOS4)
+        out[f"resize_cubic_{seed}"] = cv2.resize(img, (61, 47), interpolation=cv2.INTER_CUBIC)      # (183 elements per row: a scalar tail of 7; which
+        #  of the three forms of oracle/cv2_restate.c: orc_resize_cubic_u8 this build computes -- if any: IPP builds compute none -- tests/test_real_cv2.py says)
         # HashDetector.hash_frame (hash_detector.py:117-151)
         gray = cv2.cvtColor(img, cv2.COLOR_BGR2GRAY)
         out[f"gray{seed}"] = gray
