@@ -242,7 +242,8 @@ struct RsParams {
     int store_vec;           // STORE: a tile's pixels leave through LDS as 16-byte stores (whole, 16-byte aligned tiles), else byte stores
     int depth;               // staging buffers: 2 = one frame ahead, 3 = two frames ahead
     uint8_t* vout;           // VOUT: the resized frame's V plane (max(B, G, R), one byte per pixel), frame t at vout + t * dh * dw
-    u32* hpart;              // LUMA / VOUT: per (frame, tile) partial luma (V) histograms, 128 words of two 16-bit counts (bins 2i | 2i+1 << 16)
+    u32* hpart;              // LUMA / VOUT: per (frame, tile) partial luma (V) histograms, `hstride` words each (rs_hist_flush)
+    int hstride;
 };
 
 // 24-bit multiplies (v_mul_lo_u32 issues at a quarter of their rate; hipcc does not pick them for `>> 4`-ed or table operands)
@@ -278,6 +279,17 @@ constexpr int RS_WG = PSD_RS_WG, RS_NW = RS_WG / 64, RS_SLOTS = 16, RS_REP = 16;
 #define PSD_RS_HREP 1
 #endif
 constexpr int RS_HREP = PSD_RS_HREP;
+// A tile's partial histogram in memory (third session of round 6).  A tile has at most 2048 pixels, and its 256 counts used to leave as 128
+// words of two 16-bit counts: 512 bytes per (frame, tile), 165 MB per 4096 x 1080p -- scattered writes between streaming reads, which cost
+// up to 0.16 ms of the pass's 1.34 ("two states").  Now the LOW BYTES of the counts leave as 64 words (bins 4 i .. 4 i + 3 in
+// lane i of wave 0), and what a byte cannot hold -- a count >= 256: at most tile pixels / 256 lanes can own one -- as an escape: words 64 /
+// 65 = the ballot of the lanes that own such a bin, words 66 .. = those lanes' four carries (count >> 8, four bits each), in lane order.
+// 272 bytes per (frame, tile) at 1080p -> 256 x 144 instead of 512.
+#ifndef PSD_RS_HPACK8
+#define PSD_RS_HPACK8 1
+#endif
+constexpr bool RS_HPACK8 = PSD_RS_HPACK8 != 0;
+static int rs_hist_stride_words(int tile_pixels) { return RS_HPACK8 ? 66 + std::min(64, (tile_pixels + 255) / 256) : 128; }
 
 // LDS increment the compiler does not see as an LDS store: hipcc orders every LDS store / atomic behind ALL outstanding LDS-DMA
 // (s_waitcnt vmcnt(0)), i.e. behind the staging of the NEXT frame, which would serialise the prefetch with this frame's
@@ -385,6 +397,42 @@ __device__ __forceinline__ void rs_hsv(u32 b, u32 g, u32 r, const u32* lut_s, co
     __builtin_assume(hraw >= -2048 && hraw < 2048);                        // (|hraw| <= 1275)
     const int hh = (hraw * (int)lh + (2048 << 4)) >> 16;
     h = min((u32)hh, (u32)(hh + 180));                                     // hh in [-90, 179]: the negative ones wrap by + 180
+}
+
+// A tile's finished histogram (RS_HREP copies in LDS) out to memory in the layout above; CLEAR: the slot is zeroed for the frame after next,
+// with stores the compiler does not see, for the reason given at rs_lds_add: a visible LDS store here would make the wave wait for the NEXT
+// frame's staging, issued a few lines up (the reads are of a different object than the staging buffers and are not held back).
+template <bool CLEAR>
+__device__ __forceinline__ void rs_hist_flush(u32* hs, u32* dst, int tid)
+{
+    if constexpr (RS_HPACK8) {
+        if (tid >= 64) return;                       // wave 0, whole: the ballot below is over all 64 lanes
+        u32 c[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < RS_HREP; r++) {
+            const uint4 w = *reinterpret_cast<const uint4*>(&hs[r * 256 + 4 * tid]);
+            c[0] += w.x; c[1] += w.y; c[2] += w.z; c[3] += w.w;
+            if (CLEAR) {
+                asm volatile("ds_write_b64 %0, %1" ::"v"((u32)(uintptr_t)&hs[r * 256 + 4 * tid]), "v"(0ull) : "memory");
+                asm volatile("ds_write_b64 %0, %1" ::"v"((u32)(uintptr_t)&hs[r * 256 + 4 * tid + 2]), "v"(0ull) : "memory");
+            }
+        }
+        const u32 bytes = (c[0] & 255u) | ((c[1] & 255u) << 8) | ((c[2] & 255u) << 16) | (c[3] << 24);
+        const u32 carry = (c[0] >> 8) | ((c[1] >> 8) << 4) | ((c[2] >> 8) << 8) | ((c[3] >> 8) << 12);      // (a tile has <= 2048 pixels: <= 8 each)
+        const unsigned long long over = __ballot(carry != 0u);
+        dst[tid] = bytes;
+        if (tid < 2) dst[64 + tid] = tid ? (u32)(over >> 32) : (u32)over;
+        if (carry) dst[66 + __popcll(over & ((1ull << tid) - 1ull))] = carry;
+    } else {
+        if (tid >= 128) return;
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int r = 0; r < RS_HREP; r++) {
+            lo += hs[r * 256 + 2 * tid]; hi += hs[r * 256 + 2 * tid + 1];
+            if (CLEAR) asm volatile("ds_write_b64 %0, %1" ::"v"((u32)(uintptr_t)&hs[r * 256 + 2 * tid]), "v"(0ull) : "memory");
+        }
+        dst[tid] = lo | (hi << 16);
+    }
 }
 
 // grid.x = n_tiles * n_chunks.  Dynamic LDS: depth buffers x (2 R rows x row_pad bytes) + 16 bytes of slack (the 8-byte tap reads).
@@ -579,20 +627,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             if (v) atomicAdd(q == 0 ? (unsigned long long*)&rec->sad_h : q == 1 ? (unsigned long long*)&rec->sad_s
                              : q == 2 ? (unsigned long long*)&rec->sad_v : (unsigned long long*)&rec->byte_sum, (unsigned long long)v);
         }
-        if (HIST && rel >= 1 && tid < 128) {
-            // frame rel-1's histogram of this tile is complete: out as 128 packed words, and the slot is free for frame rel+1
-            u32* hs = lhist[(rel - 1) & 1];
-            u32 lo = 0, hi = 0;
-#pragma unroll
-            for (int r = 0; r < RS_HREP; r++) {
-                lo += hs[r * 256 + 2 * tid]; hi += hs[r * 256 + 2 * tid + 1];
-                // (cleared with a store the compiler does not see, for the reason given at rs_lds_add: a visible LDS store here would
-                //  make these two waves wait for the NEXT frame's staging, issued a few lines up; the reads above are of a different
-                //  object than the staging buffers and are not held back)
-                asm volatile("ds_write_b64 %0, %1" ::"v"((u32)(uintptr_t)&hs[r * 256 + 2 * tid]), "v"(0ull) : "memory");
-            }
-            p.hpart[((size_t)(t - 1) * p.n_tiles + tile) * 128 + tid] = lo | (hi << 16);
-        }
+        if (HIST && rel >= 1) rs_hist_flush<true>(lhist[(rel - 1) & 1], p.hpart + ((size_t)(t - 1) * p.n_tiles + tile) * p.hstride, tid);
         if ((STORE || VOUT) && rel >= 1) {
             if (p.store_vec) store_tile(t - 1, (rel - 1) & 1);       // frame t-1's pixels are complete (every wave wrote them before this barrier)
         }
@@ -706,36 +741,47 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             if (v) atomicAdd(q == 0 ? (unsigned long long*)&rec->sad_h : q == 1 ? (unsigned long long*)&rec->sad_s
                              : q == 2 ? (unsigned long long*)&rec->sad_v : (unsigned long long*)&rec->byte_sum, (unsigned long long)v);
         }
-        if (HIST && done > 0 && tid < 128) {   // the chunk's last frame
-            const u32* hs = lhist[(done - 1) & 1];
-            u32 lo = 0, hi = 0;
-#pragma unroll
-            for (int r = 0; r < RS_HREP; r++) { lo += hs[r * 256 + 2 * tid]; hi += hs[r * 256 + 2 * tid + 1]; }
-            p.hpart[((size_t)(t1 - 1) * p.n_tiles + tile) * 128 + tid] = lo | (hi << 16);
-        }
+        if (HIST && done > 0) rs_hist_flush<false>(lhist[(done - 1) & 1], p.hpart + ((size_t)(t1 - 1) * p.n_tiles + tile) * p.hstride, tid);   // the chunk's last frame
     }
 }
 
-// rec[t].hist = sum over the tiles of frame t of their packed partial histograms.  grid = frames; 128 threads (one per packed
-// word) or a multiple: the tiles are split over blockDim / 128 groups of threads and joined in LDS.
-// out_words + t * stride_words = the 256 bins of frame t (a record's `hist`, or a row of the edge term's V histograms).
-__global__ __launch_bounds__(512) void hist_reduce_kernel(const u32* hpart, int n_tiles, u32* out_words, size_t stride_words)
+// rec[t].hist = sum over the tiles of frame t of their partial histograms (rs_hist_flush's layout).  grid = frames; W threads per group
+// (W = 64: one per word of four low bytes; 128 in the 16-bit layout) or a multiple: the tiles are split over blockDim / W groups of threads
+// and joined in LDS.  out_words + t * stride_words = the 256 bins of frame t (a record's `hist`, or a row of the edge term's V histograms).
+__global__ __launch_bounds__(512) void hist_reduce_kernel(const u32* hpart, int n_tiles, int hstride, u32* out_words, size_t stride_words)
 {
-    __shared__ u32 part[3][256];
-    const int t = blockIdx.x, i = threadIdx.x & 127, q = threadIdx.x >> 7, nq = blockDim.x >> 7;
-    const u32* src = hpart + (size_t)t * n_tiles * 128 + i;
-    u32 lo = 0, hi = 0;
+    constexpr int W = RS_HPACK8 ? 64 : 128, B = 256 / W;        // threads per group, bins per thread
+    __shared__ u32 part[512 / W - 1][256];
+    const int t = blockIdx.x, i = threadIdx.x % W, q = threadIdx.x / W, nq = blockDim.x / W;
+    const u32* src = hpart + (size_t)t * n_tiles * hstride;
+    u32 c[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) c[b] = 0;
     for (int k = q; k < n_tiles; k += nq) {
-        const u32 v = src[(size_t)k * 128];
-        lo += v & 0xffffu;
-        hi += v >> 16;
+        const u32* tp = src + (size_t)k * hstride;
+        const u32 v = tp[i];
+        if constexpr (RS_HPACK8) {
+            c[0] += v & 255u; c[1] += (v >> 8) & 255u; c[2] += (v >> 16) & 255u; c[3] += v >> 24;
+            const unsigned long long over = (unsigned long long)tp[64] | ((unsigned long long)tp[65] << 32);
+            if ((over >> i) & 1ull) {
+                const u32 carry = tp[66 + __popcll(over & ((1ull << i) - 1ull))];
+                c[0] += (carry & 15u) << 8; c[1] += ((carry >> 4) & 15u) << 8; c[2] += ((carry >> 8) & 15u) << 8; c[3] += (carry >> 12) << 8;
+            }
+        } else {
+            c[0] += v & 0xffffu; c[1] += v >> 16;
+        }
     }
-    if (q) { part[q - 1][2 * i] = lo; part[q - 1][2 * i + 1] = hi; }
+    if (q) {
+#pragma unroll
+        for (int b = 0; b < B; b++) part[q - 1][B * i + b] = c[b];
+    }
     __syncthreads();
     if (q == 0) {
-        for (int r = 0; r + 1 < nq; r++) { lo += part[r][2 * i]; hi += part[r][2 * i + 1]; }
-        out_words[(size_t)t * stride_words + 2 * i] = lo;
-        out_words[(size_t)t * stride_words + 2 * i + 1] = hi;
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            for (int r = 0; r + 1 < nq; r++) c[b] += part[r][B * i + b];
+            out_words[(size_t)t * stride_words + B * i + b] = c[b];
+        }
     }
 }
 
@@ -910,7 +956,8 @@ static int resize_linear_impl(psd_engine* e, const uint8_t* d_src, int n, int sr
     if (want_hsv) note_walk_geometry(p.frames_per_chunk, p.n_tiles);
     if (want_luma || want_v) {
         void* scratch = nullptr;
-        rc = engine_hist_scratch(e, (size_t)n * p.n_tiles * 128 * sizeof(u32), stream, &scratch);
+        p.hstride = rs_hist_stride_words(R * dst_w);
+        rc = engine_hist_scratch(e, (size_t)n * p.n_tiles * p.hstride * sizeof(u32), stream, &scratch);
         if (rc != PSD_OK) return rc;
         p.hpart = static_cast<u32*>(scratch);
     }
@@ -926,8 +973,8 @@ static int resize_linear_impl(psd_engine* e, const uint8_t* d_src, int n, int sr
         u32* words = want_v ? d_vhist : reinterpret_cast<u32*>(&d_out[0].hist[0]);
         const size_t stride = want_v ? 256 : sizeof(psd_frame_scores) / sizeof(u32);
         for (int t0 = 0; t0 < n; t0 += 65535)
-            hipLaunchKernelGGL(hist_reduce_kernel, dim3(std::min(65535, n - t0)), dim3(128), 0, stream, p.hpart + (size_t)t0 * p.n_tiles * 128,
-                               p.n_tiles, words + (size_t)t0 * stride, stride);
+            hipLaunchKernelGGL(hist_reduce_kernel, dim3(std::min(65535, n - t0)), dim3(128), 0, stream, p.hpart + (size_t)t0 * p.n_tiles * p.hstride,
+                               p.n_tiles, p.hstride, words + (size_t)t0 * stride, stride);
         HIP_TRY(hipGetLastError());
         if (launches) *launches += 1;
     }

@@ -264,6 +264,48 @@ def test_downscale_then_all_four_constant_frames_and_headline_size(hip_engine):
         same(whole[a:a + 3], want)
 
 
+@pytest.mark.parametrize("shape", [(180, 320, 144, 256), (360, 640, 144, 256), (1080, 1920, 144, 256), (2160, 3840, 144, 256), (360, 640, 203, 361)])
+def test_partial_histograms_whose_counts_pass_a_byte(hip_engine, shape):
+    """The fused downscale kernel hands a tile's luma histogram over as the low bytes of its counts plus escapes for the bins a byte cannot
+    hold (rs_hist_flush).  Frames that fill the escapes: constant ones (every pixel of a tile in ONE bin: 2048 at 320 x 180 -> 256 x 144, the
+    largest tile there is), two and eight flat bands (bins of exactly 256, 512 ... per tile; several escape lanes at once), a flat frame with a
+    sprinkle of noise (counts of 255 / 256 / 257 side by side), next to plain noise -- histograms, byte sums and SADs against the oracle;
+    the V-histogram instance of the same machinery through the edge term."""
+    sh, sw, dh, dw = shape
+    rng = np.random.default_rng(sh + dw)
+    frames = []
+    for v in (0, 255, 128, 17):
+        frames.append(np.full((sh, sw, 3), v, np.uint8))
+    two = np.zeros((sh, sw, 3), np.uint8)
+    two[:, sw // 2:] = (200, 90, 30)
+    frames.append(two)
+    bands = np.zeros((sh, sw, 3), np.uint8)
+    for k in range(8):
+        bands[:, k * sw // 8:(k + 1) * sw // 8] = (31 * k, 255 - 29 * k, 7 * k)
+    frames.append(bands)
+    rows = np.zeros((sh, sw, 3), np.uint8)
+    for k in range(sh):
+        rows[k] = (k * 7) % 256                      # (every source row its own grey: the tiles of a frame differ)
+    frames.append(rows)
+    for density in (0.001, 0.01, 0.4):
+        f = np.full((sh, sw, 3), 90, np.uint8)
+        m = rng.random((sh, sw)) < density
+        f[m] = rng.integers(0, 256, (int(m.sum()), 3), dtype=np.uint8)
+        frames.append(f)
+    frames.append(rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8))
+    frames = np.stack(frames + frames[::-1])
+    buf = device_copy(hip_engine, frames)
+    small, want = oracle_downscaled(frames, None, dh, dw)
+    assert want["hist"].max() == dh * dw
+    for flags in (NOEDGE, E.SCORE_LUMA_HIST | E.SCORE_BYTE_SUM):
+        got = hip_engine.score_device_downscaled(buf.ptr, len(frames), sh, sw, dh, dw, flags=flags)
+        same(got, want, FIELDS if flags == NOEDGE else ("hist", "byte_sum"))
+    if dw == 256:
+        got = hip_engine.score_device_downscaled(buf.ptr, len(frames), sh, sw, dh, dw, flags=E.SCORE_HSV_SAD | E.SCORE_EDGES)
+        same(got, oracle_score(small, edges=True), ("sad_h", "sad_s", "sad_v", "edge_xor"))
+    buf.free()
+
+
 def test_downscale_then_score_other_terms_and_modes(hip_engine):
     """Edges and the NEAREST / AREA / LANCZOS4 / CUBIC modes go through the resize-then-score path of the same entry point."""
     import cv2  # the oracle shim
