@@ -32,6 +32,9 @@
 //   1 = no LDS table reads, 2 = no per-frame barrier/flush, 4 = no global loads inside the time loop,
 //   8 = no HSV arithmetic (loads + byte SAD only), 16 = no histogram increments in the fused fp32 quad, 32 = no V-plane store (V mode).
 //   tools/ablate.sh builds and times the variants.
+#ifndef PSD_HIST_PAIR_ATOMICS
+#define PSD_HIST_PAIR_ATOMICS 1
+#endif
 #ifndef PSD_ABLATE
 #define PSD_ABLATE 0
 #endif
@@ -970,14 +973,22 @@ __device__ __forceinline__ void flush_slot(u32* slot_acc, psd_frame_scores* rec,
     s += __shfl_xor(s, 1);
     if (half == 0 && s) {
         if (LUMA && a < 256) {
+#if !(PSD_ABLATE & 64)
             atomicAdd(hist_dst ? &hist_dst[a] : &rec->hist[a], s);   // hist_dst: V mode, the edge term's per-frame V histogram
+#else
+            asm volatile("" :: "v"(s));
+#endif
         } else {
             const int e = LUMA ? a - 256 : a;
             unsigned long long* dst = e == 0 ? (unsigned long long*)&rec->sad_h
                                     : e == 1 ? (unsigned long long*)&rec->sad_s
                                     : e == 2 ? (unsigned long long*)&rec->sad_v
                                              : (unsigned long long*)&rec->byte_sum;
+#if !(PSD_ABLATE & 128)
             atomicAdd(dst, (unsigned long long)s);
+#else
+            asm volatile("" :: "v"(s), "v"(dst));
+#endif
         }
     }
 }
@@ -1272,7 +1283,30 @@ __global__ __launch_bounds__(kLumaWG) void luma_hist_kernel(const ScoreParams p)
     __hip_atomic_fetch_add(&my_acc[ACC_BYTES * AC], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     lds_hidden_fence();
     __syncthreads();
+#if PSD_HIST_PAIR_ATOMICS
+    // The tile's flush (third session of round 6).  A device-scope atomic leaves the XCD as a memory transaction of its own whatever its
+    // width, and this pass -- memory-bound -- pays for their number: without the histogram's atomics it is 2.8 % faster, without any 5 %
+    // (profiles/r06_ag_*).  So thread b sums the copies of bin b, and bins 2 i and 2 i + 1 leave in ONE 64-bit atomic (a bin counts pixels of
+    // one frame: nothing ever carries from the low word into the high one; rec->hist is 8-byte aligned): half the transactions of the
+    // one-per-bin form, which also took three passes over 2 x 260 half-accumulators.  4K Histogram + Threshold +2 %.
+    static_assert(WG == 256 && AC == 16, "one thread per bin");
+    psd_frame_scores* rec = p.out + t;
+    {
+        const u32x4* q = reinterpret_cast<const u32x4*>(acc + tid * AC);
+        const u32x4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+        const u32 s = (v0.x + v0.y + v0.z + v0.w) + (v1.x + v1.y + v1.z + v1.w) + (v2.x + v2.y + v2.z + v2.w) + (v3.x + v3.y + v3.z + v3.w);
+        const u32 up = __shfl_down(s, 1);
+        if (!(tid & 1) && (s | up))
+            atomicAdd(reinterpret_cast<unsigned long long*>(&rec->hist[tid]), (unsigned long long)s | ((unsigned long long)up << 32));
+    }
+    if (tid < AC) {        // the byte sum's sixteen copies: lanes 0 .. 15 of wave 0
+        u32 v = acc[ACC_BYTES * AC + tid];
+        v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        if (tid == 0 && v) atomicAdd((unsigned long long*)&rec->byte_sum, (unsigned long long)v);
+    }
+#else
     for (int i = tid; i < 2 * NACC; i += WG) flush_slot<true, AC>(acc, p.out + t, i);
+#endif
 }
 
 static hipError_t launch_luma_hist(ScoreParams p, int group_begin, int group_end, hipStream_t stream, int* launches)
