@@ -439,7 +439,7 @@ __device__ __forceinline__ void rs_hist_flush(u32* hs, u32* dst, int tid)
 // LUMA: the luma histogram and the byte sum of the RESIZED frame as well (HistogramDetector / ThresholdDetector behind the
 // reference's default downscale, histogram_detector.py:156-159 and threshold_detector.py:127 on what scene_manager.py:666-678
 // hands them).  A workgroup counts its tile's pixels of frame t into one of two 256-bin LDS histograms and, one barrier
-// later, writes it as 128 packed words to hpart[t][tile] with plain coalesced stores; hist_reduce_kernel adds the tiles of a
+// later, writes it to hpart[t][tile] with plain coalesced stores (rs_hist_flush: low bytes + escapes); hist_reduce_kernel adds the tiles of a
 // frame up.  (Global atomics instead -- up to 256 per tile and frame, 75 M per 4096-frame launch on one address per bin and
 // frame from every XCD -- would cost more than the pixels.)  The byte sum rides with the three SADs.
 // SEG: the instance for batches of packed clips (p.seg != nullptr; psd_score_segments_downscaled_device): a frame that starts
