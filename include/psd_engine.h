@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PSD_ABI_VERSION 7 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records);
+#define PSD_ABI_VERSION 8 /* 2: additive over 1 (downscaled / segmented scoring, host feed, RCCL exchange, device-resident records);
                             * 3: additive over 2 (psd_frame_sums: records without the histogram, psd_score_collect_sums, psd_epilogue_*_sums);
                             * 4: additive over 3 (psd_resize_source_rows, psd_upload_rows: a host feeder uploads only the rows a downscale reads);
                             * 5: additive over 4 (psd_upload_rows_batch: many frames' rows gathered by worker threads into page-locked
@@ -50,7 +50,9 @@ extern "C" {
                             * 7: additive over 6 (psd_score_segments_downscaled_device: MANY clips packed into one batch behind the
                             *    reference's default downscale -- what `detect(path, detector_cls())` of benchmark/__main__.py:44-61
                             *    computes per video, for a whole shard of videos in one launch; psd_allgather_host: the exchange step for
-                            *    records a rank already holds on the host; psd_hash_bits_device: HashDetector's DCT / median on the device) */
+                            *    records a rank already holds on the host; psd_hash_bits_device: HashDetector's DCT / median on the device);
+                            * 8: additive over 7 (psd_hist_diff_device + psd_epilogue_hist_cuts_from_diff: HistogramDetector's normalisation and
+                            *    compareHist for records that are still in HBM -- 8 bytes per frame travel instead of the 1 KiB histogram) */
 
 typedef enum psd_status {
     PSD_OK = 0,
@@ -398,6 +400,17 @@ typedef struct psd_hist_params {
 int psd_epilogue_hist_cuts(const psd_frame_scores* recs, int n, const psd_frame_scores* prev_rec,
                            int64_t first_frame, int64_t fps_num, int64_t fps_den,
                            const psd_hist_params* p, double* hist_diff, int64_t* cuts, int* n_cuts);
+
+/* The same values for n records that are still in DEVICE memory (psd_last_records_device of a submission with PSD_SCORE_LUMA_HIST;
+ * histogram_detector.py:98,156-163 = calcHist's re-binning, cv2.normalize(NORM_L2) in float32, cv2.compareHist(CORREL) in float64),
+ * frame pairs in parallel on the device with every sum in the order psd_epilogue_hist_cuts keeps: bit for bit its hist_diff.
+ * h_diff[0] = NaN (no predecessor inside the batch); the caller overwrites h_diff[f] with NaN where frame f starts a clip.  With it
+ * the histograms need not travel: collect the sums (psd_score_collect_sums, 40 bytes per frame) and these 8 bytes per frame.
+ * Synchronous; `stream` = NULL: the engine's stream (behind the submission that produced the records). */
+int psd_hist_diff_device(psd_engine* e, const psd_frame_scores* d_recs, int n, int bins, double* h_diff, void* stream);
+/* ... and the decision of psd_epilogue_hist_cuts over such values (NaN = no predecessor: never a cut). */
+int psd_epilogue_hist_cuts_from_diff(const double* hist_diff, int n, int64_t first_frame, int64_t fps_num, int64_t fps_den,
+                                     const psd_hist_params* p, int64_t* cuts, int* n_cuts);
 
 /* The two per-frame steps of the above, for hosts that decide frame by frame (HistogramDetector.process_frame):
  * cv2.calcHist(bins) + cv2.normalize (L2, float32) of one 256-bin luma histogram, and cv2.compareHist(CORREL). */

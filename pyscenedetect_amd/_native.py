@@ -27,7 +27,7 @@ SCORE_EDGES = 8
 SCORE_ALL = 15
 
 MAX_INFLIGHT = 4
-ABI_VERSION = 7  # PSD_ABI_VERSION of include/psd_engine.h this binding was written against
+ABI_VERSION = 8  # PSD_ABI_VERSION of include/psd_engine.h this binding was written against
 
 #: numpy view of ``psd_frame_scores`` (1064 bytes).
 RECORD_DTYPE = np.dtype(
@@ -46,6 +46,10 @@ assert RECORD_DTYPE.itemsize == 1064
 #: ThresholdDetector decide from (``psd_score_collect_sums``).
 SUMS_DTYPE = np.dtype([(name, "<u8") for name in ("sad_h", "sad_s", "sad_v", "edge_xor", "byte_sum")])
 assert SUMS_DTYPE.itemsize == 40 and all(SUMS_DTYPE.fields[k][1] == RECORD_DTYPE.fields[k][1] for k in SUMS_DTYPE.names)
+#: the five sums + HistogramDetector's ``hist_diff`` of the frame, computed on the device (``psd_hist_diff_device``; NaN where a frame has no
+#: predecessor): what a pass with a HistogramDetector moves to the host instead of the 1 KiB histogram (``ScoringEngine.score_clips(hist_diff_bins=)``)
+SUMS_DIFF_DTYPE = np.dtype([(name, "<u8") for name in SUMS_DTYPE.names] + [("hist_diff", "<f8")])
+assert SUMS_DIFF_DTYPE.itemsize == 48 and all(SUMS_DIFF_DTYPE.fields[k][1] == RECORD_DTYPE.fields[k][1] for k in SUMS_DTYPE.names)
 
 
 class ContentParams(ctypes.Structure):
@@ -161,6 +165,8 @@ SYMBOLS = {
     "psd_epilogue_content_cuts": (_i, [_vp, _i, _i64, _i64, _i64, _P(ContentParams), _vp, _P(_i)]),
     "psd_epilogue_adaptive_cuts": (_i, [_vp, _i, _i64, _i64, _i64, _P(AdaptiveParams), _vp, _vp, _P(_i)]),
     "psd_epilogue_hist_cuts": (_i, [_vp, _i, _vp, _i64, _i64, _i64, _P(HistParams), _vp, _vp, _P(_i)]),
+    "psd_epilogue_hist_cuts_from_diff": (_i, [_vp, _i, _i64, _i64, _i64, _P(HistParams), _vp, _P(_i)]),
+    "psd_hist_diff_device": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "psd_epilogue_hist_normalize": (_i, [_vp, _i, _vp]),
     "psd_epilogue_hist_correl": (_i, [_vp, _vp, _i, _P(ctypes.c_double)]),
     "psd_epilogue_threshold_cuts": (_i, [_vp, _i, _i, _i, _i64, _i64, _i64, _P(ThresholdParams), _vp, _vp, _P(_i)]),

@@ -54,7 +54,11 @@ def decide(records: np.ndarray, height: int, width: int, fps, detectors: dict) -
                 out[name] = epilogue.adaptive_cuts(scores["content_val"], fps, p["adaptive_threshold"], p["min_scene_len"],
                                                    p["window_width"], p["min_content_val"])[0]
         elif name == "hist":
-            out[name] = epilogue.hist_cuts(records, fps, p["threshold"], p["bins"], p["min_scene_len"])[0]
+            if records.dtype.names and "hist_diff" in records.dtype.names:
+                # (the values came from the device, for THIS detector's bin count: score_clips(hist_diff_bins=) -- detect_corpus asks for them)
+                out[name] = epilogue.hist_cuts_from_diff(records["hist_diff"], fps, p["threshold"], p["min_scene_len"])
+            else:
+                out[name] = epilogue.hist_cuts(records, fps, p["threshold"], p["bins"], p["min_scene_len"])[0]
         elif name == "threshold":
             out[name] = epilogue.threshold_cuts(records, height, width, fps, p["threshold"], p["min_scene_len"], p["fade_bias"],
                                                 p["add_final_scene"], p["method"])[0]
@@ -94,7 +98,7 @@ def score_clip(engine, clip, flags: int, edge_kernel: int = 0, downscale=None, i
 
 
 def score_clips(engine, clips, flags: int, edge_kernel: int = 0, on_ready=None, sums_only: bool | None = None,
-                downscale=None, interpolation: int = 1) -> list[np.ndarray]:
+                downscale=None, interpolation: int = 1, hist_diff_bins: int | None = None) -> list[np.ndarray]:
     """Records of every clip; engines that can pack clips of one resolution into shared batches (``ScoringEngine.score_clips``:
     one launch per term per batch, SAD chain broken at clip starts) do so, others score clip by clip.
     ``on_ready(i, records)``: called per clip as its records arrive (see ``ScoringEngine.score_clips``).
@@ -106,7 +110,11 @@ def score_clips(engine, clips, flags: int, edge_kernel: int = 0, on_ready=None, 
     the same dtype for the same flags.
 
     ``downscale`` / ``interpolation``: the resize in front of the detectors -- ``"auto"`` (the reference's default pipeline,
-    a factor per resolution), a number, or ``None`` (``ScoringEngine.score_clips``)."""
+    a factor per resolution), a number, or ``None`` (``ScoringEngine.score_clips``).
+
+    ``hist_diff_bins``: engines that can (``ScoringEngine.score_clips``) compute HistogramDetector's ``hist_diff`` for that bin count on
+    the device and return ``SUMS_DIFF_DTYPE`` for resident clips -- 48 bytes per frame instead of the 1 KiB histogram, and nothing left of
+    the histogram epilogue but its decision loop; other engines ignore it and return full records (``decide`` takes either)."""
     from pyscenedetect_amd.engine import _sums_of
 
     if sums_only is None:
@@ -125,6 +133,8 @@ def score_clips(engine, clips, flags: int, edge_kernel: int = 0, on_ready=None, 
             kw["on_ready"] = on_ready
         if resized:
             kw["downscale"], kw["interpolation"] = downscale, interpolation
+        if hist_diff_bins is not None and "hist_diff_bins" in params and hasattr(engine, "hist_diff_device"):
+            kw["hist_diff_bins"] = hist_diff_bins
         out = engine.score_clips(clips, flags=flags, edge_kernel=edge_kernel, **kw)
         if sums_only and "sums_only" not in params:
             out = [_sums_of(r) for r in out]
@@ -170,7 +180,9 @@ def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: 
     sizes = [scored_size(c.shape[1], c.shape[2], ds) for c in clips]       # what the detectors see (and divide by)
     # (worker threads only where a decision is mostly native code: the histogram epilogue takes 0.2 us per frame with the GIL released;
     #  the others are microseconds per clip, and handing THEM to a pool costs a GIL hand-over per clip -- the BBC flow lost 15 %)
-    pool = _decide_pool() if "hist" in detectors else None
+    # (... unless the engine computes hist_diff on the device for clips that are resident there: then that epilogue is a loop over n doubles too)
+    device_diff = (not use_dist and hasattr(engine, "hist_diff_device") and len(clips) > 0 and all(hasattr(c, "data_ptr") for c in clips))
+    pool = _decide_pool() if "hist" in detectors and not device_diff else None
     if not use_dist:
         # one process: a clip is decided as soon as its records are on the host, while the batches behind it are still on the GPU --
         # and (round 6) on a worker thread, several clips at a time: the native epilogues release the GIL, and behind the default
@@ -183,7 +195,11 @@ def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: 
             else:
                 result[i] = pool.submit(decide, recs, sizes[i][0], sizes[i][1], fps_list[i], detectors)
 
-        score_clips(engine, clips, flags, edge_kernel, on_ready=decide_now, downscale=ds, interpolation=interpolation)
+        # (a HistogramDetector's hist_diff comes from the device where the engine offers it: the histograms stay in HBM)
+        bins = None
+        if "hist" in detectors:
+            bins = dict(DETECTORS["hist"][1], **(detectors["hist"] or {}))["bins"]
+        score_clips(engine, clips, flags, edge_kernel, on_ready=decide_now, downscale=ds, interpolation=interpolation, hist_diff_bins=bins)
         return result if pool is None else [f.result() for f in result]
     if pool is None:
         return [decide(r, hw[0], hw[1], f, detectors) for r, hw, f in zip(records, sizes, fps_list)]

@@ -3,6 +3,7 @@
 // Owns: one HIP device, one stream, the fixed-point HSV tables in device memory, a small ring
 // of record slots (device buffer + pinned host mirror + timing events) so submissions can be
 // pipelined, and a pair of device staging buffers for callers that hand over host frames.
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -114,6 +115,8 @@ struct psd_engine {
     size_t hash_bytes = 0;
     uint8_t* d_hbits = nullptr; // hash bits of psd_hash_bits_device
     size_t hbits_bytes = 0;
+    uint8_t* d_hdiff = nullptr; // psd_hist_diff_device: hist_diff (double[n])
+    size_t hdiff_bytes = 0;
     hipEvent_t ev_hash[2] = {nullptr, nullptr};
     void* resize_cache = nullptr;   // coefficient tables per (src, dst) shape of every resize mode + the hash thumbnails, owned by psd_resize_kernels.hip
     uint8_t* d_small = nullptr;     // resized frames of psd_score_downscaled_* when the terms need them in memory
@@ -260,6 +263,7 @@ void psd_destroy(psd_engine* e)
     for (auto& d : e->d_stage) if (d) (void)hipFree(d);
     if (e->d_hash) (void)hipFree(e->d_hash);
     if (e->d_hbits) (void)hipFree(e->d_hbits);
+    if (e->d_hdiff) (void)hipFree(e->d_hdiff);
     for (auto& ev : e->ev_hash) if (ev) (void)hipEventDestroy(ev);
     if (e->d_lut) (void)hipFree(e->d_lut);
     if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
@@ -994,6 +998,101 @@ int psd_hash_bits_device(psd_engine* e, const uint8_t* d_frames, int n, int heig
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipEventElapsedTime(&e->last_ms, e->ev_hash[0], e->ev_hash[1]));
     e->last_launches = (n + 32767) / 32768 + (n + 65534) / 65535;
+    return PSD_OK;
+}
+
+// ---- HistogramDetector's hist_diff on the device (psd_hist_diff_device) -------------------------------------------------------
+// psd_epilogue_hist_cuts spends 0.2 us per frame and core on calculate_histogram's tail and compareHist (histogram_detector.py:98,
+// 156-163): re-bin, cv2.normalize(NORM_L2), cv2.compareHist(CORREL) in float64.  A frame pair depends on nothing but its two
+// records, so for records that are still in HBM the pairs go to waves of the device, every sum in
+// the order of the host epilogue (psd_epilogue.cpp: normalized_hist, correl), IEEE float32 / float64 arithmetic without contraction
+// (the file is built with -ffp-contract=off; f64 division and square root are correctly rounded): the same bits, and what travels to
+// the host is 8 bytes per frame instead of the 1 KiB histogram.
+struct HistRuns { int start[257]; };     // bin i of `bins` takes luma values start[i] .. start[i + 1] - 1 (cv2.calcHist's LUT is monotone)
+
+// One wave per frame pair (t - 1, t).  What is elementwise is spread over the lanes (re-bin, int -> float32, the scaling); what the host
+// sums in an order keeps that order: lane k adds the squares of histogram k one after the other (normalized_hist: exact in any order while
+// every bin is below 2^24, sequential beyond -- sequential is both), lanes 0 / 1 ARE the two float64 lanes of OpenCV's compareHist loop.
+__global__ __launch_bounds__(64) void hist_diff_kernel(const psd_frame_scores* __restrict__ recs, int n, int bins, HistRuns runs,
+                                                       double* __restrict__ diff)
+{
+    __shared__ float f[2][256];
+    __shared__ float sc[2];
+    __shared__ double red[2][5];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= n) return;
+    if (t == 0) { if (lane == 0) diff[0] = NAN; return; }       // (no predecessor inside the batch; the caller marks clip starts)
+    for (int k = 0; k < 2; k++) {
+        const uint32_t* h = recs[t - 1 + k].hist;
+        for (int i = lane; i < bins; i += 64) {
+            unsigned long long c = 0;
+            for (int j = runs.start[i]; j < runs.start[i + 1]; j++) c += h[j];
+            f[k][i] = (float)(long long)c;                       // (exact below 2^24, one rounding above: as the host's cvtsi2ss)
+        }
+    }
+    __syncthreads();
+    if (lane < 2) {
+        double ss = 0.0;
+        for (int i = 0; i < bins; i++) { const double v = f[lane][i]; ss += v * v; }
+        const double nrm = sqrt(ss);
+        sc[lane] = (float)(nrm > DBL_EPSILON ? 1.0 / nrm : 0.0);
+    }
+    __syncthreads();
+    for (int i = lane; i < bins; i += 64) { f[0][i] = f[0][i] * sc[0]; f[1][i] = f[1][i] * sc[1]; }
+    __syncthreads();
+    const int body = bins >= 4 ? (bins & ~3) : 0;                // OpenCV's vector body: whole groups of four
+    if (lane < 2) {
+        double s1 = 0, s2 = 0, s11 = 0, s12 = 0, s22 = 0;
+        for (int j = lane; j < body; j += 2) {
+            const double a = f[0][j], b = f[1][j];
+            s12 += a * b; s11 += a * a; s22 += b * b; s1 += a; s2 += b;
+        }
+        red[lane][0] = s1; red[lane][1] = s2; red[lane][2] = s11; red[lane][3] = s12; red[lane][4] = s22;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        double S1 = red[0][0] + red[1][0], S2 = red[0][1] + red[1][1], S11 = red[0][2] + red[1][2], S12 = red[0][3] + red[1][3],
+               S22 = red[0][4] + red[1][4];
+        for (int j = body; j < bins; j++) {
+            const double a = f[0][j], b = f[1][j];
+            S12 += a * b; S1 += a; S11 += a * a; S2 += b; S22 += b * b;
+        }
+        const double scale = 1. / bins;
+        const double num = S12 - S1 * S2 * scale;
+        const double denom2 = (S11 - S1 * S1 * scale) * (S22 - S2 * S2 * scale);
+        diff[t] = fabs(denom2) > DBL_EPSILON ? num / sqrt(denom2) : 1.;
+    }
+}
+
+int psd_hist_diff_device(psd_engine* e, const psd_frame_scores* d_recs, int n, int bins, double* h_diff, void* stream_)
+{
+    if (!e || n < 0 || (n > 0 && (!d_recs || !h_diff)) || bins < 1 || bins > 256) {
+        psd_set_error("psd_hist_diff_device: invalid argument (n = %d, bins = %d)", n, bins);
+        return PSD_ERR_INVALID;
+    }
+    if (n == 0) return PSD_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : e->stream;
+    int rc = grow_buffer(e, &e->d_hdiff, &e->hdiff_bytes, (size_t)n * sizeof(double));
+    if (rc != PSD_OK) return rc;
+    HistRuns runs;
+    for (int i = 0; i <= 256; i++) runs.start[i] = 256;
+    {
+        // cv2.calcHist's bin of luma value j, as psd_epilogue_hist_cuts builds it: floor(j * (bins / 256.0)), clamped
+        int prev = -1;
+        for (int j = 0; j < 256; j++) {
+            int idx = (int)std::floor(j * (bins / 256.0));
+            idx = idx < 0 ? 0 : (idx > bins - 1 ? bins - 1 : idx);
+            for (int b = prev + 1; b <= idx; b++) runs.start[b] = j;       // (monotone: bins between two values stay empty runs)
+            prev = idx;
+        }
+        for (int b = prev + 1; b <= bins; b++) runs.start[b] = 256;
+    }
+    double* diff = reinterpret_cast<double*>(e->d_hdiff);
+    hipLaunchKernelGGL(hist_diff_kernel, dim3(n), dim3(64), 0, stream, d_recs, n, bins, runs, diff);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_diff, diff, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
     return PSD_OK;
 }
 

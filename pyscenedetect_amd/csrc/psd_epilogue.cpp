@@ -312,6 +312,27 @@ int psd_epilogue_hist_cuts(const psd_frame_scores* recs, int n, const psd_frame_
     return PSD_OK;
 }
 
+int psd_epilogue_hist_cuts_from_diff(const double* hist_diff, int n, int64_t first_frame, int64_t fps_num, int64_t fps_den,
+                                     const psd_hist_params* p, int64_t* cuts, int* n_cuts)
+{
+    if ((!hist_diff && n > 0) || n < 0 || !p || !cuts || !n_cuts || !check_fps(fps_num, fps_den)) {
+        psd_set_error("psd_epilogue_hist_cuts_from_diff: invalid argument");
+        return PSD_ERR_INVALID;
+    }
+    // (the decision loop of psd_epilogue_hist_cuts over values computed elsewhere -- psd_hist_diff_device: a frame without a
+    //  predecessor carries NaN, which is not <= anything)
+    const MinLen len(p->min_len_frames, p->min_len_secs, fps_of(fps_num, fps_den));
+    const double thr = std::fmax(0.0, std::fmin(1.0, 1.0 - p->threshold));
+    int nc = 0;
+    int64_t last_cut = first_frame;
+    for (int t = 0; t < n; t++) {
+        const int64_t tc = first_frame + t;
+        if (hist_diff[t] <= thr && len.met(tc, last_cut)) { cuts[nc++] = tc; last_cut = tc; }
+    }
+    *n_cuts = nc;
+    return PSD_OK;
+}
+
 int psd_epilogue_hist_normalize(const uint32_t hist256[256], int bins, float* out)
 {
     if (!hist256 || !out || bins < 1 || bins > 256) {

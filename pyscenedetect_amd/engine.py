@@ -13,6 +13,7 @@ import numpy as np
 from pyscenedetect_amd import _native
 from pyscenedetect_amd._native import (  # noqa: F401  (re-exported)
     RECORD_DTYPE,
+    SUMS_DIFF_DTYPE,
     SUMS_DTYPE,
     SCORE_ALL,
     SCORE_BYTE_SUM,
@@ -554,7 +555,7 @@ class ScoringEngine(TapRowPolicy):
 
     def score_clips(self, clips, flags: int = SCORE_ALL & ~SCORE_EDGES, edge_kernel: int = 0,
                     max_batch_bytes: int = 4 << 30, sums_only: bool = False, on_ready=None, downscale=None,
-                    interpolation: int = 1) -> list[np.ndarray]:
+                    interpolation: int = 1, hist_diff_bins: int | None = None) -> list[np.ndarray]:
         """Records of many clips (host ``uint8[n,H,W,3]`` arrays, or device tensors with ``data_ptr()``): clips of one
         resolution share device batches of up to ``max_batch_bytes``, scored with ONE launch per term per batch
         (``psd_score_segments_device``) instead of one per clip -- thousands of short clips are launch-bound otherwise.
@@ -568,10 +569,18 @@ class ScoringEngine(TapRowPolicy):
         666-678``) -- ``"auto"`` = ``auto_downscale`` (the default of ``detect()``: every resolution gets its own factor,
         ``compute_downscale_factor(max(width, height))``), a number = ``SceneManager.downscale``, ``None`` / 1 = none.  The
         records are then those of the RESIZED frames (``psd_score_segments_downscaled_device``; ``downscale_size`` gives
-        their size), i.e. ``[score_host(c, downscale=factor) for c in clips]``."""
+        their size), i.e. ``[score_host(c, downscale=factor) for c in clips]``.
+
+        ``hist_diff_bins`` (with ``PSD_SCORE_LUMA_HIST`` in ``flags``): HistogramDetector's ``hist_diff`` for that bin count is computed on
+        the device from the records while they are still in HBM (``psd_hist_diff_device``: bit for bit what ``epilogue.hist_cuts`` computes
+        from the histograms) and the result is ``SUMS_DIFF_DTYPE`` -- the five sums and ``hist_diff`` (NaN at a clip's first frame), 48 bytes
+        per frame instead of 1064 -- for resident clips; clips in host memory come back as full records."""
+        want_diff = hist_diff_bins is not None and bool(flags & SCORE_LUMA_HIST)
+        if want_diff:
+            sums_only = False        # (host clips: full records; resident ones: sums + hist_diff)
         out: list = [None] * len(clips)
         ready = on_ready if on_ready is not None else (lambda i, r: None)
-        dtype = SUMS_DTYPE if sums_only else RECORD_DTYPE
+        dtype = SUMS_DIFF_DTYPE if want_diff else SUMS_DTYPE if sums_only else RECORD_DTYPE
         groups: dict[tuple[int, int], list[int]] = {}
         for i, c in enumerate(clips):
             if len(c.shape) != 4 or c.shape[3] != 3:
@@ -646,8 +655,20 @@ class ScoringEngine(TapRowPolicy):
                     in_flight.append(pc)
                     k += 1
                 pc = in_flight.pop(0)
-                ri, _, cnt, _, a, inside, _, _ = pc
-                recs = self.collect(cnt, sums_only)
+                ri, _, cnt, seg, a, inside, _, _ = pc
+                if want_diff:
+                    # the sums travel; the histograms stay in HBM and give hist_diff there (a clip's first frame has no predecessor)
+                    sums = self.collect(cnt, True)
+                    recs = np.empty(cnt, SUMS_DIFF_DTYPE)
+                    for name in SUMS_DTYPE.names:
+                        recs[name] = sums[name]
+                    d_recs, n_dev = self.last_records_device()
+                    assert n_dev == cnt
+                    diff = self.hist_diff_device(d_recs, cnt, hist_diff_bins)
+                    diff[np.asarray(seg, dtype=np.int64)] = np.nan
+                    recs["hist_diff"] = diff
+                else:
+                    recs = self.collect(cnt, sums_only)
                 r = runs[ri]
                 if inside:
                     recs = recs[1:]
@@ -741,6 +762,14 @@ class ScoringEngine(TapRowPolicy):
             out = np.empty(n, RECORD_DTYPE)
             _native.check(self._lib.psd_score_collect(self._h, out.ctypes.data if n else None, int(n)))
         self.kernel_ms_acc += self.last_kernel_ms()[0]      # callers that time a flow of several submissions reset and read this
+        return out
+
+    def hist_diff_device(self, d_recs: int, n: int, bins: int = 128) -> np.ndarray:
+        """HistogramDetector's ``hist_diff`` (``histogram_detector.py:98,156-163``: re-bin to ``bins``, ``cv2.normalize``, ``cv2.compareHist``
+        CORREL) of n records that are still in HBM (``last_records_device``), frame pairs in parallel on the device with the host
+        epilogue's order of operations -- the same bits as ``epilogue.hist_cuts``; element 0 is NaN (``psd_hist_diff_device``)."""
+        out = np.empty(n, np.float64)
+        _native.check(self._lib.psd_hist_diff_device(self._h, d_recs, int(n), int(bins), out.ctypes.data if n else None, None))
         return out
 
     def last_records_device(self) -> tuple[int, int]:

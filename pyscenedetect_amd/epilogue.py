@@ -50,8 +50,8 @@ def _sums(records: np.ndarray) -> tuple[np.ndarray, int]:
     """(array, stride in bytes) for the epilogues that only read the five sums: full records (``RECORD_DTYPE``) are read in
     place, records without the histogram (``SUMS_DTYPE``, ``ScoringEngine.collect(sums_only=True)``) likewise."""
     records = np.asarray(records)
-    if records.dtype != _native.RECORD_DTYPE and records.dtype != _native.SUMS_DTYPE:
-        raise ValueError("records must have dtype RECORD_DTYPE or SUMS_DTYPE")
+    if records.dtype != _native.RECORD_DTYPE and records.dtype != _native.SUMS_DTYPE and records.dtype != _native.SUMS_DIFF_DTYPE:
+        raise ValueError("records must have dtype RECORD_DTYPE, SUMS_DTYPE or SUMS_DIFF_DTYPE")
     if records.ndim != 1 or (len(records) > 1 and records.strides[0] < records.dtype.itemsize):
         records = np.ascontiguousarray(records).reshape(-1)
     return records, (records.strides[0] if len(records) > 1 else records.dtype.itemsize)
@@ -120,6 +120,22 @@ def hist_cuts(records, fps, threshold: float = 0.20, bins: int = 128, min_scene_
                                                        rate.numerator, rate.denominator, ctypes.byref(p),
                                                        diff.ctypes.data, cuts.ctypes.data, ctypes.byref(nc)))
     return cuts[: nc.value].tolist(), diff
+
+
+def hist_cuts_from_diff(hist_diff, fps, threshold: float = 0.20, min_scene_len=15, first_frame: int = 0):
+    """Cuts from ``hist_diff`` values computed elsewhere (``ScoringEngine.hist_diff_device``: NaN where a frame has no predecessor) -- the
+    decision loop of :func:`hist_cuts`."""
+    rate = _fps(fps)
+    diff = np.ascontiguousarray(hist_diff, dtype=np.float64)
+    p = HistParams()
+    p.threshold = float(threshold)
+    p.bins = 0
+    p.min_len_frames, p.min_len_secs = _min_len(min_scene_len, rate, int_is_frames=False)
+    cuts = np.zeros(len(diff) + 1, np.int64)
+    nc = ctypes.c_int(0)
+    _native.check(_native.load().psd_epilogue_hist_cuts_from_diff(diff.ctypes.data if len(diff) else None, len(diff), first_frame, rate.numerator,
+                                                                 rate.denominator, ctypes.byref(p), cuts.ctypes.data, ctypes.byref(nc)))
+    return cuts[: nc.value].tolist()
 
 
 def threshold_cuts(records, height: int, width: int, fps, threshold: float = 12, min_scene_len=15,

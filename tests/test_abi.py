@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_record_layout_matches_header():
     assert _native.RECORD_DTYPE.itemsize == 1064
     assert _native.RECORD_DTYPE.fields["hist"][1] == 40
-    assert _native.load().psd_abi_version() == _native.ABI_VERSION == 7
+    assert _native.load().psd_abi_version() == _native.ABI_VERSION == 8
 
 
 def test_hsv_tables_match_oracle():
