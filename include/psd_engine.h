@@ -406,7 +406,8 @@ int psd_epilogue_hist_cuts(const psd_frame_scores* recs, int n, const psd_frame_
  * frame pairs in parallel on the device with every sum in the order psd_epilogue_hist_cuts keeps: bit for bit its hist_diff.
  * h_diff[0] = NaN (no predecessor inside the batch); the caller overwrites h_diff[f] with NaN where frame f starts a clip.  With it
  * the histograms need not travel: collect the sums (psd_score_collect_sums, 40 bytes per frame) and these 8 bytes per frame.
- * Synchronous; `stream` = NULL: the engine's stream (behind the submission that produced the records). */
+ * The records must be COMPLETE (those of a collected submission): the call does not order itself behind the engine's scoring stream --
+ * `stream` = NULL runs it on a side stream of the engine's, beside whatever submission is in flight.  Synchronous. */
 int psd_hist_diff_device(psd_engine* e, const psd_frame_scores* d_recs, int n, int bins, double* h_diff, void* stream);
 /* ... and the decision of psd_epilogue_hist_cuts over such values (NaN = no predecessor: never a cut). */
 int psd_epilogue_hist_cuts_from_diff(const double* hist_diff, int n, int64_t first_frame, int64_t fps_num, int64_t fps_den,

@@ -1008,6 +1008,7 @@ int psd_hash_bits_device(psd_engine* e, const uint8_t* d_frames, int n, int heig
 // the order of the host epilogue (psd_epilogue.cpp: normalized_hist, correl), IEEE float32 / float64 arithmetic without contraction
 // (the file is built with -ffp-contract=off; f64 division and square root are correctly rounded): the same bits, and what travels to
 // the host is 8 bytes per frame instead of the 1 KiB histogram.
+static int ensure_copy_stream(psd_engine* e);
 struct HistRuns { int start[257]; };     // bin i of `bins` takes luma values start[i] .. start[i + 1] - 1 (cv2.calcHist's LUT is monotone)
 
 // One wave per frame pair (t - 1, t).  What is elementwise is spread over the lanes (re-bin, int -> float32, the scaling); what the host
@@ -1072,8 +1073,12 @@ int psd_hist_diff_device(psd_engine* e, const psd_frame_scores* d_recs, int n, i
     }
     if (n == 0) return PSD_OK;
     HIP_TRY(hipSetDevice(e->device));
-    hipStream_t stream = stream_ ? (hipStream_t)stream_ : e->stream;
-    int rc = grow_buffer(e, &e->d_hdiff, &e->hdiff_bytes, (size_t)n * sizeof(double));
+    // (no stream given: a side stream of the engine's, NOT its scoring stream -- the records are complete, and behind the scoring stream this
+    //  small kernel would wait for whatever submission is in flight there: in the packed flow, for the next piece's whole pass)
+    int rc = stream_ ? PSD_OK : ensure_copy_stream(e);
+    if (rc != PSD_OK) return rc;
+    hipStream_t stream = stream_ ? (hipStream_t)stream_ : e->copy_stream;
+    rc = grow_buffer(e, &e->d_hdiff, &e->hdiff_bytes, (size_t)n * sizeof(double));
     if (rc != PSD_OK) return rc;
     HistRuns runs;
     for (int i = 0; i <= 256; i++) runs.start[i] = 256;
