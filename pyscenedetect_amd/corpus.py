@@ -175,13 +175,16 @@ def detect_corpus(engine, clips, fps, detectors: dict, group=None, edge_kernel: 
     if use_dist:
         from pyscenedetect_amd.distributed import score_clips_distributed
 
-        records = score_clips_distributed(engine, clips, flags, edge_kernel, group, downscale=ds, interpolation=interpolation)
+        # (with a HistogramDetector the ranks exchange the sums and hist_diff -- 48 bytes per frame -- not the 1 KiB histograms)
+        bins = dict(DETECTORS["hist"][1], **(detectors["hist"] or {}))["bins"] if "hist" in detectors else None
+        records = score_clips_distributed(engine, clips, flags, edge_kernel, group, downscale=ds, interpolation=interpolation, hist_diff_bins=bins)
     fps_list = fps if isinstance(fps, (list, tuple)) else [fps] * len(clips)
     sizes = [scored_size(c.shape[1], c.shape[2], ds) for c in clips]       # what the detectors see (and divide by)
     # (worker threads only where a decision is mostly native code: the histogram epilogue takes 0.2 us per frame with the GIL released;
     #  the others are microseconds per clip, and handing THEM to a pool costs a GIL hand-over per clip -- the BBC flow lost 15 %)
     # (... unless the engine computes hist_diff on the device for clips that are resident there: then that epilogue is a loop over n doubles too)
-    device_diff = (not use_dist and hasattr(engine, "hist_diff_device") and len(clips) > 0 and all(hasattr(c, "data_ptr") for c in clips))
+    # (the sharded path: every rank receives the sums and hist_diff of every clip, however the sending rank got them)
+    device_diff = use_dist or (hasattr(engine, "hist_diff_device") and len(clips) > 0 and all(hasattr(c, "data_ptr") for c in clips))
     pool = _decide_pool() if "hist" in detectors and not device_diff else None
     if not use_dist:
         # one process: a clip is decided as soon as its records are on the host, while the batches behind it are still on the GPU --

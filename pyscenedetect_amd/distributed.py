@@ -11,7 +11,7 @@ count.
 
 import numpy as np
 
-from pyscenedetect_amd._native import RECORD_DTYPE, SCORE_LUMA_HIST, SUMS_DTYPE
+from pyscenedetect_amd._native import RECORD_DTYPE, SCORE_LUMA_HIST, SUMS_DIFF_DTYPE, SUMS_DTYPE
 
 
 def shard_range(n_items: int, world_size: int, rank: int) -> tuple[int, int]:
@@ -60,8 +60,8 @@ def all_gather_records(local: np.ndarray, group=None, device_records: tuple[int,
     import torch.distributed as dist
 
     local = np.ascontiguousarray(local)
-    dtype = local.dtype     # RECORD_DTYPE, or SUMS_DTYPE (records without the histogram: 40 B/frame); the same on every rank
-    assert dtype in (RECORD_DTYPE, SUMS_DTYPE)
+    dtype = local.dtype     # RECORD_DTYPE, SUMS_DTYPE (records without the histogram: 40 B/frame) or SUMS_DIFF_DTYPE (+ hist_diff: 48); the same on every rank
+    assert dtype in (RECORD_DTYPE, SUMS_DTYPE, SUMS_DIFF_DTYPE)
     world = dist.get_world_size(group)
     on_gpu = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
@@ -75,7 +75,7 @@ def all_gather_records(local: np.ndarray, group=None, device_records: tuple[int,
         if len(counts) != world or counts[dist.get_rank(group)] != len(local):
             raise ValueError("counts must hold one entry per rank, this rank's equal to its number of records")
     cap = max(max(counts), 1) * dtype.itemsize
-    if on_gpu and device_records is not None and device_records[1] == len(local) and len(local):
+    if on_gpu and device_records is not None and device_records[1] == len(local) and len(local) and dtype != SUMS_DIFF_DTYPE:
         send = torch.zeros(cap, dtype=torch.uint8, device=dev)
         # (the device records are always 1064 bytes apart; sums are their first 40)
         send[: local.nbytes] = device_records_tensor(device_records[0], len(local), dev)[:, : dtype.itemsize].reshape(-1)
@@ -107,14 +107,33 @@ def score_clip_sharded(engine, get_frames, n_frames: int, flags: int, edge_kerne
     return np.concatenate(parts) if parts else np.zeros(0, RECORD_DTYPE)
 
 
+def sums_with_hist_diff(records: np.ndarray, bins: int) -> np.ndarray:
+    """``SUMS_DIFF_DTYPE`` of one clip's records: as they are if the engine computed ``hist_diff`` on the device, else from full records
+    through the host epilogue (``epilogue.hist_cuts``' values: the same bits) -- what the sharded flow exchanges with a HistogramDetector."""
+    if records.dtype == SUMS_DIFF_DTYPE:
+        return records
+    from pyscenedetect_amd import epilogue
+
+    out = np.empty(len(records), SUMS_DIFF_DTYPE)
+    for name in SUMS_DTYPE.names:
+        out[name] = records[name]
+    out["hist_diff"] = epilogue.hist_cuts(records, 25.0, 0.2, bins, 15)[1] if len(records) else np.zeros(0)     # (the values depend on the bins only)
+    return out
+
+
 def score_clips_distributed(engine, clips, flags: int, edge_kernel: int = 0, group=None, downscale=None,
-                            interpolation: int = 1) -> list[np.ndarray]:
+                            interpolation: int = 1, hist_diff_bins: int | None = None) -> list[np.ndarray]:
     """Score independent clips sharded by clip; returns every clip's records on every rank.
 
     ``clips`` is a list of objects with ``len()`` and ``[a:b]`` slicing to ``uint8[n,H,W,3]``
     (each rank only touches the clips assigned to it).  ``downscale`` / ``interpolation``: the resize in front of the
     detectors, as in ``corpus.score_clips`` (``"auto"``: the reference's default pipeline, a factor per resolution).
     The shards are balanced on the SOURCE pixels either way: that is what a rank reads from HBM.
+
+    ``hist_diff_bins`` (a HistogramDetector's bin count, with ``SCORE_LUMA_HIST`` in ``flags``): the ranks exchange ``SUMS_DIFF_DTYPE`` --
+    the five sums and the frame's ``hist_diff``, 48 bytes per frame -- instead of records with their 1 KiB histograms: every rank turns its
+    clips' records into that form before the exchange (on the device where the engine can, ``psd_hist_diff_device``; through the host
+    epilogue otherwise: the same bits), so all ranks send the same dtype whatever engine and wherever the clips sit.
     """
     import torch.distributed as dist
 
@@ -124,13 +143,17 @@ def score_clips_distributed(engine, clips, flags: int, edge_kernel: int = 0, gro
     from pyscenedetect_amd.corpus import score_clips
 
     # this rank's clips, packed by resolution into shared device batches where the engine can (one launch per batch)
-    mine = score_clips(engine, [clips[i] for i in plan[rank]], flags, edge_kernel, downscale=downscale, interpolation=interpolation)
+    want_diff = hist_diff_bins is not None and bool(flags & SCORE_LUMA_HIST)
+    mine = score_clips(engine, [clips[i] for i in plan[rank]], flags, edge_kernel, downscale=downscale, interpolation=interpolation,
+                       hist_diff_bins=hist_diff_bins if want_diff else None)
+    if want_diff:
+        mine = [sums_with_hist_diff(r, hist_diff_bins) for r in mine]
     # (a rank without clips must still send the dtype the others send: what corpus.score_clips returns for these flags WHATEVER
     #  engine is behind it -- sums unless the luma histogram was asked for.  Until round 6 this line also asked whether the engine
     #  packs clips, so with a clip-by-clip engine, no HistogramDetector and more ranks than clips the idle ranks offered 1064-byte
     #  records to an all-gather of 40-byte ones: found by the world-8 gloo test of the resized corpus.)
     sums = not (flags & SCORE_LUMA_HIST)
-    local = np.concatenate(mine) if mine else np.zeros(0, SUMS_DTYPE if sums else RECORD_DTYPE)
+    local = np.concatenate(mine) if mine else np.zeros(0, SUMS_DIFF_DTYPE if want_diff else SUMS_DTYPE if sums else RECORD_DTYPE)
     # every rank can count every rank's records: the plan is deterministic and a clip's length is known wherever its shape is
     counts = [sum(int(clips[i].shape[0]) for i in plan[r]) for r in range(world)]
     comm = native_comm_for(engine, group)
@@ -245,7 +268,7 @@ class NativeComm:
 
         local = np.ascontiguousarray(local)
         dtype = local.dtype
-        assert dtype in (RECORD_DTYPE, SUMS_DTYPE)
+        assert dtype in (RECORD_DTYPE, SUMS_DTYPE, SUMS_DIFF_DTYPE)
         counts = np.ascontiguousarray(counts, dtype=np.int32)
         if counts.shape != (self.n_ranks,):
             raise ValueError("counts must hold one entry per rank")     # (the same array everywhere: every rank raises)

@@ -70,6 +70,14 @@ def _worker(rank, world, port, tmp):
     recs = D.score_clip_sharded(eng, lambda a, b: frames[a:b], len(frames), flags=7)
     clips = [make_clip(40 + i, n, 24, 40, shot_len=(5, 9))[0] for i, n in enumerate((30, 11, 22, 5))]
     per_clip = D.score_clips_distributed(eng, clips, flags=7)
+    # with a HistogramDetector's bin count the ranks exchange the sums and hist_diff (48 bytes per frame), not the histograms: the same
+    # sums, and the values the host epilogue computes from the full records
+    from pyscenedetect_amd._native import SUMS_DIFF_DTYPE
+    slim = D.score_clips_distributed(eng, clips, flags=7, hist_diff_bins=100)
+    for a, b in zip(slim, per_clip):
+        assert a.dtype == SUMS_DIFF_DTYPE and len(a) == len(b) and all(np.array_equal(a[k], b[k]) for k in ("sad_h", "sad_s", "sad_v", "byte_sum"))
+        want = epilogue.hist_cuts(b, 25.0, 0.2, 100, 15)[1]
+        assert np.isnan(a["hist_diff"][0]) and np.array_equal(a["hist_diff"][1:].view(np.uint64), want[1:].view(np.uint64))
     sc = epilogue.content_scores(recs, 36, 64)
     cuts = epilogue.content_cuts(sc["content_val"], 25.0, min_scene_len=5)
     # mixed-resolution corpus, all four detectors (BASELINE.json config 5 in miniature)
