@@ -435,6 +435,36 @@ __device__ __forceinline__ u32 pixel_fp_back(const PxFp& x, float hraw, u32& hq)
     return __float_as_uint(__builtin_fmaf(x.diff, x.sdiv, 8388608.0f));    // low byte = S
 }
 
+#ifndef PSD_HPAIR
+#define PSD_HPAIR 0     // the hue wrap on pixel PAIRS (pixel_fp_back_quad): measured, see DESIGN.md 4.1
+#endif
+// The hue wrap min(h, h + 180) on two pixels per instruction: the float add that rounds the second pixel's hue writes its low half
+// (the 16-bit two's complement h) into the UPPER half of the first pixel's register (SDWA dst_sel:WORD_1), one v_pk_add_u16 and one
+// v_pk_min_u16 wrap both, and one v_perm_b32 per quad takes the four low bytes: 13 instructions per quad where four integer adds
+// and four SDWA minima made it 16.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 hue_pair_wrapped(float t0, float t1, float c)
+{
+    u32 hb = __float_as_uint(t0 + c);
+    asm("v_add_f32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(hb) : "v"(t1), "v"(c));
+    const u16x2 h = __builtin_bit_cast(u16x2, hb), k = {180, 180};
+    return __builtin_bit_cast(u32, __builtin_elementwise_min(h, (u16x2)(h + k)));
+}
+__device__ __forceinline__ void pixel_fp_back_quad(const PxFp& x0, const PxFp& x1, const PxFp& x2, const PxFp& x3, float r0, float r1, float r2,
+                                                   float r3, u32& hq, u32& s0, u32& s1, u32& s2, u32& s3)
+{
+    const float t0 = __builtin_fmaf(r0, x0.hdiv, 0.0001220703125f), t1 = __builtin_fmaf(r1, x1.hdiv, 0.0001220703125f);
+    const float t2 = __builtin_fmaf(r2, x2.hdiv, 0.0001220703125f), t3 = __builtin_fmaf(r3, x3.hdiv, 0.0001220703125f);
+    float c = 12582912.0f;
+    asm("" : "+v"(c));                // (a VGPR for the additions: the SDWA form takes no literal; not volatile -- hoisted out of the walk)
+    const u32 w01 = hue_pair_wrapped(t0, t1, c), w23 = hue_pair_wrapped(t2, t3, c);
+    hq = __builtin_amdgcn_perm(w23, w01, 0x06040200u);
+    s0 = __float_as_uint(__builtin_fmaf(x0.diff, x0.sdiv, 8388608.0f));
+    s1 = __float_as_uint(__builtin_fmaf(x1.diff, x1.sdiv, 8388608.0f));
+    s2 = __float_as_uint(__builtin_fmaf(x2.diff, x2.sdiv, 8388608.0f));
+    s3 = __float_as_uint(__builtin_fmaf(x3.diff, x3.sdiv, 8388608.0f));
+}
+
 // luma of the fused pass from the hue differences: the coefficients of OpenCV's fixed-point BGR -> Y sum to 2^14, so
 //   (1868 b + 9617 g + 4899 r + 8192) >> 14 = g + floor((-6767 p - 4899 q) / 16384 + 1/2),  p = g - b, q = b - r
 // and in float32 (every product and sum below is exact: multiples of 2^-15 under 2^8; the 2^-15 pushes the exact ties up
@@ -588,8 +618,13 @@ __device__ __forceinline__ void convert_group(Group& g, Hsv16& o, const u32* __r
                 __builtin_amdgcn_sched_barrier(0);
             }
             u32 hq = 0;
+#if PSD_HPAIR
+            u32 s0, s1, s2, s3;
+            pixel_fp_back_quad(x0, x1, x2, x3, r0, r1, r2, r3, hq, s0, s1, s2, s3);
+#else
             const u32 s0 = pixel_fp_back<0>(x0, r0, hq), s1 = pixel_fp_back<1>(x1, r1, hq);
             const u32 s2 = pixel_fp_back<2>(x2, r2, hq), s3 = pixel_fp_back<3>(x3, r3, hq);
+#endif
             const u32 s01 = perm_b32(s1, s0, 0x0c0c0400u), v01 = perm_b32(__float_as_uint(x1.V), __float_as_uint(x0.V), 0x0c0c0400u);
             const u32 s23 = perm_b32(s3, s2, 0x0c0c0400u), v23 = perm_b32(__float_as_uint(x3.V), __float_as_uint(x2.V), 0x0c0c0400u);
             o.h[q] = hq;
