@@ -276,11 +276,30 @@ __device__ __forceinline__ int mag_at(const uint2 (*smq)[N2_NCG], int row, int c
     return q[((c & 1) << 1) | ((c >> 1) & 1)];
 }
 
+// PSD_SOBEL_P1_DPP (round 6, fifth session): the segments of ONE column group sit in neighbouring lanes (lane = 7 cg' + seg, nine
+// column groups per wave, lane 63 idle), every work item runs the horizontal step on six rows -- its five and the first of the
+// two it shares with the segment below -- and takes the seventh, the segment below's second row, from lane + 1 with four DPP
+// moves (wave_shl:1) instead of an eleven-instruction step and three LDS reads: 66 + 4 + 65 instructions per work item where
+// the rolling form has 77 + 65 (static count of the phase: 205 -> 193 VALU, 25 -> 18 LDS instructions).  The arithmetic per value
+// is the same, so the magnitudes are; whole edge + HSV term +1 % on shot-like and object frames (profiles/r06_an_ab_sobel_p1_dpp.txt;
+// spreading the V rows over the LDS banks for the new lane order -- a 212-byte row stride -- measured nothing).  (The bottom segment's seventh
+// row -- another column group's row 1 -- only feeds magnitude row 34, which does not exist.)
+#ifndef PSD_SOBEL_P1_DPP
+#define PSD_SOBEL_P1_DPP 1
+#endif
 template <bool INNER>
 __device__ __forceinline__ void sobel_phase1_quads(const uint8_t (*sv)[N2_SVW], uint2 (*smq)[N2_NCG], int tid, int x0, int y0, int H, int W)
 {
+#if PSD_SOBEL_P1_DPP
+    static_assert(N2_NSEG == 7 && 9 * 4 >= N2_NCG && N2_SEG == 5, "nine column groups of seven segments per wave, four waves");
+    const int lane_ = tid & 63, cgl = lane_ / N2_NSEG, seg = lane_ - cgl * N2_NSEG;
+    const int cg_raw = (tid >> 6) * 9 + cgl;
+    const bool live = lane_ < 63 && cg_raw < N2_NCG;      // (the others run along on a clamped column group and store nothing)
+    const int cg = min(cg_raw, N2_NCG - 1);
+#else
     if (tid >= N2_NCG * N2_NSEG) return;
     const int cg = tid % N2_NCG, seg = tid / N2_NCG;
+#endif
     const int m0 = seg * N2_SEG, m1 = min(m0 + N2_SEG, N2_H + 2);
     const int cl = max(cg - 1, 0) * 4, cm = cg * 4, cr = min(cg + 1, N2_NCG - 1) * 4;   // clamped neighbours only feed unused columns
     u32 keepE = 0xffffffffu, keepO = 0xffffffffu;
@@ -299,7 +318,11 @@ __device__ __forceinline__ void sobel_phase1_quads(const uint8_t (*sv)[N2_SVW], 
     auto H2 = [](u32 a) { return __builtin_bit_cast(h16x2, a); };
     auto U = [](h16x2 a) { return __builtin_bit_cast(u32, a); };
     const h16x2 two = {(_Float16)2.0f, (_Float16)2.0f};
+#if PSD_SOBEL_P1_DPP
+    h16x2 h1E[N2_SEG + 2], h1O[N2_SEG + 2], h2E[N2_SEG + 2], h2O[N2_SEG + 2];
+#else
     h16x2 h1E[3], h1O[3], h2E[3], h2O[3];
+#endif
     auto horiz = [&](int r, int slot) {
         const u32 wl = *reinterpret_cast<const u32*>(&sv[r][cl]), wm = *reinterpret_cast<const u32*>(&sv[r][cm]),
                   wr = *reinterpret_cast<const u32*>(&sv[r][cr]);
@@ -311,14 +334,28 @@ __device__ __forceinline__ void sobel_phase1_quads(const uint8_t (*sv)[N2_SVW], 
         h2E[slot] = __builtin_elementwise_fma(P1, two, P0) + P2;                         // left + 2 mid + right
         h2O[slot] = __builtin_elementwise_fma(P2, two, P1) + P3;
     };
+#if PSD_SOBEL_P1_DPP
+#pragma unroll
+    for (int k = 0; k <= N2_SEG; k++) horiz(m0 + k, k);      // rows m0 .. m0 + 5 (<= 35: inside the tile's 36 rows)
+    {
+        auto below = [&](h16x2 v) { return H2((u32)__builtin_amdgcn_update_dpp(0, (int)U(v), 0x130, 0xf, 0xf, false)); };   // lane i <- lane i + 1
+        h1E[N2_SEG + 1] = below(h1E[1]); h1O[N2_SEG + 1] = below(h1O[1]); h2E[N2_SEG + 1] = below(h2E[1]); h2O[N2_SEG + 1] = below(h2O[1]);
+    }
+#else
     horiz(m0, 0);
     horiz(m0 + 1, 1);
+#endif
 #pragma unroll
     for (int k = 0; k < N2_SEG; k++) {
         const int my = m0 + k;
+#if PSD_SOBEL_P1_DPP
+        if (my < m1 && live) {
+            const int a = k, b = k + 1, c = k + 2;
+#else
         if (my < m1) {
             const int a = k % 3, b = (k + 1) % 3, c = (k + 2) % 3;
             horiz(my + 2, c);
+#endif
             const h16x2 dxE = __builtin_elementwise_fma(h1E[b], two, h1E[a]) + h1E[c], dxO = __builtin_elementwise_fma(h1O[b], two, h1O[a]) + h1O[c];
             const h16x2 dyE = h2E[c] - h2E[a], dyO = h2O[c] - h2O[a];
             u32 mE = U(H2(U(dxE) & 0x7fff7fffu) + H2(U(dyE) & 0x7fff7fffu)), mO = U(H2(U(dxO) & 0x7fff7fffu) + H2(U(dyO) & 0x7fff7fffu));
