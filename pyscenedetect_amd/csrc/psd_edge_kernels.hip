@@ -358,7 +358,9 @@ __device__ __forceinline__ void sobel_phase1_quads(const uint8_t (*sv)[N2_SVW], 
 #endif
             const h16x2 dxE = __builtin_elementwise_fma(h1E[b], two, h1E[a]) + h1E[c], dxO = __builtin_elementwise_fma(h1O[b], two, h1O[a]) + h1O[c];
             const h16x2 dyE = h2E[c] - h2E[a], dyO = h2O[c] - h2O[a];
-            u32 mE = U(H2(U(dxE) & 0x7fff7fffu) + H2(U(dyE) & 0x7fff7fffu)), mO = U(H2(U(dxO) & 0x7fff7fffu) + H2(U(dyO) & 0x7fff7fffu));
+            // |dx| + |dy|: both are non-negative integers <= 1020 per half by now, so the sum is a plain 32-bit add (full rate; no carry
+            // can leave a half) -- the same bits the packed fp16 add of the two patterns gives
+            u32 mE = (U(dxE) & 0x7fff7fffu) + (U(dyE) & 0x7fff7fffu), mO = (U(dxO) & 0x7fff7fffu) + (U(dyO) & 0x7fff7fffu);
             if (!INNER) {
                 const int y = y0 - 1 + my;
                 if (y < 0 || y >= H) { mE = 0; mO = 0; }
