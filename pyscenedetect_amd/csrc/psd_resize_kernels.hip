@@ -448,11 +448,17 @@ __device__ __forceinline__ void rs_hist_flush(u32* hs, u32* dst, int tid)
 // weights.delta_edges or a StatsManager, content_detector.py:155-174 on what scene_manager.py:666-678 hands it.  The HSV term as
 // always, and of the resized frame only what cv2.Canny needs leaves the CU: its V plane (a third of the frame's bytes, through
 // LDS as 16-byte stores) and its V histogram (the luma instances' machinery counting V: numpy.median for the thresholds).
+#ifndef PSD_RS_STORE_WAIT
+#define PSD_RS_STORE_WAIT 1
+#endif
+#ifndef PSD_RS_VOUT_HIST
+#define PSD_RS_VOUT_HIST 0     // 1: the VOUT instances count their V histogram themselves (rounds 6.2-6.4); 0: vplane_hist_kernel below
+#endif
 template <bool STORE, bool HSV, int G, bool LUMA = false, bool SEG = false, bool VOUT = false>
 __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
 {
     static_assert(!VOUT || (HSV && !LUMA && !STORE), "VOUT rides on the HSV conversion");
-    constexpr bool HIST = LUMA || VOUT;
+    constexpr bool HIST = LUMA || (VOUT && PSD_RS_VOUT_HIST);
     extern __shared__ __attribute__((aligned(16))) uint8_t rs_stage[];
     __shared__ u32 lut_s[HSV ? 256 : 1], lut_h[HSV ? 256 : 1];
     // per-frame sums (sad_h, sad_s, sad_v, byte_sum), RS_REP copies each: a lane adds into copy lane % RS_REP
@@ -577,6 +583,9 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
     if constexpr (SEG) {
         if (tb < t1 && tb >= 0) seg_next = p.seg[tb];
     }
+    // 16-byte store instructions of this wave per store_tile (uniform: thread tid takes the pieces tid, tid + 256, ...)
+    const int n16 = (npx * ((STORE || VOUT) ? (VOUT ? 1 : 3) : 0)) >> 4;
+    const int my_stores = n16 > 64 * wave ? (n16 - 64 * wave + RS_WG - 1) / RS_WG : 0;
     auto store_tile = [&](int t, int slot) {
         const uint4* from = reinterpret_cast<const uint4*>(obuf[slot]);
         constexpr int BPP = VOUT ? 1 : 3;          // bytes per pixel that leave: the V plane or the BGR frame
@@ -596,6 +605,16 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             else if (mine >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
+#if PSD_RS_STORE_WAIT
+            // STORE / VOUT: the 16-byte stores of frame t-2's pixels went out in the step before this one BEHIND the DMA of frame t, and
+            // vector memory operations complete in order: "at most my_stores outstanding" means frame t has landed, and the wave does
+            // not sit out the write acknowledgements (round 6, fifth session)
+            const int younger = ((STORE || VOUT) && p.store_vec && t - t0 >= 2) ? my_stores : 0;
+            if (younger >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (HSV || LUMA || STORE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's hidden LDS increments / pixel bytes of frame t-1
@@ -633,7 +652,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
         }
         const uint8_t* base = rs_stage + (size_t)buf * buf_bytes;
         u32 sh = 0, ss = 0, sv = 0, bsum = 0;
-        const bool count_luma = HIST && t >= t0;           // (the halo frame only feeds the HSV carry)
+        const bool count_luma = (HIST || VOUT) && t >= t0;   // (the halo frame only feeds the HSV carry; VOUT: neither is its V plane stored)
         u32* hcur = lhist[HIST ? (rel & 1) : 0] + (HIST ? (tid & (RS_HREP - 1)) * 256 : 0);
         const bool chain = have_prev && !(SEG && flag_now != 0);
         constexpr int C = G < 4 ? G : 4;        // pixels whose taps are in flight together (six dwords each)
@@ -681,7 +700,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
                     nh[g] = h; ns[g] = s; nv[g] = v;
                     if (VOUT) {
                         if (count_luma) {
-                            rs_lds_add(&hcur[v], live[g] ? 1u : 0u);
+                            if (PSD_RS_VOUT_HIST) rs_lds_add(&hcur[v], live[g] ? 1u : 0u);
                             if (live[g]) {
                                 if (p.store_vec) {
                                     asm volatile("ds_write_b8 %0, %1" ::"v"((u32)(uintptr_t)&obuf[rel & 1][g * RS_WG + tid]), "v"(v) : "memory");
@@ -742,6 +761,50 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
                              : q == 2 ? (unsigned long long*)&rec->sad_v : (unsigned long long*)&rec->byte_sum, (unsigned long long)v);
         }
         if (HIST && done > 0) rs_hist_flush<false>(lhist[(done - 1) & 1], p.hpart + ((size_t)(t1 - 1) * p.n_tiles + tile) * p.hstride, tid);   // the chunk's last frame
+    }
+}
+
+// The V histograms of the VOUT instances' planes (numpy.median for Canny's thresholds, content_detector.py:229-233), round 6, fifth session.
+// Until then the VOUT instance counted V with the luma instances' machinery -- an LDS increment per destination pixel, a 256-bin flush
+// per tile and frame, hist_reduce_kernel behind it: 1.385 ms per 4096 x 1080p -> 256 x 144 against 1.03 ms for the instance that only
+// scores (profiles/r06_aq_*).  The plane it writes is small (36 KB per frame at the default downscale, 1 / 170 of the source bytes) and
+// stays in the L2 / Infinity Cache, so counting it again costs next to nothing: one workgroup per frame (`parts` of them for large
+// planes: global atomics then, the histogram zeroed by the caller), sixteen bytes per lane and step, a 16-fold replicated LDS
+// histogram laid out [bin][copy] (lanes that meet in a bin -- flat regions -- land on sixteen banks), plain stores of the 256 sums.
+// -DPSD_RS_VOUT_HIST=1 restores the count inside the downscale kernel (A/B).
+__global__ __launch_bounds__(1024) void vplane_hist_kernel(const uint8_t* v, size_t npix, u32* hist, int parts)
+{
+    __shared__ __attribute__((aligned(16))) u32 h[256][16];
+    const int tid = threadIdx.x, frame = blockIdx.x / parts, part = blockIdx.x - frame * parts;
+    for (int i = tid; i < 256 * 16; i += 1024) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const uint8_t* src = v + (size_t)frame * npix;
+    u32* mine = &h[0][tid & 15];
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const size_t chunks = npix / 16, c0 = chunks * part / parts, c1 = chunks * (part + 1) / parts;
+        for (size_t c = c0 + tid; c < c1; c += 1024) {
+            const uint4 w = reinterpret_cast<const uint4*>(src)[c];
+            const u32 d[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                atomicAdd(mine + 16 * (d[k] & 255u), 1u); atomicAdd(mine + 16 * ((d[k] >> 8) & 255u), 1u);
+                atomicAdd(mine + 16 * ((d[k] >> 16) & 255u), 1u); atomicAdd(mine + 16 * (d[k] >> 24), 1u);
+            }
+        }
+        if (part == parts - 1 && (size_t)tid < npix - chunks * 16) atomicAdd(mine + 16 * src[chunks * 16 + tid], 1u);
+    } else {
+        // (a plane that does not start on 16 bytes: odd-sized frames behind the first; byte loads)
+        const size_t b0 = npix * part / parts, b1 = npix * (part + 1) / parts;
+        for (size_t b = b0 + tid; b < b1; b += 1024) atomicAdd(mine + 16 * src[b], 1u);
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const uint4* q = reinterpret_cast<const uint4*>(&h[tid][0]);
+        u32 sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint4 w = q[k]; sum += w.x + w.y + w.z + w.w; }
+        if (parts == 1) hist[(size_t)frame * 256 + tid] = sum;
+        else if (sum) atomicAdd(&hist[(size_t)frame * 256 + tid], sum);
     }
 }
 
@@ -954,7 +1017,8 @@ static int resize_linear_impl(psd_engine* e, const uint8_t* d_src, int n, int sr
     chunks = (n + p.frames_per_chunk - 1) / p.frames_per_chunk;
     const int grid = p.n_tiles * chunks;
     if (want_hsv) note_walk_geometry(p.frames_per_chunk, p.n_tiles);
-    if (want_luma || want_v) {
+    const bool tile_hist = want_luma || (want_v && PSD_RS_VOUT_HIST);
+    if (tile_hist) {
         void* scratch = nullptr;
         p.hstride = rs_hist_stride_words(R * dst_w);
         rc = engine_hist_scratch(e, (size_t)n * p.n_tiles * p.hstride * sizeof(u32), stream, &scratch);
@@ -967,7 +1031,18 @@ static int resize_linear_impl(psd_engine* e, const uint8_t* d_src, int n, int sr
     }
     HIP_TRY(hipGetLastError());
     if (launches) *launches += 1;
-    if (want_luma || want_v) {
+    if (want_v && !PSD_RS_VOUT_HIST) {
+        // the planes' histograms from the planes (vplane_hist_kernel): one workgroup per frame up to 256 K pixels, more above
+        const size_t npix = (size_t)dst_h * dst_w;
+        const int parts = (int)std::min<size_t>(64, (npix + 262143) / 262144);
+        if (parts > 1) HIP_TRY(hipMemsetAsync(d_vhist, 0, (size_t)n * 256 * sizeof(u32), stream));
+        for (int t0 = 0; t0 < n; t0 += 32768)
+            hipLaunchKernelGGL(vplane_hist_kernel, dim3(std::min(32768, n - t0) * parts), dim3(1024), 0, stream, d_vout + (size_t)t0 * npix, npix,
+                               d_vhist + (size_t)t0 * 256, parts);
+        HIP_TRY(hipGetLastError());
+        if (launches) *launches += 1;
+    }
+    if (tile_hist) {
         // (one quarter-less pass of 128 threads per frame: in the pipelined flow the small workgroups slip in beside the next
         //  submission's kernels -- 1.29-1.30 ms per 4096 frames against 1.31-1.32 with 512 threads, which are faster alone)
         u32* words = want_v ? d_vhist : reinterpret_cast<u32*>(&d_out[0].hist[0]);

@@ -306,6 +306,30 @@ def test_partial_histograms_whose_counts_pass_a_byte(hip_engine, shape):
     buf.free()
 
 
+@pytest.mark.parametrize("shape", [(1080, 1920, 540, 960), (360, 640, 203, 361), (1080, 1920, 144, 256), (2160, 3840, 1080, 1920)])
+def test_v_histograms_of_the_fused_front_end_from_its_planes(hip_engine, shape):
+    """HSV + edge term behind a downscale: the V histograms (numpy.median for Canny's thresholds, content_detector.py:229-233) are counted
+    from the V planes the fused downscale kernel wrote (vplane_hist_kernel): one workgroup per frame at the default size, several with
+    global atomics above 256 K pixels (960 x 540, 1920 x 1080), byte loads where a plane does not start on 16 bytes (361 x 203: odd
+    pixel count).  Flat frames, bands and noise -- medians at the ends, between two bins, in the middle -- against the oracle."""
+    sh, sw, dh, dw = shape
+    rng = np.random.default_rng(sh * 7 + dw)
+    frames = [np.full((sh, sw, 3), v, np.uint8) for v in (0, 255, 90)]
+    two = np.zeros((sh, sw, 3), np.uint8)
+    two[:, sw // 2:] = (200, 90, 30)                        # half the pixels V = 0, half V = 200: the median lies between two bins
+    frames.append(two)
+    box = rng.integers(60, 70, (sh, sw, 3), dtype=np.uint8)
+    box[sh // 4:3 * sh // 4, sw // 3:2 * sw // 3] = (250, 10, 10)
+    frames.append(box)
+    frames.append(rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8))
+    frames = np.stack(frames + frames[::-1])
+    buf = device_copy(hip_engine, frames)
+    small, _ = oracle_downscaled(frames, None, dh, dw)
+    got = hip_engine.score_device_downscaled(buf.ptr, len(frames), sh, sw, dh, dw, flags=E.SCORE_HSV_SAD | E.SCORE_EDGES)
+    same(got, oracle_score(small, edges=True), ("sad_h", "sad_s", "sad_v", "edge_xor"))
+    buf.free()
+
+
 def test_downscale_then_score_other_terms_and_modes(hip_engine):
     """Edges and the NEAREST / AREA / LANCZOS4 / CUBIC modes go through the resize-then-score path of the same entry point."""
     import cv2  # the oracle shim
