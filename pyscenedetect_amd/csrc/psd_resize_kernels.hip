@@ -609,7 +609,9 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             // STORE / VOUT: the 16-byte stores of frame t-2's pixels went out in the step before this one BEHIND the DMA of frame t, and
             // vector memory operations complete in order: "at most my_stores outstanding" means frame t has landed, and the wave does
             // not sit out the write acknowledgements (round 6, fifth session)
-            const int younger = ((STORE || VOUT) && p.store_vec && t - t0 >= 2) ? my_stores : 0;
+            // (HIST: rs_hist_flush's stores of frame t-2's partial histogram as well -- wave 0 issues at least two, `bytes` and `over`)
+            const int hist_stores = !HIST ? 0 : RS_HPACK8 ? (wave == 0 ? 2 : 0) : (wave < 2 ? 1 : 0);
+            const int younger = t - t0 >= 2 ? (((STORE || VOUT) && p.store_vec) ? my_stores : 0) + hist_stores : 0;
             if (younger >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");

@@ -218,10 +218,77 @@ def test_fused_downscale_seg_instance_reads_the_flag_behind_the_dma_issue(tmp_pa
                     dma_blocks.add(label)
             enters = any(x.startswith("s_cbranch") and x.split()[-1] in dma_blocks for x in step[:at])
             assert any(x.startswith("global_load_lds_dwordx4") for x in step[:at]) or enters, name
-            assert not any(x.startswith("s_waitcnt") and "vmcnt(0)" in x for x in step[at:]), name
+            # (a wait in a block hipcc placed behind the loop body that branches back IN FRONT of the step's barrier belongs to the
+            #  step's own wait at its top -- the ladder of s_waitcnt vmcnt(n) alternatives, fifth session of round 6 -- not to the
+            #  stretch behind the flag's load)
+            bar0 = next(k for k, x in enumerate(step) if x.startswith("s_barrier"))
+            label_pos, n_ins = {}, 0
+            for x in lines[a:b + 1]:
+                lm = re.match(r"^(\.LBB\d+_\d+):", x)
+                if lm:
+                    label_pos[lm.group(1)] = n_ins
+                elif x.startswith("\t") and x.strip():
+                    n_ins += 1
+
+            def top_of_step_wait(k):
+                for y in step[k + 1:]:
+                    if y.startswith(("s_branch", "s_cbranch")):
+                        return label_pos.get(y.split()[-1], 1 << 30) < bar0
+                return False
+            assert not any(x.startswith("s_waitcnt") and "vmcnt(0)" in x and not top_of_step_wait(at + k) for k, x in enumerate(step[at:])), name
             # ... and the flag becomes an SGPR in front of the step's barrier (right behind the step's own wait)
             bar = next(k for k, x in enumerate(step) if x.startswith("s_barrier"))
             assert any(x.startswith("v_readfirstlane_b32") for x in step[:bar]), name
         assert in_loop in (1, 2), (name, in_loop)     # (two where the frame loop was unswitched)
         checked += 1
     assert checked == 16      # (HSV | HSV + store | HSV + luma | HSV + V plane) x four pixel-slot counts
+
+
+def test_fused_downscale_kernel_issues_its_stores_behind_the_dma_of_the_step(tmp_path):
+    """Round 6, fifth session: a step of the walk waits with `s_waitcnt vmcnt(n)`, n = the store instructions the wave
+    issued in the step before, for the LDS-DMA of its frame -- correct only because those stores (the pixels / V plane of the frame
+    before last, a tile's partial histogram) are YOUNGER than the DMA: in every instance that stores inside the frame loop the step's
+    DMA issue -- in the text or in blocks hipcc placed out of line and entered by a branch -- lies between the step's barrier and its
+    first 16-byte / dword store."""
+    bodies = kernel_bodies(device_asm("psd_resize_kernels", tmp_path))
+    checked = 0
+    for name, lines in bodies.items():
+        m = re.search(r"resize_walk_kernelILb([01])ELb([01])ELi(\d)ELb([01])ELb([01])ELb([01])E", name)
+        if not m:
+            continue
+        store, hsv, g, luma, seg, vout = (int(x) for x in m.groups())
+        if not (store or vout or luma):
+            continue
+        dma_blocks, label = set(), None
+        for x in lines:
+            lm = re.match(r"^(\.LBB\d+_\d+):", x)
+            if lm:
+                label = lm.group(1)
+            elif x.strip().startswith("global_load_lds_dwordx4") and label:
+                dma_blocks.add(label)
+        # the frame loop: the depth-1 loop header whose blocks (its own and those marked "in Loop: Header=...", wherever hipcc
+        # placed them) hold a barrier; its instructions in layout order from the header on
+        step = None
+        for h, x in enumerate(lines):
+            hm = re.match(r"^\.L(BB\d+_\d+):.*Loop Header: Depth=1", x)
+            if not hm:
+                continue
+            inside, body = True, []
+            mine = {hm.group(1)} | {cm.group(1) for y in lines for cm in [re.match(r"^\.L(BB\d+_\d+):.*Parent Loop " + hm.group(1) + r"\b", y)] if cm}
+            for y in lines[h + 1:]:
+                if re.match(r"^\.LBB\d+_\d+:", y):
+                    inside = any(("Header=" + k + " ") in y + " " or ("Parent Loop " + k + " ") in y + " " for k in mine)
+                elif inside and y.startswith("\t") and y.strip():
+                    body.append(y.strip())
+            if any(y.startswith("s_barrier") for y in body):
+                step = body
+                break
+        assert step, name
+        bar = next(k for k, x in enumerate(step) if x.startswith("s_barrier"))
+        stores = [k for k, x in enumerate(step) if x.startswith(("global_store_dwordx4", "global_store_dword "))]
+        assert stores and min(stores) > bar, name
+        head = step[bar:min(stores)]
+        assert any(x.startswith("global_load_lds_dwordx4") for x in head) or \
+            any(x.startswith("s_cbranch") and x.split()[-1] in dma_blocks for x in head), name
+        checked += 1
+    assert checked >= 24, checked
