@@ -448,6 +448,9 @@ __device__ __forceinline__ void rs_hist_flush(u32* hs, u32* dst, int tid)
 // weights.delta_edges or a StatsManager, content_detector.py:155-174 on what scene_manager.py:666-678 hands it.  The HSV term as
 // always, and of the resized frame only what cv2.Canny needs leaves the CU: its V plane (a third of the frame's bytes, through
 // LDS as 16-byte stores) and its V histogram (the luma instances' machinery counting V: numpy.median for the thresholds).
+#ifndef PSD_RS_HPART_TILE_MAJOR
+#define PSD_RS_HPART_TILE_MAJOR 1   // partial histograms laid out [tile][frame]: a workgroup's walk writes ONE contiguous run (0: [frame][tile], rounds 4-6.4)
+#endif
 #ifndef PSD_RS_STORE_WAIT
 #define PSD_RS_STORE_WAIT 1
 #endif
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             if (v) atomicAdd(q == 0 ? (unsigned long long*)&rec->sad_h : q == 1 ? (unsigned long long*)&rec->sad_s
                              : q == 2 ? (unsigned long long*)&rec->sad_v : (unsigned long long*)&rec->byte_sum, (unsigned long long)v);
         }
-        if (HIST && rel >= 1) rs_hist_flush<true>(lhist[(rel - 1) & 1], p.hpart + ((size_t)(t - 1) * p.n_tiles + tile) * p.hstride, tid);
+        if (HIST && rel >= 1) rs_hist_flush<true>(lhist[(rel - 1) & 1], p.hpart + (PSD_RS_HPART_TILE_MAJOR ? (size_t)tile * p.n + (t - 1) : (size_t)(t - 1) * p.n_tiles + tile) * p.hstride, tid);
         if ((STORE || VOUT) && rel >= 1) {
             if (p.store_vec) store_tile(t - 1, (rel - 1) & 1);       // frame t-1's pixels are complete (every wave wrote them before this barrier)
         }
@@ -762,7 +765,7 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
             if (v) atomicAdd(q == 0 ? (unsigned long long*)&rec->sad_h : q == 1 ? (unsigned long long*)&rec->sad_s
                              : q == 2 ? (unsigned long long*)&rec->sad_v : (unsigned long long*)&rec->byte_sum, (unsigned long long)v);
         }
-        if (HIST && done > 0) rs_hist_flush<false>(lhist[(done - 1) & 1], p.hpart + ((size_t)(t1 - 1) * p.n_tiles + tile) * p.hstride, tid);   // the chunk's last frame
+        if (HIST && done > 0) rs_hist_flush<false>(lhist[(done - 1) & 1], p.hpart + (PSD_RS_HPART_TILE_MAJOR ? (size_t)tile * p.n + (t1 - 1) : (size_t)(t1 - 1) * p.n_tiles + tile) * p.hstride, tid);   // the chunk's last frame
     }
 }
 
@@ -813,17 +816,21 @@ __global__ __launch_bounds__(1024) void vplane_hist_kernel(const uint8_t* v, siz
 // rec[t].hist = sum over the tiles of frame t of their partial histograms (rs_hist_flush's layout).  grid = frames; W threads per group
 // (W = 64: one per word of four low bytes; 128 in the 16-bit layout) or a multiple: the tiles are split over blockDim / W groups of threads
 // and joined in LDS.  out_words + t * stride_words = the 256 bins of frame t (a record's `hist`, or a row of the edge term's V histograms).
-__global__ __launch_bounds__(512) void hist_reduce_kernel(const u32* hpart, int n_tiles, int hstride, u32* out_words, size_t stride_words)
+// (tile-major partials, fifth session of round 6: frame t's tile k lies at hpart + (k * n_frames + t_base + t) * hstride -- the downscale kernel's
+//  workgroups each write one contiguous run over their walk; these reads are the scattered side now, 272 bytes each, by a kernel that is not in a hurry)
+__global__ __launch_bounds__(512) void hist_reduce_kernel(const u32* hpart, int n_tiles, int hstride, u32* out_words, size_t stride_words, int n_frames,
+                                                          int t_base)
 {
     constexpr int W = RS_HPACK8 ? 64 : 128, B = 256 / W;        // threads per group, bins per thread
     __shared__ u32 part[512 / W - 1][256];
     const int t = blockIdx.x, i = threadIdx.x % W, q = threadIdx.x / W, nq = blockDim.x / W;
-    const u32* src = hpart + (size_t)t * n_tiles * hstride;
+    const u32* src = PSD_RS_HPART_TILE_MAJOR ? hpart + (size_t)(t_base + t) * hstride : hpart + (size_t)(t_base + t) * n_tiles * hstride;
+    const size_t tile_step = PSD_RS_HPART_TILE_MAJOR ? (size_t)n_frames * hstride : (size_t)hstride;
     u32 c[B];
 #pragma unroll
     for (int b = 0; b < B; b++) c[b] = 0;
     for (int k = q; k < n_tiles; k += nq) {
-        const u32* tp = src + (size_t)k * hstride;
+        const u32* tp = src + (size_t)k * tile_step;
         const u32 v = tp[i];
         if constexpr (RS_HPACK8) {
             c[0] += v & 255u; c[1] += (v >> 8) & 255u; c[2] += (v >> 16) & 255u; c[3] += v >> 24;
@@ -1050,8 +1057,8 @@ static int resize_linear_impl(psd_engine* e, const uint8_t* d_src, int n, int sr
         u32* words = want_v ? d_vhist : reinterpret_cast<u32*>(&d_out[0].hist[0]);
         const size_t stride = want_v ? 256 : sizeof(psd_frame_scores) / sizeof(u32);
         for (int t0 = 0; t0 < n; t0 += 65535)
-            hipLaunchKernelGGL(hist_reduce_kernel, dim3(std::min(65535, n - t0)), dim3(128), 0, stream, p.hpart + (size_t)t0 * p.n_tiles * p.hstride,
-                               p.n_tiles, p.hstride, words + (size_t)t0 * stride, stride);
+            hipLaunchKernelGGL(hist_reduce_kernel, dim3(std::min(65535, n - t0)), dim3(128), 0, stream, p.hpart, p.n_tiles, p.hstride,
+                               words + (size_t)t0 * stride, stride, n, t0);
         HIP_TRY(hipGetLastError());
         if (launches) *launches += 1;
     }
