@@ -772,8 +772,8 @@ __global__ __launch_bounds__(RS_WG) void resize_walk_kernel(const RsParams p)
 // The V histograms of the VOUT instances' planes (numpy.median for Canny's thresholds, content_detector.py:229-233), round 6, fifth session.
 // Until then the VOUT instance counted V with the luma instances' machinery -- an LDS increment per destination pixel, a 256-bin flush
 // per tile and frame, hist_reduce_kernel behind it: 1.385 ms per 4096 x 1080p -> 256 x 144 against 1.03 ms for the instance that only
-// scores (profiles/r06_aq_*).  The plane it writes is small (36 KB per frame at the default downscale, 1 / 170 of the source bytes) and
-// stays in the L2 / Infinity Cache, so counting it again costs next to nothing: one workgroup per frame (`parts` of them for large
+// scores (profiles/r06_aq_*).  The plane it writes is small (36 KB per frame at the default downscale, 1 / 170 of the source bytes), so
+// reading it once more costs next to nothing (151 MB per 4096 frames, 37 us: profiles/r06_bb_pmc_*): one workgroup per frame (`parts` of them for large
 // planes: global atomics then, the histogram zeroed by the caller), sixteen bytes per lane and step, a 16-fold replicated LDS
 // histogram laid out [bin][copy] (lanes that meet in a bin -- flat regions -- land on sixteen banks), plain stores of the 256 sums.
 // -DPSD_RS_VOUT_HIST=1 restores the count inside the downscale kernel (A/B).
